@@ -1,0 +1,941 @@
+/*
+ * oracle/mldsa_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see mldsa_oracle.h).
+ *
+ * Plain-C restatement of integritychain/fips204 v0.4.6: src/ntt.rs, src/helpers.rs,
+ * src/hashing.rs (the hot path) and src/conversion.rs, src/encodings.rs,
+ * src/high_low.rs, src/ml_dsa.rs, src/lib.rs (callers, needed to reach the KAT byte
+ * strings).  Same algorithmic structure as the reference: per-op ExpandA, scalar
+ * radix-2 NTT with 64-bit Montgomery products, byte-granular XOF reads, signed lazy
+ * i32 arithmetic with wrap-on-overflow (build with -fwrapv; the reference's release
+ * profile has overflow-checks off, Cargo.toml:62-69).
+ */
+#include "mldsa_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define Q ORC_Q
+#define D ORC_D
+#define N ORC_N
+
+/* ------------------------------------------------------------------------- */
+/* parameter sets: src/lib.rs:639-656 (44), 681-698 (65), 723-740 (87)        */
+/* ------------------------------------------------------------------------- */
+static const orc_params PARAMS[3] = {
+    {44, 4, 4, 2, 39, 128, 1 << 17, (Q - 1) / 88, 80, 78, 32, 1312, 2560, 2420, 768},
+    {65, 6, 5, 4, 49, 192, 1 << 19, (Q - 1) / 32, 55, 196, 48, 1952, 4032, 3309, 768},
+    {87, 8, 7, 2, 60, 256, 1 << 19, (Q - 1) / 32, 75, 120, 64, 2592, 4896, 4627, 1024},
+};
+
+const orc_params *orc_get_params(int set) {
+    for (int i = 0; i < 3; i++)
+        if (PARAMS[i].set == set) return &PARAMS[i];
+    return NULL;
+}
+
+/* helpers.rs:81 bit_length */
+static int bit_length(int x) {
+    int n = 0;
+    while (x > 0) { n++; x >>= 1; }
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* FIPS 202 Keccak-f[1600] + SHAKE (sha3 crate 0.10.x, called at             */
+/* hashing.rs:13-27).  Byte-granular squeeze like XofReader::read.           */
+/* ------------------------------------------------------------------------- */
+static const uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+static const int KECCAK_ROTC[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14,
+                                    27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+static const int KECCAK_PILN[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4,
+                                    15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+
+#define ROTL64(x, n) (((x) << (n)) | ((x) >> (64 - (n))))
+
+void orc_keccak_f1600(uint64_t s[25]) {
+    uint64_t bc[5], t;
+    for (int round = 0; round < 24; round++) {
+        for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
+        for (int i = 0; i < 5; i++) {
+            t = bc[(i + 4) % 5] ^ ROTL64(bc[(i + 1) % 5], 1);
+            for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
+        }
+        t = s[1];
+        for (int i = 0; i < 24; i++) {
+            int j = KECCAK_PILN[i];
+            bc[0] = s[j];
+            s[j] = ROTL64(t, KECCAK_ROTC[i]);
+            t = bc[0];
+        }
+        for (int j = 0; j < 25; j += 5) {
+            for (int i = 0; i < 5; i++) bc[i] = s[j + i];
+            for (int i = 0; i < 5; i++) s[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        s[0] ^= KECCAK_RC[round];
+    }
+}
+
+typedef struct {
+    uint64_t s[25];
+    unsigned rate; /* bytes: 168 (SHAKE128) or 136 (SHAKE256) */
+    unsigned pos;
+    int squeezing;
+} xof_t;
+
+static void xof_init(xof_t *x, int bits) {
+    memset(x, 0, sizeof(*x));
+    x->rate = (bits == 128) ? 168 : 136;
+}
+
+static void xof_absorb(xof_t *x, const uint8_t *in, size_t len) {
+    for (size_t i = 0; i < len; i++) {
+        x->s[x->pos >> 3] ^= (uint64_t)in[i] << (8 * (x->pos & 7));
+        if (++x->pos == x->rate) {
+            orc_keccak_f1600(x->s);
+            x->pos = 0;
+        }
+    }
+}
+
+static void xof_finalize(xof_t *x) {
+    x->s[x->pos >> 3] ^= (uint64_t)0x1F << (8 * (x->pos & 7));
+    x->s[(x->rate - 1) >> 3] ^= (uint64_t)0x80 << (8 * ((x->rate - 1) & 7));
+    orc_keccak_f1600(x->s);
+    x->pos = 0;
+    x->squeezing = 1;
+}
+
+static void xof_read(xof_t *x, uint8_t *out, size_t len) {
+    if (!x->squeezing) xof_finalize(x);
+    for (size_t i = 0; i < len; i++) {
+        if (x->pos == x->rate) {
+            orc_keccak_f1600(x->s);
+            x->pos = 0;
+        }
+        out[i] = (uint8_t)(x->s[x->pos >> 3] >> (8 * (x->pos & 7)));
+        x->pos++;
+    }
+}
+
+void orc_shake(int bits, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen) {
+    xof_t x;
+    xof_init(&x, bits);
+    xof_absorb(&x, in, inlen);
+    xof_read(&x, out, outlen);
+}
+
+/* ------------------------------------------------------------------------- */
+/* helpers.rs                                                                */
+/* ------------------------------------------------------------------------- */
+
+/* helpers.rs:156-165 mont_reduce: a * 2^-32 mod q, result in (-q, q) */
+int32_t orc_mont_reduce(int64_t a) {
+    const int32_t QINV = 58728449;
+    int32_t t = (int32_t)((uint32_t)(int32_t)a * (uint32_t)QINV);
+    return (int32_t)((a - (int64_t)t * (int64_t)Q) >> 32);
+}
+
+/* helpers.rs:33-44 partial_reduce64 */
+int32_t orc_partial_reduce64(int64_t a) {
+    const int64_t M = ((int64_t)1 << 48) / (int64_t)Q;
+    int64_t x = a >> 23;
+    a = a - x * (int64_t)Q;
+    x = a >> 23;
+    a = a - x * (int64_t)Q;
+    int64_t q = (a * M) >> 48;
+    return (int32_t)(a - q * (int64_t)Q);
+}
+
+/* helpers.rs:61-67 partial_reduce32 */
+int32_t orc_partial_reduce32(int32_t a) {
+    int32_t x = (a + (1 << 22)) >> 23;
+    return a - x * Q;
+}
+
+/* helpers.rs:70-76 full_reduce32 */
+int32_t orc_full_reduce32(int32_t a) {
+    int32_t x = orc_partial_reduce32(a);
+    return x + ((x >> 31) & Q);
+}
+
+/* helpers.rs:88-95 center_mod */
+int32_t orc_center_mod(int32_t m) {
+    int32_t t = orc_full_reduce32(m);
+    int32_t over2 = (Q / 2) - t;
+    return t - ((over2 >> 31) & Q);
+}
+
+/* helpers.rs:171-184 gen_zeta_table_mont / ZETA_TABLE_MONT */
+static int32_t ZETA_TABLE_MONT[256];
+static int zeta_ready = 0;
+
+static uint8_t rev8(uint8_t b) {
+    b = (uint8_t)((b & 0xF0) >> 4 | (b & 0x0F) << 4);
+    b = (uint8_t)((b & 0xCC) >> 2 | (b & 0x33) << 2);
+    b = (uint8_t)((b & 0xAA) >> 1 | (b & 0x55) << 1);
+    return b;
+}
+
+static void zeta_init(void) {
+    if (zeta_ready) return;
+    int64_t x = 1;
+    for (unsigned i = 0; i < 256; i++) {
+        ZETA_TABLE_MONT[rev8((uint8_t)i)] = (int32_t)((x << 32) % (int64_t)Q);
+        x = (x * 1753) % (int64_t)Q;
+    }
+    zeta_ready = 1;
+}
+
+void orc_zeta_table(int32_t out[256]) {
+    zeta_init();
+    memcpy(out, ZETA_TABLE_MONT, sizeof(ZETA_TABLE_MONT));
+}
+
+/* helpers.rs:131-135 to_mont */
+void orc_to_mont(const int32_t *in, int32_t *out, size_t n_polys) {
+    for (size_t i = 0; i < n_polys * N; i++)
+        out[i] = orc_partial_reduce64((int64_t)((uint64_t)(int64_t)in[i] << 32));
+}
+
+/* helpers.rs:100-114 mat_vec_mul */
+void orc_mat_vec_mul(int k, int l, const int32_t *a_hat, const int32_t *u_hat, int32_t *w_hat) {
+    int32_t u_hat_mont[ORC_LMAX * N];
+    orc_to_mont(u_hat, u_hat_mont, (size_t)l);
+    memset(w_hat, 0, sizeof(int32_t) * (size_t)k * N);
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < l; j++)
+            for (int n = 0; n < N; n++)
+                w_hat[i * N + n] += orc_mont_reduce((int64_t)a_hat[(i * l + j) * N + n] *
+                                                    (int64_t)u_hat_mont[j * N + n]);
+}
+
+/* scalar-vector pointwise product inlined at ml_dsa.rs:243-250, 253-260, 288-295 */
+void orc_pointwise_mont(const int32_t *c_hat, const int32_t *v_hat_mont, int32_t *out, size_t n_polys) {
+    for (size_t p = 0; p < n_polys; p++)
+        for (int n = 0; n < N; n++)
+            out[p * N + n] = orc_mont_reduce((int64_t)c_hat[n] * (int64_t)v_hat_mont[p * N + n]);
+}
+
+/* helpers.rs:138-147 infinity_norm */
+int32_t orc_infinity_norm(const int32_t *polys, size_t n_polys) {
+    int32_t mx = 0;
+    for (size_t i = 0; i < n_polys * N; i++) {
+        int32_t c = orc_center_mod(polys[i]);
+        if (c < 0) c = -c;
+        if (c > mx) mx = c;
+    }
+    return mx;
+}
+
+/* helpers.rs:25-27 is_in_range */
+static int is_in_range(const int32_t w[N], int lo, int hi) {
+    for (int i = 0; i < N; i++)
+        if (w[i] < -lo || w[i] > hi) return 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ntt.rs                                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* ntt.rs:14-76 ntt (Alg 41) */
+void orc_ntt(const int32_t *in, int32_t *out, size_t n_polys) {
+    zeta_init();
+    if (out != in) memmove(out, in, sizeof(int32_t) * n_polys * N);
+    for (size_t p = 0; p < n_polys; p++) {
+        int32_t *w = out + p * N;
+        int m = 0;
+        for (int len = 128; len >= 1; len >>= 1) {
+            for (int start = 0; start < 256; start += 2 * len) {
+                m += 1;
+                int64_t zeta = (int64_t)ZETA_TABLE_MONT[m];
+                for (int j = start; j < start + len; j++) {
+                    int32_t t = orc_mont_reduce(zeta * (int64_t)w[j + len]);
+                    w[j + len] = w[j] - t;
+                    w[j] += t;
+                }
+            }
+        }
+    }
+}
+
+/* ntt.rs:85-161 inv_ntt (Alg 42) */
+void orc_inv_ntt(const int32_t *in, int32_t *out, size_t n_polys) {
+    /* ntt.rs:88 F_MONT = 8347681 * 2^32 mod q */
+    const int64_t F_MONT = (int64_t)(((__int128)8347681 << 32) % (__int128)Q);
+    zeta_init();
+    if (out != in) memmove(out, in, sizeof(int32_t) * n_polys * N);
+    for (size_t p = 0; p < n_polys; p++) {
+        int32_t *w = out + p * N;
+        int m = 256;
+        for (int len = 1; len < 256; len <<= 1) {
+            for (int start = 0; start < 256; start += 2 * len) {
+                m -= 1;
+                int32_t zeta = -ZETA_TABLE_MONT[m];
+                for (int j = start; j < start + len; j++) {
+                    int32_t t = w[j];
+                    w[j] = t + w[j + len];
+                    w[j + len] = t - w[j + len];
+                    w[j + len] = orc_mont_reduce((int64_t)zeta * (int64_t)w[j + len]);
+                }
+            }
+        }
+        for (int i = 0; i < N; i++) w[i] = orc_full_reduce32(orc_mont_reduce(F_MONT * (int64_t)w[i]));
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* conversion.rs                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* conversion.rs:40-61 coeff_from_three_bytes (CTEST = false) */
+int orc_coeff_from_three_bytes(const uint8_t b[3], int32_t *out) {
+    int32_t b2p = (int32_t)(b[2] & 0x7F);
+    int32_t z = (b2p << 16) | ((int32_t)b[1] << 8) | (int32_t)b[0];
+    if (z < Q) { *out = z; return 1; }
+    return 0;
+}
+
+/* conversion.rs:80-111 coeff_from_half_byte (CTEST = false) */
+int orc_coeff_from_half_byte(int eta, uint8_t b8, int32_t *out) {
+    const int32_t M5 = ((1 << 24) / 5) + 1;
+    int32_t b = (int32_t)b8;
+    if (eta == 2 && b < 15) {
+        int32_t quot = (b * M5) >> 24;
+        int32_t rem = b - quot * 5;
+        *out = 2 - rem;
+        return 1;
+    }
+    if (eta == 4 && b < 9) { *out = 4 - b; return 1; }
+    return 0;
+}
+
+/* conversion.rs:143-182 bit_pack (simple_bit_pack delegates with a = 0, 120-133) */
+void orc_bit_pack(const int32_t w[N], int a, int b, uint8_t *out) {
+    int bitlen = bit_length(a + b);
+    uint32_t temp = 0;
+    int byte_index = 0, bit_index = 0;
+    for (int i = 0; i < N; i++) {
+        int32_t coeff = w[i];
+        if (a > 0) {
+            uint32_t diff = (b >= coeff) ? (uint32_t)(b - coeff) : (uint32_t)(coeff - b);
+            temp |= diff << bit_index;
+        } else {
+            uint32_t u = (coeff < 0) ? (uint32_t)(-coeff) : (uint32_t)coeff;
+            temp |= u << bit_index;
+        }
+        bit_index += bitlen;
+        while (bit_index > 7) {
+            out[byte_index++] = (uint8_t)temp;
+            temp >>= 8;
+            bit_index -= 8;
+        }
+    }
+}
+
+/* conversion.rs:227-262 bit_unpack (simple_bit_unpack delegates with a = 0, 198-213) */
+int orc_bit_unpack(const uint8_t *v, size_t vlen, int a, int b, int32_t w[N]) {
+    int bitlen = bit_length(a + b);
+    int32_t temp = 0;
+    int r_index = 0, bit_index = 0;
+    memset(w, 0, sizeof(int32_t) * N);
+    for (size_t i = 0; i < vlen; i++) {
+        temp |= (int32_t)v[i] << bit_index;
+        bit_index += 8;
+        while (bit_index >= bitlen) {
+            int32_t tmask = temp & ((1 << bitlen) - 1);
+            w[r_index] = (a == 0) ? tmask : b - tmask;
+            bit_index -= bitlen;
+            temp >>= bitlen;
+            r_index++;
+        }
+    }
+    int bot = abs(b - (1 << bitlen) + 1);
+    return is_in_range(w, bot, b);
+}
+
+/* conversion.rs:277-328 hint_bit_pack (CTEST = false) */
+void orc_hint_bit_pack(int k, int omega, const int32_t *h, uint8_t *y) {
+    memset(y, 0, (size_t)(omega + k));
+    int index = 0;
+    for (int i = 0; i < k; i++) {
+        for (int j = 0; j < 256; j++) {
+            if (h[i * N + j] != 0) {
+                y[index] = (uint8_t)j;
+                index++;
+            }
+        }
+        y[omega + i] = (uint8_t)index;
+    }
+}
+
+/* conversion.rs:340-414 hint_bit_unpack; returns 1 = Ok, 0 = Err */
+int orc_hint_bit_unpack(int k, int omega, const uint8_t *y, int32_t *h) {
+    memset(h, 0, sizeof(int32_t) * (size_t)k * N);
+    uint8_t index = 0;
+    for (int i = 0; i < k; i++) {
+        if (y[omega + i] < index || y[omega + i] > (uint8_t)omega) return 0;
+        uint8_t first = index;
+        while (index < y[omega + i]) {
+            if (index > first) {
+                if (y[index - 1] >= y[index]) return 0;
+            }
+            h[i * N + y[index]] = 1;
+            index++;
+        }
+    }
+    for (int i = index; i < (uint8_t)omega; i++)
+        if (y[i] != 0) return 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* hashing.rs                                                                */
+/* ------------------------------------------------------------------------- */
+
+/* hashing.rs:43-100 sample_in_ball (CTEST = false) */
+void orc_sample_in_ball(int tau, const uint8_t *rho, size_t rho_len, int32_t c[N]) {
+    xof_t x;
+    uint8_t h[8];
+    memset(c, 0, sizeof(int32_t) * N);
+    xof_init(&x, 256);
+    xof_absorb(&x, rho, rho_len);
+    xof_read(&x, h, 8);
+    for (int i = 256 - tau; i <= 255; i++) {
+        uint8_t j;
+        xof_read(&x, &j, 1);
+        while ((int)j > i) xof_read(&x, &j, 1);
+        c[i] = c[j];
+        int index = i + tau - 256;
+        uint8_t bite = h[index / 8];
+        uint8_t shifted = (uint8_t)(bite >> (index & 7));
+        c[j] = 1 - 2 * (int32_t)(shifted & 1);
+    }
+}
+
+/* hashing.rs:111-146 rej_ntt_poly */
+void orc_rej_ntt_poly(const uint8_t seed34[34], int32_t a_hat[N]) {
+    xof_t x;
+    xof_init(&x, 128);
+    xof_absorb(&x, seed34, 34);
+    int j = 0;
+    while (j < 256) {
+        uint8_t h5[3];
+        int32_t v;
+        xof_read(&x, h5, 3);
+        if (orc_coeff_from_three_bytes(h5, &v)) a_hat[j++] = v;
+    }
+}
+
+/* hashing.rs:158-213 rej_bounded_poly; returns number of XOF bytes consumed */
+int orc_rej_bounded_poly(int eta, const uint8_t seed66[66], int32_t a[N]) {
+    xof_t x;
+    xof_init(&x, 256);
+    xof_absorb(&x, seed66, 66);
+    int j = 0, used = 0;
+    while (j < 256) {
+        uint8_t z;
+        int32_t z0, z1;
+        xof_read(&x, &z, 1);
+        used++;
+        int ok0 = orc_coeff_from_half_byte(eta, z & 0x0f, &z0);
+        int ok1 = orc_coeff_from_half_byte(eta, z >> 4, &z1);
+        if (ok0) a[j++] = z0;
+        if (ok1 && j < 256) a[j++] = z1;
+    }
+    return used;
+}
+
+/* hashing.rs:225-239 expand_a: A[r][s] = RejNTTPoly(rho || s || r) */
+void orc_expand_a(int k, int l, const uint8_t rho[32], int32_t *a_hat) {
+    uint8_t seed[34];
+    memcpy(seed, rho, 32);
+    for (int r = 0; r < k; r++)
+        for (int s = 0; s < l; s++) {
+            seed[32] = (uint8_t)s;
+            seed[33] = (uint8_t)r;
+            orc_rej_ntt_poly(seed, a_hat + (r * l + s) * N);
+        }
+}
+
+/* hashing.rs:252-272 expand_s */
+void orc_expand_s(int k, int l, int eta, const uint8_t rho[64], int32_t *s1, int32_t *s2) {
+    uint8_t seed[66];
+    memcpy(seed, rho, 64);
+    seed[65] = 0;
+    for (int r = 0; r < l; r++) {
+        seed[64] = (uint8_t)r;
+        orc_rej_bounded_poly(eta, seed, s1 + r * N);
+    }
+    for (int r = 0; r < k; r++) {
+        seed[64] = (uint8_t)(r + l);
+        orc_rej_bounded_poly(eta, seed, s2 + r * N);
+    }
+}
+
+/* hashing.rs:281-313 expand_mask */
+void orc_expand_mask(int l, int gamma1, const uint8_t rho[64], uint16_t mu, int32_t *y) {
+    uint8_t v[32 * 20];
+    int c = 1 + bit_length(gamma1 - 1);
+    for (int r = 0; r < l; r++) {
+        uint16_t n = (uint16_t)(mu + r);
+        uint8_t seed[66];
+        xof_t x;
+        memcpy(seed, rho, 64);
+        seed[64] = (uint8_t)(n & 0xff);
+        seed[65] = (uint8_t)(n >> 8);
+        xof_init(&x, 256);
+        xof_absorb(&x, seed, 66);
+        xof_read(&x, v, sizeof(v));
+        orc_bit_unpack(v, (size_t)(32 * c), gamma1 - 1, gamma1, y + r * N);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* high_low.rs                                                               */
+/* ------------------------------------------------------------------------- */
+
+/* high_low.rs:15-48 power2round */
+void orc_power2round(const int32_t *r, int32_t *r1, int32_t *r0, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        r1[i] = (r[i] + (1 << (D - 1)) - 1) >> D;
+        r0[i] = r[i] - (r1[i] << D);
+    }
+}
+
+/* high_low.rs:66-96 decompose */
+void orc_decompose(int gamma2, int32_t r, int32_t *r1, int32_t *r0) {
+    int32_t rp = orc_full_reduce32(r);
+    int32_t xr1;
+    if ((gamma2 & (1 << 17)) == 0) {
+        xr1 = (rp + 127) >> 7;
+        xr1 = (xr1 * 11275 + (1 << 23)) >> 24;
+        xr1 ^= ((43 - xr1) >> 31) & xr1;
+    } else {
+        xr1 = (rp + 127) >> 7;
+        xr1 = (xr1 * 1025 + (1 << 21)) >> 22;
+        xr1 &= 15;
+    }
+    int32_t xr0 = rp - xr1 * 2 * gamma2;
+    xr0 = xr0 - ((((Q - 1) / 2 - xr0) >> 31) & Q);
+    *r1 = xr1;
+    *r0 = xr0;
+}
+
+/* high_low.rs:104-111 */
+int32_t orc_high_bits(int gamma2, int32_t r) {
+    int32_t r1, r0;
+    orc_decompose(gamma2, r, &r1, &r0);
+    return r1;
+}
+
+/* high_low.rs:119-126 */
+int32_t orc_low_bits(int gamma2, int32_t r) {
+    int32_t r1, r0;
+    orc_decompose(gamma2, r, &r1, &r0);
+    return r0;
+}
+
+/* high_low.rs:134-144 */
+int orc_make_hint(int gamma2, int32_t z, int32_t r) {
+    return orc_high_bits(gamma2, r) != orc_high_bits(gamma2, r + z);
+}
+
+/* high_low.rs:155-192 */
+int32_t orc_use_hint(int gamma2, int32_t h, int32_t r) {
+    int32_t r1, r0;
+    orc_decompose(gamma2, r, &r1, &r0);
+    if (h == 0) return r1;
+    if ((gamma2 & (1 << 17)) == 0) {
+        if (r0 > 0) return (r1 == 43) ? 0 : r1 + 1;
+        return (r1 == 0) ? 43 : r1 - 1;
+    }
+    if (r0 > 0) return (r1 + 1) & 15;
+    return (r1 - 1) & 15;
+}
+
+/* ------------------------------------------------------------------------- */
+/* encodings.rs                                                              */
+/* ------------------------------------------------------------------------- */
+#define BLQD 10 /* bit_length(Q-1) - D, encodings.rs:21 */
+
+/* encodings.rs:18-40 pk_encode */
+void orc_pk_encode(int set, const uint8_t rho[32], const int32_t *t1, uint8_t *pk) {
+    const orc_params *p = orc_get_params(set);
+    memcpy(pk, rho, 32);
+    for (int i = 0; i < p->k; i++) orc_bit_pack(t1 + i * N, 0, (1 << BLQD) - 1, pk + 32 + 32 * BLQD * i);
+}
+
+/* encodings.rs:55-80 pk_decode */
+int orc_pk_decode(int set, const uint8_t *pk, uint8_t rho[32], int32_t *t1) {
+    const orc_params *p = orc_get_params(set);
+    memcpy(rho, pk, 32);
+    for (int i = 0; i < p->k; i++)
+        if (!orc_bit_unpack(pk + 32 + 32 * i * BLQD, 32 * BLQD, 0, (1 << BLQD) - 1, t1 + i * N)) return 0;
+    return 1;
+}
+
+/* encodings.rs:94-152 sk_encode */
+void orc_sk_encode(int set, const uint8_t rho[32], const uint8_t k[32], const uint8_t tr[64],
+                   const int32_t *s1, const int32_t *s2, const int32_t *t0, uint8_t *sk) {
+    const orc_params *p = orc_get_params(set);
+    const int top = 1 << (D - 1);
+    memcpy(sk, rho, 32);
+    memcpy(sk + 32, k, 32);
+    memcpy(sk + 64, tr, 64);
+    size_t start = 128, step = (size_t)(32 * bit_length(2 * p->eta));
+    for (int i = 0; i < p->l; i++) orc_bit_pack(s1 + i * N, p->eta, p->eta, sk + start + i * step);
+    start += (size_t)p->l * step;
+    for (int i = 0; i < p->k; i++) orc_bit_pack(s2 + i * N, p->eta, p->eta, sk + start + i * step);
+    start += (size_t)p->k * step;
+    step = 32 * D;
+    for (int i = 0; i < p->k; i++) orc_bit_pack(t0 + i * N, top - 1, top, sk + start + i * step);
+}
+
+/* encodings.rs:168-224 sk_decode */
+int orc_sk_decode(int set, const uint8_t *sk, uint8_t rho[32], uint8_t k[32], uint8_t tr[64],
+                  int32_t *s1, int32_t *s2, int32_t *t0) {
+    const orc_params *p = orc_get_params(set);
+    const int top = 1 << (D - 1);
+    memcpy(rho, sk, 32);
+    memcpy(k, sk + 32, 32);
+    memcpy(tr, sk + 64, 64);
+    size_t start = 128, step = (size_t)(32 * bit_length(2 * p->eta));
+    for (int i = 0; i < p->l; i++)
+        if (!orc_bit_unpack(sk + start + i * step, step, p->eta, p->eta, s1 + i * N)) return 0;
+    start += (size_t)p->l * step;
+    for (int i = 0; i < p->k; i++)
+        if (!orc_bit_unpack(sk + start + i * step, step, p->eta, p->eta, s2 + i * N)) return 0;
+    start += (size_t)p->k * step;
+    step = 32 * D;
+    for (int i = 0; i < p->k; i++)
+        if (!orc_bit_unpack(sk + start + i * step, step, top - 1, top, t0 + i * N)) return 0;
+    return 1;
+}
+
+/* encodings.rs:238-276 sig_encode */
+void orc_sig_encode(int set, const uint8_t *c_tilde, const int32_t *z, const int32_t *h, uint8_t *sig) {
+    const orc_params *p = orc_get_params(set);
+    memcpy(sig, c_tilde, (size_t)p->ctilde_len);
+    size_t start = (size_t)p->ctilde_len, step = (size_t)(32 * (1 + bit_length(p->gamma1 - 1)));
+    for (int i = 0; i < p->l; i++) orc_bit_pack(z + i * N, p->gamma1 - 1, p->gamma1, sig + start + i * step);
+    orc_hint_bit_pack(p->k, p->omega, h, sig + start + (size_t)p->l * step);
+}
+
+/* encodings.rs:292-328 sig_decode; returns 1 = Ok, 0 = Err */
+int orc_sig_decode(int set, const uint8_t *sig, uint8_t *c_tilde, int32_t *z, int32_t *h) {
+    const orc_params *p = orc_get_params(set);
+    memcpy(c_tilde, sig, (size_t)p->ctilde_len);
+    size_t start = (size_t)p->ctilde_len, step = (size_t)(32 * (bit_length(p->gamma1 - 1) + 1));
+    for (int i = 0; i < p->l; i++)
+        if (!orc_bit_unpack(sig + start + i * step, step, p->gamma1 - 1, p->gamma1, z + i * N)) return 0;
+    return orc_hint_bit_unpack(p->k, p->omega, sig + start + (size_t)p->l * step, h);
+}
+
+/* encodings.rs:338-360 w1_encode */
+void orc_w1_encode(int set, const int32_t *w1, uint8_t *out) {
+    const orc_params *p = orc_get_params(set);
+    int qm = (Q - 1) / (2 * p->gamma2) - 1;
+    size_t step = (size_t)(32 * bit_length(qm));
+    for (int i = 0; i < p->k; i++) orc_bit_pack(w1 + i * N, 0, qm, out + i * step);
+}
+
+/* ------------------------------------------------------------------------- */
+/* ml_dsa.rs / lib.rs                                                        */
+/* ------------------------------------------------------------------------- */
+
+/* ml_dsa.rs:108-113 / 492-495: t1 -> to_mont(mont_reduce(to_mont(ntt(t1)) << D)) */
+static void t1_to_d2_hat_mont(int k, const int32_t *t1, int32_t out[ORC_KMAX][N]) {
+    int32_t tmp[ORC_KMAX * N], tm[ORC_KMAX * N];
+    orc_ntt(t1, tmp, (size_t)k);
+    orc_to_mont(tmp, tm, (size_t)k);
+    for (int i = 0; i < k * N; i++) tmp[i] = orc_mont_reduce((int64_t)((uint64_t)(int64_t)tm[i] << D));
+    orc_to_mont(tmp, &out[0][0], (size_t)k);
+}
+
+static void ntt_to_mont(const int32_t *in, int32_t *out, size_t n_polys) {
+    int32_t tmp[ORC_KMAX * N];
+    orc_ntt(in, tmp, n_polys);
+    orc_to_mont(tmp, out, n_polys);
+}
+
+/* ml_dsa.rs:57-134 key_gen_internal */
+void orc_keygen_from_seed(int set, const uint8_t xi[32], orc_pubkey *pk, orc_privkey *sk) {
+    const orc_params *p = orc_get_params(set);
+    const int k = p->k, l = p->l;
+    uint8_t seed[34], hout[128];
+    memcpy(seed, xi, 32);
+    seed[32] = (uint8_t)k;
+    seed[33] = (uint8_t)l;
+    orc_shake(256, seed, 34, hout, 128); /* ml_dsa.rs:68-74 */
+    const uint8_t *rho = hout, *rho_prime = hout + 32, *cap_k = hout + 96;
+
+    int32_t s1[ORC_LMAX * N], s2[ORC_KMAX * N];
+    orc_expand_s(k, l, p->eta, rho_prime, s1, s2); /* :79 */
+
+    int32_t *a_hat = (int32_t *)malloc(sizeof(int32_t) * (size_t)k * (size_t)l * N);
+    int32_t s1_hat[ORC_LMAX * N], as1_hat[ORC_KMAX * N], t[ORC_KMAX * N], t1[ORC_KMAX * N], t0[ORC_KMAX * N];
+    orc_expand_a(k, l, rho, a_hat);            /* :85 */
+    orc_ntt(s1, s1_hat, (size_t)l);            /* :86 */
+    orc_mat_vec_mul(k, l, a_hat, s1_hat, as1_hat); /* :87 */
+    orc_inv_ntt(as1_hat, t, (size_t)k);        /* :88 */
+    for (int i = 0; i < k * N; i++) t[i] = orc_full_reduce32(t[i] + s2[i]); /* :88-91 */
+    orc_power2round(t, t1, t0, (size_t)k * N); /* :92 */
+    free(a_hat);
+
+    uint8_t pk_bytes[2592];
+    orc_pk_encode(set, rho, t1, pk_bytes);     /* :100 */
+    memset(pk, 0, sizeof(*pk));
+    memset(sk, 0, sizeof(*sk));
+    orc_shake(256, pk_bytes, (size_t)p->pk_len, pk->tr, 64); /* :99-101 */
+    memcpy(pk->rho, rho, 32);
+    t1_to_d2_hat_mont(k, t1, pk->t1_d2_hat_mont); /* :108-113 */
+
+    memcpy(sk->rho, rho, 32);
+    memcpy(sk->cap_k, cap_k, 32);
+    memcpy(sk->tr, pk->tr, 64);
+    ntt_to_mont(s1, &sk->s_1_hat_mont[0][0], (size_t)l); /* :121 */
+    ntt_to_mont(s2, &sk->s_2_hat_mont[0][0], (size_t)k); /* :124 */
+    ntt_to_mont(t0, &sk->t_0_hat_mont[0][0], (size_t)k); /* :127 */
+}
+
+/* ml_dsa.rs:477-498 expand_public */
+int orc_pk_try_from_bytes(int set, const uint8_t *pk_bytes, orc_pubkey *pk) {
+    const orc_params *p = orc_get_params(set);
+    int32_t t1[ORC_KMAX * N];
+    memset(pk, 0, sizeof(*pk));
+    if (!orc_pk_decode(set, pk_bytes, pk->rho, t1)) return 0;
+    orc_shake(256, pk_bytes, (size_t)p->pk_len, pk->tr, 64);
+    t1_to_d2_hat_mont(p->k, t1, pk->t1_d2_hat_mont);
+    return 1;
+}
+
+/* ml_dsa.rs:445-469 expand_private */
+int orc_sk_try_from_bytes(int set, const uint8_t *sk_bytes, orc_privkey *sk) {
+    const orc_params *p = orc_get_params(set);
+    int32_t s1[ORC_LMAX * N], s2[ORC_KMAX * N], t0[ORC_KMAX * N];
+    memset(sk, 0, sizeof(*sk));
+    if (!orc_sk_decode(set, sk_bytes, sk->rho, sk->cap_k, sk->tr, s1, s2, t0)) return 0;
+    ntt_to_mont(s1, &sk->s_1_hat_mont[0][0], (size_t)p->l);
+    ntt_to_mont(s2, &sk->s_2_hat_mont[0][0], (size_t)p->k);
+    ntt_to_mont(t0, &sk->t_0_hat_mont[0][0], (size_t)p->k);
+    return 1;
+}
+
+/* lib.rs:478-493 PublicKey::into_bytes */
+void orc_pk_into_bytes(int set, const orc_pubkey *pk, uint8_t *out) {
+    const orc_params *p = orc_get_params(set);
+    int32_t tmp[ORC_KMAX * N], t1[ORC_KMAX * N];
+    for (int i = 0; i < p->k * N; i++) tmp[i] = orc_mont_reduce((int64_t)(&pk->t1_d2_hat_mont[0][0])[i]);
+    orc_inv_ntt(tmp, t1, (size_t)p->k);
+    for (int i = 0; i < p->k * N; i++) t1[i] >>= D;
+    orc_pk_encode(set, pk->rho, t1, out);
+}
+
+/* lib.rs:427-464: mont->norm, inverse NTT, centre around 0 */
+static void unmont_intt_center(const int32_t *in, int32_t *out, size_t n_polys) {
+    int32_t tmp[ORC_KMAX * N];
+    for (size_t i = 0; i < n_polys * N; i++) tmp[i] = orc_mont_reduce((int64_t)in[i]);
+    orc_inv_ntt(tmp, out, n_polys);
+    for (size_t i = 0; i < n_polys * N; i++)
+        if (out[i] > Q / 2) out[i] -= Q;
+}
+
+/* lib.rs:427-464 PrivateKey::into_bytes */
+void orc_sk_into_bytes(int set, const orc_privkey *sk, uint8_t *out) {
+    const orc_params *p = orc_get_params(set);
+    int32_t s1[ORC_LMAX * N], s2[ORC_KMAX * N], t0[ORC_KMAX * N];
+    unmont_intt_center(&sk->s_1_hat_mont[0][0], s1, (size_t)p->l);
+    unmont_intt_center(&sk->s_2_hat_mont[0][0], s2, (size_t)p->k);
+    unmont_intt_center(&sk->t_0_hat_mont[0][0], t0, (size_t)p->k);
+    orc_sk_encode(set, sk->rho, sk->cap_k, sk->tr, s1, s2, t0, out);
+}
+
+/* ml_dsa.rs:502-563 private_to_public_key */
+void orc_get_public_key(int set, const orc_privkey *sk, orc_pubkey *pk) {
+    const orc_params *p = orc_get_params(set);
+    const int k = p->k, l = p->l;
+    int32_t *a_hat = (int32_t *)malloc(sizeof(int32_t) * (size_t)k * (size_t)l * N);
+    int32_t s1_hat[ORC_LMAX * N], s2[ORC_KMAX * N], as1_hat[ORC_KMAX * N], t[ORC_KMAX * N];
+    int32_t t1[ORC_KMAX * N], t0[ORC_KMAX * N];
+    orc_expand_a(k, l, sk->rho, a_hat);
+    for (int i = 0; i < l * N; i++) s1_hat[i] = orc_mont_reduce((int64_t)(&sk->s_1_hat_mont[0][0])[i]);
+    unmont_intt_center(&sk->s_2_hat_mont[0][0], s2, (size_t)k);
+    orc_mat_vec_mul(k, l, a_hat, s1_hat, as1_hat);
+    orc_inv_ntt(as1_hat, t, (size_t)k);
+    for (int i = 0; i < k * N; i++) t[i] = orc_full_reduce32(t[i] + s2[i]);
+    orc_power2round(t, t1, t0, (size_t)k * N);
+    free(a_hat);
+    memset(pk, 0, sizeof(*pk));
+    memcpy(pk->rho, sk->rho, 32);
+    memcpy(pk->tr, sk->tr, 64);
+    t1_to_d2_hat_mont(k, t1, pk->t1_d2_hat_mont);
+}
+
+/* mu = H(tr || M'), ml_dsa.rs:185-196 / 386-397 */
+static void compute_mu(const uint8_t tr[64], const uint8_t *msg, size_t mlen, const uint8_t *ctx,
+                       size_t ctxlen, int mode, uint8_t mu[64]) {
+    xof_t x;
+    xof_init(&x, 256);
+    xof_absorb(&x, tr, 64);
+    if (mode != 1) {
+        uint8_t pre[2] = {(uint8_t)(mode == 2 ? 1 : 0), (uint8_t)ctxlen};
+        xof_absorb(&x, pre, 2);
+        xof_absorb(&x, ctx, ctxlen);
+    }
+    xof_absorb(&x, msg, mlen);
+    xof_read(&x, mu, 64);
+}
+
+/* ml_dsa.rs:153-337 sign_internal. Returns 0 on success, <0 on argument error
+ * (lib.rs:274: ctx longer than 255 bytes). */
+int orc_sign_internal(int set, const orc_privkey *esk, const uint8_t *msg, size_t mlen,
+                      const uint8_t *ctx, size_t ctxlen, const uint8_t rnd[32], int mode,
+                      uint8_t *sig, int *iterations) {
+    const orc_params *p = orc_get_params(set);
+    if (!p) return -1;
+    if (ctxlen > 255) return -2;
+    const int k = p->k, l = p->l, gamma1 = p->gamma1, gamma2 = p->gamma2;
+    int32_t *a_hat = (int32_t *)malloc(sizeof(int32_t) * (size_t)k * (size_t)l * N);
+    orc_expand_a(k, l, esk->rho, a_hat); /* :181 */
+
+    uint8_t mu[64], rho_prime[64], buf[128];
+    compute_mu(esk->tr, msg, mlen, ctx, ctxlen, mode, mu); /* :185-196 */
+    memcpy(buf, esk->cap_k, 32);
+    memcpy(buf + 32, rnd, 32);
+    memcpy(buf + 64, mu, 64);
+    orc_shake(256, buf, 128, rho_prime, 64); /* :199-201 */
+
+    uint16_t kappa = 0; /* :204 */
+    int32_t y[ORC_LMAX * N], y_hat[ORC_LMAX * N], ay_hat[ORC_KMAX * N], w[ORC_KMAX * N], w1[ORC_KMAX * N];
+    int32_t c[N], c_hat[N], tmpL[ORC_LMAX * N], tmpK[ORC_KMAX * N];
+    int32_t cs1[ORC_LMAX * N], cs2[ORC_KMAX * N], ct0[ORC_KMAX * N], z[ORC_LMAX * N], r0[ORC_KMAX * N], h[ORC_KMAX * N];
+    uint8_t c_tilde[64], w1_tilde[64 + 1024];
+    int iters = 0;
+
+    for (;;) {
+        iters++;
+        orc_expand_mask(l, gamma1, rho_prime, kappa, y); /* :215 */
+        orc_ntt(y, y_hat, (size_t)l);                    /* :219 */
+        orc_mat_vec_mul(k, l, a_hat, y_hat, ay_hat);     /* :220 */
+        orc_inv_ntt(ay_hat, w, (size_t)k);               /* :221 */
+        for (int i = 0; i < k * N; i++) w1[i] = orc_high_bits(gamma2, w[i]); /* :225-226 */
+
+        memcpy(w1_tilde, mu, 64);
+        orc_w1_encode(set, w1, w1_tilde + 64);           /* :231-232 */
+        orc_shake(256, w1_tilde, (size_t)(64 + p->w1_len), c_tilde, (size_t)p->ctilde_len); /* :233-234 */
+
+        orc_sample_in_ball(p->tau, c_tilde, (size_t)p->ctilde_len, c); /* :237 */
+        orc_ntt(c, c_hat, 1);                                         /* :240 */
+
+        orc_pointwise_mont(c_hat, &esk->s_1_hat_mont[0][0], tmpL, (size_t)l); /* :243-250 */
+        orc_inv_ntt(tmpL, cs1, (size_t)l);
+        orc_pointwise_mont(c_hat, &esk->s_2_hat_mont[0][0], tmpK, (size_t)k); /* :253-260 */
+        orc_inv_ntt(tmpK, cs2, (size_t)k);
+
+        for (int i = 0; i < l * N; i++) z[i] = orc_partial_reduce32(y[i] + cs1[i]); /* :263-265 */
+        for (int i = 0; i < k * N; i++)
+            r0[i] = orc_low_bits(gamma2, orc_partial_reduce32(w[i] - cs2[i])); /* :268-272 */
+
+        int32_t z_norm = orc_infinity_norm(z, (size_t)l);   /* :277 */
+        int32_t r0_norm = orc_infinity_norm(r0, (size_t)k); /* :278 */
+        if (z_norm >= gamma1 - p->beta || r0_norm >= gamma2 - p->beta) { /* :280 */
+            kappa = (uint16_t)(kappa + l);
+            continue;
+        }
+
+        orc_pointwise_mont(c_hat, &esk->t_0_hat_mont[0][0], tmpK, (size_t)k); /* :288-295 */
+        orc_inv_ntt(tmpK, ct0, (size_t)k);
+
+        int32_t hsum = 0;
+        for (int i = 0; i < k * N; i++) { /* :298-306 */
+            h[i] = orc_make_hint(gamma2, Q - ct0[i], orc_partial_reduce32(w[i] - cs2[i] + ct0[i]));
+            hsum += h[i];
+        }
+        if (orc_infinity_norm(ct0, (size_t)k) >= gamma2 || hsum > p->omega) { /* :312-319 */
+            kappa = (uint16_t)(kappa + l);
+            continue;
+        }
+        break;
+    }
+    for (int i = 0; i < l * N; i++) z[i] = orc_center_mod(z[i]); /* :334-335 */
+    orc_sig_encode(set, c_tilde, z, h, sig);                     /* :336 */
+    free(a_hat);
+    if (iterations) *iterations = iters;
+    return 0;
+}
+
+/* ml_dsa.rs:406-417 less ExpandA: w' = inv_ntt(A*ntt(z) - ntt(c) o t1_d2_hat_mont) */
+void orc_verify_arith(int k, int l, const int32_t *a_hat, const int32_t *z, const int32_t *c,
+                      const int32_t *t1_d2_hat_mont, int32_t *w_out) {
+    int32_t z_hat[ORC_LMAX * N], az_hat[ORC_KMAX * N], c_hat[N], tmp[ORC_KMAX * N];
+    orc_ntt(z, z_hat, (size_t)l);
+    orc_mat_vec_mul(k, l, a_hat, z_hat, az_hat);
+    orc_ntt(c, c_hat, 1);
+    for (int i = 0; i < k; i++)
+        for (int n = 0; n < N; n++)
+            tmp[i * N + n] = az_hat[i * N + n] -
+                             orc_mont_reduce((int64_t)c_hat[n] * (int64_t)t1_d2_hat_mont[i * N + n]);
+    orc_inv_ntt(tmp, w_out, (size_t)k);
+}
+
+/* ml_dsa.rs:351-437 verify_internal. Returns 1 = true, 0 = false. */
+int orc_verify_internal(int set, const orc_pubkey *epk, const uint8_t *msg, size_t mlen,
+                        const uint8_t *ctx, size_t ctxlen, const uint8_t *sig, int mode) {
+    const orc_params *p = orc_get_params(set);
+    if (!p) return 0;
+    if (ctxlen > 255) return 0; /* lib.rs:368-370 */
+    const int k = p->k, l = p->l;
+    uint8_t c_tilde[64], c_tilde_p[64], mu[64], buf[64 + 1024];
+    int32_t z[ORC_LMAX * N], h[ORC_KMAX * N], c[N], wp[ORC_KMAX * N], wp1[ORC_KMAX * N];
+    if (!orc_sig_decode(set, sig, c_tilde, z, h)) return 0; /* :368-376 */
+    compute_mu(epk->tr, msg, mlen, ctx, ctxlen, mode, mu);  /* :386-397 */
+    orc_sample_in_ball(p->tau, c_tilde, (size_t)p->ctilde_len, c); /* :400 */
+
+    int32_t *a_hat = (int32_t *)malloc(sizeof(int32_t) * (size_t)k * (size_t)l * N);
+    orc_expand_a(k, l, epk->rho, a_hat); /* :406 */
+    orc_verify_arith(k, l, a_hat, z, c, &epk->t1_d2_hat_mont[0][0], wp); /* :407-416 */
+    free(a_hat);
+
+    for (int i = 0; i < k * N; i++) wp1[i] = orc_use_hint(p->gamma2, h[i], wp[i]); /* :420-422 */
+    memcpy(buf, mu, 64);
+    orc_w1_encode(set, wp1, buf + 64);                                             /* :427-428 */
+    orc_shake(256, buf, (size_t)(64 + p->w1_len), c_tilde_p, (size_t)p->ctilde_len); /* :429-431 */
+
+    int left = orc_infinity_norm(z, (size_t)l) < (p->gamma1 - p->beta); /* :434 */
+    int right = memcmp(c_tilde, c_tilde_p, (size_t)p->ctilde_len) == 0; /* :435 */
+    return left && right;
+}
+
+/* ------------------------------------------------------------------------- */
+/* batch legs for bench.py's cpu_baseline (single thread; bench.py may run    */
+/* several of these from separate host threads over disjoint slices)         */
+/* ------------------------------------------------------------------------- */
+void orc_verify_batch(int set, const orc_pubkey *pks, size_t n_keys, const uint8_t *msgs,
+                      size_t mlen, const uint8_t *sigs, size_t n_ops, int mode, uint8_t *ok) {
+    const orc_params *p = orc_get_params(set);
+    for (size_t i = 0; i < n_ops; i++)
+        ok[i] = (uint8_t)orc_verify_internal(set, &pks[i % n_keys], msgs + i * mlen, mlen, NULL, 0,
+                                             sigs + i * (size_t)p->sig_len, mode);
+}
+
+void orc_sign_batch(int set, const orc_privkey *sks, size_t n_keys, const uint8_t *msgs,
+                    size_t mlen, const uint8_t *rnds, size_t n_ops, int mode, uint8_t *sigs) {
+    const orc_params *p = orc_get_params(set);
+    for (size_t i = 0; i < n_ops; i++)
+        orc_sign_internal(set, &sks[i % n_keys], msgs + i * mlen, mlen, NULL, 0, rnds + i * 32, mode,
+                          sigs + i * (size_t)p->sig_len, NULL);
+}
+
+void orc_verify_arith_batch(int k, int l, const int32_t *a_hat, const int32_t *z, const int32_t *c,
+                            const int32_t *t1, int32_t *w_out, size_t n_ops) {
+    for (size_t i = 0; i < n_ops; i++)
+        orc_verify_arith(k, l, a_hat + i * (size_t)(k * l) * N, z + i * (size_t)l * N, c + i * N,
+                         t1 + i * (size_t)k * N, w_out + i * (size_t)k * N);
+}
