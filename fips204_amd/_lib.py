@@ -1,0 +1,98 @@
+"""ctypes loader for the C-ABI library (include/mldsa_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails the
+caller gets an exception.  Nothing here imports or calls oracle/.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmldsa_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mldsa_hip.h")
+
+OK = 0
+
+
+class MldsaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mldsa_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "set", "k", "l", "eta", "tau", "lambda_", "gamma1", "gamma2", "omega", "beta",
+        "ctilde_len", "pk_len", "sk_len", "sig_len", "w1_len")]
+
+
+_P, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
+
+# name -> argtypes (all return int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "mldsa_ctx_create": [_I, C.POINTER(_P)],
+    "mldsa_ctx_destroy": [_P],
+    "mldsa_last_error": [],
+    "mldsa_get_params": [_I, C.POINTER(Params)],
+    "mldsa_device_count": [],
+    "mldsa_malloc": [C.POINTER(_P), _SZ],
+    "mldsa_free": [_P],
+    "mldsa_memcpy_h2d": [_P, _P, _SZ, _P],
+    "mldsa_memcpy_d2h": [_P, _P, _SZ, _P],
+    "mldsa_memset": [_P, _I, _SZ, _P],
+    "mldsa_stream_sync": [_P],
+    "mldsa_ntt": [_P, _P, _P, _SZ, _P],
+    "mldsa_inv_ntt": [_P, _P, _P, _SZ, _P],
+    "mldsa_to_mont": [_P, _P, _P, _SZ, _P],
+    "mldsa_mat_vec_mul": [_P, _I, _P, _P, _P, _SZ, _P],
+    "mldsa_pointwise_mont": [_P, _P, _P, _P, _SZ, _SZ, _P],
+    "mldsa_add_vector_ntt": [_P, _P, _P, _P, _SZ, _P],
+    "mldsa_infinity_norm": [_P, _P, _SZ, _SZ, _P, _P],
+    "mldsa_verify_arith": [_P, _I, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_expand_a": [_P, _I, _P, _P, _SZ, _P],
+    "mldsa_expand_s": [_P, _I, _P, _P, _SZ, _P],
+    "mldsa_expand_mask": [_P, _I, _P, _P, _P, _SZ, _P],
+    "mldsa_sample_in_ball": [_P, _I, _P, _P, _SZ, _P],
+}
+_RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p}
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function name declared in include/mldsa_hip.h."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mldsa_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m fips204_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:  # share one HIP runtime with PyTorch when both live in this process
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        raise MldsaError(rc, load().mldsa_last_error().decode(errors="replace"))
+
+
+def get_params(pset):
+    p = Params()
+    check(load().mldsa_get_params(pset, C.byref(p)))
+    return p

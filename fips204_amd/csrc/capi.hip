@@ -1,0 +1,219 @@
+// extern "C" entry points of include/mldsa_hip.h: argument validation, context and
+// device-memory helpers.  Kernels live in kernels_*.hip, op-level sequencing in pipeline.hip.
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+
+#include "ctx.h"
+#include "tables.h"
+
+namespace mldsa {
+
+static thread_local char g_err[256] = "";
+
+int set_error(int code, const char *what, hipError_t e) {
+    if (e != hipSuccess)
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+// src/lib.rs:639-656 (44), 681-698 (65), 723-740 (87); derived consts lib.rs:129-131
+static const mldsa_params PARAMS[3] = {
+    {44, 4, 4, 2, 39, 128, 1 << 17, (Q - 1) / 88, 80, 78, 32, 1312, 2560, 2420, 768},
+    {65, 6, 5, 4, 49, 192, 1 << 19, (Q - 1) / 32, 55, 196, 48, 1952, 4032, 3309, 768},
+    {87, 8, 7, 2, 60, 256, 1 << 19, (Q - 1) / 32, 75, 120, 64, 2592, 4896, 4627, 1024},
+};
+
+const mldsa_params *params_of(int set) {
+    for (const auto &p : PARAMS)
+        if (p.set == set) return &p;
+    return nullptr;
+}
+
+}  // namespace mldsa
+
+using namespace mldsa;
+
+#define REQUIRE(cond, msg) \
+    do { if (!(cond)) return set_error(MLDSA_ERR_PARAM, msg); } while (0)
+
+extern "C" {
+
+const char *mldsa_last_error(void) { return g_err; }
+
+int mldsa_get_params(int set, mldsa_params *out) {
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p && out, "mldsa_get_params: unknown parameter set");
+    *out = *p;
+    return MLDSA_OK;
+}
+
+int mldsa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
+    REQUIRE(out, "mldsa_ctx_create: NULL out");
+    *out = nullptr;
+    MLDSA_HIP_CHECK(hipSetDevice(device_id));
+    mldsa_ctx *ctx = new (std::nothrow) mldsa_ctx();
+    if (!ctx) return set_error(MLDSA_ERR_NOMEM, "mldsa_ctx_create: host allocation failed");
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cu = prop.multiProcessorCount;
+    std::vector<HostTwiddle> f, i;
+    try {
+        f = gen_fwd_lane_twiddles();
+        i = gen_inv_lane_twiddles();
+    } catch (const std::exception &e) {
+        delete ctx;
+        return set_error(MLDSA_ERR_PARAM, e.what());
+    }
+    static_assert(sizeof(HostTwiddle) == sizeof(Twiddle), "twiddle layout");
+    hipError_t e = hipMalloc((void **)&ctx->d_fwd_tw, f.size() * sizeof(Twiddle));
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_inv_tw, i.size() * sizeof(Twiddle));
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_fwd_tw, f.data(), f.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_inv_tw, i.data(), i.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        mldsa_ctx_destroy(ctx);
+        return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload", e);
+    }
+    *out = ctx;
+    return MLDSA_OK;
+}
+
+void mldsa_ctx_destroy(mldsa_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->ws) {
+        (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // secrets (y, rho'', s1..) live here: types.rs:19
+        (void)hipFree(ctx->ws);
+    }
+    if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
+    if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
+    delete ctx;
+}
+
+int mldsa_malloc(void **dev_ptr, size_t bytes) {
+    REQUIRE(dev_ptr, "mldsa_malloc: NULL out");
+    *dev_ptr = nullptr;
+    if (bytes == 0) return MLDSA_OK;
+    hipError_t e = hipMalloc(dev_ptr, bytes);
+    if (e != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "mldsa_malloc", e);
+    return MLDSA_OK;
+}
+
+int mldsa_free(void *dev_ptr) {
+    if (dev_ptr) MLDSA_HIP_CHECK(hipFree(dev_ptr));
+    return MLDSA_OK;
+}
+
+int mldsa_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return MLDSA_OK;
+    REQUIRE(dst && src, "mldsa_memcpy_h2d: NULL pointer");
+    MLDSA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return MLDSA_OK;
+}
+
+int mldsa_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return MLDSA_OK;
+    REQUIRE(dst && src, "mldsa_memcpy_d2h: NULL pointer");
+    MLDSA_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MLDSA_OK;
+}
+
+int mldsa_memset(void *dst, int value, size_t bytes, void *stream) {
+    if (bytes == 0) return MLDSA_OK;
+    REQUIRE(dst, "mldsa_memset: NULL pointer");
+    MLDSA_HIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return MLDSA_OK;
+}
+
+int mldsa_stream_sync(void *stream) {
+    MLDSA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return MLDSA_OK;
+}
+
+// ------------------------------------------------------------------ seam-level primitives
+int mldsa_ntt(mldsa_ctx *ctx, const int32_t *w, int32_t *w_hat, size_t n_polys, void *stream) {
+    REQUIRE(ctx && (n_polys == 0 || (w && w_hat)), "mldsa_ntt: NULL pointer");
+    return launch_ntt(ctx, w, w_hat, n_polys, (hipStream_t)stream);
+}
+
+int mldsa_inv_ntt(mldsa_ctx *ctx, const int32_t *w_hat, int32_t *w, size_t n_polys, void *stream) {
+    REQUIRE(ctx && (n_polys == 0 || (w && w_hat)), "mldsa_inv_ntt: NULL pointer");
+    return launch_inv_ntt(ctx, w_hat, w, n_polys, (hipStream_t)stream);
+}
+
+int mldsa_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n_polys, void *stream) {
+    REQUIRE(ctx && (n_polys == 0 || (in && out)), "mldsa_to_mont: NULL pointer");
+    return launch_to_mont(ctx, in, out, n_polys, (hipStream_t)stream);
+}
+
+int mldsa_mat_vec_mul(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *u_hat,
+                      int32_t *w_hat, size_t n_ops, void *stream) {
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_mat_vec_mul: unknown parameter set");
+    REQUIRE(ctx && (n_ops == 0 || (a_hat && u_hat && w_hat)), "mldsa_mat_vec_mul: NULL pointer");
+    return launch_mat_vec_mul(ctx, p->k, p->l, a_hat, u_hat, w_hat, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_pointwise_mont(mldsa_ctx *ctx, const int32_t *c_hat, const int32_t *v_hat_mont,
+                         int32_t *out, size_t polys_per_op, size_t n_ops, void *stream) {
+    REQUIRE(ctx && (n_ops * polys_per_op == 0 || (c_hat && v_hat_mont && out)), "mldsa_pointwise_mont: NULL pointer");
+    return launch_pointwise_mont(ctx, c_hat, v_hat_mont, out, polys_per_op, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_add_vector_ntt(mldsa_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out,
+                         size_t n_polys, void *stream) {
+    REQUIRE(ctx && (n_polys == 0 || (a && b && out)), "mldsa_add_vector_ntt: NULL pointer");
+    return launch_add(ctx, a, b, out, n_polys, (hipStream_t)stream);
+}
+
+int mldsa_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t polys_per_op, size_t n_ops,
+                        int32_t *norms, void *stream) {
+    REQUIRE(ctx && polys_per_op > 0 && (n_ops == 0 || (polys && norms)), "mldsa_infinity_norm: bad argument");
+    return launch_infinity_norm(ctx, polys, polys_per_op, n_ops, norms, (hipStream_t)stream);
+}
+
+int mldsa_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *z,
+                       const int32_t *c, const int32_t *t1_d2_hat_mont, int32_t *w_out,
+                       size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_verify_arith: unknown parameter set");
+    REQUIRE(ctx && (n_ops == 0 || (a_hat && z && c && t1_d2_hat_mont && w_out)), "mldsa_verify_arith: NULL pointer");
+    return launch_verify_arith(ctx, set, a_hat, z, c, t1_d2_hat_mont, w_out, n_ops, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ samplers
+int mldsa_expand_a(mldsa_ctx *ctx, int set, const uint8_t *rho, int32_t *a_hat, size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_expand_a: unknown parameter set");
+    REQUIRE(ctx && (n_ops == 0 || (rho && a_hat)), "mldsa_expand_a: NULL pointer");
+    return launch_expand_a(ctx, set, rho, 32, nullptr, a_hat, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_expand_s(mldsa_ctx *ctx, int set, const uint8_t *rho_prime, int32_t *s1s2, size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_expand_s: unknown parameter set");
+    REQUIRE(ctx && (n_ops == 0 || (rho_prime && s1s2)), "mldsa_expand_s: NULL pointer");
+    return launch_expand_s(ctx, set, rho_prime, 64, s1s2, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_expand_mask(mldsa_ctx *ctx, int set, const uint8_t *rho_pp, const uint16_t *kappa, int32_t *y,
+                      size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_expand_mask: unknown parameter set");
+    REQUIRE(ctx && (n_ops == 0 || (rho_pp && kappa && y)), "mldsa_expand_mask: NULL pointer");
+    return launch_expand_mask(ctx, set, rho_pp, 64, kappa, nullptr, y, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_t *c, size_t n_ops, void *stream) {
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_sample_in_ball: unknown parameter set");
+    REQUIRE(ctx && (n_ops == 0 || (c_tilde && c)), "mldsa_sample_in_ball: NULL pointer");
+    return launch_sample_in_ball(ctx, set, c_tilde, (size_t)p->ctilde_len, c, n_ops, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// Internal context of the C ABI (include/mldsa_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/mldsa_hip.h"
+#include "ntt_wave.h"
+
+struct mldsa_ctx {
+    int device = 0;
+    int n_cu = 256;
+    mldsa::Twiddle *d_fwd_tw = nullptr;  // [FWD_TW][64]
+    mldsa::Twiddle *d_inv_tw = nullptr;  // [INV_TW][64]
+    // op-level pipeline workspace (grown on demand, pipeline.hip)
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+namespace mldsa {
+
+const mldsa_params *params_of(int set);
+int set_error(int code, const char *what, hipError_t e = hipSuccess);
+
+#define MLDSA_HIP_CHECK(expr)                                                        \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) return mldsa::set_error(MLDSA_ERR_DEVICE, #expr, _e);  \
+    } while (0)
+
+// persistent-style grid: enough workgroups to fill 256 CUs several times over, capped so
+// that waves loop over units and keep their twiddles in registers
+inline unsigned grid_for(const mldsa_ctx *ctx, size_t units, unsigned units_per_block, unsigned blocks_per_cu) {
+    size_t need = (units + units_per_block - 1) / units_per_block;
+    size_t cap = (size_t)ctx->n_cu * blocks_per_cu;
+    if (need < 1) need = 1;
+    return (unsigned)(need < cap ? need : cap);
+}
+
+// ---- launchers (kernels_poly.hip) ----
+int launch_ntt(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
+int launch_inv_ntt(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
+int launch_to_mont(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
+int launch_mat_vec_mul(mldsa_ctx *, int k, int l, const int32_t *, const int32_t *, int32_t *, size_t n_ops, hipStream_t);
+int launch_pointwise_mont(mldsa_ctx *, const int32_t *, const int32_t *, int32_t *, size_t ppo, size_t n_ops, hipStream_t);
+int launch_add(mldsa_ctx *, const int32_t *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
+int launch_infinity_norm(mldsa_ctx *, const int32_t *, size_t ppo, size_t n_ops, int32_t *, hipStream_t);
+int launch_verify_arith(mldsa_ctx *, int set, const int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t *, size_t n_ops, hipStream_t);
+
+
+// ---- launchers (kernels_sample.hip) ----
+int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride, const uint32_t *key_idx, int32_t *a_hat, size_t n_ops, hipStream_t);
+int launch_expand_s(mldsa_ctx *, int set, const uint8_t *rho_prime, size_t rho_stride, int32_t *s12, size_t n_ops, hipStream_t);
+int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t);
+int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t ct_stride, int32_t *c, size_t n_ops, hipStream_t);
+
+}  // namespace mldsa

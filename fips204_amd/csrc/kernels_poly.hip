@@ -1,0 +1,286 @@
+// Polynomial-arithmetic kernels for gfx950: batched NTT / inverse NTT, K x L pointwise
+// matrix-vector product, scalar-vector product, infinity norm, and the fused
+// verify-arithmetic unit.  All integer (no MFMA); every kernel is a streaming kernel whose
+// roofline is HBM (DESIGN.md "Kernels").
+//
+// Replaces src/ntt.rs (ntt, inv_ntt) and the poly helpers of src/helpers.rs (mat_vec_mul,
+// to_mont, add_vector_ntt, infinity_norm) of the reference.
+#include "ctx.h"
+
+namespace mldsa {
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+
+// ------------------------------------------------------------------ NTT (ntt.rs:14-76)
+__global__ __launch_bounds__(BLOCK) void k_ntt(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                               size_t n_polys, const Twiddle *__restrict__ tab) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
+    FwdTw tw;
+    load_fwd_tw(tw, tab, lane);
+    for (size_t p = wave; p < n_polys; p += n_waves) {
+        int32_t r[4];
+        load_strided(r, in + p * N, lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
+        ntt_fwd_wave(r, tw, lane);
+        store_packed(r, out + p * N, lane);
+    }
+}
+
+// -------------------------------------------------------- inverse NTT (ntt.rs:85-161)
+__global__ __launch_bounds__(BLOCK) void k_inv_ntt(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                   size_t n_polys, const Twiddle *__restrict__ tab) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
+    InvTw tw;
+    load_inv_tw(tw, tab, lane);
+    for (size_t p = wave; p < n_polys; p += n_waves) {
+        int32_t r[4];
+        load_packed(r, in + p * N, lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
+        ntt_inv_wave(r, tw, lane, F_MONT, F_MONT_QINV);
+        store_strided(r, out + p * N, lane);
+    }
+}
+
+// ------------------------------------------------------ element-wise helpers (16 B/lane)
+template <int OP>  // 0: to_mont (helpers.rs:131-135)   1: add (helpers.rs:125-127)
+__global__ __launch_bounds__(BLOCK) void k_elementwise(const int4 *__restrict__ a, const int4 *__restrict__ b,
+                                                       int4 *__restrict__ out, size_t n_vec) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (; i < n_vec; i += stride) {
+        int4 x = a[i];
+        if constexpr (OP == 0) {
+            out[i] = make_int4(to_mont(x.x), to_mont(x.y), to_mont(x.z), to_mont(x.w));
+        } else {
+            int4 y = b[i];
+            out[i] = make_int4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        }
+    }
+}
+
+// ------------------------------------------ mat_vec_mul (helpers.rs:100-114), one wave per row
+// w_hat[op][i] = sum_j a_hat[op][i][j] o u_hat[op][j];  u is converted with to_mont first,
+// exactly as the reference does, so each term is mont_reduce(a * u * 2^32) = a*u in (-q, q).
+template <int K, int L>
+__global__ __launch_bounds__(BLOCK) void k_mat_vec_mul(const int32_t *__restrict__ a_hat,
+                                                       const int32_t *__restrict__ u_hat,
+                                                       int32_t *__restrict__ w_hat, size_t n_ops) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
+    const size_t n_rows = n_ops * K;
+    for (size_t row = wave; row < n_rows; row += n_waves) {
+        const size_t op = row / K;
+        const int32_t *a = a_hat + row * (size_t)L * N;
+        const int32_t *u = u_hat + op * (size_t)L * N;
+        int32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            int32_t av[4], uv[4];
+            load_packed(av, a + j * N, lane);
+            load_packed(uv, u + j * N, lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] += mont_mul(av[k], to_mont(reduce32(uv[k])));
+        }
+        store_packed(acc, w_hat + row * N, lane);
+    }
+}
+
+// ------------------------- c_hat o v_hat_mont (ml_dsa.rs:243-250 / 253-260 / 288-295)
+__global__ __launch_bounds__(BLOCK) void k_pointwise_mont(const int32_t *__restrict__ c_hat,
+                                                          const int32_t *__restrict__ v,
+                                                          int32_t *__restrict__ out, size_t ppo, size_t n_ops) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
+    const size_t n_polys = n_ops * ppo;
+    for (size_t p = wave; p < n_polys; p += n_waves) {
+        int32_t cv[4], vv[4], r[4];
+        load_packed(cv, c_hat + (p / ppo) * N, lane);
+        load_packed(vv, v + p * N, lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = mont_mul(reduce32(cv[k]), vv[k]);
+        store_packed(r, out + p * N, lane);
+    }
+}
+
+// ------------------------------------------------ infinity_norm (helpers.rs:138-147)
+__global__ __launch_bounds__(BLOCK) void k_infinity_norm(const int32_t *__restrict__ polys, size_t ppo,
+                                                         size_t n_ops, int32_t *__restrict__ norms) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
+    for (size_t op = wave; op < n_ops; op += n_waves) {
+        int32_t mx = 0;
+        for (size_t p = 0; p < ppo; p++) {
+            int32_t v[4];
+            load_packed(v, polys + (op * ppo + p) * N, lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int32_t c = center(v[k]);
+                c = c < 0 ? -c : c;
+                mx = c > mx ? c : mx;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            int32_t o = __shfl_xor(mx, m);
+            mx = o > mx ? o : mx;
+        }
+        if (lane == 0) norms[op] = mx;
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Fused verify-arithmetic unit (ml_dsa.rs:407-416):
+//   w' = inv_ntt( A_hat * ntt(z)  -  ntt(c) o t1_d2_hat_mont )
+// One workgroup per operation, one wave per polynomial: W = max(L + 1, K) waves.
+//   phase 1: wave j < L transforms z[j], wave L transforms c; results go to LDS (1 KiB each)
+//   phase 2: wave i < K streams row i of A_hat from HBM (L coalesced 1-KiB reads, issued
+//            before phase 1 so their latency hides under the transforms), multiplies with
+//            z_hat from LDS, subtracts c_hat o t1[i], and runs the inverse NTT in place.
+// Domain bookkeeping: products mont_mul(a, z_hat) carry a factor 2^-32, so c_hat is stored
+// as c_hat * 2^-32 (then mont_mul(c_hat', t1 * 2^32) carries the same factor) and the
+// inverse NTT finishes with F_MONT2 = 256^-1 * 2^64.
+// HBM traffic per op = algorithmic bytes: (K*L + L + 1 + K) KiB in, K KiB out.
+template <int K, int L>
+__global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
+    const int32_t *__restrict__ a_hat, const int32_t *__restrict__ z, const int32_t *__restrict__ c,
+    const int32_t *__restrict__ t1, int32_t *__restrict__ w_out, size_t n_ops,
+    const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab) {
+    constexpr int W = K > L + 1 ? K : L + 1;
+    __shared__ int4 lds[(L + 1) * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    FwdTw ftw;
+    InvTw itw;
+    if (wave <= L) load_fwd_tw(ftw, fwd_tab, lane);
+    if (wave < K) load_inv_tw(itw, inv_tab, lane);
+
+    for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
+        // issue this wave's row of A_hat and its t1 row early
+        int4 av[L];
+        int4 tv = make_int4(0, 0, 0, 0);
+        if (wave < K) {
+            const int4 *ap = reinterpret_cast<const int4 *>(a_hat + ((op * K + wave) * (size_t)L) * N);
+#pragma unroll
+            for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
+            tv = reinterpret_cast<const int4 *>(t1 + (op * K + wave) * (size_t)N)[lane];
+        }
+        if (wave <= L) {
+            int32_t r[4];
+            const int32_t *src = (wave < L) ? z + (op * L + wave) * (size_t)N : c + op * (size_t)N;
+            load_strided(r, src, lane);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
+            ntt_fwd_wave(r, ftw, lane);
+            if (wave == L) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = mont_mul_c(r[k], 1, QINV);  // c_hat * 2^-32
+            }
+            lds[wave * 64 + lane] = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        __syncthreads();
+        if (wave < K) {
+            int32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                int4 zv = lds[j * 64 + lane];
+                acc[0] += mont_mul(av[j].x, zv.x);
+                acc[1] += mont_mul(av[j].y, zv.y);
+                acc[2] += mont_mul(av[j].z, zv.z);
+                acc[3] += mont_mul(av[j].w, zv.w);
+            }
+            int4 cv = lds[L * 64 + lane];
+            acc[0] -= mont_mul(cv.x, tv.x);
+            acc[1] -= mont_mul(cv.y, tv.y);
+            acc[2] -= mont_mul(cv.z, tv.z);
+            acc[3] -= mont_mul(cv.w, tv.w);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
+            ntt_inv_wave(acc, itw, lane, F_MONT2, F_MONT2_QINV);
+            store_strided(acc, w_out + (op * K + wave) * (size_t)N, lane);
+        }
+        __syncthreads();
+    }
+    (void)W;
+}
+
+// ------------------------------------------------------------------------- launchers
+int launch_ntt(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n, hipStream_t s) {
+    if (n == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_ntt, dim3(grid_for(ctx, n, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, in, out, n, ctx->d_fwd_tw);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_inv_ntt(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n, hipStream_t s) {
+    if (n == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_inv_ntt, dim3(grid_for(ctx, n, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, in, out, n, ctx->d_inv_tw);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n, hipStream_t s) {
+    if (n == 0) return MLDSA_OK;
+    size_t n_vec = n * (N / 4);
+    hipLaunchKernelGGL(k_elementwise<0>, dim3(grid_for(ctx, n_vec, BLOCK, 8)), dim3(BLOCK), 0, s,
+                       reinterpret_cast<const int4 *>(in), (const int4 *)nullptr, reinterpret_cast<int4 *>(out), n_vec);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_add(mldsa_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out, size_t n, hipStream_t s) {
+    if (n == 0) return MLDSA_OK;
+    size_t n_vec = n * (N / 4);
+    hipLaunchKernelGGL(k_elementwise<1>, dim3(grid_for(ctx, n_vec, BLOCK, 8)), dim3(BLOCK), 0, s,
+                       reinterpret_cast<const int4 *>(a), reinterpret_cast<const int4 *>(b), reinterpret_cast<int4 *>(out), n_vec);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_mat_vec_mul(mldsa_ctx *ctx, int k, int l, const int32_t *a, const int32_t *u, int32_t *w, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    dim3 grid(grid_for(ctx, n_ops * (size_t)k, WAVES_PER_BLOCK, 8)), block(BLOCK);
+    if (k == 4 && l == 4) hipLaunchKernelGGL((k_mat_vec_mul<4, 4>), grid, block, 0, s, a, u, w, n_ops);
+    else if (k == 6 && l == 5) hipLaunchKernelGGL((k_mat_vec_mul<6, 5>), grid, block, 0, s, a, u, w, n_ops);
+    else if (k == 8 && l == 7) hipLaunchKernelGGL((k_mat_vec_mul<8, 7>), grid, block, 0, s, a, u, w, n_ops);
+    else return set_error(MLDSA_ERR_PARAM, "mat_vec_mul: unsupported (K, L)");
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_pointwise_mont(mldsa_ctx *ctx, const int32_t *c, const int32_t *v, int32_t *out, size_t ppo, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0 || ppo == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_pointwise_mont, dim3(grid_for(ctx, n_ops * ppo, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, c, v, out, ppo, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t ppo, size_t n_ops, int32_t *norms, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_infinity_norm, dim3(grid_for(ctx, n_ops, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, polys, ppo, n_ops, norms);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t *z, const int32_t *c, const int32_t *t1,
+                        int32_t *w, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    dim3 grid(grid_for(ctx, n_ops, 1, 6));
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4>), grid, dim3(64 * 5), 0, s, a, z, c, t1, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5>), grid, dim3(64 * 6), 0, s, a, z, c, t1, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7>), grid, dim3(64 * 8), 0, s, a, z, c, t1, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+}  // namespace mldsa

@@ -1,0 +1,370 @@
+// SHAKE-driven samplers for gfx950: ExpandA / RejNTTPoly, ExpandS / RejBoundedPoly,
+// ExpandMask, SampleInBall.  Replaces src/hashing.rs:43-313 of the reference (and the leaf
+// functions coeff_from_three_bytes / coeff_from_half_byte / bit_unpack of conversion.rs).
+//
+// One XOF stream per lane (keccak.h), 64 streams per wavefront.  Every lane parses its own
+// squeezed block into a small lane-private LDS staging row; the wave then flushes the rows
+// cooperatively so that HBM only sees contiguous runs (one coalesced store instruction per
+// stream and flush) instead of 64 lanes scattering single dwords 1 KiB apart.
+#include <type_traits>
+
+#include "ctx.h"
+#include "keccak.h"
+
+namespace mldsa {
+
+constexpr int SWAVES = 4;         // waves per block for the sampler kernels
+constexpr int STAGE_STRIDE = 33;  // dwords per lane row (odd: conflict-free), capacity 32
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+// 32-bit word W (compile time) of the sponge state
+template <int W>
+__device__ __forceinline__ uint32_t state_word(const KeccakState& s) {
+    if constexpr (W & 1) return s.hi[W / 2]; else return s.lo[W / 2];
+}
+
+// 32 bits of the squeezed block starting at byte B (compile time)
+template <int B>
+__device__ __forceinline__ uint32_t block_bits(const KeccakState& s) {
+    constexpr int W = B / 4, SH = (B % 4) * 8;
+    if constexpr (SH == 0) return state_word<W>(s);
+    else if constexpr (W + 1 < 50) return __builtin_amdgcn_alignbit(state_word<W + 1>(s), state_word<W>(s), SH);
+    else return state_word<W>(s) >> SH;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Flush: lane row `r` holds take[r] dwords that continue stream r's polynomial at
+// coefficient n[r].  Two streams per iteration (half-wave each, <= 32 dwords per row).
+__device__ __forceinline__ void flush_rows(const uint32_t* stage, int32_t* __restrict__ out, size_t wave_base,
+                                           int take, int n, int lane) {
+    wave_lds_sync();
+    const int half = lane >> 5, l5 = lane & 31;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        const int row = 2 * i + half;
+        const int c_r = __shfl(take, row);
+        const int n_r = __shfl(n, row);
+        if (l5 < c_r) out[(wave_base + row) * N + n_r + l5] = (int32_t)stage[row * STAGE_STRIDE + l5];
+    }
+    wave_lds_sync();
+}
+
+// ------------------------------------------------------------------------------------
+// ExpandA (hashing.rs:225-239) = K*L x RejNTTPoly (hashing.rs:111-146):
+// stream (op, r, s): SHAKE128(rho || s || r); 3 bytes -> 23-bit candidate, keep if < q
+// (coeff_from_three_bytes, conversion.rs:40-61).  Output A_hat[op][r][s], canonical [0, q).
+template <int K, int L>
+__global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restrict__ rho, size_t rho_stride,
+                                                          const uint32_t* __restrict__ key_idx,
+                                                          int32_t* __restrict__ a_hat, size_t n_ops) {
+    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
+    uint32_t* my = stage + lane * STAGE_STRIDE;
+    const size_t g = (size_t)blockIdx.x * (64 * SWAVES) + threadIdx.x;
+    const size_t wave_base = g - lane;
+    const size_t n_streams = n_ops * (size_t)(K * L);
+    const bool valid = g < n_streams;
+    const size_t op = valid ? g / (K * L) : 0;
+    const int rs = valid ? (int)(g % (K * L)) : 0;
+    const int r = rs / L, sidx = rs % L;
+
+    KeccakState st;
+    keccak_zero(st);
+    {
+        const size_t key = key_idx ? key_idx[op] : op;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(rho + key * rho_stride);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+        st.lo[4] = (uint32_t)sidx | ((uint32_t)r << 8) | (0x1Fu << 16);  // hashing.rs:236: rho || s || r
+        st.hi[SHAKE128_RATE / 8 - 1] = 0x80000000u;
+    }
+    int n = valid ? 0 : N;
+    while (__any(n < N)) {
+        keccak_f1600(st);
+        static_for<0, 2>([&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            int cnt = 0;
+            static_for<0, 28>([&](auto cc) {  // 28 candidates per half block: bytes 84 H + 3 C
+                constexpr int C = decltype(cc)::value;
+                const uint32_t z = block_bits<84 * H + 3 * C>(st) & 0x7FFFFFu;
+                my[cnt] = z;
+                cnt += (z < (uint32_t)Q) ? 1 : 0;
+            });
+            const int take = min(cnt, N - n);
+            flush_rows(stage, a_hat, wave_base, take, n, lane);
+            n += take;
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// ExpandS (hashing.rs:252-272) = (L + K) x RejBoundedPoly (hashing.rs:158-213):
+// stream (op, r): SHAKE256(rho' || r || 0), r < L -> s1[r], r >= L -> s2[r - L]; each byte
+// gives two half-byte candidates (coeff_from_half_byte, conversion.rs:80-111).
+// Output polys [op][L + K] (s1 then s2) with coefficients in [-eta, eta].
+template <int ETA>
+__device__ __forceinline__ bool half_byte(uint32_t b, int32_t& out) {
+    if constexpr (ETA == 2) {
+        out = 2 - (int32_t)(b - ((b * 13108u) >> 16) * 5u);  // b mod 5 for b < 16 (conversion.rs:91-93)
+        return b < 15;
+    } else {
+        out = 4 - (int32_t)b;
+        return b < 9;
+    }
+}
+
+template <int ETA>
+__global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restrict__ rho_prime, size_t rho_stride,
+                                                          int32_t* __restrict__ s12, int polys_per_op, size_t n_ops) {
+    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
+    uint32_t* my = stage + lane * STAGE_STRIDE;
+    const size_t g = (size_t)blockIdx.x * (64 * SWAVES) + threadIdx.x;
+    const size_t wave_base = g - lane;
+    const size_t n_streams = n_ops * (size_t)polys_per_op;
+    const bool valid = g < n_streams;
+    const size_t op = valid ? g / polys_per_op : 0;
+    const uint32_t r = valid ? (uint32_t)(g % polys_per_op) : 0;
+
+    KeccakState st;
+    keccak_zero(st);
+    {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(rho_prime + op * rho_stride);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+        st.lo[8] = r | (0x1Fu << 16);  // hashing.rs:260/266: rho' || r || 0  (then pad)
+        st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
+    }
+    int n = valid ? 0 : N;
+    while (__any(n < N)) {
+        keccak_f1600(st);
+        // 136 bytes = 34 words; 4 words (32 half-bytes) per flush, last group has 2 words
+        static_for<0, 9>([&](auto gc) {
+            constexpr int G = decltype(gc)::value;
+            constexpr int NW = (G == 8) ? 2 : 4;
+            int cnt = 0;
+            static_for<0, NW>([&](auto wc) {
+                constexpr int W = 4 * G + decltype(wc)::value;
+                const uint32_t w = state_word<W>(st);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {  // low nibble of each byte first (hashing.rs:177-180)
+                    int32_t v;
+                    const bool ok = half_byte<ETA>((w >> (4 * k)) & 15u, v);
+                    my[cnt] = (uint32_t)v;
+                    cnt += ok ? 1 : 0;
+                }
+            });
+            const int take = min(cnt, N - n);
+            flush_rows(stage, s12, wave_base, take, n, lane);
+            n += take;
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// ExpandMask (hashing.rs:281-313): stream (op, r < L): v = SHAKE256(rho'' || (kappa + r) LE16),
+// y[r][i] = gamma1 - (c-bit field i of v), c = 1 + bitlen(gamma1 - 1) (bit_unpack,
+// conversion.rs:227-262).  No rejection: all lanes advance in lock step.
+template <int GB>  // gamma1 = 2^GB, GB = 17 or 19
+__global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __restrict__ rho_pp, size_t rho_stride,
+                                                             const uint16_t* __restrict__ kappa,
+                                                             const uint32_t* __restrict__ op_idx,
+                                                             int32_t* __restrict__ y, int l, size_t n_ops) {
+    constexpr int CB = GB + 1;
+    constexpr uint32_t MASK = (1u << CB) - 1u;
+    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
+    uint32_t* my = stage + lane * STAGE_STRIDE;
+    const size_t g = (size_t)blockIdx.x * (64 * SWAVES) + threadIdx.x;
+    const size_t wave_base = g - lane;
+    const size_t n_streams = n_ops * (size_t)l;
+    const bool valid = g < n_streams;
+    const size_t slot = valid ? g / l : 0;          // position in the (compacted) batch
+    const uint32_t r = valid ? (uint32_t)(g % l) : 0;
+    const size_t op = op_idx ? op_idx[slot] : slot; // which op's rho'' / kappa
+
+    KeccakState st;
+    keccak_zero(st);
+    {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(rho_pp + op * rho_stride);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+        const uint32_t nn = ((uint32_t)kappa[op] + r) & 0xFFFFu;  // hashing.rs:293 (u16 arithmetic)
+        st.lo[8] = nn | (0x1Fu << 16);
+        st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
+    }
+    // bit buffer; everything below is lane-uniform and resolves at compile time
+    uint64_t acc = 0;
+    int nbits = 0, n = 0;
+#pragma unroll
+    for (int blk = 0; blk < 5; blk++) {
+        keccak_f1600(st);
+        static_for<0, 2>([&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            int cnt = 0;
+            static_for<0, 17>([&](auto wc) {
+                constexpr int W = 17 * H + decltype(wc)::value;
+                if (n + cnt < N) {  // the reference squeezes 640 bytes but unpacks only 32*c (hashing.rs:297-301)
+                    acc |= (uint64_t)state_word<W>(st) << nbits;
+                    nbits += 32;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        if (nbits >= CB && n + cnt < N) {
+                            my[cnt] = (uint32_t)((1 << GB) - (int32_t)((uint32_t)acc & MASK));
+                            cnt++;
+                            acc >>= CB;
+                            nbits -= CB;
+                        }
+                    }
+                }
+            });
+            if (cnt > 0) {
+                // uniform counts: every row has cnt dwords continuing at coefficient n
+                wave_lds_sync();
+                const int half = lane >> 5, l5 = lane & 31;
+#pragma unroll 4
+                for (int i = 0; i < 32; i++) {
+                    const int row = 2 * i + half;
+                    if (l5 < cnt && wave_base + row < n_streams)
+                        y[(wave_base + row) * N + n + l5] = (int32_t)stage[row * STAGE_STRIDE + l5];
+                }
+                wave_lds_sync();
+            }
+            n += cnt;
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// SampleInBall (hashing.rs:43-100): one op per lane.  SHAKE256(c_tilde): first 8 bytes =
+// sign bits h; for i = 256 - tau .. 255: draw bytes j until j <= i; c[i] = c[j];
+// c[j] = 1 - 2 * bit(i + tau - 256) of h.  The Fisher-Yates array and the squeezed block
+// live in lane-private LDS rows (dynamic indexing); output c[op] as int32[256].
+constexpr int SIB_C_STRIDE = 65;    // dwords: 256 int8 + pad (odd: conflict-free)
+constexpr int SIB_BLK_STRIDE = 35;  // dwords: 136 bytes + pad
+
+template <int CT>  // c_tilde bytes: 32, 48 or 64
+__global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict__ c_tilde, size_t ct_stride,
+                                                       int tau, int32_t* __restrict__ c_out, size_t n_ops) {
+    __shared__ uint32_t c_lds[64 * SIB_C_STRIDE];
+    __shared__ uint32_t b_lds[64 * SIB_BLK_STRIDE];
+    const int lane = threadIdx.x;
+    const size_t op = (size_t)blockIdx.x * 64 + lane;
+    const size_t wave_base = (size_t)blockIdx.x * 64;
+    const bool valid = op < n_ops;
+    int8_t* c = reinterpret_cast<int8_t*>(c_lds + lane * SIB_C_STRIDE);
+    uint32_t* bw = b_lds + lane * SIB_BLK_STRIDE;
+    const uint8_t* bb = reinterpret_cast<const uint8_t*>(bw);
+
+    KeccakState st;
+    keccak_zero(st);
+    if (valid) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(c_tilde + op * ct_stride);
+#pragma unroll
+        for (int i = 0; i < CT / 8; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+    }
+    shake_pad<SHAKE256_RATE, CT>(st);
+#pragma unroll
+    for (int i = 0; i < 64; i++) c_lds[lane * SIB_C_STRIDE + i] = 0;
+
+    keccak_f1600(st);
+    const uint64_t h64 = ((uint64_t)st.hi[0] << 32) | st.lo[0];  // hashing.rs:55-56
+    static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
+    int pos = 8;
+    int i = valid ? 256 - tau : 256;
+    for (;;) {
+        while (i < 256 && pos < SHAKE256_RATE) {
+            const int j = bb[pos++];
+            if (j <= i) {  // hashing.rs:68-83
+                c[i] = c[j];
+                const int index = i + tau - 256;
+                const uint32_t bit = (uint32_t)((h64 >> index) & 1u);
+                c[j] = (int8_t)(1 - 2 * (int)bit);
+                i++;
+            }
+        }
+        if (!__any(i < 256)) break;
+        if (i < 256) {  // this lane used up its block (rare): squeeze the next one
+            keccak_f1600(st);
+            static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
+            pos = 0;
+        }
+    }
+    wave_lds_sync();
+    for (int row = 0; row < 64; row++) {
+        if (wave_base + row >= n_ops) break;
+        const uint32_t packed = c_lds[row * SIB_C_STRIDE + lane];
+        int4 v = make_int4((int8_t)(packed & 0xFF), (int8_t)((packed >> 8) & 0xFF), (int8_t)((packed >> 16) & 0xFF),
+                           (int8_t)(packed >> 24));
+        reinterpret_cast<int4*>(c_out + (wave_base + row) * N)[lane] = v;
+    }
+}
+
+// ------------------------------------------------------------------------- launchers
+static inline unsigned stream_blocks(size_t n_streams) { return (unsigned)((n_streams + 64 * SWAVES - 1) / (64 * SWAVES)); }
+
+int launch_expand_a(mldsa_ctx*, int set, const uint8_t* rho, size_t rho_stride, const uint32_t* key_idx, int32_t* a_hat,
+                    size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    const mldsa_params* p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "expand_a: unknown parameter set");
+    dim3 grid(stream_blocks(n_ops * (size_t)(p->k * p->l))), block(64 * SWAVES);
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_expand_a<4, 4>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_expand_a<6, 5>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);
+    else hipLaunchKernelGGL((k_expand_a<8, 7>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_stride, int32_t* s12, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    const mldsa_params* p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "expand_s: unknown parameter set");
+    const int ppo = p->k + p->l;
+    dim3 grid(stream_blocks(n_ops * (size_t)ppo)), block(64 * SWAVES);
+    if (p->eta == 2) hipLaunchKernelGGL((k_expand_s<2>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
+    else hipLaunchKernelGGL((k_expand_s<4>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_stride, const uint16_t* kappa,
+                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    const mldsa_params* p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
+    dim3 grid(stream_blocks(n_ops * (size_t)p->l)), block(64 * SWAVES);
+    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, op_idx, y, p->l, n_ops);
+    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, op_idx, y, p->l, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_sample_in_ball(mldsa_ctx*, int set, const uint8_t* c_tilde, size_t ct_stride, int32_t* c, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    const mldsa_params* p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "sample_in_ball: unknown parameter set");
+    dim3 grid((unsigned)((n_ops + 63) / 64)), block(64);
+    if (p->ctilde_len == 32) hipLaunchKernelGGL((k_sample_in_ball<32>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops);
+    else if (p->ctilde_len == 48) hipLaunchKernelGGL((k_sample_in_ball<48>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops);
+    else hipLaunchKernelGGL((k_sample_in_ball<64>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+}  // namespace mldsa

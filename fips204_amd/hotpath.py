@@ -1,0 +1,180 @@
+"""Host-side mirror of the reference's crate-private hot-path seams, batched, on the GPU.
+
+Same names, argument meaning and error behaviour as the reference functions they stand
+for (src/ntt.rs, src/helpers.rs, src/hashing.rs); every call goes through the C ABI of
+include/mldsa_hip.h.  PyTorch is used only as device-memory / stream plumbing: arguments
+and results are int32 / uint8 CUDA tensors whose data_ptr() is handed to the library.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+N = 256
+Q = 8380417
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bytes(t, name, row):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+        raise TypeError(f"{name}: expected a contiguous uint8 CUDA tensor")
+    if row and t.numel() % row:
+        raise ValueError(f"{name}: length is not a multiple of {row}")
+    return t
+
+
+def _polys(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise TypeError(f"{name}: expected a contiguous int32 CUDA tensor")
+    if t.numel() % N:
+        raise ValueError(f"{name}: number of coefficients is not a multiple of 256")
+    return t
+
+
+class HotPath:
+    """Owns one mldsa_ctx (device tables + workspaces) on `device`."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("fips204_amd needs a HIP device; there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        _lib.check(self.lib.mldsa_ctx_create(device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mldsa_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- src/ntt.rs ---------------------------------------------------------------
+    def ntt(self, w, out=None):
+        """ntt::<KL>(&[R; KL]) -> [T; KL]   (src/ntt.rs:14)"""
+        w = _polys(w, "w")
+        out = torch.empty_like(w) if out is None else out
+        _lib.check(self.lib.mldsa_ntt(self._h, _ptr(w), _ptr(out), w.numel() // N, _stream()))
+        return out
+
+    def inv_ntt(self, w_hat, out=None):
+        """inv_ntt::<KL>(&[T; KL]) -> [R; KL]   (src/ntt.rs:85)"""
+        w_hat = _polys(w_hat, "w_hat")
+        out = torch.empty_like(w_hat) if out is None else out
+        _lib.check(self.lib.mldsa_inv_ntt(self._h, _ptr(w_hat), _ptr(out), w_hat.numel() // N, _stream()))
+        return out
+
+    # ---- src/helpers.rs -----------------------------------------------------------
+    def to_mont(self, v):
+        """to_mont(&[T; L]) -> [T; L]   (src/helpers.rs:131)"""
+        v = _polys(v, "v")
+        out = torch.empty_like(v)
+        _lib.check(self.lib.mldsa_to_mont(self._h, _ptr(v), _ptr(out), v.numel() // N, _stream()))
+        return out
+
+    def mat_vec_mul(self, pset, a_hat, u_hat):
+        """mat_vec_mul::<K, L>(&[[T; L]; K], &[T; L]) -> [T; K], batched over ops (src/helpers.rs:100)"""
+        p = _lib.get_params(pset)
+        a_hat, u_hat = _polys(a_hat, "a_hat"), _polys(u_hat, "u_hat")
+        n_ops = u_hat.numel() // (p.l * N)
+        if u_hat.numel() != n_ops * p.l * N or a_hat.numel() != n_ops * p.k * p.l * N:
+            raise ValueError("mat_vec_mul: shape mismatch")
+        out = torch.empty((n_ops, p.k, N), dtype=torch.int32, device=a_hat.device)
+        _lib.check(self.lib.mldsa_mat_vec_mul(self._h, pset, _ptr(a_hat), _ptr(u_hat), _ptr(out), n_ops, _stream()))
+        return out
+
+    def pointwise_mont(self, c_hat, v_hat_mont):
+        """c_hat o v_hat_mont, inlined at src/ml_dsa.rs:243-260, 288-295"""
+        c_hat, v = _polys(c_hat, "c_hat"), _polys(v_hat_mont, "v_hat_mont")
+        n_ops = c_hat.numel() // N
+        if n_ops == 0 or v.numel() % (n_ops * N):
+            raise ValueError("pointwise_mont: shape mismatch")
+        ppo = v.numel() // (n_ops * N)
+        out = torch.empty_like(v)
+        _lib.check(self.lib.mldsa_pointwise_mont(self._h, _ptr(c_hat), _ptr(v), _ptr(out), ppo, n_ops, _stream()))
+        return out
+
+    def add_vector_ntt(self, a, b):
+        """add_vector_ntt (src/helpers.rs:125)"""
+        a, b = _polys(a, "a"), _polys(b, "b")
+        if a.numel() != b.numel():
+            raise ValueError("add_vector_ntt: shape mismatch")
+        out = torch.empty_like(a)
+        _lib.check(self.lib.mldsa_add_vector_ntt(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel() // N, _stream()))
+        return out
+
+    def infinity_norm(self, w, polys_per_op):
+        """infinity_norm::<ROW>(&[R; ROW]) -> i32 per op (src/helpers.rs:138)"""
+        w = _polys(w, "w")
+        n_ops = w.numel() // (polys_per_op * N)
+        out = torch.empty(n_ops, dtype=torch.int32, device=w.device)
+        _lib.check(self.lib.mldsa_infinity_norm(self._h, _ptr(w), polys_per_op, n_ops, _ptr(out), _stream()))
+        return out
+
+    def verify_arith(self, pset, a_hat, z, c, t1_d2_hat_mont, out=None):
+        """w' = inv_ntt(A_hat * ntt(z) - ntt(c) o t1_d2_hat_mont)   (src/ml_dsa.rs:407-416)"""
+        p = _lib.get_params(pset)
+        for t, nm in ((a_hat, "a_hat"), (z, "z"), (c, "c"), (t1_d2_hat_mont, "t1_d2_hat_mont")):
+            _polys(t, nm)
+        n_ops = c.numel() // N
+        if (a_hat.numel() != n_ops * p.k * p.l * N or z.numel() != n_ops * p.l * N
+                or t1_d2_hat_mont.numel() != n_ops * p.k * N):
+            raise ValueError("verify_arith: shape mismatch")
+        if out is None:
+            out = torch.empty((n_ops, p.k, N), dtype=torch.int32, device=c.device)
+        _lib.check(self.lib.mldsa_verify_arith(self._h, pset, _ptr(a_hat), _ptr(z), _ptr(c),
+                                               _ptr(t1_d2_hat_mont), _ptr(out), n_ops, _stream()))
+        return out
+
+    # ---- src/hashing.rs -----------------------------------------------------------
+    def expand_a(self, pset, rho):
+        """expand_a::<K, L>(&[u8; 32]) -> [[T; L]; K], one rho per op (src/hashing.rs:225)"""
+        p = _lib.get_params(pset)
+        rho = _bytes(rho, "rho", 32)
+        n_ops = rho.numel() // 32
+        out = torch.empty((n_ops, p.k, p.l, N), dtype=torch.int32, device=rho.device)
+        _lib.check(self.lib.mldsa_expand_a(self._h, pset, _ptr(rho), _ptr(out), n_ops, _stream()))
+        return out
+
+    def expand_s(self, pset, rho_prime):
+        """expand_s::<K, L>(eta, &[u8; 64]) -> ([R; L], [R; K]) per op (src/hashing.rs:252)"""
+        p = _lib.get_params(pset)
+        rho_prime = _bytes(rho_prime, "rho_prime", 64)
+        n_ops = rho_prime.numel() // 64
+        out = torch.empty((n_ops, p.l + p.k, N), dtype=torch.int32, device=rho_prime.device)
+        _lib.check(self.lib.mldsa_expand_s(self._h, pset, _ptr(rho_prime), _ptr(out), n_ops, _stream()))
+        return out[:, :p.l], out[:, p.l:]
+
+    def expand_mask(self, pset, rho_pp, kappa):
+        """expand_mask::<L>(gamma1, &[u8; 64], mu: u16) -> [R; L] per op (src/hashing.rs:281)"""
+        p = _lib.get_params(pset)
+        rho_pp = _bytes(rho_pp, "rho_pp", 64)
+        n_ops = rho_pp.numel() // 64
+        if not (kappa.is_cuda and kappa.dtype == torch.int16 and kappa.numel() == n_ops):
+            raise TypeError("kappa: expected an int16 CUDA tensor (u16 bit pattern) with one entry per op")
+        out = torch.empty((n_ops, p.l, N), dtype=torch.int32, device=rho_pp.device)
+        _lib.check(self.lib.mldsa_expand_mask(self._h, pset, _ptr(rho_pp), _ptr(kappa), _ptr(out), n_ops, _stream()))
+        return out
+
+    def sample_in_ball(self, pset, c_tilde):
+        """sample_in_ball(tau, &c_tilde) -> R per op (src/hashing.rs:43)"""
+        p = _lib.get_params(pset)
+        c_tilde = _bytes(c_tilde, "c_tilde", p.ctilde_len)
+        n_ops = c_tilde.numel() // p.ctilde_len
+        out = torch.empty((n_ops, N), dtype=torch.int32, device=c_tilde.device)
+        _lib.check(self.lib.mldsa_sample_in_ball(self._h, pset, _ptr(c_tilde), _ptr(out), n_ops, _stream()))
+        return out

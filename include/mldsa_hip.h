@@ -1,0 +1,140 @@
+/*
+ * mldsa_hip.h -- C ABI of the MI355X-native batched ML-DSA hot path.
+ *
+ * Drop-in boundary for the crate-private seams of integritychain/fips204 v0.4.6 (the
+ * reference has no FFI of its own).  Each entry point names the
+ * reference function it replaces (file:line relative to the crate root).  One call =
+ * `n` independent units (polynomials or sign/verify operations).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  All data pointers are DEVICE pointers (hipMalloc'd
+ *    by anyone: this library's mldsa_malloc, PyTorch, a Rust hip-sys binding ...) unless
+ *    the name ends in _host.  `stream` is a hipStream_t passed as void* (NULL = the
+ *    default stream); calls are asynchronous on it.
+ *  - Polynomials are the reference's `R` / `T` (src/types.rs:45-55): 256 contiguous
+ *    int32_t, arrays of polynomials contiguous and row-major ([[T; L]; K] = K*L*256).
+ *    Inputs may be any signed representative inside the contract the reference's
+ *    debug_asserts state (|x| < 2^31 - 2^22, helpers.rs:62); outputs documented per call.
+ *  - Key material is passed by FIELD pointer, never as a struct: the reference's
+ *    PublicKey / PrivateKey are not repr(C) (src/types.rs:19-41).
+ *  - Return value: 0 = MLDSA_OK, negative = error (never aborts).  A failed signature
+ *    verification is ok[i] = 0, not an error (src/lib.rs:368-370, ml_dsa.rs:368-376).
+ *  - Randomness is always supplied by the caller (src/traits.rs:228-232).
+ */
+#ifndef MLDSA_HIP_H
+#define MLDSA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLDSA_OK 0
+#define MLDSA_ERR_PARAM (-1)    /* unknown parameter set / NULL pointer / bad length   */
+#define MLDSA_ERR_CTX_LEN (-2)  /* ctx longer than 255 bytes (src/lib.rs:274)           */
+#define MLDSA_ERR_DEVICE (-3)   /* HIP runtime error; see mldsa_last_error()            */
+#define MLDSA_ERR_NOMEM (-4)    /* device workspace allocation failed                   */
+
+/* parameter sets: src/lib.rs:639-656, 681-698, 723-740 */
+#define MLDSA_44 44
+#define MLDSA_65 65
+#define MLDSA_87 87
+
+/* message-representative modes of sign_internal / verify_internal
+ * (src/ml_dsa.rs:185-194, 386-395) */
+#define MLDSA_MODE_PURE 0      /* mu = H(tr | 0x00 | len(ctx) | ctx | M)      ML-DSA.Sign/Verify   */
+#define MLDSA_MODE_INTERNAL 1  /* mu = H(tr | M)   (`nist = true`, the ACVP "internal" interface)   */
+#define MLDSA_MODE_PREHASH 2   /* mu = H(tr | 0x01 | len(ctx) | ctx | OID | PH(M)); msg = OID|PH(M) */
+
+typedef struct mldsa_ctx mldsa_ctx;
+
+typedef struct {
+    int set, k, l, eta, tau, lambda, gamma1, gamma2, omega, beta;
+    int ctilde_len, pk_len, sk_len, sig_len, w1_len;
+} mldsa_params;
+
+/* ---- context: device, twiddle tables, workspaces ------------------------------------ */
+int mldsa_ctx_create(int device_id, mldsa_ctx **out);
+void mldsa_ctx_destroy(mldsa_ctx *ctx);
+const char *mldsa_last_error(void);
+int mldsa_get_params(int set, mldsa_params *out);
+int mldsa_device_count(void);
+
+/* ---- device memory helpers for hosts without their own HIP binding ------------------ */
+int mldsa_malloc(void **dev_ptr, size_t bytes);
+int mldsa_free(void *dev_ptr);
+int mldsa_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int mldsa_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int mldsa_memset(void *dst_dev, int value, size_t bytes, void *stream);
+int mldsa_stream_sync(void *stream);
+
+/* ---- seam-level batched primitives (hot path) ------------------ */
+
+/* ntt::<KL>() src/ntt.rs:14-76 (FIPS 204 Alg 41).  w_hat may alias w.
+ * Output: plain domain, bit-reversed order as the reference, representative in (-9q, 9q). */
+int mldsa_ntt(mldsa_ctx *ctx, const int32_t *w, int32_t *w_hat, size_t n_polys, void *stream);
+
+/* inv_ntt::<KL>() src/ntt.rs:85-161 (Alg 42).  Output canonical [0, q) like the
+ * reference's full_reduce32 (ntt.rs:152-154).  w may alias w_hat. */
+int mldsa_inv_ntt(mldsa_ctx *ctx, const int32_t *w_hat, int32_t *w, size_t n_polys, void *stream);
+
+/* to_mont() src/helpers.rs:131-135: x * 2^32 mod q, output in (-q, q). */
+int mldsa_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n_polys, void *stream);
+
+/* mat_vec_mul::<K,L>() src/helpers.rs:100-114: w_hat[i] = sum_j a_hat[i][j] o u_hat[j]
+ * for n_ops independent (a_hat, u_hat) pairs.  a_hat: n_ops*K*L polys, u_hat: n_ops*L,
+ * w_hat: n_ops*K; output representative in (-L q, L q). */
+int mldsa_mat_vec_mul(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *u_hat,
+                      int32_t *w_hat, size_t n_ops, void *stream);
+
+/* scalar-vector product c_hat o v_hat_mont inlined at src/ml_dsa.rs:243-250, 253-260,
+ * 288-295 (FIPS 204 Alg 45/47): out[op][p] = mont_reduce(c_hat[op] * v_hat_mont[op][p]),
+ * output in (-q, q).  c_hat: n_ops polys, v_hat_mont/out: n_ops*polys_per_op polys. */
+int mldsa_pointwise_mont(mldsa_ctx *ctx, const int32_t *c_hat, const int32_t *v_hat_mont,
+                         int32_t *out, size_t polys_per_op, size_t n_ops, void *stream);
+
+/* add_vector_ntt() src/helpers.rs:125-127: element-wise a + b (no reduction). */
+int mldsa_add_vector_ntt(mldsa_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out,
+                         size_t n_polys, void *stream);
+
+/* infinity_norm::<ROW>() src/helpers.rs:138-147: norms[op] = max |center_mod(w)| over the
+ * op's polys_per_op polynomials. */
+int mldsa_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t polys_per_op, size_t n_ops,
+                        int32_t *norms, void *stream);
+
+/* The verify-arithmetic unit (BASELINE config 2), src/ml_dsa.rs:407-416 fused in one
+ * kernel: w'[op] = inv_ntt(a_hat[op] * ntt(z[op]) - ntt(c[op]) o t1_d2_hat_mont[op]).
+ * a_hat: n_ops*K*L, z: n_ops*L, c: n_ops, t1_d2_hat_mont: n_ops*K (Montgomery form as in
+ * PublicKey, src/types.rs:40), w_out: n_ops*K polys, canonical [0, q). */
+int mldsa_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *z,
+                       const int32_t *c, const int32_t *t1_d2_hat_mont, int32_t *w_out,
+                       size_t n_ops, void *stream);
+
+/* ---- SHAKE-driven samplers (hot path, src/hashing.rs) -------------------------------- */
+
+/* expand_a::<K,L>() src/hashing.rs:225-239 (Alg 32; rej_ntt_poly 111-146): one rho (32 B)
+ * per op -> a_hat[op][K][L][256], canonical [0, q), NTT domain. */
+int mldsa_expand_a(mldsa_ctx *ctx, int set, const uint8_t *rho, int32_t *a_hat, size_t n_ops,
+                   void *stream);
+
+/* expand_s::<K,L>() src/hashing.rs:252-272 (Alg 33; rej_bounded_poly 158-213): one rho'
+ * (64 B) per op -> s1s2[op][L + K][256] (s1 = first L polys, s2 = next K), in [-eta, eta]. */
+int mldsa_expand_s(mldsa_ctx *ctx, int set, const uint8_t *rho_prime, int32_t *s1s2,
+                   size_t n_ops, void *stream);
+
+/* expand_mask::<L>() src/hashing.rs:281-313 (Alg 34): rho'' (64 B) and counter kappa per op
+ * -> y[op][L][256] in [-gamma1 + 1, gamma1]. */
+int mldsa_expand_mask(mldsa_ctx *ctx, int set, const uint8_t *rho_pp, const uint16_t *kappa,
+                      int32_t *y, size_t n_ops, void *stream);
+
+/* sample_in_ball() src/hashing.rs:43-100 (Alg 29): c_tilde (lambda/4 bytes) per op ->
+ * c[op][256] with tau coefficients +-1. */
+int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_t *c,
+                         size_t n_ops, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLDSA_HIP_H */
