@@ -124,6 +124,22 @@ __device__ __forceinline__ void keccak_f1600(KeccakState& s) {
     }
 }
 
+// little-endian 32-bit load with no alignment requirement (signature / key byte strings
+// start at arbitrary byte offsets: SIG_LEN = 3309 and 4627 are odd)
+__device__ __forceinline__ uint32_t load_le32(const uint8_t* p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// absorb NW 8-byte words from (unaligned) memory into state words 0..NW-1 of a fresh state
+template <int NW>
+__device__ __forceinline__ void absorb_words(KeccakState& s, const uint8_t* p) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        s.lo[i] ^= load_le32(p + 8 * i);
+        s.hi[i] ^= load_le32(p + 8 * i + 4);
+    }
+}
+
 // ---- sponge helpers with compile-time word positions (no dynamic register indexing) ----
 
 // XOR an 8-byte little-endian word into lane `w` of the state

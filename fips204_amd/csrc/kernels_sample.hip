@@ -85,9 +85,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restr
     keccak_zero(st);
     {
         const size_t key = key_idx ? key_idx[op] : op;
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(rho + key * rho_stride);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+        absorb_words<4>(st, rho + key * rho_stride);
         st.lo[4] = (uint32_t)sidx | ((uint32_t)r << 8) | (0x1Fu << 16);  // hashing.rs:236: rho || s || r
         st.hi[SHAKE128_RATE / 8 - 1] = 0x80000000u;
     }
@@ -143,9 +141,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
     KeccakState st;
     keccak_zero(st);
     {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(rho_prime + op * rho_stride);
-#pragma unroll
-        for (int i = 0; i < 8; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+        absorb_words<8>(st, rho_prime + op * rho_stride);
         st.lo[8] = r | (0x1Fu << 16);  // hashing.rs:260/266: rho' || r || 0  (then pad)
         st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
     }
@@ -201,9 +197,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
     KeccakState st;
     keccak_zero(st);
     {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(rho_pp + op * rho_stride);
-#pragma unroll
-        for (int i = 0; i < 8; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+        absorb_words<8>(st, rho_pp + op * rho_stride);
         const uint32_t nn = ((uint32_t)kappa[op] + r) & 0xFFFFu;  // hashing.rs:293 (u16 arithmetic)
         st.lo[8] = nn | (0x1Fu << 16);
         st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
@@ -274,9 +268,7 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
     KeccakState st;
     keccak_zero(st);
     if (valid) {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(c_tilde + op * ct_stride);
-#pragma unroll
-        for (int i = 0; i < CT / 8; i++) { st.lo[i] = p[2 * i]; st.hi[i] = p[2 * i + 1]; }
+        absorb_words<CT / 8>(st, c_tilde + op * ct_stride);
     }
     shake_pad<SHAKE256_RATE, CT>(st);
 #pragma unroll
