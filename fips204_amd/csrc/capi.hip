@@ -186,7 +186,7 @@ int mldsa_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int3
                        size_t n_ops, void *stream) {
     REQUIRE(params_of(set), "mldsa_verify_arith: unknown parameter set");
     REQUIRE(ctx && (n_ops == 0 || (a_hat && z && c && t1_d2_hat_mont && w_out)), "mldsa_verify_arith: NULL pointer");
-    return launch_verify_arith(ctx, set, a_hat, z, c, t1_d2_hat_mont, w_out, n_ops, (hipStream_t)stream);
+    return launch_verify_arith(ctx, set, a_hat, z, c, t1_d2_hat_mont, nullptr, w_out, n_ops, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ samplers
@@ -214,6 +214,18 @@ int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_
     REQUIRE(p, "mldsa_sample_in_ball: unknown parameter set");
     REQUIRE(ctx && (n_ops == 0 || (c_tilde && c)), "mldsa_sample_in_ball: NULL pointer");
     return launch_sample_in_ball(ctx, set, c_tilde, (size_t)p->ctilde_len, c, n_ops, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ op-level API
+int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr,
+                 const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                 const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                 const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_verify: unknown parameter set");
+    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_verify: bad mode");
+    REQUIRE(ctx && (n_ops == 0 || (rho && tr && t1_d2_hat_mont && msg_off && sigs && ok)), "mldsa_verify: NULL pointer");
+    return verify_batch(ctx, set, mode, rho, tr, t1_d2_hat_mont, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
+                        (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -45,7 +45,7 @@ int launch_mat_vec_mul(mldsa_ctx *, int k, int l, const int32_t *, const int32_t
 int launch_pointwise_mont(mldsa_ctx *, const int32_t *, const int32_t *, int32_t *, size_t ppo, size_t n_ops, hipStream_t);
 int launch_add(mldsa_ctx *, const int32_t *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
 int launch_infinity_norm(mldsa_ctx *, const int32_t *, size_t ppo, size_t n_ops, int32_t *, hipStream_t);
-int launch_verify_arith(mldsa_ctx *, int set, const int32_t *, const int32_t *, const int32_t *, const int32_t *, int32_t *, size_t n_ops, hipStream_t);
+int launch_verify_arith(mldsa_ctx *, int set, const int32_t *, const int32_t *, const int32_t *, const int32_t *, const uint32_t *key_idx, int32_t *, size_t n_ops, hipStream_t);
 
 
 // ---- launchers (kernels_sample.hip) ----
@@ -53,5 +53,24 @@ int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride,
 int launch_expand_s(mldsa_ctx *, int set, const uint8_t *rho_prime, size_t rho_stride, int32_t *s12, size_t n_ops, hipStream_t);
 int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t);
 int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t ct_stride, int32_t *c, size_t n_ops, hipStream_t);
+
+
+// ---- launchers (kernels_codec.hip) ----
+int launch_sig_unpack_z(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, int32_t *z, int32_t *znorm, size_t n_ops, hipStream_t);
+int launch_hint_unpack(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, uint32_t *hmask, int32_t *hvalid, size_t n_ops, hipStream_t);
+int launch_use_hint_w1(mldsa_ctx *, const mldsa_params *, const int32_t *w, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, size_t n_ops, hipStream_t);
+int launch_mu(mldsa_ctx *, const uint8_t *tr, size_t tr_stride, const uint32_t *key_idx, int mode, const uint8_t *msgs,
+              const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, uint8_t *mu, size_t mu_stride, int32_t *ctx_bad,
+              size_t n_ops, hipStream_t);
+int launch_shake256_2(mldsa_ctx *, int out_len, const uint8_t *a, size_t sa, int la, const uint32_t *a_idx, const uint8_t *b, size_t sb,
+                      int lb, uint32_t tail, int tail_len, uint8_t *out, size_t so, size_t n_ops, hipStream_t);
+int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, const uint8_t *ctilde_p, size_t cp_stride,
+                          const int32_t *znorm, const int32_t *hvalid, const int32_t *ctx_bad, uint8_t *ok, size_t n_ops, hipStream_t);
+
+// ---- op-level pipelines (pipeline.hip) ----
+int ensure_workspace(mldsa_ctx *, size_t bytes);
+int verify_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1_d2_hat_mont,
+                 const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
+                 const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t);
 
 }  // namespace mldsa

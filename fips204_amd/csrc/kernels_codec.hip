@@ -1,0 +1,376 @@
+// Wire-format codecs, rounding and the fixed-shape SHAKE256 hashes either side of the hot
+// path, so that whole verify / sign / keygen stay on
+// the device.  Replaces, for batches: src/conversion.rs (bit_pack / bit_unpack /
+// hint_bit_pack / hint_bit_unpack), src/encodings.rs (pk / sk / sig codecs, w1_encode),
+// src/high_low.rs (power2round, decompose, high/low bits, make_hint, use_hint) and the
+// h256_xof call sites of src/ml_dsa.rs (mu, rho'', c_tilde, tr, keygen seed expansion).
+#include <type_traits>
+
+#include "ctx.h"
+#include "keccak.h"
+
+namespace mldsa {
+
+constexpr int CWAVES = 4;
+constexpr int CBLOCK = 64 * CWAVES;
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for_c(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for_c<I + 1, E>(f);
+    }
+}
+
+// ------------------------------------------------------------------ high_low.rs on device
+
+// decompose (high_low.rs:66-96) for canonical r in [0, q); G2HI = (gamma2 == (q-1)/32)
+template <bool G2HI>
+__device__ __forceinline__ void decompose(int32_t rp, int32_t& r1, int32_t& r0) {
+    constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
+    int32_t x = (rp + 127) >> 7;
+    if constexpr (!G2HI) {
+        x = (x * 11275 + (1 << 23)) >> 24;
+        x ^= ((43 - x) >> 31) & x;
+    } else {
+        x = (x * 1025 + (1 << 21)) >> 22;
+        x &= 15;
+    }
+    int32_t y = rp - x * 2 * GAMMA2;
+    y -= (((Q - 1) / 2 - y) >> 31) & Q;
+    r1 = x;
+    r0 = y;
+}
+
+// use_hint (high_low.rs:155-192), r canonical
+template <bool G2HI>
+__device__ __forceinline__ int32_t use_hint(int32_t h, int32_t r) {
+    int32_t r1, r0;
+    decompose<G2HI>(r, r1, r0);
+    if (h == 0) return r1;
+    if constexpr (!G2HI) {
+        if (r0 > 0) return r1 == 43 ? 0 : r1 + 1;
+        return r1 == 0 ? 43 : r1 - 1;
+    } else {
+        return r0 > 0 ? (r1 + 1) & 15 : (r1 - 1) & 15;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// sig_decode part 1 (encodings.rs:312-321 -> bit_unpack, conversion.rs:227-262): z[j] =
+// gamma1 - (c-bit fields), one wave per polynomial, plus the verifier's norm test
+// ||z||inf < gamma1 - beta (ml_dsa.rs:434) as a per-op maximum.
+template <int GB>
+__global__ __launch_bounds__(CBLOCK) void k_sig_unpack_z(const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
+                                                         int l, int32_t* __restrict__ z, int32_t* __restrict__ znorm,
+                                                         size_t n_ops) {
+    constexpr int CB = GB + 1;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * CWAVES;
+    const size_t n_polys = n_ops * (size_t)l;
+    for (size_t p = wave; p < n_polys; p += n_waves) {
+        const size_t op = p / l;
+        const int j = (int)(p % l);
+        const uint8_t* src = sigs + op * sig_len + ctilde_len + (size_t)j * (32 * CB);
+        int32_t mx = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 64 * k + lane;
+            const int bo = i * CB;
+            const uint32_t v = (load_le32(src + (bo >> 3)) >> (bo & 7)) & ((1u << CB) - 1u);
+            const int32_t c = (1 << GB) - (int32_t)v;
+            z[p * N + i] = c;
+            const int32_t a = c < 0 ? -c : c;
+            mx = a > mx ? a : mx;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int32_t o = __shfl_xor(mx, m);
+            mx = o > mx ? o : mx;
+        }
+        if (lane == 0) atomicMax(&znorm[op], mx);
+    }
+}
+
+// sig_decode part 2: hint_bit_unpack (conversion.rs:340-414), one op per lane.  Output: a
+// 256-bit mask per hint polynomial and a validity flag (0 = the reference returns Err).
+__global__ __launch_bounds__(CBLOCK) void k_hint_unpack(const uint8_t* __restrict__ sigs, size_t sig_len, int hint_off,
+                                                        int k, int omega, uint32_t* __restrict__ hmask,
+                                                        int32_t* __restrict__ hvalid, size_t n_ops) {
+    const size_t op = (size_t)blockIdx.x * CBLOCK + threadIdx.x;
+    if (op >= n_ops) return;
+    const uint8_t* y = sigs + op * sig_len + hint_off;
+    uint32_t* hm = hmask + op * (size_t)k * 8;
+    for (int i = 0; i < k * 8; i++) hm[i] = 0;
+    int valid = 1, index = 0;
+    for (int i = 0; i < k && valid; i++) {
+        const int yi = y[omega + i];
+        if (yi < index || yi > omega) { valid = 0; break; }
+        const int first = index;
+        while (index < yi) {
+            if (index > first && y[index - 1] >= y[index]) { valid = 0; break; }
+            const int pos = y[index];
+            hm[i * 8 + (pos >> 5)] |= 1u << (pos & 31);
+            index++;
+        }
+    }
+    if (valid)
+        for (int i = index; i < omega; i++)
+            if (y[i] != 0) { valid = 0; break; }
+    hvalid[op] = valid;
+}
+
+// ------------------------------------------------------------------------------------
+// w1' = use_hint(h, w') (ml_dsa.rs:420-422) followed by w1_encode (encodings.rs:338-360 ->
+// simple_bit_pack): 6 bits per coefficient for gamma2 = (q-1)/88, 4 bits otherwise.
+// One wave per polynomial, 4 consecutive coefficients per lane.  With hmask == nullptr this
+// is high_bits + w1_encode of the signer (ml_dsa.rs:225-232).
+template <bool G2HI>
+__global__ __launch_bounds__(CBLOCK) void k_use_hint_w1(const int32_t* __restrict__ w, const uint32_t* __restrict__ hmask,
+                                                        uint8_t* __restrict__ w1, int k, size_t w1_stride, size_t n_ops) {
+    constexpr int BITS = G2HI ? 4 : 6;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * CWAVES;
+    const size_t n_polys = n_ops * (size_t)k;
+    for (size_t p = wave; p < n_polys; p += n_waves) {
+        const size_t op = p / k;
+        const int i = (int)(p % k);
+        const int4 v = reinterpret_cast<const int4*>(w + p * N)[lane];
+        uint32_t hb = 0;
+        if (hmask) hb = (hmask[p * 8 + (lane >> 3)] >> ((lane & 7) * 4)) & 0xFu;
+        const uint32_t a0 = (uint32_t)use_hint<G2HI>(hb & 1, v.x), a1 = (uint32_t)use_hint<G2HI>((hb >> 1) & 1, v.y);
+        const uint32_t a2 = (uint32_t)use_hint<G2HI>((hb >> 2) & 1, v.z), a3 = (uint32_t)use_hint<G2HI>((hb >> 3) & 1, v.w);
+        const uint32_t packed = a0 | (a1 << BITS) | (a2 << (2 * BITS)) | (a3 << (3 * BITS));
+        uint8_t* dst = w1 + op * w1_stride + (size_t)i * (32 * BITS);
+        if constexpr (G2HI) {
+            reinterpret_cast<uint16_t*>(dst)[lane] = (uint16_t)packed;  // 2 bytes per lane
+        } else {
+            dst[3 * lane] = (uint8_t)packed;
+            dst[3 * lane + 1] = (uint8_t)(packed >> 8);
+            dst[3 * lane + 2] = (uint8_t)(packed >> 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// mu = H(tr || M', 64) (ml_dsa.rs:185-196 / 386-397), one op per lane, variable-length
+// messages.  M' = M (internal), 0x00 | len(ctx) | ctx | M (pure) or 0x01 | len(ctx) | ctx |
+// OID | PH(M) (pre-hash; the caller passes OID | PH(M) as the message).  Each lane builds
+// its 136-byte rate block in a lane-private LDS row, then absorbs it.
+constexpr int MU_BLK_STRIDE = 35;  // dwords per lane row (136 bytes + pad, odd stride)
+
+__global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_t tr_stride,
+                                           const uint32_t* __restrict__ key_idx, int mode,
+                                           const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ msg_off,
+                                           const uint8_t* __restrict__ ctxs, const uint64_t* __restrict__ ctx_off,
+                                           uint8_t* __restrict__ mu, size_t mu_stride, int32_t* __restrict__ ctx_bad, size_t n_ops) {
+    __shared__ uint32_t blk[64 * MU_BLK_STRIDE];
+    const int lane = threadIdx.x;
+    const size_t op = (size_t)blockIdx.x * 64 + lane;
+    const bool valid = op < n_ops;
+    uint32_t* row = blk + lane * MU_BLK_STRIDE;
+    uint8_t* rowb = reinterpret_cast<uint8_t*>(row);
+
+    const uint8_t *trp = nullptr, *mp = nullptr, *cp = nullptr;
+    size_t mlen = 0, clen = 0;
+    if (valid) {
+        trp = tr + (key_idx ? key_idx[op] : op) * tr_stride;
+        mp = msgs + msg_off[op];
+        mlen = (size_t)(msg_off[op + 1] - msg_off[op]);
+        if (ctx_off) {
+            cp = ctxs + ctx_off[op];
+            clen = (size_t)(ctx_off[op + 1] - ctx_off[op]);
+        }
+        if (ctx_bad) ctx_bad[op] = clen > 255 ? 1 : 0;  // lib.rs:274, 368, 589, 605 (every entry point)
+    }
+    const size_t pre = (mode == MLDSA_MODE_INTERNAL) ? 0 : 2 + clen;
+    const size_t total = valid ? 64 + pre + mlen : 0;
+    const size_t my_blocks = total / SHAKE256_RATE + 1;  // the pad always fits in the last block
+    size_t max_blocks = my_blocks;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const size_t o = (size_t)__shfl_xor((unsigned long long)max_blocks, m);
+        max_blocks = o > max_blocks ? o : max_blocks;
+    }
+    KeccakState st;
+    keccak_zero(st);
+    for (size_t b = 0; b < max_blocks; b++) {
+        if (valid && b < my_blocks) {
+            const size_t base = b * SHAKE256_RATE;
+            for (int i = 0; i < SHAKE256_RATE; i++) {
+                const size_t pos = base + i;
+                uint8_t v = 0;
+                if (pos < total) {
+                    if (pos < 64) v = trp[pos];
+                    else if (pos < 64 + pre) {
+                        const size_t q = pos - 64;
+                        v = q == 0 ? (uint8_t)(mode == MLDSA_MODE_PREHASH ? 1 : 0) : q == 1 ? (uint8_t)clen : cp[q - 2];
+                    } else v = mp[pos - 64 - pre];
+                } else if (pos == total) v = 0x1F;
+                rowb[i] = v;
+            }
+            if (b == my_blocks - 1) rowb[SHAKE256_RATE - 1] |= 0x80;
+            static_for_c<0, 17>([&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+                st.lo[W] ^= row[2 * W];
+                st.hi[W] ^= row[2 * W + 1];
+            });
+            keccak_f1600(st);
+        }
+    }
+    if (valid) {
+        uint32_t* out = reinterpret_cast<uint32_t*>(mu + op * mu_stride);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { out[2 * i] = st.lo[i]; out[2 * i + 1] = st.hi[i]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Fixed-shape SHAKE256 over two concatenated device buffers A (LA bytes, per-op stride sa,
+// optional index) and B (LB bytes): out = first OUT bytes.  LA must be a multiple of 8.
+//   c_tilde' = H(mu | w1)  (ml_dsa.rs:233, 429)     rho'' = H(K | rnd | mu)  (ml_dsa.rs:199)
+//   tr = H(pk)             (ml_dsa.rs:100, 486)     keygen seed = H(xi | K | L, 128) (ml_dsa.rs:68)
+// One op per lane.
+template <int OUT>
+__global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict__ a, size_t sa, int la,
+                                                       const uint32_t* __restrict__ a_idx,
+                                                       const uint8_t* __restrict__ b, size_t sb, int lb,
+                                                       uint32_t tail, int tail_len,
+                                                       uint8_t* __restrict__ out, size_t so, size_t n_ops) {
+    const size_t op = (size_t)blockIdx.x * CBLOCK + threadIdx.x;
+    if (op >= n_ops) return;
+    const uint8_t* pa = a + (a_idx ? a_idx[op] : op) * sa;
+    const uint8_t* pb = b ? b + op * sb : nullptr;
+    const int total = la + lb + tail_len;  // `tail`: up to 4 literal bytes appended (e.g. K, L of keygen)
+    KeccakState st;
+    keccak_zero(st);
+    const int n_blocks = total / SHAKE256_RATE + 1;
+    for (int blk = 0; blk < n_blocks; blk++) {
+        const int base = blk * SHAKE256_RATE;
+        static_for_c<0, 17>([&](auto wc) {
+            constexpr int W = decltype(wc)::value;
+            const int off = base + 8 * W;
+            uint32_t lo = 0, hi = 0;
+            if (off + 8 <= la) {
+                lo = load_le32(pa + off);
+                hi = load_le32(pa + off + 4);
+            } else if (off >= la && off + 8 <= la + lb) {
+                lo = load_le32(pb + (off - la));
+                hi = load_le32(pb + (off - la) + 4);
+            } else if (off < total + 1) {
+                // a word that straddles a segment end or holds the pad: assemble by bytes
+                for (int i = 0; i < 8; i++) {
+                    const int pos = off + i;
+                    uint32_t v = 0;
+                    if (pos < la) v = pa[pos];
+                    else if (pos < la + lb) v = pb[pos - la];
+                    else if (pos < total) v = (tail >> (8 * (pos - la - lb))) & 0xFF;
+                    else if (pos == total) v = 0x1F;
+                    if (i < 4) lo |= v << (8 * i); else hi |= v << (8 * (i - 4));
+                }
+            }
+            st.lo[W] ^= lo;
+            st.hi[W] ^= hi;
+        });
+        if (blk == n_blocks - 1) st.hi[16] ^= 0x80000000u;
+        keccak_f1600(st);
+    }
+    uint8_t* po = out + op * so;
+    static_for_c<0, OUT / 8>([&](auto wc) {
+        constexpr int W = decltype(wc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            po[8 * W + i] = (uint8_t)(st.lo[W] >> (8 * i));
+            po[8 * W + 4 + i] = (uint8_t)(st.hi[W] >> (8 * i));
+        }
+    });
+}
+
+// final verdict of verify_internal (ml_dsa.rs:434-436) combined with the decode failures
+// that make the reference return false early (ml_dsa.rs:368-376, lib.rs:368-370)
+__global__ __launch_bounds__(CBLOCK) void k_verify_verdict(const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
+                                                           const uint8_t* __restrict__ ctilde_p, size_t cp_stride,
+                                                           const int32_t* __restrict__ znorm, int32_t zbound,
+                                                           const int32_t* __restrict__ hvalid,
+                                                           const int32_t* __restrict__ ctx_bad,
+                                                           uint8_t* __restrict__ ok, size_t n_ops) {
+    const size_t op = (size_t)blockIdx.x * CBLOCK + threadIdx.x;
+    if (op >= n_ops) return;
+    const uint8_t* c0 = sigs + op * sig_len;
+    const uint8_t* c1 = ctilde_p + op * cp_stride;
+    int same = 1;
+    for (int i = 0; i < ctilde_len; i++) same &= (c0[i] == c1[i]);
+    ok[op] = (uint8_t)(same && znorm[op] < zbound && hvalid[op] && !ctx_bad[op]);
+}
+
+// ------------------------------------------------------------------------- launchers
+static inline unsigned lane_blocks(size_t n) { return (unsigned)((n + CBLOCK - 1) / CBLOCK); }
+
+int launch_sig_unpack_z(mldsa_ctx* ctx, const mldsa_params* p, const uint8_t* sigs, int32_t* z, int32_t* znorm, size_t n_ops,
+                        hipStream_t s) {
+    dim3 grid(grid_for(ctx, n_ops * (size_t)p->l, CWAVES, 8)), block(CBLOCK);
+    if (p->gamma1 == (1 << 17))
+        hipLaunchKernelGGL((k_sig_unpack_z<17>), grid, block, 0, s, sigs, (size_t)p->sig_len, p->ctilde_len, p->l, z, znorm, n_ops);
+    else
+        hipLaunchKernelGGL((k_sig_unpack_z<19>), grid, block, 0, s, sigs, (size_t)p->sig_len, p->ctilde_len, p->l, z, znorm, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_hint_unpack(mldsa_ctx*, const mldsa_params* p, const uint8_t* sigs, uint32_t* hmask, int32_t* hvalid, size_t n_ops,
+                       hipStream_t s) {
+    const int c = (p->gamma1 == (1 << 17)) ? 18 : 20;
+    const int hint_off = p->ctilde_len + p->l * 32 * c;
+    hipLaunchKernelGGL(k_hint_unpack, dim3(lane_blocks(n_ops)), dim3(CBLOCK), 0, s, sigs, (size_t)p->sig_len, hint_off, p->k,
+                       p->omega, hmask, hvalid, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_use_hint_w1(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* w, const uint32_t* hmask, uint8_t* w1,
+                       size_t w1_stride, size_t n_ops, hipStream_t s) {
+    dim3 grid(grid_for(ctx, n_ops * (size_t)p->k, CWAVES, 8)), block(CBLOCK);
+    if (p->gamma2 == (Q - 1) / 32)
+        hipLaunchKernelGGL((k_use_hint_w1<true>), grid, block, 0, s, w, hmask, w1, p->k, w1_stride, n_ops);
+    else
+        hipLaunchKernelGGL((k_use_hint_w1<false>), grid, block, 0, s, w, hmask, w1, p->k, w1_stride, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* key_idx, int mode, const uint8_t* msgs,
+              const uint64_t* msg_off, const uint8_t* ctxs, const uint64_t* ctx_off, uint8_t* mu, size_t mu_stride,
+              int32_t* ctx_bad, size_t n_ops, hipStream_t s) {
+    hipLaunchKernelGGL(k_mu, dim3((unsigned)((n_ops + 63) / 64)), dim3(64), 0, s, tr, tr_stride, key_idx, mode, msgs, msg_off,
+                       ctxs, ctx_off, mu, mu_stride, ctx_bad, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_shake256_2(mldsa_ctx*, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
+                      size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s) {
+    dim3 grid(lane_blocks(n_ops)), block(CBLOCK);
+    if ((la & 7) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: first segment must be a multiple of 8 bytes");
+    switch (out_len) {
+        case 32: hipLaunchKernelGGL((k_shake256_2<32>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
+        case 48: hipLaunchKernelGGL((k_shake256_2<48>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
+        case 64: hipLaunchKernelGGL((k_shake256_2<64>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
+        case 128: hipLaunchKernelGGL((k_shake256_2<128>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
+        default: return set_error(MLDSA_ERR_PARAM, "shake256_2: unsupported output length");
+    }
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_verify_verdict(mldsa_ctx*, const mldsa_params* p, const uint8_t* sigs, const uint8_t* ctilde_p, size_t cp_stride,
+                          const int32_t* znorm, const int32_t* hvalid, const int32_t* ctx_bad, uint8_t* ok, size_t n_ops,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_verify_verdict, dim3(lane_blocks(n_ops)), dim3(CBLOCK), 0, s, sigs, (size_t)p->sig_len, p->ctilde_len,
+                       ctilde_p, cp_stride, znorm, p->gamma1 - p->beta, hvalid, ctx_bad, ok, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+}  // namespace mldsa

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(BLOCK) void k_infinity_norm(const int32_t *__restri
 template <int K, int L>
 __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const int32_t *__restrict__ z, const int32_t *__restrict__ c,
-    const int32_t *__restrict__ t1, int32_t *__restrict__ w_out, size_t n_ops,
+    const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx, int32_t *__restrict__ w_out, size_t n_ops,
     const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab) {
     constexpr int W = K > L + 1 ? K : L + 1;
     __shared__ int4 lds[(L + 1) * 64];
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
             const int4 *ap = reinterpret_cast<const int4 *>(a_hat + ((op * K + wave) * (size_t)L) * N);
 #pragma unroll
             for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
-            tv = reinterpret_cast<const int4 *>(t1 + (op * K + wave) * (size_t)N)[lane];
+            const size_t key = key_idx ? key_idx[op] : op;  // t1 belongs to the key, not to the op
+            tv = reinterpret_cast<const int4 *>(t1 + (key * K + wave) * (size_t)N)[lane];
         }
         if (wave <= L) {
             int32_t r[4];
@@ -272,12 +273,12 @@ int launch_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t ppo, size_
 }
 
 int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t *z, const int32_t *c, const int32_t *t1,
-                        int32_t *w, size_t n_ops, hipStream_t s) {
+                        const uint32_t *key_idx, int32_t *w, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, 1, 6));
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4>), grid, dim3(64 * 5), 0, s, a, z, c, t1, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5>), grid, dim3(64 * 6), 0, s, a, z, c, t1, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7>), grid, dim3(64 * 8), 0, s, a, z, c, t1, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4>), grid, dim3(64 * 5), 0, s, a, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5>), grid, dim3(64 * 6), 0, s, a, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7>), grid, dim3(64 * 8), 0, s, a, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;

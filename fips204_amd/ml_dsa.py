@@ -1,0 +1,102 @@
+"""Batched mirror of the reference's public API for the accelerated path.
+
+`ml_dsa_44`, `ml_dsa_65`, `ml_dsa_87` mirror the modules the `functionality!()` macro stamps
+out (src/lib.rs:116-614): KeyGen / Signer / Verifier / SerDes (src/traits.rs), with every
+method taking a *batch* of independent operations.  Keys live on the device in the
+reference's expanded form (src/types.rs:19-41), field by field.  All compute goes through
+the C ABI (include/mldsa_hip.h); there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hotpath import HotPath, N, _ptr, _stream
+
+MODE_PURE, MODE_INTERNAL, MODE_PREHASH = 0, 1, 2
+
+
+def _cat_with_offsets(items, device):
+    """list of bytes -> (uint8 device buffer, uint64 offsets[n + 1] on device)"""
+    lens = np.fromiter((len(b) for b in items), dtype=np.uint64, count=len(items))
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    flat = b"".join(bytes(b) for b in items) or b"\0"
+    buf = torch.frombuffer(bytearray(flat), dtype=torch.uint8).to(device)
+    return buf, torch.from_numpy(off.view(np.int64)).to(device)
+
+
+class PublicKeys:
+    """n expanded public keys: PublicKey { rho, tr, t1_d2_hat_mont } (src/types.rs:35-41)."""
+
+    def __init__(self, pset, rho, tr, t1_d2_hat_mont):
+        self.pset, self.rho, self.tr, self.t1_d2_hat_mont = pset, rho, tr, t1_d2_hat_mont
+
+    def __len__(self):
+        return self.rho.shape[0]
+
+
+class PrivateKeys:
+    """n expanded private keys (src/types.rs:19-28)."""
+
+    def __init__(self, pset, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont):
+        self.pset, self.rho, self.cap_k, self.tr = pset, rho, cap_k, tr
+        self.s_1_hat_mont, self.s_2_hat_mont, self.t_0_hat_mont = s_1_hat_mont, s_2_hat_mont, t_0_hat_mont
+
+    def __len__(self):
+        return self.rho.shape[0]
+
+
+class MlDsa:
+    """One parameter set (src/lib.rs:639-656 / 681-698 / 723-740) on one GPU."""
+
+    def __init__(self, pset, device=0, hotpath=None):
+        self.pset = pset
+        self.hp = hotpath or HotPath(device)
+        self.lib = self.hp.lib
+        p = _lib.get_params(pset)
+        self.params = p
+        self.PK_LEN, self.SK_LEN, self.SIG_LEN = p.pk_len, p.sk_len, p.sig_len
+        self.device = self.hp.device
+
+    # ---- Verifier (src/traits.rs:330-362; src/lib.rs:364-411) -------------------------
+    def verify(self, pks, messages, sigs, ctxs=None, key_idx=None, mode=MODE_PURE):
+        """PublicKey::verify for a batch: returns a bool array, one entry per operation.
+
+        `sigs`: uint8 CUDA tensor [n_ops, SIG_LEN] or a list of byte strings (a signature of
+        the wrong length verifies as False, like a failed `try_into()` in the reference's
+        callers).  `ctxs`: list of byte strings or None (= empty)."""
+        n_ops = len(messages)
+        wrong_len = None
+        if not isinstance(sigs, torch.Tensor):
+            wrong_len = np.array([len(s) != self.SIG_LEN for s in sigs], dtype=bool)
+            flat = b"".join(bytes(s) if len(s) == self.SIG_LEN else bytes(self.SIG_LEN) for s in sigs)
+            sigs = torch.frombuffer(bytearray(flat or b"\0"), dtype=torch.uint8).to(self.device)
+        msg_buf, msg_off = _cat_with_offsets(messages, self.device)
+        ctx_buf = ctx_off = None
+        if ctxs is not None:
+            ctx_buf, ctx_off = _cat_with_offsets(ctxs, self.device)
+        if key_idx is None and len(pks) != n_ops:
+            key_idx = np.arange(n_ops, dtype=np.uint32) % len(pks)
+        kidx = None
+        if key_idx is not None:
+            kidx = torch.as_tensor(np.asarray(key_idx, dtype=np.uint32).view(np.int32)).to(self.device)
+        ok = torch.zeros(max(n_ops, 1), dtype=torch.uint8, device=self.device)
+        self.verify_device(pks, msg_buf, msg_off, sigs, ok, n_ops, ctx_buf, ctx_off, kidx, mode)
+        torch.cuda.synchronize()
+        res = ok[:n_ops].cpu().numpy().astype(bool)
+        if wrong_len is not None:
+            res &= ~wrong_len
+        return res
+
+    def verify_device(self, pks, msg_buf, msg_off, sigs, ok, n_ops, ctx_buf=None, ctx_off=None, key_idx=None,
+                      mode=MODE_PURE):
+        """Same, everything already resident in HBM (what bench.py times)."""
+        null = C.c_void_p(0)
+        _lib.check(self.lib.mldsa_verify(
+            self.hp._h, self.pset, mode, _ptr(pks.rho), _ptr(pks.tr), _ptr(pks.t1_d2_hat_mont),
+            _ptr(key_idx) if key_idx is not None else null, _ptr(msg_buf), _ptr(msg_off),
+            _ptr(ctx_buf) if ctx_buf is not None else null, _ptr(ctx_off) if ctx_off is not None else null,
+            _ptr(sigs), _ptr(ok), n_ops, _stream()))
+        return ok

@@ -134,6 +134,23 @@ int mldsa_expand_mask(mldsa_ctx *ctx, int set, const uint8_t *rho_pp, const uint
 int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_t *c,
                          size_t n_ops, void *stream);
 
+/* ---- op-level batched API (mirrors the Verifier / Signer / KeyGen / SerDes traits) ---- */
+
+/* Verifier::verify / _internal_verify / hash_verify (src/lib.rs:364-411, 605-612) ->
+ * verify_internal (src/ml_dsa.rs:351-437) for n_ops independent operations.
+ *   Public keys are passed EXPANDED, field by field, as the reference's PublicKey holds them
+ *   (src/types.rs:35-41): rho[n_keys][32], tr[n_keys][64], t1_d2_hat_mont[n_keys][K][256]
+ *   (produce them with mldsa_pk_expand).  key_idx[op] selects the key of op (NULL: op i uses
+ *   key i).  A_hat is re-derived from rho for every op, as the reference does (ml_dsa.rs:406).
+ *   msgs/msg_off: concatenated messages and n_ops + 1 byte offsets; ctxs/ctx_off likewise
+ *   (ctx_off NULL = every ctx empty).  mode: MLDSA_MODE_*.  sigs: n_ops * SIG_LEN bytes.
+ *   ok[op] = 1 iff the reference returns true; malformed hints, |ctx| > 255, z too large and
+ *   c_tilde mismatch all give 0 (ml_dsa.rs:368-376, 434-436; lib.rs:368-370). */
+int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr,
+                 const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                 const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                 const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
