@@ -54,6 +54,10 @@ _SIGNATURES = {
     "mldsa_expand_mask": [_P, _I, _P, _P, _P, _SZ, _P],
     "mldsa_sample_in_ball": [_P, _I, _P, _P, _SZ, _P],
     "mldsa_verify": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_pk_expand": [_P, _I, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_sk_expand": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_keygen": [_P, _I, _P, _P, _P, _SZ, _P],
+    "mldsa_sign": [_P, _I, _I] + [_P] * 14 + [_SZ, _P],
 }
 _RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p}
 

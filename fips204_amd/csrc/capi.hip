@@ -228,4 +228,37 @@ int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
                         (hipStream_t)stream);
 }
 
+int mldsa_pk_expand(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, uint8_t *tr, int32_t *t1_d2_hat_mont,
+                    size_t n_keys, void *stream) {
+    REQUIRE(params_of(set), "mldsa_pk_expand: unknown parameter set");
+    REQUIRE(ctx && (n_keys == 0 || (pk && rho && tr && t1_d2_hat_mont)), "mldsa_pk_expand: NULL pointer");
+    return pk_expand_batch(ctx, set, pk, rho, tr, t1_d2_hat_mont, n_keys, (hipStream_t)stream);
+}
+
+int mldsa_sk_expand(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, uint8_t *cap_k, uint8_t *tr,
+                    int32_t *s_1_hat_mont, int32_t *s_2_hat_mont, int32_t *t_0_hat_mont, size_t n_keys, void *stream) {
+    REQUIRE(params_of(set), "mldsa_sk_expand: unknown parameter set");
+    REQUIRE(ctx && (n_keys == 0 || (sk && rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont)),
+            "mldsa_sk_expand: NULL pointer");
+    return sk_expand_batch(ctx, set, sk, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, n_keys, (hipStream_t)stream);
+}
+
+int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, void *stream) {
+    REQUIRE(params_of(set), "mldsa_keygen: unknown parameter set");
+    REQUIRE(ctx && (n_keys == 0 || (xi && pk && sk)), "mldsa_keygen: NULL pointer");
+    return keygen_batch(ctx, set, xi, pk, sk, n_keys, (hipStream_t)stream);
+}
+
+int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
+               const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont, const int32_t *t_0_hat_mont,
+               const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
+               const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_sign: unknown parameter set");
+    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_sign: bad mode");
+    REQUIRE(ctx && (n_ops == 0 || (rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont && msg_off && rnd && sigs)),
+            "mldsa_sign: NULL pointer");
+    return sign_batch(ctx, set, mode, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, key_idx, msgs, msg_off, ctxs,
+                      ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream);
+}
+
 }  // extern "C"

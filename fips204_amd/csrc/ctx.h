@@ -67,7 +67,30 @@ int launch_shake256_2(mldsa_ctx *, int out_len, const uint8_t *a, size_t sa, int
 int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, const uint8_t *ctilde_p, size_t cp_stride,
                           const int32_t *znorm, const int32_t *hvalid, const int32_t *ctx_bad, uint8_t *ok, size_t n_ops, hipStream_t);
 
+// ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
+int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, size_t n_ops, hipStream_t);
+int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
+                      uint32_t scale_q, int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
+int launch_sign_cs(mldsa_ctx *, int set, const int32_t *c, const uint32_t *act, const uint32_t *key_idx, const int32_t *s1,
+                   const int32_t *s2, const int32_t *t0, int32_t *cs1, int32_t *cs2, int32_t *ct0, size_t n_slots, hipStream_t);
+int launch_sign_finish(mldsa_ctx *, const mldsa_params *, const int32_t *y, const int32_t *w, const int32_t *cs1, const int32_t *cs2,
+                       const int32_t *ct0, const uint8_t *ctilde, const uint32_t *act, uint16_t *kappa, int32_t *done,
+                       uint8_t *sigs, size_t n_slots, hipStream_t);
+int launch_compact(mldsa_ctx *, const uint32_t *act_in, size_t n, const int32_t *done, uint32_t *act_out, uint32_t *counter, hipStream_t);
+int launch_init_active(mldsa_ctx *, size_t n, const int32_t *ctx_bad, int32_t *done, uint16_t *kappa, int32_t *status,
+                       uint32_t *act_out, uint32_t *counter, hipStream_t);
+int launch_keygen_encode(mldsa_ctx *, const mldsa_params *, const int32_t *s1s2, const int32_t *as1, uint8_t *pk, uint8_t *sk,
+                         size_t n_keys, hipStream_t);
+
 // ---- op-level pipelines (pipeline.hip) ----
+int pk_expand_batch(mldsa_ctx *, int set, const uint8_t *pk, uint8_t *rho, uint8_t *tr, int32_t *t1, size_t n, hipStream_t);
+int sk_expand_batch(mldsa_ctx *, int set, const uint8_t *sk, uint8_t *rho, uint8_t *cap_k, uint8_t *tr, int32_t *s1, int32_t *s2,
+                    int32_t *t0, size_t n, hipStream_t);
+int keygen_batch(mldsa_ctx *, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t);
+int sign_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1,
+               const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off,
+               const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops,
+               hipStream_t);
 int ensure_workspace(mldsa_ctx *, size_t bytes);
 int verify_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1_d2_hat_mont,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,

@@ -150,18 +150,21 @@ __global__ __launch_bounds__(BLOCK) void k_infinity_norm(const int32_t *__restri
 // as c_hat * 2^-32 (then mont_mul(c_hat', t1 * 2^32) carries the same factor) and the
 // inverse NTT finishes with F_MONT2 = 256^-1 * 2^64.
 // HBM traffic per op = algorithmic bytes: (K*L + L + 1 + K) KiB in, K KiB out.
-template <int K, int L>
+// With HAS_C = false the kernel is the signer's w = inv_ntt(A_hat * ntt(y)) (ml_dsa.rs:218-222);
+// a_idx then maps a compacted slot to the op whose A_hat it uses.
+template <int K, int L, bool HAS_C>
 __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
-    const int32_t *__restrict__ a_hat, const int32_t *__restrict__ z, const int32_t *__restrict__ c,
-    const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx, int32_t *__restrict__ w_out, size_t n_ops,
-    const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab) {
+    const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
+    const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
+    int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab) {
     constexpr int W = K > L + 1 ? K : L + 1;
+    constexpr int NIN = HAS_C ? L + 1 : L;  // polynomials transformed in phase 1
     __shared__ int4 lds[(L + 1) * 64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     FwdTw ftw;
     InvTw itw;
-    if (wave <= L) load_fwd_tw(ftw, fwd_tab, lane);
+    if (wave < NIN) load_fwd_tw(ftw, fwd_tab, lane);
     if (wave < K) load_inv_tw(itw, inv_tab, lane);
 
     for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
@@ -169,13 +172,16 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
         int4 av[L];
         int4 tv = make_int4(0, 0, 0, 0);
         if (wave < K) {
-            const int4 *ap = reinterpret_cast<const int4 *>(a_hat + ((op * K + wave) * (size_t)L) * N);
+            const size_t aop = a_idx ? a_idx[op] : op;
+            const int4 *ap = reinterpret_cast<const int4 *>(a_hat + ((aop * K + wave) * (size_t)L) * N);
 #pragma unroll
             for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
-            const size_t key = key_idx ? key_idx[op] : op;  // t1 belongs to the key, not to the op
-            tv = reinterpret_cast<const int4 *>(t1 + (key * K + wave) * (size_t)N)[lane];
+            if constexpr (HAS_C) {
+                const size_t key = key_idx ? key_idx[op] : op;  // t1 belongs to the key, not to the op
+                tv = reinterpret_cast<const int4 *>(t1 + (key * K + wave) * (size_t)N)[lane];
+            }
         }
-        if (wave <= L) {
+        if (wave < NIN) {
             int32_t r[4];
             const int32_t *src = (wave < L) ? z + (op * L + wave) * (size_t)N : c + op * (size_t)N;
             load_strided(r, src, lane);
@@ -199,11 +205,13 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
                 acc[2] += mont_mul(av[j].z, zv.z);
                 acc[3] += mont_mul(av[j].w, zv.w);
             }
-            int4 cv = lds[L * 64 + lane];
-            acc[0] -= mont_mul(cv.x, tv.x);
-            acc[1] -= mont_mul(cv.y, tv.y);
-            acc[2] -= mont_mul(cv.z, tv.z);
-            acc[3] -= mont_mul(cv.w, tv.w);
+            if constexpr (HAS_C) {
+                int4 cv = lds[L * 64 + lane];
+                acc[0] -= mont_mul(cv.x, tv.x);
+                acc[1] -= mont_mul(cv.y, tv.y);
+                acc[2] -= mont_mul(cv.z, tv.z);
+                acc[3] -= mont_mul(cv.w, tv.w);
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
             ntt_inv_wave(acc, itw, lane, F_MONT2, F_MONT2_QINV);
@@ -276,10 +284,26 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
                         const uint32_t *key_idx, int32_t *w, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, 1, 6));
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4>), grid, dim3(64 * 5), 0, s, a, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5>), grid, dim3(64 * 6), 0, s, a, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7>), grid, dim3(64 * 8), 0, s, a, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    const uint32_t *no_idx = nullptr;
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), grid, dim3(64 * 5), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), grid, dim3(64 * 6), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), grid, dim3(64 * 8), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+// w[slot] = inv_ntt(A_hat[a_idx[slot]] * ntt(y[slot]))   (ml_dsa.rs:218-222)
+int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, size_t n_ops,
+                  hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    dim3 grid(grid_for(ctx, n_ops, 1, 6));
+    const int32_t *none = nullptr;
+    const uint32_t *no_idx = nullptr;
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, false>), grid, dim3(64 * 5), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, false>), grid, dim3(64 * 6), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, false>), grid, dim3(64 * 8), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    else return set_error(MLDSA_ERR_PARAM, "sign_w: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -101,4 +101,187 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
     return MLDSA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------
+// PublicKey::try_from_bytes -> expand_public (ml_dsa.rs:477-498)
+int pk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, uint8_t *tr, int32_t *t1, size_t n, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "pk_expand: unknown parameter set");
+    if (n == 0) return MLDSA_OK;
+    MLDSA_HIP_CHECK(hipMemcpy2DAsync(rho, 32, pk, (size_t)p->pk_len, 32, n, hipMemcpyDeviceToDevice, s));
+    TRY(launch_shake256_2(ctx, 64, pk, (size_t)p->pk_len, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, tr, 64, n, s));  // tr = H(pk)
+    // t1_d2_hat_mont = ntt(t1) * 2^13 * 2^32  (ml_dsa.rs:492-495)
+    TRY(launch_unpack_ntt(ctx, pk, (size_t)p->pk_len, 32, 10, -1, 6346488, 2134890232u, t1, p->k, n, s));
+    return MLDSA_OK;
+}
+
+// PrivateKey::try_from_bytes -> expand_private (ml_dsa.rs:445-469)
+int sk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, uint8_t *cap_k, uint8_t *tr, int32_t *s1,
+                    int32_t *s2, int32_t *t0, size_t n, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "sk_expand: unknown parameter set");
+    if (n == 0) return MLDSA_OK;
+    const size_t skl = (size_t)p->sk_len;
+    const int eb = p->eta == 2 ? 3 : 4;
+    MLDSA_HIP_CHECK(hipMemcpy2DAsync(rho, 32, sk, skl, 32, n, hipMemcpyDeviceToDevice, s));
+    MLDSA_HIP_CHECK(hipMemcpy2DAsync(cap_k, 32, sk + 32, skl, 32, n, hipMemcpyDeviceToDevice, s));
+    MLDSA_HIP_CHECK(hipMemcpy2DAsync(tr, 64, sk + 64, skl, 64, n, hipMemcpyDeviceToDevice, s));
+    TRY(launch_unpack_ntt(ctx, sk, skl, 128, eb, p->eta, R2_MOD_Q, R2_MOD_Q_QINV, s1, p->l, n, s));
+    TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)p->l * 32 * eb, eb, p->eta, R2_MOD_Q, R2_MOD_Q_QINV, s2, p->k, n, s));
+    TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)(p->l + p->k) * 32 * eb, 13, 1 << 12, R2_MOD_Q, R2_MOD_Q_QINV, t0, p->k, n, s));
+    return MLDSA_OK;
+}
+
+// KG::keygen_from_seed -> key_gen_internal (ml_dsa.rs:57-134) + into_bytes: xi -> (pk, sk) bytes
+namespace {
+struct KeygenWs {
+    uint8_t *hbuf;
+    int32_t *s1s2, *s1c, *a_hat, *as1;
+    size_t bytes;
+    KeygenWs(void *base, const mldsa_params *p, size_t n) {
+        Carver cv(base);
+        hbuf = cv.take<uint8_t>(n * 128);
+        s1s2 = cv.take<int32_t>(n * (size_t)(p->l + p->k) * N);
+        s1c = cv.take<int32_t>(n * (size_t)p->l * N);
+        a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
+        as1 = cv.take<int32_t>(n * (size_t)p->k * N);
+        bytes = cv.off + 256;
+    }
+};
+}  // namespace
+
+int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "keygen: unknown parameter set");
+    if (n_keys == 0) return MLDSA_OK;
+    const size_t chunk = n_keys < CHUNK_OPS ? n_keys : CHUNK_OPS;
+    TRY(ensure_workspace(ctx, KeygenWs(nullptr, p, chunk).bytes));
+    const size_t pkl = (size_t)p->pk_len, skl = (size_t)p->sk_len;
+    for (size_t o = 0; o < n_keys; o += chunk) {
+        const size_t n = (n_keys - o) < chunk ? (n_keys - o) : chunk;
+        KeygenWs w(ctx->ws, p, chunk);
+        uint8_t *pko = pk + o * pkl, *sko = sk + o * skl;
+        // 1: (rho, rho', K) <- H(xi || k || l, 128)                          ml_dsa.rs:68-74
+        TRY(launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
+                              w.hbuf, 128, n, s));
+        TRY(launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
+        TRY(launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s));                // :85
+        MLDSA_HIP_CHECK(hipMemcpy2DAsync(w.s1c, (size_t)p->l * N * 4, w.s1s2, (size_t)(p->l + p->k) * N * 4,
+                                         (size_t)p->l * N * 4, n, hipMemcpyDeviceToDevice, s));
+        TRY(launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1c, w.as1, n, s));                 // :86-88 inv_ntt(A * ntt(s1))
+        TRY(launch_keygen_encode(ctx, p, w.s1s2, w.as1, pko, sko, n, s));                   // :88-92, pk/sk encode
+        MLDSA_HIP_CHECK(hipMemcpy2DAsync(pko, pkl, w.hbuf, 128, 32, n, hipMemcpyDeviceToDevice, s));        // rho
+        MLDSA_HIP_CHECK(hipMemcpy2DAsync(sko, skl, w.hbuf, 128, 32, n, hipMemcpyDeviceToDevice, s));        // rho
+        MLDSA_HIP_CHECK(hipMemcpy2DAsync(sko + 32, skl, w.hbuf + 96, 128, 32, n, hipMemcpyDeviceToDevice, s));  // K
+        TRY(launch_shake256_2(ctx, 64, pko, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, sko + 64, skl, n, s));  // tr = H(pk), :99-101
+    }
+    return MLDSA_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Signer::try_sign_* -> sign_internal (ml_dsa.rs:153-337) with the rejection loop re-batched:
+// every round runs one loop iteration for all unfinished ops, then compacts the active list.
+namespace {
+struct SignWs {
+    int32_t *a_hat, *y, *w, *cs1, *cs2, *ct0, *c, *done, *ctx_bad;
+    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde;
+    uint16_t *kappa;
+    uint32_t *act0, *act1, *counter;
+    size_t bytes;
+    SignWs(void *base, const mldsa_params *p, size_t n) {
+        Carver cv(base);
+        a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
+        y = cv.take<int32_t>(n * (size_t)p->l * N);
+        w = cv.take<int32_t>(n * (size_t)p->k * N);
+        cs1 = cv.take<int32_t>(n * (size_t)p->l * N);
+        cs2 = cv.take<int32_t>(n * (size_t)p->k * N);
+        ct0 = cv.take<int32_t>(n * (size_t)p->k * N);
+        c = cv.take<int32_t>(n * (size_t)N);
+        done = cv.take<int32_t>(n);
+        ctx_bad = cv.take<int32_t>(n);
+        rnd_mu = cv.take<uint8_t>(n * 96);  // rnd || mu per op: H(K || rnd || mu) input, ml_dsa.rs:199
+        rho_pp = cv.take<uint8_t>(n * 64);
+        w1 = cv.take<uint8_t>(n * (size_t)p->w1_len);
+        ctilde = cv.take<uint8_t>(n * 64);
+        kappa = cv.take<uint16_t>(n);
+        act0 = cv.take<uint32_t>(n);
+        act1 = cv.take<uint32_t>(n);
+        counter = cv.take<uint32_t>(64);
+        bytes = cv.off + 256;
+    }
+};
+}  // namespace
+
+constexpr size_t SIGN_CHUNK_OPS = 32768;
+
+int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
+               const int32_t *s1, const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs,
+               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
+               int32_t *status, size_t n_ops, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "sign: unknown parameter set");
+    if (n_ops == 0) return MLDSA_OK;
+    const size_t chunk = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
+    TRY(ensure_workspace(ctx, SignWs(nullptr, p, chunk).bytes));
+    uint32_t *h_count = nullptr;
+    MLDSA_HIP_CHECK(hipHostMalloc((void **)&h_count, sizeof(uint32_t)));
+    int rc = MLDSA_OK;
+#define TRYC(expr) do { rc = (expr); if (rc != MLDSA_OK) goto out; } while (0)
+#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rc = set_error(MLDSA_ERR_DEVICE, #expr, _e); goto out; } } while (0)
+    for (size_t o = 0; o < n_ops; o += chunk) {
+        const size_t n = (n_ops - o) < chunk ? (n_ops - o) : chunk;
+        SignWs w(ctx->ws, p, chunk);
+        const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
+        const size_t key_base = key_idx ? 0 : o;
+        uint8_t *sg = sigs + o * (size_t)p->sig_len;
+        HIPC(hipMemsetAsync(sg, 0, n * (size_t)p->sig_len, s));
+        // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
+        TRYC(launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
+        // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
+        TRYC(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
+                       w.rnd_mu + 32, 96, w.ctx_bad, n, s));
+        HIPC(hipMemcpy2DAsync(w.rnd_mu, 96, rnd + o * 32, 32, 32, n, hipMemcpyDeviceToDevice, s));
+        // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
+        TRYC(launch_shake256_2(ctx, 64, cap_k + key_base * 32, 32, 32, kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
+        // 8: kappa <- 0; active = all ops with a legal ctx
+        HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
+        TRYC(launch_init_active(ctx, n, w.ctx_bad, w.done, w.kappa, status ? status + o : nullptr, w.act0, w.counter, s));
+        HIPC(hipMemcpyAsync(h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        size_t m = *h_count;
+        uint32_t *act = w.act0, *act_next = w.act1;
+        while (m > 0) {  // 10: while (z, h) = bottom                          ml_dsa.rs:212
+            // 11: y <- ExpandMask(rho'', kappa)                               :215
+            TRYC(launch_expand_mask(ctx, set, w.rho_pp, 64, w.kappa, act, w.y, m, s));
+            // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
+            TRYC(launch_sign_w(ctx, set, w.a_hat, act, w.y, w.w, m, s));
+            // 13-15: w1 <- HighBits(w); c_tilde <- H(mu || w1Encode(w1))      :225-234
+            TRYC(launch_use_hint_w1(ctx, p, w.w, nullptr, w.w1, (size_t)p->w1_len, m, s));
+            TRYC(launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, act, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
+                                   w.ctilde, 64, m, s));
+            // 16: c <- SampleInBall(c_tilde)                                  :237
+            TRYC(launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, m, s));
+            // 17-19, 25: c_hat, <<c s1>>, <<c s2>>, <<c t0>>                   :240-260, 288-295
+            TRYC(launch_sign_cs(ctx, set, w.c, act, kidx, s1 + key_base * (size_t)p->l * N, s2 + key_base * (size_t)p->k * N,
+                                t0 + key_base * (size_t)p->k * N, w.cs1, w.cs2, w.ct0, m, s));
+            // 20-33: z, r0, h, validity checks, sigEncode or kappa += l      :262-336
+            TRYC(launch_sign_finish(ctx, p, w.y, w.w, w.cs1, w.cs2, w.ct0, w.ctilde, act, w.kappa, w.done, sg, m, s));
+            HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
+            TRYC(launch_compact(ctx, act, m, w.done, act_next, w.counter, s));
+            HIPC(hipMemcpyAsync(h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPC(hipStreamSynchronize(s));
+            m = *h_count;
+            uint32_t *tmp = act; act = act_next; act_next = tmp;
+        }
+    }
+out:
+    // y, rho'', cs1/cs2 are secret-dependent: clear them (the reference zeroizes on drop, types.rs:19)
+    (void)hipMemsetAsync(ctx->ws, 0, ctx->ws_bytes, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipHostFree(h_count);
+    return rc;
+#undef TRYC
+#undef HIPC
+}
+
 }  // namespace mldsa

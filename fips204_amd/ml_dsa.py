@@ -100,3 +100,90 @@ class MlDsa:
             _ptr(ctx_buf) if ctx_buf is not None else null, _ptr(ctx_off) if ctx_off is not None else null,
             _ptr(sigs), _ptr(ok), n_ops, _stream()))
         return ok
+
+    # ---- SerDes (src/traits.rs:372-424; src/lib.rs:421-424, 471-475) ------------------
+    def _key_bytes(self, keys, length, what):
+        if isinstance(keys, torch.Tensor):
+            if keys.dtype != torch.uint8 or keys.numel() % length:
+                raise ValueError(f"{what}: expected uint8 tensor of n * {length} bytes")
+            return keys.to(self.device).contiguous().view(-1, length)
+        for b in keys:
+            if len(b) != length:  # the reference's ByteArray is a fixed-size array type
+                raise ValueError(f"{what}: wrong length {len(b)} (expected {length})")
+        return torch.frombuffer(bytearray(b"".join(bytes(b) for b in keys)), dtype=torch.uint8).to(self.device).view(-1, length)
+
+    def public_keys_from_bytes(self, pk_bytes):
+        """PublicKey::try_from_bytes for a batch -> PublicKeys (expand_public, src/ml_dsa.rs:477)"""
+        pk = self._key_bytes(pk_bytes, self.PK_LEN, "pk")
+        n, k = pk.shape[0], self.params.k
+        rho = torch.empty((n, 32), dtype=torch.uint8, device=self.device)
+        tr = torch.empty((n, 64), dtype=torch.uint8, device=self.device)
+        t1 = torch.empty((n, k, N), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.mldsa_pk_expand(self.hp._h, self.pset, _ptr(pk), _ptr(rho), _ptr(tr), _ptr(t1), n, _stream()))
+        return PublicKeys(self.pset, rho, tr, t1)
+
+    def private_keys_from_bytes(self, sk_bytes):
+        """PrivateKey::try_from_bytes for a batch -> PrivateKeys (expand_private, src/ml_dsa.rs:445)"""
+        sk = self._key_bytes(sk_bytes, self.SK_LEN, "sk")
+        n, k, l = sk.shape[0], self.params.k, self.params.l
+        dev = self.device
+        rho = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        cap_k = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        tr = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+        s1 = torch.empty((n, l, N), dtype=torch.int32, device=dev)
+        s2 = torch.empty((n, k, N), dtype=torch.int32, device=dev)
+        t0 = torch.empty((n, k, N), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.mldsa_sk_expand(self.hp._h, self.pset, _ptr(sk), _ptr(rho), _ptr(cap_k), _ptr(tr), _ptr(s1),
+                                            _ptr(s2), _ptr(t0), n, _stream()))
+        return PrivateKeys(self.pset, rho, cap_k, tr, s1, s2, t0)
+
+    # ---- KeyGen (src/traits.rs:8-114; src/lib.rs:247-250) ------------------------------
+    def keygen_from_seed(self, xi):
+        """KG::keygen_from_seed for a batch of 32-byte seeds -> (pk bytes, sk bytes) tensors
+        [n, PK_LEN] / [n, SK_LEN] in FIPS 204 wire format (= the reference's into_bytes())."""
+        xi = self._key_bytes(xi, 32, "xi")
+        n = xi.shape[0]
+        pk = torch.empty((n, self.PK_LEN), dtype=torch.uint8, device=self.device)
+        sk = torch.empty((n, self.SK_LEN), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.mldsa_keygen(self.hp._h, self.pset, _ptr(xi), _ptr(pk), _ptr(sk), n, _stream()))
+        return pk, sk
+
+    def try_keygen_with_rng(self, rng, n=1):
+        """KG::try_keygen_with_rng: xi drawn from the caller's rng (rng.fill_bytes(32) per key)"""
+        xi = [rng.fill_bytes(32) for _ in range(n)]
+        return self.keygen_from_seed(xi)
+
+    # ---- Signer (src/traits.rs:118-308; src/lib.rs:268-342, 586-600) -------------------
+    def try_sign_with_seed(self, sks, messages, rnd, ctxs=None, key_idx=None, mode=MODE_PURE):
+        """PrivateKey::try_sign_with_seed for a batch: rnd = one 32-byte seed per op (zeros =
+        deterministic signing).  Raises ValueError if any ctx is longer than 255 bytes
+        (src/lib.rs:274).  Returns a uint8 tensor [n_ops, SIG_LEN]."""
+        n_ops = len(messages)
+        msg_buf, msg_off = _cat_with_offsets(messages, self.device)
+        ctx_buf = ctx_off = None
+        if ctxs is not None:
+            ctx_buf, ctx_off = _cat_with_offsets(ctxs, self.device)
+        if key_idx is None and len(sks) != n_ops:
+            key_idx = np.arange(n_ops, dtype=np.uint32) % len(sks)
+        kidx = None
+        if key_idx is not None:
+            kidx = torch.as_tensor(np.asarray(key_idx, dtype=np.uint32).view(np.int32)).to(self.device)
+        rnd = self._key_bytes(rnd, 32, "rnd") if n_ops else torch.zeros((1, 32), dtype=torch.uint8, device=self.device)
+        sigs = torch.empty((max(n_ops, 1), self.SIG_LEN), dtype=torch.uint8, device=self.device)
+        status = torch.zeros(max(n_ops, 1), dtype=torch.int32, device=self.device)
+        self.sign_device(sks, msg_buf, msg_off, rnd, sigs, n_ops, ctx_buf, ctx_off, kidx, mode, status)
+        torch.cuda.synchronize()
+        if n_ops and int(status[:n_ops].min()) < 0:
+            raise ValueError("ML-DSA.Sign: ctx too long")
+        return sigs[:n_ops]
+
+    def sign_device(self, sks, msg_buf, msg_off, rnd, sigs, n_ops, ctx_buf=None, ctx_off=None, key_idx=None,
+                    mode=MODE_PURE, status=None):
+        null = C.c_void_p(0)
+        _lib.check(self.lib.mldsa_sign(
+            self.hp._h, self.pset, mode, _ptr(sks.rho), _ptr(sks.cap_k), _ptr(sks.tr), _ptr(sks.s_1_hat_mont),
+            _ptr(sks.s_2_hat_mont), _ptr(sks.t_0_hat_mont), _ptr(key_idx) if key_idx is not None else null,
+            _ptr(msg_buf), _ptr(msg_off), _ptr(ctx_buf) if ctx_buf is not None else null,
+            _ptr(ctx_off) if ctx_off is not None else null, _ptr(rnd), _ptr(sigs),
+            _ptr(status) if status is not None else null, n_ops, _stream()))
+        return sigs

@@ -151,6 +151,41 @@ int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
                  const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                  const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream);
 
+/* SerDes::try_from_bytes for PublicKey (src/lib.rs:471-475) -> expand_public
+ * (src/ml_dsa.rs:477-498): pk[n][PK_LEN] -> rho[n][32], tr[n][64] = H(pk),
+ * t1_d2_hat_mont[n][K][256] = NTT(t1) * 2^13 in Montgomery form.  Never fails (the
+ * reference's range check is vacuous for 10-bit fields, conversion.rs:259-260). */
+int mldsa_pk_expand(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, uint8_t *tr,
+                    int32_t *t1_d2_hat_mont, size_t n_keys, void *stream);
+
+/* SerDes::try_from_bytes for PrivateKey (src/lib.rs:421-424) -> expand_private
+ * (src/ml_dsa.rs:445-469): sk[n][SK_LEN] -> rho, cap_k [n][32], tr [n][64],
+ * s_1_hat_mont [n][L][256], s_2_hat_mont / t_0_hat_mont [n][K][256] (Montgomery form). */
+int mldsa_sk_expand(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, uint8_t *cap_k,
+                    uint8_t *tr, int32_t *s_1_hat_mont, int32_t *s_2_hat_mont,
+                    int32_t *t_0_hat_mont, size_t n_keys, void *stream);
+
+/* KeyGen::keygen_from_seed (src/lib.rs:247-250) -> key_gen_internal (src/ml_dsa.rs:57-134)
+ * followed by SerDes::into_bytes: xi[n][32] -> pk[n][PK_LEN], sk[n][SK_LEN] (FIPS 204 wire
+ * format; expand with mldsa_pk_expand / mldsa_sk_expand to use them). */
+int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk,
+                 size_t n_keys, void *stream);
+
+/* Signer::try_sign_with_seed / _internal_sign / try_hash_sign_with_seed (src/lib.rs:268-342,
+ * 586-600) -> sign_internal (src/ml_dsa.rs:153-337) for n_ops independent operations.
+ *   Private keys EXPANDED, field by field (src/types.rs:19-28), from mldsa_sk_expand;
+ *   key_idx / msgs / ctxs / mode as in mldsa_verify.  rnd[n_ops][32]: the caller's per-
+ *   signature randomness (all zero = deterministic variant), src/lib.rs:282-283.
+ *   sigs[n_ops][SIG_LEN].  status (may be NULL): per-op MLDSA_OK or MLDSA_ERR_CTX_LEN
+ *   (|ctx| > 255, src/lib.rs:274; that op's signature is all zero).
+ *   The rejection loop (ml_dsa.rs:212-330) runs in rounds over the unfinished ops; the call
+ *   synchronises `stream` between rounds and before returning. */
+int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k,
+               const uint8_t *tr, const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont,
+               const int32_t *t_0_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+               const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
