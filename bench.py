@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("MLDSA_BENCH_WORKLOAD", "verify_arith44"))
+    ap.add_argument("--workload", default=os.environ.get("MLDSA_BENCH_WORKLOAD", "verify65"))
     ap.add_argument("--batch", type=int, default=0, help="ops per GPU (0 = the workload's BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -143,10 +143,150 @@ class VerifyArith:
                            f"oracle/liboracle.so single thread, {dt:.1f} s")
 
 
+def _shake(tag, i, width):
+    import hashlib
+    return hashlib.shake_256(tag + i.to_bytes(width, "little")).digest(32)
+
+
+class WholeOp:
+    """Whole ML-DSA verify or sign on wire-format inputs resident in HBM:
+    n_keys = min(B, 1024) keys from xi_i = SHAKE256("mldsa-bench-key" | set | i_le32), round-robin;
+    32-byte messages m_i = SHAKE256("mldsa-bench-msg" | i_le64); hedged rnd_i =
+    SHAKE256("mldsa-bench-rnd" | i_le64); empty ctx, external interface.  A_hat is re-derived
+    from rho inside every op (no cross-op reuse), like the reference (ml_dsa.rs:181, 406)."""
+
+    def __init__(self, hp, pset, kind, batch, rank):
+        from fips204_amd.ml_dsa import MlDsa, _cat_with_offsets
+        self.hp, self.pset, self.kind, self.batch, self.rank = hp, pset, kind, batch, rank
+        self.ml = ml = MlDsa(pset, hotpath=hp)
+        p = ml.params
+        self.k, self.l = p.k, p.l
+        n_keys = min(batch, 1024)
+        base = rank * batch  # global op index of this rank's first op (weak scaling: distinct data per rank)
+        xi = [_shake(b"mldsa-bench-key" + bytes([pset]), base + i, 4) for i in range(n_keys)]
+        self.msgs = [_shake(b"mldsa-bench-msg", base + i, 8) for i in range(batch)]
+        self.rnd_host = [_shake(b"mldsa-bench-rnd", base + i, 8) for i in range(batch)]
+        self.pk_bytes, self.sk_bytes = ml.keygen_from_seed(xi)
+        self.pks = ml.public_keys_from_bytes(self.pk_bytes)
+        self.sks = ml.private_keys_from_bytes(self.sk_bytes)
+        self.key_idx_host = np.arange(batch, dtype=np.uint32) % n_keys
+        self.key_idx = torch.from_numpy(self.key_idx_host.view(np.int32)).cuda()
+        self.msg_buf, self.msg_off = _cat_with_offsets(self.msgs, ml.device)
+        self.rnd = torch.frombuffer(bytearray(b"".join(self.rnd_host)), dtype=torch.uint8).cuda().view(batch, 32)
+        self.sigs = torch.empty((batch, ml.SIG_LEN), dtype=torch.uint8, device="cuda")
+        self.ok = torch.zeros(batch, dtype=torch.uint8, device="cuda")
+        self.status = torch.zeros(batch, dtype=torch.int32, device="cuda")
+        ml.sign_device(self.sks, self.msg_buf, self.msg_off, self.rnd, self.sigs, batch, key_idx=self.key_idx, status=self.status)
+        torch.cuda.synchronize()
+        self.n_sets = 1
+        kl = self.k * self.l
+        if kind == "verify":
+            self.bytes_per_op = p.pk_len + p.sig_len + 32 + 1          # SURVEY 8d: whole verify
+            self.unit = "verifies/s"
+            self.metric = f"ML-DSA-{pset} verifies/sec per GPU (batched); % HBM roofline"
+        else:
+            self.bytes_per_op = p.sk_len + 32 + 32 + p.sig_len          # SURVEY 8d: whole sign
+            self.unit = "signs/s"
+            self.metric = f"ML-DSA-{pset} signs/sec per GPU (batched); % HBM roofline"
+        # algorithmic bytes per unit of each stage's kernel (DESIGN.md "Kernels")
+        self.stage_bytes = {
+            "expand_a": 32 + 1024 * kl,
+            "verify_arith": 1024 * (kl + self.l + 1 + 2 * self.k),
+            "sign_w": 1024 * (kl + self.l + self.k),
+            "expand_mask": 66 * self.l + 1024 * self.l,
+            "sign_cs": 1024 * (1 + 2 * (self.l + 2 * self.k)),
+            "sign_finish": 1024 * (2 * self.l + 3 * self.k) + p.sig_len,
+        }
+        self.name = (f"ml_dsa_{pset} batch={batch} whole {kind} on FIPS 204 wire formats, GPU ExpandA"
+                     + ("/ExpandMask + rejection-loop re-batch" if kind == "sign" else "")
+                     + ", 32-byte messages, inputs resident in HBM")
+        self.dtype = "int32"
+        self.kernel = None
+
+    def step(self, i):
+        if self.kind == "verify":
+            self.ml.verify_device(self.pks, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch, key_idx=self.key_idx)
+        else:
+            self.ml.sign_device(self.sks, self.msg_buf, self.msg_off, self.rnd, self.sigs, self.batch, key_idx=self.key_idx,
+                                status=self.status)
+
+    def kernel_launches_per_step(self):
+        return 1
+
+    def _oracle_keys(self, n):
+        from oracle import oracle as orc
+        pkb, skb = self.pk_bytes.cpu().numpy(), self.sk_bytes.cpu().numpy()
+        pk = [orc.pk_try_from_bytes(self.pset, pkb[i].tobytes()) for i in range(n)]
+        sk = [orc.sk_try_from_bytes(self.pset, skb[i].tobytes()) for i in range(n)]
+        return pk, sk
+
+    def check(self):
+        from oracle import oracle as orc
+        n = min(8, self.batch)
+        pk, sk = self._oracle_keys(min(n, self.pk_bytes.shape[0]))
+        sig = self.sigs[:n].cpu().numpy()
+        for i in range(n):
+            ki = int(self.key_idx_host[i])
+            want = orc.sign_internal(self.pset, sk[ki], self.msgs[i], self.rnd_host[i], mode=0)
+            assert sig[i].tobytes() == want, "GPU signature differs from the oracle"
+            assert orc.verify_internal(self.pset, pk[ki], self.msgs[i], want, mode=0)
+        self.ml.verify_device(self.pks, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch, key_idx=self.key_idx)
+        torch.cuda.synchronize()
+        assert bool(self.ok.all()), "GPU verify rejected a GPU-made signature"
+
+    def cpu_baseline(self, budget_s=12.0):
+        """The KAT-pinned oracle (C, -O3 -march=native) on this box's host cores: one Python
+        thread per core, each looping over its share of the same synthetic ops (ctypes
+        releases the GIL during the C call)."""
+        import threading
+        from oracle import oracle as orc
+        n_ops = min(4096, self.batch)
+        pk, sk = self._oracle_keys(self.pk_bytes.shape[0])
+        sig = [x.tobytes() for x in self.sigs[:n_ops].cpu().numpy()]
+        kidx = [int(x) for x in self.key_idx_host[:n_ops]]
+
+        def one_op(j):
+            if self.kind == "verify":
+                orc.verify_internal(self.pset, pk[kidx[j]], self.msgs[j], sig[j], mode=0)
+            else:
+                orc.sign_internal(self.pset, sk[kidx[j]], self.msgs[j], self.rnd_host[j], mode=0)
+
+        t0 = time.perf_counter()
+        one = 0
+        while time.perf_counter() - t0 < min(3.0, budget_s / 4):
+            one_op(one % n_ops)
+            one += 1
+        one_rate = one / (time.perf_counter() - t0)
+
+        cores = os.cpu_count() or 1
+        counts = [0] * cores
+        stop = time.perf_counter() + budget_s
+
+        def work(t):
+            i = t
+            while time.perf_counter() < stop:
+                one_op(i % n_ops)
+                counts[t] += 1
+                i += cores
+
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        dt = time.perf_counter() - t0
+        done = sum(counts)
+        return dict(value=done / dt, unit=self.unit, cores=cores, kind="port", single_thread_value=one_rate,
+                    sample=f"{done} whole {self.kind} ops of the same synthetic batch (first {n_ops} ops cycled) on {cores} host "
+                           f"threads, oracle/liboracle.so (KAT-pinned C restatement, per-op ExpandA), {dt:.1f} s")
+
+
 def make_workload(name, hp, batch, rank):
     if name.startswith("verify_arith"):
         pset = int(name[len("verify_arith"):])
         return VerifyArith(hp, pset, batch or 4096, rank)
+    for kind in ("verify", "sign"):
+        if name.startswith(kind) and name[len(kind):].isdigit():
+            return WholeOp(hp, int(name[len(kind):]), kind, batch or 65536, rank)
     raise SystemExit(f"unknown workload {name!r}")
 
 
@@ -162,6 +302,9 @@ def main():
     for i in range(args.warmup):
         wl.step(i)
     torch.cuda.synchronize()
+    whole = isinstance(wl, WholeOp)
+    if whole:
+        hp.profile_enable(True)  # event pairs around every kernel launch, resolved after the timed region
 
     # timed region: exactly K steps, barrier + synchronize on both sides; per-step HIP events
     # on the launch stream give the dominant kernel's average duration for the roofline
@@ -181,10 +324,25 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / wl.kernel_launches_per_step()
     total_ops = wl.batch * world * args.steps
     value = total_ops / dt
+    stages = None
+    if whole:
+        stages = hp.profile_report()
+        hp.profile_enable(False)
     if rank != 0:
         return
 
     alg_bytes = wl.bytes_per_op * wl.batch
+    if whole:
+        # dominant kernel = the stage with the largest share of device time; its average launch
+        # duration comes from the event pairs recorded inside the timed region
+        dom = max((k for k in stages if k in wl.stage_bytes), key=lambda k: stages[k]["ms"])
+        kern_ms = stages[dom]["ms"] / stages[dom]["calls"]
+        # units (ops, or op-rounds for the per-round stages of sign) one launch processed on average
+        per_round = dom in ("expand_mask", "sign_w", "sign_cs", "sign_finish")
+        units_total = stages["_sign_slots"]["calls"] if (wl.kind == "sign" and per_round) else wl.batch * args.steps
+        per_launch_units = units_total / stages[dom]["calls"]
+        alg_bytes = wl.stage_bytes[dom] * per_launch_units
+        wl.kernel = "k_" + dom
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
@@ -200,6 +358,16 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
     }
+    if whole:
+        slots = stages.pop("_sign_slots", None)
+        total_ms = sum(v["ms"] for v in stages.values())
+        line["stage_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
+        if slots:
+            line["sign_iterations_per_signature"] = slots["calls"] / (wl.batch * args.steps)
+        line["device_busy_frac"] = total_ms / (dt * 1e3)
+        line["whole_op_hbm"] = {"algorithmic_bytes_per_op": wl.bytes_per_op,
+                                "achieved_GBs": wl.bytes_per_op * value / world / 1e9,
+                                "frac_of_peak": wl.bytes_per_op * value / world / 1e9 / HBM_PEAK_GBS}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = wl.cpu_baseline()
     print(json.dumps(line))

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "mldsa_last_error": [],
     "mldsa_get_params": [_I, C.POINTER(Params)],
     "mldsa_device_count": [],
+    "mldsa_profile_enable": [_P, _I],
+    "mldsa_profile_report": [_P, C.c_char_p, _SZ],
     "mldsa_malloc": [C.POINTER(_P), _SZ],
     "mldsa_free": [_P],
     "mldsa_memcpy_h2d": [_P, _P, _SZ, _P],

@@ -94,6 +94,7 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
         (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // secrets (y, rho'', s1..) live here: types.rs:19
         (void)hipFree(ctx->ws);
     }
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
     delete ctx;
@@ -136,6 +137,47 @@ int mldsa_memset(void *dst, int value, size_t bytes, void *stream) {
 
 int mldsa_stream_sync(void *stream) {
     MLDSA_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return MLDSA_OK;
+}
+
+// ------------------------------------------------------------------ per-stage timing
+int mldsa_profile_enable(mldsa_ctx *ctx, int on) {
+    REQUIRE(ctx, "mldsa_profile_enable: NULL ctx");
+    ctx->prof_on = on != 0;
+    ctx->prof_used = 0;
+    ctx->prof_sign_slots = 0;
+    return MLDSA_OK;
+}
+
+int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len) {
+    REQUIRE(ctx && buf && buf_len > 2, "mldsa_profile_report: bad argument");
+    MLDSA_HIP_CHECK(hipDeviceSynchronize());
+    struct Acc { const char *name; double ms; size_t calls; };
+    std::vector<Acc> acc;
+    for (size_t i = 0; i < ctx->prof_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]) != hipSuccess) continue;
+        bool found = false;
+        for (auto &a : acc)
+            if (strcmp(a.name, ctx->prof_name[i]) == 0) { a.ms += ms; a.calls++; found = true; break; }
+        if (!found) acc.push_back({ctx->prof_name[i], ms, 1});
+    }
+    std::string out = "{";
+    for (size_t i = 0; i < acc.size(); i++) {
+        char tmp[160];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"ms\": %.6f, \"calls\": %zu}", i ? ", " : "", acc[i].name, acc[i].ms, acc[i].calls);
+        out += tmp;
+    }
+    if (ctx->prof_sign_slots) {
+        char tmp[96];
+        snprintf(tmp, sizeof(tmp), "%s\"_sign_slots\": {\"ms\": 0, \"calls\": %llu}", acc.empty() ? "" : ", ", ctx->prof_sign_slots);
+        out += tmp;
+    }
+    out += "}";
+    if (out.size() + 1 > buf_len) return set_error(MLDSA_ERR_PARAM, "mldsa_profile_report: buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    ctx->prof_used = 0;
+    ctx->prof_sign_slots = 0;
     return MLDSA_OK;
 }
 

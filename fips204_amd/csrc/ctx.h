@@ -4,6 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <string>
+#include <vector>
+
 #include "../../include/mldsa_hip.h"
 #include "ntt_wave.h"
 
@@ -15,6 +18,13 @@ struct mldsa_ctx {
     // op-level pipeline workspace (grown on demand, pipeline.hip)
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // optional per-stage timing: HIP event pairs recorded on the launch stream, resolved
+    // only when the caller asks for the report (no synchronisation in the timed region)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;      // 2 events per recorded stage launch
+    std::vector<const char *> prof_name;  // stage of pair i
+    size_t prof_used = 0;                 // pairs in use
+    unsigned long long prof_sign_slots = 0;  // op-rounds run by mldsa_sign while profiling
 };
 
 namespace mldsa {
@@ -36,6 +46,31 @@ inline unsigned grid_for(const mldsa_ctx *ctx, size_t units, unsigned units_per_
     if (need < 1) need = 1;
     return (unsigned)(need < cap ? need : cap);
 }
+
+// RAII stage marker used by pipeline.hip: records an event pair around one kernel launch
+struct ProfScope {
+    mldsa_ctx *c;
+    hipStream_t s;
+    long idx = -1;
+    ProfScope(mldsa_ctx *ctx, hipStream_t stream, const char *name) : c(ctx), s(stream) {
+        if (!c->prof_on) return;
+        if (c->prof_used * 2 + 2 > c->prof_ev.size()) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return;
+                c->prof_ev.push_back(e);
+            }
+            c->prof_name.push_back(name);
+        } else {
+            c->prof_name[c->prof_used] = name;
+        }
+        idx = (long)c->prof_used++;
+        (void)hipEventRecord(c->prof_ev[2 * idx], s);
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(c->prof_ev[2 * idx + 1], s);
+    }
+};
 
 // ---- launchers (kernels_poly.hip) ----
 int launch_ntt(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);

@@ -61,6 +61,7 @@ struct VerifyWs {
 }  // namespace
 
 #define TRY(expr) do { int _rc = (expr); if (_rc != MLDSA_OK) return _rc; } while (0)
+#define STAGE(name, expr) do { ProfScope _ps(ctx, s, name); TRY(expr); } while (0)
 
 // verify_internal (ml_dsa.rs:351-437) for n_ops independent (key, message, signature) triples
 int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1,
@@ -80,23 +81,23 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
         MLDSA_HIP_CHECK(hipMemsetAsync(w.znorm, 0, n * sizeof(int32_t), s));
         // 2: (c_tilde, z, h) <- sigDecode(sigma)                         ml_dsa.rs:368-376
-        TRY(launch_sig_unpack_z(ctx, p, sg, w.z, w.znorm, n, s));
-        TRY(launch_hint_unpack(ctx, p, sg, w.hmask, w.hvalid, n, s));
+        STAGE("sig_unpack_z", launch_sig_unpack_z(ctx, p, sg, w.z, w.znorm, n, s));
+        STAGE("hint_unpack", launch_hint_unpack(ctx, p, sg, w.hmask, w.hvalid, n, s));
         // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
-        TRY(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
+        STAGE("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
                       w.mu_w1, mw, w.ctx_bad, n, s));
         // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
-        TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, s));
+        STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, s));
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
-        TRY(launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
+        STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
         // 9: w'_approx <- invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))   ml_dsa.rs:407-416
-        TRY(launch_verify_arith(ctx, set, w.a_hat, w.z, w.c, t1 + key_base * (size_t)p->k * N, kidx, w.wp, n, s));
+        STAGE("verify_arith", launch_verify_arith(ctx, set, w.a_hat, w.z, w.c, t1 + key_base * (size_t)p->k * N, kidx, w.wp, n, s));
         // 10: w1' <- UseHint(h, w'_approx); w1Encode                       ml_dsa.rs:420-428
-        TRY(launch_use_hint_w1(ctx, p, w.wp, w.hmask, w.mu_w1 + 64, mw, n, s));
+        STAGE("use_hint_w1", launch_use_hint_w1(ctx, p, w.wp, w.hmask, w.mu_w1 + 64, mw, n, s));
         // 12: c_tilde' <- H(mu || w1Encode(w1'), lambda/4)                 ml_dsa.rs:429-431
-        TRY(launch_shake256_2(ctx, p->ctilde_len, w.mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, w.ctilde_p, 64, n, s));
+        STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, w.ctilde_p, 64, n, s));
         // 13: [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]      ml_dsa.rs:434-436
-        TRY(launch_verify_verdict(ctx, p, sg, w.ctilde_p, 64, w.znorm, w.hvalid, w.ctx_bad, ok + o, n, s));
+        STAGE("verdict", launch_verify_verdict(ctx, p, sg, w.ctilde_p, 64, w.znorm, w.hvalid, w.ctx_bad, ok + o, n, s));
     }
     return MLDSA_OK;
 }
@@ -227,6 +228,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     MLDSA_HIP_CHECK(hipHostMalloc((void **)&h_count, sizeof(uint32_t)));
     int rc = MLDSA_OK;
 #define TRYC(expr) do { rc = (expr); if (rc != MLDSA_OK) goto out; } while (0)
+#define STAGEC(name, expr) do { { ProfScope _ps(ctx, s, name); rc = (expr); } if (rc != MLDSA_OK) goto out; } while (0)
 #define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rc = set_error(MLDSA_ERR_DEVICE, #expr, _e); goto out; } } while (0)
     for (size_t o = 0; o < n_ops; o += chunk) {
         const size_t n = (n_ops - o) < chunk ? (n_ops - o) : chunk;
@@ -236,13 +238,13 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         uint8_t *sg = sigs + o * (size_t)p->sig_len;
         HIPC(hipMemsetAsync(sg, 0, n * (size_t)p->sig_len, s));
         // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
-        TRYC(launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
+        STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
         // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
-        TRYC(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
+        STAGEC("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
                        w.rnd_mu + 32, 96, w.ctx_bad, n, s));
         HIPC(hipMemcpy2DAsync(w.rnd_mu, 96, rnd + o * 32, 32, 32, n, hipMemcpyDeviceToDevice, s));
         // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
-        TRYC(launch_shake256_2(ctx, 64, cap_k + key_base * 32, 32, 32, kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
+        STAGEC("rho_pp_hash", launch_shake256_2(ctx, 64, cap_k + key_base * 32, 32, 32, kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
         // 8: kappa <- 0; active = all ops with a legal ctx
         HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
         TRYC(launch_init_active(ctx, n, w.ctx_bad, w.done, w.kappa, status ? status + o : nullptr, w.act0, w.counter, s));
@@ -251,23 +253,24 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         size_t m = *h_count;
         uint32_t *act = w.act0, *act_next = w.act1;
         while (m > 0) {  // 10: while (z, h) = bottom                          ml_dsa.rs:212
+            if (ctx->prof_on) ctx->prof_sign_slots += m;
             // 11: y <- ExpandMask(rho'', kappa)                               :215
-            TRYC(launch_expand_mask(ctx, set, w.rho_pp, 64, w.kappa, act, w.y, m, s));
+            STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.kappa, act, w.y, m, s));
             // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-            TRYC(launch_sign_w(ctx, set, w.a_hat, act, w.y, w.w, m, s));
+            STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, act, w.y, w.w, m, s));
             // 13-15: w1 <- HighBits(w); c_tilde <- H(mu || w1Encode(w1))      :225-234
-            TRYC(launch_use_hint_w1(ctx, p, w.w, nullptr, w.w1, (size_t)p->w1_len, m, s));
-            TRYC(launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, act, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
+            STAGEC("high_bits_w1", launch_use_hint_w1(ctx, p, w.w, nullptr, w.w1, (size_t)p->w1_len, m, s));
+            STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, act, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
                                    w.ctilde, 64, m, s));
             // 16: c <- SampleInBall(c_tilde)                                  :237
-            TRYC(launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, m, s));
+            STAGEC("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, m, s));
             // 17-19, 25: c_hat, <<c s1>>, <<c s2>>, <<c t0>>                   :240-260, 288-295
-            TRYC(launch_sign_cs(ctx, set, w.c, act, kidx, s1 + key_base * (size_t)p->l * N, s2 + key_base * (size_t)p->k * N,
+            STAGEC("sign_cs", launch_sign_cs(ctx, set, w.c, act, kidx, s1 + key_base * (size_t)p->l * N, s2 + key_base * (size_t)p->k * N,
                                 t0 + key_base * (size_t)p->k * N, w.cs1, w.cs2, w.ct0, m, s));
             // 20-33: z, r0, h, validity checks, sigEncode or kappa += l      :262-336
-            TRYC(launch_sign_finish(ctx, p, w.y, w.w, w.cs1, w.cs2, w.ct0, w.ctilde, act, w.kappa, w.done, sg, m, s));
+            STAGEC("sign_finish", launch_sign_finish(ctx, p, w.y, w.w, w.cs1, w.cs2, w.ct0, w.ctilde, act, w.kappa, w.done, sg, m, s));
             HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
-            TRYC(launch_compact(ctx, act, m, w.done, act_next, w.counter, s));
+            STAGEC("compact", launch_compact(ctx, act, m, w.done, act_next, w.counter, s));
             HIPC(hipMemcpyAsync(h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIPC(hipStreamSynchronize(s));
             m = *h_count;
@@ -281,6 +284,7 @@ out:
     (void)hipHostFree(h_count);
     return rc;
 #undef TRYC
+#undef STAGEC
 #undef HIPC
 }
 

@@ -63,6 +63,16 @@ class HotPath:
         except Exception:
             pass
 
+    # ---- per-stage timing (HIP events on the launch stream) -----------------------
+    def profile_enable(self, on=True):
+        _lib.check(self.lib.mldsa_profile_enable(self._h, 1 if on else 0))
+
+    def profile_report(self):
+        import json
+        buf = C.create_string_buffer(8192)
+        _lib.check(self.lib.mldsa_profile_report(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
     # ---- src/ntt.rs ---------------------------------------------------------------
     def ntt(self, w, out=None):
         """ntt::<KL>(&[R; KL]) -> [T; KL]   (src/ntt.rs:14)"""

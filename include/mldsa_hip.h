@@ -62,6 +62,13 @@ const char *mldsa_last_error(void);
 int mldsa_get_params(int set, mldsa_params *out);
 int mldsa_device_count(void);
 
+/* Per-stage timing of the op-level calls (bench.py's roofline figure): while enabled, every
+ * kernel launch of mldsa_verify / mldsa_sign is bracketed by a HIP event pair on the launch
+ * stream.  mldsa_profile_report synchronises the device, writes a JSON object
+ * {"stage": {"ms": total, "calls": n}, ...} into buf and resets the counters. */
+int mldsa_profile_enable(mldsa_ctx *ctx, int on);
+int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len);
+
 /* ---- device memory helpers for hosts without their own HIP binding ------------------ */
 int mldsa_malloc(void **dev_ptr, size_t bytes);
 int mldsa_free(void *dev_ptr);
