@@ -248,7 +248,7 @@ int mldsa_expand_mask(mldsa_ctx *ctx, int set, const uint8_t *rho_pp, const uint
                       size_t n_ops, void *stream) {
     REQUIRE(params_of(set), "mldsa_expand_mask: unknown parameter set");
     REQUIRE(ctx && (n_ops == 0 || (rho_pp && kappa && y)), "mldsa_expand_mask: NULL pointer");
-    return launch_expand_mask(ctx, set, rho_pp, 64, kappa, nullptr, y, n_ops, (hipStream_t)stream);
+    return launch_expand_mask(ctx, set, rho_pp, 64, kappa, 0, nullptr, y, n_ops, (hipStream_t)stream);
 }
 
 int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_t *c, size_t n_ops, void *stream) {

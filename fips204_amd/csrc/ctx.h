@@ -86,7 +86,8 @@ int launch_verify_arith(mldsa_ctx *, int set, const int32_t *, const int32_t *, 
 // ---- launchers (kernels_sample.hip) ----
 int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride, const uint32_t *key_idx, int32_t *a_hat, size_t n_ops, hipStream_t);
 int launch_expand_s(mldsa_ctx *, int set, const uint8_t *rho_prime, size_t rho_stride, int32_t *s12, size_t n_ops, hipStream_t);
-int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t);
+int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, int kappa_by_slot,
+                       const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t);
 int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t ct_stride, int32_t *c, size_t n_ops, hipStream_t);
 
 
@@ -109,8 +110,12 @@ int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t
 int launch_sign_cs(mldsa_ctx *, int set, const int32_t *c, const uint32_t *act, const uint32_t *key_idx, const int32_t *s1,
                    const int32_t *s2, const int32_t *t0, int32_t *cs1, int32_t *cs2, int32_t *ct0, size_t n_slots, hipStream_t);
 int launch_sign_finish(mldsa_ctx *, const mldsa_params *, const int32_t *y, const int32_t *w, const int32_t *cs1, const int32_t *cs2,
-                       const int32_t *ct0, const uint8_t *ctilde, const uint32_t *act, uint16_t *kappa, int32_t *done,
-                       uint8_t *sigs, size_t n_slots, hipStream_t);
+                       const int32_t *ct0, const uint8_t *ctilde, const uint32_t *slot_op, uint16_t *kappa, int32_t *done,
+                       uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept, size_t n_slots, hipStream_t);
+int launch_make_slots(mldsa_ctx *, const uint32_t *act, size_t m, int spec, const uint16_t *kappa, int l, uint32_t *slot_op,
+                      uint16_t *slot_kappa, hipStream_t);
+int launch_resolve(mldsa_ctx *, const mldsa_params *, const uint32_t *act, size_t m, int spec, const int32_t *accept,
+                   const uint8_t *stage, size_t stage_stride, uint8_t *sigs, int32_t *done, uint16_t *kappa, hipStream_t);
 int launch_compact(mldsa_ctx *, const uint32_t *act_in, size_t n, const int32_t *done, uint32_t *act_out, uint32_t *counter, hipStream_t);
 int launch_init_active(mldsa_ctx *, size_t n, const int32_t *ctx_bad, int32_t *done, uint16_t *kappa, int32_t *status,
                        uint32_t *act_out, uint32_t *counter, hipStream_t);

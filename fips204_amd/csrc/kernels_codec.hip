@@ -22,6 +22,12 @@ __device__ __forceinline__ void static_for_c(F&& f) {
     }
 }
 
+__device__ __forceinline__ void wave_lds_sync_c() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------ high_low.rs on device
 
 // decompose (high_low.rs:66-96) for canonical r in [0, q); G2HI = (gamma2 == (q-1)/32)
@@ -228,45 +234,64 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
 }
 
 // ------------------------------------------------------------------------------------
-// Fixed-shape SHAKE256 over two concatenated device buffers A (LA bytes, per-op stride sa,
-// optional index) and B (LB bytes): out = first OUT bytes.  LA must be a multiple of 8.
+// Fixed-shape SHAKE256 over two concatenated device buffers A (la bytes, per-op stride sa,
+// optional index) and B (lb bytes) plus up to 4 literal tail bytes: out = first OUT bytes.
 //   c_tilde' = H(mu | w1)  (ml_dsa.rs:233, 429)     rho'' = H(K | rnd | mu)  (ml_dsa.rs:199)
 //   tr = H(pk)             (ml_dsa.rs:100, 486)     keygen seed = H(xi | K | L, 128) (ml_dsa.rs:68)
-// One op per lane.
-template <int OUT>
+// One op per lane for the permutation, but the INPUT is loaded cooperatively: for every rate
+// block the wave reads the 64 ops' 136-byte pieces with consecutive lanes on consecutive
+// dwords (coalesced) into an LDS tile, and each lane then absorbs its own row.  la and lb are
+// multiples of 4; ALIGNED = all pointers / strides are multiples of 4 (dword loads).
+constexpr int H_STRIDE = 35;  // dwords per tile row (136 bytes + pad, odd stride)
+
+template <int OUT, bool ALIGNED>
 __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict__ a, size_t sa, int la,
                                                        const uint32_t* __restrict__ a_idx,
                                                        const uint8_t* __restrict__ b, size_t sb, int lb,
                                                        uint32_t tail, int tail_len,
                                                        uint8_t* __restrict__ out, size_t so, size_t n_ops) {
+    __shared__ uint32_t tiles[CWAVES * 64 * H_STRIDE];
+    __shared__ unsigned long long ptr_a[CWAVES * 64], ptr_b[CWAVES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* tile = tiles + wave * 64 * H_STRIDE;
     const size_t op = (size_t)blockIdx.x * CBLOCK + threadIdx.x;
-    if (op >= n_ops) return;
-    const uint8_t* pa = a + (a_idx ? a_idx[op] : op) * sa;
-    const uint8_t* pb = b ? b + op * sb : nullptr;
-    const int total = la + lb + tail_len;  // `tail`: up to 4 literal bytes appended (e.g. K, L of keygen)
+    const bool valid = op < n_ops;
+    ptr_a[wave * 64 + lane] = valid ? (unsigned long long)(a + (a_idx ? a_idx[op] : op) * sa) : 0ull;
+    ptr_b[wave * 64 + lane] = (valid && b) ? (unsigned long long)(b + op * sb) : 0ull;
+    wave_lds_sync_c();
+    const int data = la + lb;              // bytes that come from memory
+    const int total = data + tail_len;     // message length
+    const int n_blocks = total / SHAKE256_RATE + 1;
     KeccakState st;
     keccak_zero(st);
-    const int n_blocks = total / SHAKE256_RATE + 1;
     for (int blk = 0; blk < n_blocks; blk++) {
         const int base = blk * SHAKE256_RATE;
+        // cooperative fill: element e = 64 i + lane -> (row, word)
+        for (int i = 0; i < 34; i++) {
+            const int e = 64 * i + lane;
+            const int row = e / 34, wd = e - row * 34;
+            const int off = base + 4 * wd;
+            uint32_t v = 0;
+            if (off + 4 <= data) {
+                const bool in_a = off < la;
+                const unsigned long long pp = in_a ? ptr_a[wave * 64 + row] : ptr_b[wave * 64 + row];
+                if (pp) {
+                    const uint8_t* src = reinterpret_cast<const uint8_t*>(pp) + (in_a ? off : off - la);
+                    v = ALIGNED ? *reinterpret_cast<const uint32_t*>(src) : load_le32(src);
+                }
+            }
+            tile[row * H_STRIDE + wd] = v;
+        }
+        wave_lds_sync_c();
         static_for_c<0, 17>([&](auto wc) {
             constexpr int W = decltype(wc)::value;
+            uint32_t lo = tile[lane * H_STRIDE + 2 * W], hi = tile[lane * H_STRIDE + 2 * W + 1];
             const int off = base + 8 * W;
-            uint32_t lo = 0, hi = 0;
-            if (off + 8 <= la) {
-                lo = load_le32(pa + off);
-                hi = load_le32(pa + off + 4);
-            } else if (off >= la && off + 8 <= la + lb) {
-                lo = load_le32(pb + (off - la));
-                hi = load_le32(pb + (off - la) + 4);
-            } else if (off < total + 1) {
-                // a word that straddles a segment end or holds the pad: assemble by bytes
+            if (off + 8 > data && off <= total) {  // word holds tail bytes and / or the 0x1F pad (lane-uniform)
                 for (int i = 0; i < 8; i++) {
                     const int pos = off + i;
                     uint32_t v = 0;
-                    if (pos < la) v = pa[pos];
-                    else if (pos < la + lb) v = pb[pos - la];
-                    else if (pos < total) v = (tail >> (8 * (pos - la - lb))) & 0xFF;
+                    if (pos >= data && pos < total) v = (tail >> (8 * (pos - data))) & 0xFF;
                     else if (pos == total) v = 0x1F;
                     if (i < 4) lo |= v << (8 * i); else hi |= v << (8 * (i - 4));
                 }
@@ -275,8 +300,10 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
             st.hi[W] ^= hi;
         });
         if (blk == n_blocks - 1) st.hi[16] ^= 0x80000000u;
+        wave_lds_sync_c();
         keccak_f1600(st);
     }
+    if (!valid) return;
     uint8_t* po = out + op * so;
     static_for_c<0, OUT / 8>([&](auto wc) {
         constexpr int W = decltype(wc)::value;
@@ -351,15 +378,23 @@ int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* k
 
 int launch_shake256_2(mldsa_ctx*, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                       size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
     dim3 grid(lane_blocks(n_ops)), block(CBLOCK);
-    if ((la & 7) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: first segment must be a multiple of 8 bytes");
+    if ((la & 3) != 0 || (lb & 3) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: segment lengths must be multiples of 4 bytes");
+    const bool al = (((uintptr_t)a | (uintptr_t)sa | (uintptr_t)b | (uintptr_t)sb) & 3) == 0;
+#define MLDSA_SHAKE_CASE(O)                                                                                              \
+    case O:                                                                                                              \
+        if (al) hipLaunchKernelGGL((k_shake256_2<O, true>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); \
+        else hipLaunchKernelGGL((k_shake256_2<O, false>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops);   \
+        break;
     switch (out_len) {
-        case 32: hipLaunchKernelGGL((k_shake256_2<32>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
-        case 48: hipLaunchKernelGGL((k_shake256_2<48>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
-        case 64: hipLaunchKernelGGL((k_shake256_2<64>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
-        case 128: hipLaunchKernelGGL((k_shake256_2<128>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); break;
+        MLDSA_SHAKE_CASE(32)
+        MLDSA_SHAKE_CASE(48)
+        MLDSA_SHAKE_CASE(64)
+        MLDSA_SHAKE_CASE(128)
         default: return set_error(MLDSA_ERR_PARAM, "shake256_2: unsupported output length");
     }
+#undef MLDSA_SHAKE_CASE
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
 // conversion.rs:227-262).  No rejection: all lanes advance in lock step.
 template <int GB>  // gamma1 = 2^GB, GB = 17 or 19
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __restrict__ rho_pp, size_t rho_stride,
-                                                             const uint16_t* __restrict__ kappa,
+                                                             const uint16_t* __restrict__ kappa, int kappa_by_slot,
                                                              const uint32_t* __restrict__ op_idx,
                                                              int32_t* __restrict__ y, int l, size_t n_ops) {
     constexpr int CB = GB + 1;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
     keccak_zero(st);
     {
         absorb_words<8>(st, rho_pp + op * rho_stride);
-        const uint32_t nn = ((uint32_t)kappa[op] + r) & 0xFFFFu;  // hashing.rs:293 (u16 arithmetic)
+        const uint32_t nn = ((uint32_t)kappa[kappa_by_slot ? slot : op] + r) & 0xFFFFu;  // hashing.rs:293 (u16 arithmetic)
         st.lo[8] = nn | (0x1Fu << 16);
         st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
     }
@@ -335,14 +335,14 @@ int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_st
     return MLDSA_OK;
 }
 
-int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_stride, const uint16_t* kappa,
+int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_stride, const uint16_t* kappa, int kappa_by_slot,
                        const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
     dim3 grid(stream_blocks(n_ops * (size_t)p->l)), block(64 * SWAVES);
-    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, op_idx, y, p->l, n_ops);
-    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, op_idx, y, p->l, n_ops);
+    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops);
+    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void k_sign_finish(const int32_t* __restrict__
                                                      const int32_t* __restrict__ ct0, const uint8_t* __restrict__ ctilde,
                                                      const uint32_t* __restrict__ act, uint16_t* __restrict__ kappa,
                                                      int32_t* __restrict__ done, uint8_t* __restrict__ sigs,
+                                                     int spec, uint8_t* __restrict__ stage, size_t stage_stride,
+                                                     int32_t* __restrict__ accept,
                                                      int k, int l, int gb, int beta, int omega, int ctilde_len,
                                                      size_t sig_len) {
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
@@ -209,14 +211,18 @@ __global__ __launch_bounds__(256) void k_sign_finish(const int32_t* __restrict__
         }
         const int ok = (a < gamma1 - beta) && (b < GAMMA2 - beta) && (c < GAMMA2) && (h <= omega);
         verdict = ok;
-        if (ok) done[op] = 1;
-        else kappa[op] = (uint16_t)(kappa[op] + l);  // ml_dsa.rs:281 / 316 (u16 arithmetic)
+        if (spec == 1) {
+            if (ok) done[op] = 1;
+            else kappa[op] = (uint16_t)(kappa[op] + l);  // ml_dsa.rs:281 / 316 (u16 arithmetic)
+        } else {
+            accept[slot] = ok;  // speculative candidate: k_resolve keeps the first accepted kappa of the op
+        }
     }
     __syncthreads();
     if (!verdict) return;
 
     // ---- pass 2: sigEncode
-    uint8_t* sig = sigs + op * sig_len;
+    uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
     const int cb = gb + 1;
     if (t < ctilde_len) sig[t] = ctilde[slot * 64 + t];
     // z: BitPack(z mod+- q, gamma1 - 1, gamma1): field = gamma1 - z, cb bits, 4 fields per thread
@@ -270,6 +276,41 @@ __global__ __launch_bounds__(256) void k_sign_finish(const int32_t* __restrict__
             if (bits[pi] & (1u << j)) hy[r++] = (uint8_t)(4 * lane + j);
         if (lane == 0) hy[omega + i] = (uint8_t)(base + cnt[i]);
     }
+}
+
+// Speculative rounds.  When few ops are still unfinished the GPU would idle through a long tail
+// of tiny rounds (geometric, p ~ 0.2 per iteration).  Instead each unfinished op gets `spec`
+// slots that try kappa, kappa + l, ..., kappa + (spec-1) l in the same round; k_resolve keeps
+// the FIRST accepted candidate, which is exactly the signature the sequential loop of
+// ml_dsa.rs:212-330 would have produced (all earlier candidates were rejected).
+__global__ __launch_bounds__(256) void k_make_slots(const uint32_t* __restrict__ act, size_t m, int spec,
+                                                    const uint16_t* __restrict__ kappa, int l,
+                                                    uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa) {
+    const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= m * (size_t)spec) return;
+    const uint32_t op = act[sidx / spec];
+    slot_op[sidx] = op;
+    slot_kappa[sidx] = (uint16_t)(kappa[op] + (uint32_t)(sidx % spec) * l);
+}
+
+__global__ __launch_bounds__(64) void k_resolve(const uint32_t* __restrict__ act, int spec, const int32_t* __restrict__ accept,
+                                                const uint8_t* __restrict__ stage, size_t stage_stride,
+                                                uint8_t* __restrict__ sigs, size_t sig_len, int32_t* __restrict__ done,
+                                                uint16_t* __restrict__ kappa, int l) {
+    const size_t i = blockIdx.x;
+    const uint32_t op = act[i];
+    const int lane = threadIdx.x;
+    const int mine = lane < spec ? accept[i * spec + lane] : 0;
+    const unsigned long long mask = __ballot(mine != 0);
+    if (mask == 0) {
+        if (lane == 0) kappa[op] = (uint16_t)(kappa[op] + spec * l);
+        return;
+    }
+    const int j = __ffsll((long long)mask) - 1;
+    const uint8_t* src = stage + (i * spec + j) * stage_stride;
+    uint8_t* dst = sigs + (size_t)op * sig_len;
+    for (size_t bidx = lane; bidx < sig_len; bidx += 64) dst[bidx] = src[bidx];
+    if (lane == 0) done[op] = 1;
 }
 
 // keep the unfinished ops for the next round (order is irrelevant: ops are independent)
@@ -386,16 +427,35 @@ int launch_sign_cs(mldsa_ctx* ctx, int set, const int32_t* c, const uint32_t* ac
 
 int launch_sign_finish(mldsa_ctx*, const mldsa_params* p, const int32_t* y, const int32_t* w, const int32_t* cs1,
                        const int32_t* cs2, const int32_t* ct0, const uint8_t* ctilde, const uint32_t* act, uint16_t* kappa,
-                       int32_t* done, uint8_t* sigs, size_t n_slots, hipStream_t s) {
+                       int32_t* done, uint8_t* sigs, int spec, uint8_t* stage, size_t stage_stride, int32_t* accept,
+                       size_t n_slots, hipStream_t s) {
     if (n_slots == 0) return MLDSA_OK;
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
     dim3 grid((unsigned)n_slots), block(256);
     if (p->gamma2 == (Q - 1) / 32)
-        hipLaunchKernelGGL((k_sign_finish<true>), grid, block, 0, s, y, w, cs1, cs2, ct0, ctilde, act, kappa, done, sigs, p->k,
-                           p->l, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len);
+        hipLaunchKernelGGL((k_sign_finish<true>), grid, block, 0, s, y, w, cs1, cs2, ct0, ctilde, act, kappa, done, sigs, spec, stage,
+                           stage_stride, accept, p->k, p->l, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len);
     else
-        hipLaunchKernelGGL((k_sign_finish<false>), grid, block, 0, s, y, w, cs1, cs2, ct0, ctilde, act, kappa, done, sigs, p->k,
-                           p->l, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len);
+        hipLaunchKernelGGL((k_sign_finish<false>), grid, block, 0, s, y, w, cs1, cs2, ct0, ctilde, act, kappa, done, sigs, spec, stage,
+                           stage_stride, accept, p->k, p->l, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_make_slots(mldsa_ctx*, const uint32_t* act, size_t m, int spec, const uint16_t* kappa, int l, uint32_t* slot_op,
+                      uint16_t* slot_kappa, hipStream_t s) {
+    if (m == 0) return MLDSA_OK;
+    const size_t n = m * (size_t)spec;
+    hipLaunchKernelGGL(k_make_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act, m, spec, kappa, l, slot_op, slot_kappa);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_resolve(mldsa_ctx*, const mldsa_params* p, const uint32_t* act, size_t m, int spec, const int32_t* accept,
+                   const uint8_t* stage, size_t stage_stride, uint8_t* sigs, int32_t* done, uint16_t* kappa, hipStream_t s) {
+    if (m == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)m), dim3(64), 0, s, act, spec, accept, stage, stage_stride, sigs,
+                       (size_t)p->sig_len, done, kappa, p->l);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -2,12 +2,13 @@
 // reference's callers on the device, chunk by chunk.
 //   verify_batch  = verify_internal  (src/ml_dsa.rs:351-437)
 // Intermediates live in one context-owned workspace that grows on demand (sized for HBM:
-// a 16384-op chunk of ML-DSA-87 needs ~1.1 GiB, mostly A_hat).
+// a 65536-op chunk of ML-DSA-87 needs ~4.5 GiB, mostly A_hat; fixed per-kernel latencies are
+// amortised over whole-batch launches).
 #include "ctx.h"
 
 namespace mldsa {
 
-constexpr size_t CHUNK_OPS = 16384;
+constexpr size_t CHUNK_OPS = 65536;
 
 int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return MLDSA_OK;
@@ -183,37 +184,46 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
 // Signer::try_sign_* -> sign_internal (ml_dsa.rs:153-337) with the rejection loop re-batched:
 // every round runs one loop iteration for all unfinished ops, then compacts the active list.
 namespace {
+constexpr size_t SPEC_TARGET_SLOTS = 32768;  // keep at least this many candidate slots per round
+constexpr int SPEC_MAX = 32;                 // candidates per op per round (0.8^32 < 0.1 % all-fail)
+
 struct SignWs {
-    int32_t *a_hat, *y, *w, *cs1, *cs2, *ct0, *c, *done, *ctx_bad;
-    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde;
-    uint16_t *kappa;
-    uint32_t *act0, *act1, *counter;
-    size_t bytes;
+    int32_t *a_hat, *y, *w, *cs1, *cs2, *ct0, *c, *done, *ctx_bad, *accept;
+    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage;
+    uint16_t *kappa, *slot_kappa;
+    uint32_t *act0, *act1, *slot_op, *counter;
+    size_t bytes, stage_stride;
     SignWs(void *base, const mldsa_params *p, size_t n) {
         Carver cv(base);
+        const size_t ns = n > SPEC_TARGET_SLOTS ? n : SPEC_TARGET_SLOTS;  // slots per round
+        stage_stride = ((size_t)p->sig_len + 15) & ~(size_t)15;
         a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
-        y = cv.take<int32_t>(n * (size_t)p->l * N);
-        w = cv.take<int32_t>(n * (size_t)p->k * N);
-        cs1 = cv.take<int32_t>(n * (size_t)p->l * N);
-        cs2 = cv.take<int32_t>(n * (size_t)p->k * N);
-        ct0 = cv.take<int32_t>(n * (size_t)p->k * N);
-        c = cv.take<int32_t>(n * (size_t)N);
+        y = cv.take<int32_t>(ns * (size_t)p->l * N);
+        w = cv.take<int32_t>(ns * (size_t)p->k * N);
+        cs1 = cv.take<int32_t>(ns * (size_t)p->l * N);
+        cs2 = cv.take<int32_t>(ns * (size_t)p->k * N);
+        ct0 = cv.take<int32_t>(ns * (size_t)p->k * N);
+        c = cv.take<int32_t>(ns * (size_t)N);
         done = cv.take<int32_t>(n);
         ctx_bad = cv.take<int32_t>(n);
+        accept = cv.take<int32_t>(ns);
         rnd_mu = cv.take<uint8_t>(n * 96);  // rnd || mu per op: H(K || rnd || mu) input, ml_dsa.rs:199
         rho_pp = cv.take<uint8_t>(n * 64);
-        w1 = cv.take<uint8_t>(n * (size_t)p->w1_len);
-        ctilde = cv.take<uint8_t>(n * 64);
+        w1 = cv.take<uint8_t>(ns * (size_t)p->w1_len);
+        ctilde = cv.take<uint8_t>(ns * 64);
+        stage = cv.take<uint8_t>(SPEC_TARGET_SLOTS * stage_stride);
         kappa = cv.take<uint16_t>(n);
+        slot_kappa = cv.take<uint16_t>(ns);
         act0 = cv.take<uint32_t>(n);
         act1 = cv.take<uint32_t>(n);
+        slot_op = cv.take<uint32_t>(ns);
         counter = cv.take<uint32_t>(64);
         bytes = cv.off + 256;
     }
 };
 }  // namespace
 
-constexpr size_t SIGN_CHUNK_OPS = 32768;
+constexpr size_t SIGN_CHUNK_OPS = 65536;
 
 int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
                const int32_t *s1, const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs,
@@ -253,22 +263,33 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         size_t m = *h_count;
         uint32_t *act = w.act0, *act_next = w.act1;
         while (m > 0) {  // 10: while (z, h) = bottom                          ml_dsa.rs:212
-            if (ctx->prof_on) ctx->prof_sign_slots += m;
+            // candidates per op this round (1 while the active set fills the GPU)
+            int spec = 1;
+            if (m * 2 <= SPEC_TARGET_SLOTS) {
+                const size_t sp = SPEC_TARGET_SLOTS / m;
+                spec = sp > (size_t)SPEC_MAX ? SPEC_MAX : (int)sp;
+            }
+            const size_t ns = m * (size_t)spec;
+            if (ctx->prof_on) ctx->prof_sign_slots += ns;
+            STAGEC("make_slots", launch_make_slots(ctx, act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, s));
             // 11: y <- ExpandMask(rho'', kappa)                               :215
-            STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.kappa, act, w.y, m, s));
+            STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, s));
             // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-            STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, act, w.y, w.w, m, s));
+            STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, w.slot_op, w.y, w.w, ns, s));
             // 13-15: w1 <- HighBits(w); c_tilde <- H(mu || w1Encode(w1))      :225-234
-            STAGEC("high_bits_w1", launch_use_hint_w1(ctx, p, w.w, nullptr, w.w1, (size_t)p->w1_len, m, s));
-            STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, act, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
-                                   w.ctilde, 64, m, s));
+            STAGEC("high_bits_w1", launch_use_hint_w1(ctx, p, w.w, nullptr, w.w1, (size_t)p->w1_len, ns, s));
+            STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
+                                   w.ctilde, 64, ns, s));
             // 16: c <- SampleInBall(c_tilde)                                  :237
-            STAGEC("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, m, s));
+            STAGEC("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns, s));
             // 17-19, 25: c_hat, <<c s1>>, <<c s2>>, <<c t0>>                   :240-260, 288-295
-            STAGEC("sign_cs", launch_sign_cs(ctx, set, w.c, act, kidx, s1 + key_base * (size_t)p->l * N, s2 + key_base * (size_t)p->k * N,
-                                t0 + key_base * (size_t)p->k * N, w.cs1, w.cs2, w.ct0, m, s));
+            STAGEC("sign_cs", launch_sign_cs(ctx, set, w.c, w.slot_op, kidx, s1 + key_base * (size_t)p->l * N, s2 + key_base * (size_t)p->k * N,
+                                t0 + key_base * (size_t)p->k * N, w.cs1, w.cs2, w.ct0, ns, s));
             // 20-33: z, r0, h, validity checks, sigEncode or kappa += l      :262-336
-            STAGEC("sign_finish", launch_sign_finish(ctx, p, w.y, w.w, w.cs1, w.cs2, w.ct0, w.ctilde, act, w.kappa, w.done, sg, m, s));
+            STAGEC("sign_finish", launch_sign_finish(ctx, p, w.y, w.w, w.cs1, w.cs2, w.ct0, w.ctilde, w.slot_op, w.kappa, w.done, sg, spec,
+                                                     w.stage, w.stage_stride, w.accept, ns, s));
+            if (spec > 1)
+                STAGEC("resolve", launch_resolve(ctx, p, act, m, spec, w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa, s));
             HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
             STAGEC("compact", launch_compact(ctx, act, m, w.done, act_next, w.counter, s));
             HIPC(hipMemcpyAsync(h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
