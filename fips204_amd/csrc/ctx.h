@@ -106,7 +106,7 @@ int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs
 // ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
 int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, size_t n_ops, hipStream_t);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
-                      uint32_t scale_q, int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
+                      int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
 int launch_sign_cs(mldsa_ctx *, int set, const int32_t *c, const uint32_t *act, const uint32_t *key_idx, const int32_t *s1,
                    const int32_t *s2, const int32_t *t0, int32_t *cs1, int32_t *cs2, int32_t *ct0, size_t n_slots, hipStream_t);
 int launch_sign_finish(mldsa_ctx *, const mldsa_params *, const int32_t *y, const int32_t *w, const int32_t *cs1, const int32_t *cs2,

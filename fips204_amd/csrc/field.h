@@ -2,8 +2,7 @@
 //
 // Replaces the scalar helpers of the reference: mont_reduce (src/helpers.rs:156-165),
 // partial_reduce32 (61-67), full_reduce32 (70-76), center_mod (88-95), to_mont (131-135).
-// Only results mod q are observable (SURVEY.md appendix "Montgomery bookkeeping"), so the
-// device code uses the 32-bit hi/lo formulation: hi32(a*b) - hi32(lo32(a*b*qinv)*q).
+// Only results mod q are observable (SURVEY.md appendix "Montgomery bookkeeping").
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,25 +13,18 @@ constexpr int32_t Q = 8380417;            // lib.rs:109
 constexpr uint32_t QINV = 58728449u;      // q * QINV = 1 mod 2^32 (helpers.rs:157)
 constexpr int32_t R_MOD_Q = 4193792;      // 2^32 mod q
 constexpr int32_t R2_MOD_Q = 2365951;     // 2^64 mod q
-constexpr uint32_t R2_MOD_Q_QINV = 2145647103u;
 constexpr int32_t F_MONT = 16382;         // 256^-1 * 2^32 mod q (ntt.rs:88)
-constexpr uint32_t F_MONT_QINV = 16777214u;
 constexpr int32_t F_MONT2 = 41978;        // 256^-1 * 2^64 mod q (inverse NTT of R^-1-scaled input)
-constexpr uint32_t F_MONT2_QINV = 4286571514u;
 constexpr int N = 256;
 
-// a * b * 2^-32 mod q, result in (-q, q); |a*b| < 2^31 * q.  Both operands variable.
+// a * b * 2^-32 mod q, result in (-q, q); |a*b| < 2^31 * q.  Same computation as the reference's
+// mont_reduce (helpers.rs:156-165); hipcc lowers it to v_mad_i64_i32, v_mul_lo_u32,
+// v_mad_i64_i32 -- three full-rate instructions on gfx950 (profiles/r01_ubench_valu.txt), with
+// no precomputed zeta * qinv companion to keep in registers.
 __device__ __forceinline__ int32_t mont_mul(int32_t a, int32_t b) {
-    uint32_t lo = (uint32_t)a * (uint32_t)b;
-    int32_t t = (int32_t)(lo * QINV);
-    return __mulhi(a, b) - __mulhi(t, Q);
-}
-
-// Same with a constant/twiddle b whose companion bq = b * QINV mod 2^32 is precomputed
-// (saves one multiply per butterfly).
-__device__ __forceinline__ int32_t mont_mul_c(int32_t a, int32_t b, uint32_t bq) {
-    int32_t t = (int32_t)((uint32_t)a * bq);
-    return __mulhi(a, b) - __mulhi(t, Q);
+    const int64_t p = (int64_t)a * b;
+    const int32_t t = (int32_t)((uint32_t)p * QINV);
+    return (int32_t)(((int64_t)t * (-Q) + p) >> 32);
 }
 
 // helpers.rs:61-67: |a| < 2^31 - 2^22  ->  (-q, q)
@@ -54,6 +46,6 @@ __device__ __forceinline__ int32_t center(int32_t a) {
 }
 
 // x * 2^32 mod q (reference to_mont, helpers.rs:131-135), result in (-q, q)
-__device__ __forceinline__ int32_t to_mont(int32_t x) { return mont_mul_c(x, R2_MOD_Q, R2_MOD_Q_QINV); }
+__device__ __forceinline__ int32_t to_mont(int32_t x) { return mont_mul(x, R2_MOD_Q); }
 
 }  // namespace mldsa

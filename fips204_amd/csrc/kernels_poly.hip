@@ -5,6 +5,8 @@
 //
 // Replaces src/ntt.rs (ntt, inv_ntt) and the poly helpers of src/helpers.rs (mat_vec_mul,
 // to_mont, add_vector_ntt, infinity_norm) of the reference.
+#include <cstdlib>
+
 #include "ctx.h"
 
 namespace mldsa {
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(BLOCK) void k_inv_ntt(const int32_t *__restrict__ i
         load_packed(r, in + p * N, lane);
 #pragma unroll
         for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
-        ntt_inv_wave(r, tw, lane, F_MONT, F_MONT_QINV);
+        ntt_inv_wave(r, tw, lane, F_MONT);
         store_strided(r, out + p * N, lane);
     }
 }
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
             ntt_fwd_wave(r, ftw, lane);
             if (wave == L) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) r[k] = mont_mul_c(r[k], 1, QINV);  // c_hat * 2^-32
+                for (int k = 0; k < 4; k++) r[k] = mont_mul(r[k], 1);  // c_hat * 2^-32
             }
             lds[wave * 64 + lane] = make_int4(r[0], r[1], r[2], r[3]);
         }
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
-            ntt_inv_wave(acc, itw, lane, F_MONT2, F_MONT2_QINV);
+            ntt_inv_wave(acc, itw, lane, F_MONT2);
             store_strided(acc, w_out + (op * K + wave) * (size_t)N, lane);
         }
         __syncthreads();
@@ -280,10 +282,15 @@ int launch_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t ppo, size_
     return MLDSA_OK;
 }
 
+static unsigned tune_blocks_per_cu(unsigned dflt) {
+    const char *e = getenv("MLDSA_VA_BLOCKS_PER_CU");  // tuning knob for experiments
+    return e ? (unsigned)atoi(e) : dflt;
+}
+
 int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t *z, const int32_t *c, const int32_t *t1,
                         const uint32_t *key_idx, int32_t *w, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, 6));
+    dim3 grid(grid_for(ctx, n_ops, 1, tune_blocks_per_cu(6)));
     const uint32_t *no_idx = nullptr;
     if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), grid, dim3(64 * 5), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
     else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), grid, dim3(64 * 6), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);

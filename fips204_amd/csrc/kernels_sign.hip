@@ -10,7 +10,6 @@ namespace mldsa {
 constexpr int GWAVES = 4;
 constexpr int GBLOCK = 64 * GWAVES;
 constexpr int32_t C13_MONT2 = 6346488;       // 2^13 * 2^64 mod q:  x -> x * 2^13 * 2^32 (ml_dsa.rs:108-113)
-constexpr uint32_t C13_MONT2_QINV = 2134890232u;
 
 // `bits`-wide little-endian field starting at bit offset `bo`; never reads past the field
 __device__ __forceinline__ uint32_t load_bits(const uint8_t* p, int bo, int bits) {
@@ -28,7 +27,7 @@ __device__ __forceinline__ uint32_t load_bits(const uint8_t* p, int bo, int bits
 // polynomial: the deserialisation half of expand_public / expand_private
 // (ml_dsa.rs:445-498).  value = b - field (or the field itself when b < 0).
 __global__ __launch_bounds__(GBLOCK) void k_unpack_ntt(const uint8_t* __restrict__ src, size_t key_stride, size_t poly_off,
-                                                       int bits, int b, int32_t scale, uint32_t scale_q,
+                                                       int bits, int b, int32_t scale,
                                                        int32_t* __restrict__ out, int polys_per_key, size_t n_keys,
                                                        const Twiddle* __restrict__ fwd_tab) {
     const int lane = threadIdx.x & 63;
@@ -49,7 +48,7 @@ __global__ __launch_bounds__(GBLOCK) void k_unpack_ntt(const uint8_t* __restrict
         }
         ntt_fwd_wave(r, tw, lane);
 #pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = mont_mul_c(r[k], scale, scale_q);
+        for (int k = 0; k < 4; k++) r[k] = mont_mul(r[k], scale);
         store_packed(r, out + p * N, lane);
     }
 }
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(64 * K) void k_sign_cs(const int32_t* __restrict__ 
             r[1] = mont_mul(cv.y, v[1]);
             r[2] = mont_mul(cv.z, v[2]);
             r[3] = mont_mul(cv.w, v[3]);
-            ntt_inv_wave(r, itw, lane, F_MONT, F_MONT_QINV);
+            ntt_inv_wave(r, itw, lane, F_MONT);
             store_strided(r, dst, lane);
         }
         __syncthreads();
@@ -406,10 +405,10 @@ __global__ __launch_bounds__(GBLOCK) void k_keygen_encode(const int32_t* __restr
 
 // ------------------------------------------------------------------------- launchers
 int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
-                      uint32_t scale_q, int32_t* out, int polys_per_key, size_t n_keys, hipStream_t s) {
+                      int32_t* out, int polys_per_key, size_t n_keys, hipStream_t s) {
     if (n_keys == 0) return MLDSA_OK;
     hipLaunchKernelGGL(k_unpack_ntt, dim3(grid_for(ctx, n_keys * (size_t)polys_per_key, GWAVES, 8)), dim3(GBLOCK), 0, s, src,
-                       key_stride, poly_off, bits, b, scale, scale_q, out, polys_per_key, n_keys, ctx->d_fwd_tw);
+                       key_stride, poly_off, bits, b, scale, out, polys_per_key, n_keys, ctx->d_fwd_tw);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -24,10 +24,8 @@
 
 namespace mldsa {
 
-struct Twiddle {
-    int32_t z;    // zeta * 2^32 mod q (forward) or -zeta * 2^32 mod q (inverse), helpers.rs:171-184
-    uint32_t zq;  // z * QINV mod 2^32
-};
+// zeta * 2^32 mod q (forward) or -zeta * 2^32 mod q (inverse), helpers.rs:171-184
+typedef int32_t Twiddle;
 
 constexpr int FWD_TW = 12;  // levels s = 5..0, two butterflies per lane
 constexpr int INV_TW = 14;  // levels s = 0..6, two butterflies per lane
@@ -35,9 +33,7 @@ constexpr int INV_TW = 14;  // levels s = 0..6, two butterflies per lane
 // Uniform twiddles of the in-lane forward levels (ZETA_TABLE_MONT[1..3]) and of the last
 // inverse level (-ZETA_TABLE_MONT[1]).
 constexpr int32_t ZF1 = 25847, ZF2 = 5771523, ZF3 = 7861508;
-constexpr uint32_t ZF1Q = 1830765815u, ZF2Q = 2365092099u, ZF3Q = 2367190276u;
 constexpr int32_t ZI1 = -25847;
-constexpr uint32_t ZI1Q = 2464201481u;
 
 struct FwdTw { Twiddle t[FWD_TW]; };
 struct InvTw { Twiddle t[INV_TW]; };
@@ -103,73 +99,73 @@ __device__ __forceinline__ void xchg_lo(int32_t r[4], int lane) {
 }
 
 // ntt.rs:47-54  t = zeta * b;  b = a - t;  a = a + t   (no reduction on add/sub)
-__device__ __forceinline__ void bf_ct(int32_t& a, int32_t& b, int32_t z, uint32_t zq) {
-    int32_t t = mont_mul_c(b, z, zq);
+__device__ __forceinline__ void bf_ct(int32_t& a, int32_t& b, int32_t z) {
+    int32_t t = mont_mul(b, z);
     b = a - t;
     a = a + t;
 }
 // ntt.rs:122-132  a = t + b;  b = (-zeta) * (t - b)
-__device__ __forceinline__ void bf_gs(int32_t& a, int32_t& b, int32_t z, uint32_t zq) {
+__device__ __forceinline__ void bf_gs(int32_t& a, int32_t& b, int32_t z) {
     int32_t t = a;
     a = t + b;
-    b = mont_mul_c(t - b, z, zq);
+    b = mont_mul(t - b, z);
 }
 
 // Forward NTT.  In: r[k] = w[64k + lane], |w| < q (callers reduce32 on load).
 // Out: r[k] = w_hat[4 lane + k], |w_hat| < 9q, plain domain (ntt.rs:14-76).
 __device__ __forceinline__ void ntt_fwd_wave(int32_t r[4], const FwdTw& tw, int lane) {
-    bf_ct(r[0], r[2], ZF1, ZF1Q);
-    bf_ct(r[1], r[3], ZF1, ZF1Q);
-    bf_ct(r[0], r[1], ZF2, ZF2Q);
-    bf_ct(r[2], r[3], ZF3, ZF3Q);
+    bf_ct(r[0], r[2], ZF1);
+    bf_ct(r[1], r[3], ZF1);
+    bf_ct(r[0], r[1], ZF2);
+    bf_ct(r[2], r[3], ZF3);
     xchg_hi<32>(r, lane);
-    bf_ct(r[0], r[2], tw.t[0].z, tw.t[0].zq);
-    bf_ct(r[1], r[3], tw.t[1].z, tw.t[1].zq);
+    bf_ct(r[0], r[2], tw.t[0]);
+    bf_ct(r[1], r[3], tw.t[1]);
     xchg_lo<16>(r, lane);
-    bf_ct(r[0], r[1], tw.t[2].z, tw.t[2].zq);
-    bf_ct(r[2], r[3], tw.t[3].z, tw.t[3].zq);
+    bf_ct(r[0], r[1], tw.t[2]);
+    bf_ct(r[2], r[3], tw.t[3]);
     xchg_hi<8>(r, lane);
-    bf_ct(r[0], r[2], tw.t[4].z, tw.t[4].zq);
-    bf_ct(r[1], r[3], tw.t[5].z, tw.t[5].zq);
+    bf_ct(r[0], r[2], tw.t[4]);
+    bf_ct(r[1], r[3], tw.t[5]);
     xchg_lo<4>(r, lane);
-    bf_ct(r[0], r[1], tw.t[6].z, tw.t[6].zq);
-    bf_ct(r[2], r[3], tw.t[7].z, tw.t[7].zq);
+    bf_ct(r[0], r[1], tw.t[6]);
+    bf_ct(r[2], r[3], tw.t[7]);
     xchg_hi<2>(r, lane);
-    bf_ct(r[0], r[2], tw.t[8].z, tw.t[8].zq);
-    bf_ct(r[1], r[3], tw.t[9].z, tw.t[9].zq);
+    bf_ct(r[0], r[2], tw.t[8]);
+    bf_ct(r[1], r[3], tw.t[9]);
     xchg_lo<1>(r, lane);
-    bf_ct(r[0], r[1], tw.t[10].z, tw.t[10].zq);
-    bf_ct(r[2], r[3], tw.t[11].z, tw.t[11].zq);
+    bf_ct(r[0], r[1], tw.t[10]);
+    bf_ct(r[2], r[3], tw.t[11]);
 }
 
 // Inverse NTT.  In: r[k] = w_hat[4 lane + k], |w_hat| < q.  Out: r[k] = w[64k + lane],
 // canonical [0, q) after the final scaling by `f` (F_MONT: plain -> plain as ntt.rs:152-154;
 // F_MONT2: input carries a factor 2^-32).  |intermediates| < 256 q < 2^31.
-__device__ __forceinline__ void ntt_inv_wave(int32_t r[4], const InvTw& tw, int lane, int32_t f, uint32_t fq) {
-    bf_gs(r[0], r[1], tw.t[0].z, tw.t[0].zq);
-    bf_gs(r[2], r[3], tw.t[1].z, tw.t[1].zq);
-    bf_gs(r[0], r[2], tw.t[2].z, tw.t[2].zq);
-    bf_gs(r[1], r[3], tw.t[3].z, tw.t[3].zq);
+__device__ __forceinline__ void ntt_inv_wave(int32_t r[4], const InvTw& tw, int lane, int32_t f) {
+    bf_gs(r[0], r[1], tw.t[0]);
+    bf_gs(r[2], r[3], tw.t[1]);
+    bf_gs(r[0], r[2], tw.t[2]);
+    bf_gs(r[1], r[3], tw.t[3]);
     xchg_lo<1>(r, lane);
-    bf_gs(r[0], r[1], tw.t[4].z, tw.t[4].zq);
-    bf_gs(r[2], r[3], tw.t[5].z, tw.t[5].zq);
+    bf_gs(r[0], r[1], tw.t[4]);
+    bf_gs(r[2], r[3], tw.t[5]);
     xchg_hi<2>(r, lane);
-    bf_gs(r[0], r[2], tw.t[6].z, tw.t[6].zq);
-    bf_gs(r[1], r[3], tw.t[7].z, tw.t[7].zq);
+    bf_gs(r[0], r[2], tw.t[6]);
+    bf_gs(r[1], r[3], tw.t[7]);
     xchg_lo<4>(r, lane);
-    bf_gs(r[0], r[1], tw.t[8].z, tw.t[8].zq);
-    bf_gs(r[2], r[3], tw.t[9].z, tw.t[9].zq);
+    bf_gs(r[0], r[1], tw.t[8]);
+    bf_gs(r[2], r[3], tw.t[9]);
     xchg_hi<8>(r, lane);
-    bf_gs(r[0], r[2], tw.t[10].z, tw.t[10].zq);
-    bf_gs(r[1], r[3], tw.t[11].z, tw.t[11].zq);
+    bf_gs(r[0], r[2], tw.t[10]);
+    bf_gs(r[1], r[3], tw.t[11]);
     xchg_lo<16>(r, lane);
-    bf_gs(r[0], r[1], tw.t[12].z, tw.t[12].zq);
-    bf_gs(r[2], r[3], tw.t[13].z, tw.t[13].zq);
+    bf_gs(r[0], r[1], tw.t[12]);
+    bf_gs(r[2], r[3], tw.t[13]);
     xchg_hi<32>(r, lane);
-    bf_gs(r[0], r[2], ZI1, ZI1Q);
-    bf_gs(r[1], r[3], ZI1, ZI1Q);
+    bf_gs(r[0], r[2], ZI1);
+    bf_gs(r[1], r[3], ZI1);
 #pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = freeze(mont_mul_c(r[k], f, fq));
+    for (int k = 0; k < 4; k++) r[k] = freeze(mont_mul(r[k], f));
 }
 
 // coalesced I/O in the two layouts

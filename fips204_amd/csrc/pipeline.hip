@@ -113,7 +113,7 @@ int pk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, ui
     MLDSA_HIP_CHECK(hipMemcpy2DAsync(rho, 32, pk, (size_t)p->pk_len, 32, n, hipMemcpyDeviceToDevice, s));
     TRY(launch_shake256_2(ctx, 64, pk, (size_t)p->pk_len, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, tr, 64, n, s));  // tr = H(pk)
     // t1_d2_hat_mont = ntt(t1) * 2^13 * 2^32  (ml_dsa.rs:492-495)
-    TRY(launch_unpack_ntt(ctx, pk, (size_t)p->pk_len, 32, 10, -1, 6346488, 2134890232u, t1, p->k, n, s));
+    TRY(launch_unpack_ntt(ctx, pk, (size_t)p->pk_len, 32, 10, -1, 6346488, t1, p->k, n, s));
     return MLDSA_OK;
 }
 
@@ -128,9 +128,9 @@ int sk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, ui
     MLDSA_HIP_CHECK(hipMemcpy2DAsync(rho, 32, sk, skl, 32, n, hipMemcpyDeviceToDevice, s));
     MLDSA_HIP_CHECK(hipMemcpy2DAsync(cap_k, 32, sk + 32, skl, 32, n, hipMemcpyDeviceToDevice, s));
     MLDSA_HIP_CHECK(hipMemcpy2DAsync(tr, 64, sk + 64, skl, 64, n, hipMemcpyDeviceToDevice, s));
-    TRY(launch_unpack_ntt(ctx, sk, skl, 128, eb, p->eta, R2_MOD_Q, R2_MOD_Q_QINV, s1, p->l, n, s));
-    TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)p->l * 32 * eb, eb, p->eta, R2_MOD_Q, R2_MOD_Q_QINV, s2, p->k, n, s));
-    TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)(p->l + p->k) * 32 * eb, 13, 1 << 12, R2_MOD_Q, R2_MOD_Q_QINV, t0, p->k, n, s));
+    TRY(launch_unpack_ntt(ctx, sk, skl, 128, eb, p->eta, R2_MOD_Q, s1, p->l, n, s));
+    TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)p->l * 32 * eb, eb, p->eta, R2_MOD_Q, s2, p->k, n, s));
+    TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)(p->l + p->k) * 32 * eb, 13, 1 << 12, R2_MOD_Q, t0, p->k, n, s));
     return MLDSA_OK;
 }
 

@@ -9,7 +9,6 @@
 namespace mldsa {
 
 static constexpr int64_t Q64 = 8380417;
-static constexpr uint32_t QINV32 = 58728449u;
 
 void gen_zeta_table_mont(int32_t out[256]) {
     int64_t x = 1;
@@ -34,12 +33,7 @@ struct Layout {
     void xchg_lo(int m) { swap_pair(m, 0, 1); swap_pair(m, 2, 3); }
 };
 
-HostTwiddle make_tw(int64_t z) {
-    HostTwiddle t;
-    t.z = (int32_t)z;
-    t.zq = (uint32_t)t.z * QINV32;
-    return t;
-}
+HostTwiddle make_tw(int64_t z) { return (HostTwiddle)z; }
 
 }  // namespace
 

@@ -5,10 +5,7 @@
 
 namespace mldsa {
 
-struct HostTwiddle {
-    int32_t z;
-    uint32_t zq;
-};
+typedef int32_t HostTwiddle;
 
 // ZETA_TABLE_MONT of the reference (src/helpers.rs:171-184): table[brv8(i)] = zeta^i * 2^32 mod q
 void gen_zeta_table_mont(int32_t out[256]);
