@@ -162,12 +162,14 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
     constexpr int W = K > L + 1 ? K : L + 1;
     constexpr int NIN = HAS_C ? L + 1 : L;  // polynomials transformed in phase 1
     __shared__ int4 lds[(L + 1) * 64];
+    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];  // block-shared twiddles, read at the point of use
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    FwdTw ftw;
-    InvTw itw;
-    if (wave < NIN) load_fwd_tw(ftw, fwd_tab, lane);
-    if (wave < K) load_inv_tw(itw, inv_tab, lane);
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * W) tw_lds[i] = fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * W) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
+    __syncthreads();
+    const LdsTw ftw{tw_lds, lane};
+    const LdsTw itw{tw_lds + FWD_TW * 64, lane};
 
     for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
         // issue this wave's row of A_hat and its t1 row early
@@ -221,7 +223,6 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
         }
         __syncthreads();
     }
-    (void)W;
 }
 
 // ------------------------------------------------------------------------- launchers
@@ -290,7 +291,7 @@ static unsigned tune_blocks_per_cu(unsigned dflt) {
 int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t *z, const int32_t *c, const int32_t *t1,
                         const uint32_t *key_idx, int32_t *w, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, tune_blocks_per_cu(6)));
+    dim3 grid(grid_for(ctx, n_ops, 1, tune_blocks_per_cu(12)));
     const uint32_t *no_idx = nullptr;
     if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), grid, dim3(64 * 5), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
     else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), grid, dim3(64 * 6), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
@@ -304,7 +305,7 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, size_t n_ops,
                   hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, 6));
+    dim3 grid(grid_for(ctx, n_ops, 1, 12));
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
     if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, false>), grid, dim3(64 * 5), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);

@@ -64,11 +64,13 @@ __global__ __launch_bounds__(64 * K) void k_sign_cs(const int32_t* __restrict__ 
                                                     int32_t* __restrict__ cs2, int32_t* __restrict__ ct0, size_t n_slots,
                                                     const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab) {
     __shared__ int4 chat[64];
+    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    FwdTw ftw;
-    InvTw itw;
-    if (wave == 0) load_fwd_tw(ftw, fwd_tab, lane);
-    load_inv_tw(itw, inv_tab, lane);
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * K) tw_lds[i] = fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * K) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
+    __syncthreads();
+    const LdsTw ftw{tw_lds, lane};
+    const LdsTw itw{tw_lds + FWD_TW * 64, lane};
     for (size_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
         const size_t op = act ? act[slot] : slot;
         const size_t key = key_idx ? key_idx[op] : op;
@@ -416,7 +418,7 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
 int launch_sign_cs(mldsa_ctx* ctx, int set, const int32_t* c, const uint32_t* act, const uint32_t* key_idx, const int32_t* s1,
                    const int32_t* s2, const int32_t* t0, int32_t* cs1, int32_t* cs2, int32_t* ct0, size_t n_slots, hipStream_t s) {
     if (n_slots == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_slots, 1, 6));
+    dim3 grid(grid_for(ctx, n_slots, 1, 12));
     if (set == MLDSA_44) hipLaunchKernelGGL((k_sign_cs<4, 4>), grid, dim3(64 * 4), 0, s, c, act, key_idx, s1, s2, t0, cs1, cs2, ct0, n_slots, ctx->d_fwd_tw, ctx->d_inv_tw);
     else if (set == MLDSA_65) hipLaunchKernelGGL((k_sign_cs<6, 5>), grid, dim3(64 * 6), 0, s, c, act, key_idx, s1, s2, t0, cs1, cs2, ct0, n_slots, ctx->d_fwd_tw, ctx->d_inv_tw);
     else hipLaunchKernelGGL((k_sign_cs<8, 7>), grid, dim3(64 * 8), 0, s, c, act, key_idx, s1, s2, t0, cs1, cs2, ct0, n_slots, ctx->d_fwd_tw, ctx->d_inv_tw);

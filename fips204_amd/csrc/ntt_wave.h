@@ -35,8 +35,22 @@ constexpr int INV_TW = 14;  // levels s = 0..6, two butterflies per lane
 constexpr int32_t ZF1 = 25847, ZF2 = 5771523, ZF3 = 7861508;
 constexpr int32_t ZI1 = -25847;
 
-struct FwdTw { Twiddle t[FWD_TW]; };
-struct InvTw { Twiddle t[INV_TW]; };
+// Twiddle providers.  FwdTw / InvTw keep the lane's twiddles in registers (standalone NTT
+// kernels: a wave loops over many polynomials); LdsTw reads them from a block-shared LDS copy
+// at the point of use (fused kernels, where registers are better spent on prefetched data).
+struct FwdTw {
+    Twiddle t[FWD_TW];
+    __device__ __forceinline__ Twiddle get(int i) const { return t[i]; }
+};
+struct InvTw {
+    Twiddle t[INV_TW];
+    __device__ __forceinline__ Twiddle get(int i) const { return t[i]; }
+};
+struct LdsTw {
+    const Twiddle* base;  // [n][64] in LDS
+    int lane;
+    __device__ __forceinline__ Twiddle get(int i) const { return base[i * 64 + lane]; }
+};
 
 __device__ __forceinline__ void load_fwd_tw(FwdTw& tw, const Twiddle* __restrict__ tab, int lane) {
 #pragma unroll
@@ -113,54 +127,56 @@ __device__ __forceinline__ void bf_gs(int32_t& a, int32_t& b, int32_t z) {
 
 // Forward NTT.  In: r[k] = w[64k + lane], |w| < q (callers reduce32 on load).
 // Out: r[k] = w_hat[4 lane + k], |w_hat| < 9q, plain domain (ntt.rs:14-76).
-__device__ __forceinline__ void ntt_fwd_wave(int32_t r[4], const FwdTw& tw, int lane) {
+template <class TW>
+__device__ __forceinline__ void ntt_fwd_wave(int32_t r[4], const TW& tw, int lane) {
     bf_ct(r[0], r[2], ZF1);
     bf_ct(r[1], r[3], ZF1);
     bf_ct(r[0], r[1], ZF2);
     bf_ct(r[2], r[3], ZF3);
     xchg_hi<32>(r, lane);
-    bf_ct(r[0], r[2], tw.t[0]);
-    bf_ct(r[1], r[3], tw.t[1]);
+    bf_ct(r[0], r[2], tw.get(0));
+    bf_ct(r[1], r[3], tw.get(1));
     xchg_lo<16>(r, lane);
-    bf_ct(r[0], r[1], tw.t[2]);
-    bf_ct(r[2], r[3], tw.t[3]);
+    bf_ct(r[0], r[1], tw.get(2));
+    bf_ct(r[2], r[3], tw.get(3));
     xchg_hi<8>(r, lane);
-    bf_ct(r[0], r[2], tw.t[4]);
-    bf_ct(r[1], r[3], tw.t[5]);
+    bf_ct(r[0], r[2], tw.get(4));
+    bf_ct(r[1], r[3], tw.get(5));
     xchg_lo<4>(r, lane);
-    bf_ct(r[0], r[1], tw.t[6]);
-    bf_ct(r[2], r[3], tw.t[7]);
+    bf_ct(r[0], r[1], tw.get(6));
+    bf_ct(r[2], r[3], tw.get(7));
     xchg_hi<2>(r, lane);
-    bf_ct(r[0], r[2], tw.t[8]);
-    bf_ct(r[1], r[3], tw.t[9]);
+    bf_ct(r[0], r[2], tw.get(8));
+    bf_ct(r[1], r[3], tw.get(9));
     xchg_lo<1>(r, lane);
-    bf_ct(r[0], r[1], tw.t[10]);
-    bf_ct(r[2], r[3], tw.t[11]);
+    bf_ct(r[0], r[1], tw.get(10));
+    bf_ct(r[2], r[3], tw.get(11));
 }
 
 // Inverse NTT.  In: r[k] = w_hat[4 lane + k], |w_hat| < q.  Out: r[k] = w[64k + lane],
 // canonical [0, q) after the final scaling by `f` (F_MONT: plain -> plain as ntt.rs:152-154;
 // F_MONT2: input carries a factor 2^-32).  |intermediates| < 256 q < 2^31.
-__device__ __forceinline__ void ntt_inv_wave(int32_t r[4], const InvTw& tw, int lane, int32_t f) {
-    bf_gs(r[0], r[1], tw.t[0]);
-    bf_gs(r[2], r[3], tw.t[1]);
-    bf_gs(r[0], r[2], tw.t[2]);
-    bf_gs(r[1], r[3], tw.t[3]);
+template <class TW>
+__device__ __forceinline__ void ntt_inv_wave(int32_t r[4], const TW& tw, int lane, int32_t f) {
+    bf_gs(r[0], r[1], tw.get(0));
+    bf_gs(r[2], r[3], tw.get(1));
+    bf_gs(r[0], r[2], tw.get(2));
+    bf_gs(r[1], r[3], tw.get(3));
     xchg_lo<1>(r, lane);
-    bf_gs(r[0], r[1], tw.t[4]);
-    bf_gs(r[2], r[3], tw.t[5]);
+    bf_gs(r[0], r[1], tw.get(4));
+    bf_gs(r[2], r[3], tw.get(5));
     xchg_hi<2>(r, lane);
-    bf_gs(r[0], r[2], tw.t[6]);
-    bf_gs(r[1], r[3], tw.t[7]);
+    bf_gs(r[0], r[2], tw.get(6));
+    bf_gs(r[1], r[3], tw.get(7));
     xchg_lo<4>(r, lane);
-    bf_gs(r[0], r[1], tw.t[8]);
-    bf_gs(r[2], r[3], tw.t[9]);
+    bf_gs(r[0], r[1], tw.get(8));
+    bf_gs(r[2], r[3], tw.get(9));
     xchg_hi<8>(r, lane);
-    bf_gs(r[0], r[2], tw.t[10]);
-    bf_gs(r[1], r[3], tw.t[11]);
+    bf_gs(r[0], r[2], tw.get(10));
+    bf_gs(r[1], r[3], tw.get(11));
     xchg_lo<16>(r, lane);
-    bf_gs(r[0], r[1], tw.t[12]);
-    bf_gs(r[2], r[3], tw.t[13]);
+    bf_gs(r[0], r[1], tw.get(12));
+    bf_gs(r[2], r[3], tw.get(13));
     xchg_hi<32>(r, lane);
     bf_gs(r[0], r[2], ZI1);
     bf_gs(r[1], r[3], ZI1);
