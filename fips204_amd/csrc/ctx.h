@@ -112,6 +112,10 @@ int launch_sign_cs(mldsa_ctx *, int set, const int32_t *c, const uint32_t *act, 
 int launch_sign_finish(mldsa_ctx *, const mldsa_params *, const int32_t *y, const int32_t *w, const int32_t *cs1, const int32_t *cs2,
                        const int32_t *ct0, const uint8_t *ctilde, const uint32_t *slot_op, uint16_t *kappa, int32_t *done,
                        uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept, size_t n_slots, hipStream_t);
+int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,
+                     const uint32_t *slot_op, const uint32_t *key_idx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
+                     uint16_t *kappa, int32_t *done, uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept,
+                     size_t n_slots, hipStream_t);
 int launch_make_slots(mldsa_ctx *, const uint32_t *act, size_t m, int spec, const uint16_t *kappa, int l, uint32_t *slot_op,
                       uint16_t *slot_kappa, hipStream_t);
 int launch_resolve(mldsa_ctx *, const mldsa_params *, const uint32_t *act, size_t m, int spec, const int32_t *accept,

@@ -282,12 +282,12 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
                                    w.ctilde, 64, ns, s));
             // 16: c <- SampleInBall(c_tilde)                                  :237
             STAGEC("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns, s));
-            // 17-19, 25: c_hat, <<c s1>>, <<c s2>>, <<c t0>>                   :240-260, 288-295
-            STAGEC("sign_cs", launch_sign_cs(ctx, set, w.c, w.slot_op, kidx, s1 + key_base * (size_t)p->l * N, s2 + key_base * (size_t)p->k * N,
-                                t0 + key_base * (size_t)p->k * N, w.cs1, w.cs2, w.ct0, ns, s));
-            // 20-33: z, r0, h, validity checks, sigEncode or kappa += l      :262-336
-            STAGEC("sign_finish", launch_sign_finish(ctx, p, w.y, w.w, w.cs1, w.cs2, w.ct0, w.ctilde, w.slot_op, w.kappa, w.done, sg, spec,
-                                                     w.stage, w.stage_stride, w.accept, ns, s));
+            // 17: c_hat <- NTT(c), in place                                   :240
+            STAGEC("ntt_c", launch_ntt(ctx, w.c, w.c, ns, s));
+            // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
+            STAGEC("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1 + key_base * (size_t)p->l * N,
+                                                 s2 + key_base * (size_t)p->k * N, t0 + key_base * (size_t)p->k * N, w.kappa, w.done, sg,
+                                                 spec, w.stage, w.stage_stride, w.accept, ns, s));
             if (spec > 1)
                 STAGEC("resolve", launch_resolve(ctx, p, act, m, spec, w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa, s));
             HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
