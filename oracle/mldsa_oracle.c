@@ -11,6 +11,7 @@
  */
 #include "mldsa_oracle.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -938,4 +939,66 @@ void orc_verify_arith_batch(int k, int l, const int32_t *a_hat, const int32_t *z
     for (size_t i = 0; i < n_ops; i++)
         orc_verify_arith(k, l, a_hat + i * (size_t)(k * l) * N, z + i * (size_t)l * N, c + i * N,
                          t1 + i * (size_t)k * N, w_out + i * (size_t)k * N);
+}
+
+/* ------------------------------------------------------------------------- */
+/* multi-threaded batch legs (pthreads) for bench.py's cpu_baseline: the same */
+/* per-op functions, ops dealt round-robin to n_threads host threads          */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int set, kind, mode, tid, n_threads;
+    const orc_pubkey *pks;
+    const orc_privkey *sks;
+    const uint32_t *key_idx;
+    const uint8_t *msgs, *sigs_in, *rnds;
+    uint8_t *ok, *sigs_out;
+    size_t mlen, n_ops, repeat;
+} mt_job;
+
+static void *mt_worker(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    const orc_params *p = orc_get_params(j->set);
+    for (size_t rep = 0; rep < j->repeat; rep++)
+        for (size_t i = (size_t)j->tid; i < j->n_ops; i += (size_t)j->n_threads) {
+            const uint32_t k = j->key_idx[i];
+            if (j->kind == 0)
+                j->ok[i] = (uint8_t)orc_verify_internal(j->set, &j->pks[k], j->msgs + i * j->mlen, j->mlen, NULL, 0,
+                                                        j->sigs_in + i * (size_t)p->sig_len, j->mode);
+            else
+                orc_sign_internal(j->set, &j->sks[k], j->msgs + i * j->mlen, j->mlen, NULL, 0, j->rnds + i * 32, j->mode,
+                                  j->sigs_out + i * (size_t)p->sig_len, NULL);
+        }
+    return NULL;
+}
+
+static void mt_run(mt_job *proto, int n_threads) {
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t] = *proto;
+        jobs[t].tid = t;
+        jobs[t].n_threads = n_threads;
+        pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+}
+
+void orc_verify_batch_mt(int set, const orc_pubkey *pks, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                         const uint8_t *sigs, size_t n_ops, int mode, uint8_t *ok, int n_threads, size_t repeat) {
+    mt_job j;
+    memset(&j, 0, sizeof(j));
+    j.set = set; j.kind = 0; j.mode = mode; j.pks = pks; j.key_idx = key_idx; j.msgs = msgs; j.mlen = mlen;
+    j.sigs_in = sigs; j.n_ops = n_ops; j.ok = ok; j.repeat = repeat;
+    mt_run(&j, n_threads);
+}
+
+void orc_sign_batch_mt(int set, const orc_privkey *sks, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                       const uint8_t *rnds, size_t n_ops, int mode, uint8_t *sigs, int n_threads, size_t repeat) {
+    mt_job j;
+    memset(&j, 0, sizeof(j));
+    j.set = set; j.kind = 1; j.mode = mode; j.sks = sks; j.key_idx = key_idx; j.msgs = msgs; j.mlen = mlen;
+    j.rnds = rnds; j.n_ops = n_ops; j.sigs_out = sigs; j.repeat = repeat;
+    mt_run(&j, n_threads);
 }

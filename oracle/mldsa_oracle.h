@@ -142,6 +142,12 @@ void orc_sign_batch(int set, const orc_privkey *sks, size_t n_keys, const uint8_
 void orc_verify_arith_batch(int k, int l, const int32_t *a_hat, const int32_t *z, const int32_t *c,
                             const int32_t *t1, int32_t *w_out, size_t n_ops);
 
+/* multi-threaded (pthreads) versions: ops dealt round-robin to n_threads; `repeat` passes */
+void orc_verify_batch_mt(int set, const orc_pubkey *pks, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                         const uint8_t *sigs, size_t n_ops, int mode, uint8_t *ok, int n_threads, size_t repeat);
+void orc_sign_batch_mt(int set, const orc_privkey *sks, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                       const uint8_t *rnds, size_t n_ops, int mode, uint8_t *sigs, int n_threads, size_t repeat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,3 +307,31 @@ def verify_internal(pset, pk, msg, sig, ctx=b"", mode=MODE_INTERNAL):
         return False
     return bool(lib().orc_verify_internal(C.c_int(pset), C.byref(pk), _u8(msg), C.c_size_t(len(msg)),
                                           _u8(ctx), C.c_size_t(len(ctx)), _u8(sig), C.c_int(mode)))
+
+
+# ---- multi-threaded batch legs (cpu_baseline of bench.py) ------------------------------
+def verify_batch_mt(pset, pks, key_idx, msgs, sigs, n_threads, repeat=1, mode=MODE_PURE):
+    """pks: list of PubKey; msgs: list of equal-length byte strings; sigs: list of SIG_LEN byte strings."""
+    n = len(msgs)
+    arr = (PubKey * len(pks))(*pks)
+    kidx = np.ascontiguousarray(key_idx, dtype=np.uint32)
+    mlen = len(msgs[0])
+    mb, sb = b"".join(msgs), b"".join(sigs)
+    ok = (C.c_uint8 * n)()
+    lib().orc_verify_batch_mt(C.c_int(pset), arr, kidx.ctypes.data_as(C.c_void_p), mb, C.c_size_t(mlen), sb, C.c_size_t(n),
+                              C.c_int(mode), ok, C.c_int(n_threads), C.c_size_t(repeat))
+    return np.frombuffer(bytes(ok), dtype=np.uint8).astype(bool)
+
+
+def sign_batch_mt(pset, sks, key_idx, msgs, rnds, n_threads, repeat=1, mode=MODE_PURE):
+    n = len(msgs)
+    arr = (PrivKey * len(sks))(*sks)
+    kidx = np.ascontiguousarray(key_idx, dtype=np.uint32)
+    mlen = len(msgs[0])
+    mb, rb = b"".join(msgs), b"".join(rnds)
+    out = (C.c_uint8 * (n * params(pset).sig_len))()
+    lib().orc_sign_batch_mt(C.c_int(pset), arr, kidx.ctypes.data_as(C.c_void_p), mb, C.c_size_t(mlen), rb, C.c_size_t(n),
+                            C.c_int(mode), out, C.c_int(n_threads), C.c_size_t(repeat))
+    sl = params(pset).sig_len
+    raw = bytes(out)
+    return [raw[i * sl:(i + 1) * sl] for i in range(n)]
