@@ -8,6 +8,7 @@
 
 #include "ctx.h"
 #include "keccak.h"
+#include "ntt_wave.h"
 
 namespace mldsa {
 
@@ -157,6 +158,121 @@ __global__ __launch_bounds__(CBLOCK) void k_use_hint_w1(const int32_t* __restric
             dst[3 * lane + 1] = (uint8_t)(packed >> 8);
             dst[3 * lane + 2] = (uint8_t)(packed >> 16);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Whole-verify arithmetic in one kernel (ml_dsa.rs:368-372, 407-428): one block per op,
+//   phase 1: wave j < L unpacks z[j] straight from the signature bytes into NTT registers
+//            (bit_unpack, conversion.rs:227-262; also the ||z||inf test of ml_dsa.rs:434),
+//            wave L transforms c; results to LDS
+//   phase 2: wave i < K: A_hat[i] o z_hat - c_hat o t1_hat[i] -> inverse NTT -> UseHint
+//            (high_low.rs:155-192) -> w1Encode (encodings.rs:338-360) -> packed bytes
+// so neither z, w' nor w1' ever exist as int32 polynomials in HBM.
+template <int K, int L, int GB, bool G2HI>
+__global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
+    const int32_t* __restrict__ a_hat, const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
+    const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint32_t* __restrict__ key_idx,
+    const uint32_t* __restrict__ hmask, uint8_t* __restrict__ w1, size_t w1_stride, int32_t* __restrict__ znorm,
+    size_t n_ops, const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab) {
+    constexpr int W = K > L + 1 ? K : L + 1;
+    constexpr int CB = GB + 1;
+    constexpr int BITS = G2HI ? 4 : 6;
+    __shared__ int4 lds[(L + 1) * 64];
+    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * W) tw_lds[i] = fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * W) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
+    __syncthreads();
+    const LdsTw ftw{tw_lds, lane};
+    const LdsTw itw{tw_lds + FWD_TW * 64, lane};
+
+    for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
+        int4 av[L];
+        int4 tv = make_int4(0, 0, 0, 0);
+        uint32_t hw[4] = {0, 0, 0, 0};
+        if (wave < K) {
+            const int4* ap = reinterpret_cast<const int4*>(a_hat + ((op * K + wave) * (size_t)L) * N);
+#pragma unroll
+            for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
+            const size_t key = key_idx ? key_idx[op] : op;
+            tv = reinterpret_cast<const int4*>(t1 + (key * K + wave) * (size_t)N)[lane];
+            // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5)
+#pragma unroll
+            for (int k = 0; k < 4; k++) hw[k] = hmask[(op * K + wave) * 8 + 2 * k + (lane >> 5)];
+        }
+        if (wave <= L) {
+            int32_t r[4];
+            if (wave < L) {
+                const uint8_t* src = sigs + op * sig_len + ctilde_len + (size_t)wave * (32 * CB);
+                int32_t mx = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int bo = (64 * k + lane) * CB;
+                    const uint32_t v = (load_le32(src + (bo >> 3)) >> (bo & 7)) & ((1u << CB) - 1u);
+                    r[k] = (1 << GB) - (int32_t)v;
+                    const int32_t a = r[k] < 0 ? -r[k] : r[k];
+                    mx = a > mx ? a : mx;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const int32_t o = __shfl_xor(mx, m);
+                    mx = o > mx ? o : mx;
+                }
+                if (lane == 0) atomicMax(&znorm[op], mx);
+            } else {
+                load_strided(r, c + op * (size_t)N, lane);
+            }
+            ntt_fwd_wave(r, ftw, lane);
+            if (wave == L) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = mont_mul(r[k], 1);  // c_hat * 2^-32
+            }
+            lds[wave * 64 + lane] = make_int4(r[0], r[1], r[2], r[3]);
+        }
+        __syncthreads();
+        if (wave < K) {
+            int32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                const int4 zv = lds[j * 64 + lane];
+                acc[0] += mont_mul(av[j].x, zv.x);
+                acc[1] += mont_mul(av[j].y, zv.y);
+                acc[2] += mont_mul(av[j].z, zv.z);
+                acc[3] += mont_mul(av[j].w, zv.w);
+            }
+            const int4 cv = lds[L * 64 + lane];
+            acc[0] -= mont_mul(cv.x, tv.x);
+            acc[1] -= mont_mul(cv.y, tv.y);
+            acc[2] -= mont_mul(cv.z, tv.z);
+            acc[3] -= mont_mul(cv.w, tv.w);
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
+            ntt_inv_wave(acc, itw, lane, F_MONT2);
+            // acc[k] = w'[64 k + lane], canonical.  UseHint, then pack BITS-bit fields: coefficient
+            // pairs (4-bit) / quads (6-bit) sit in adjacent lanes of the same register.
+            uint8_t* dst = w1 + op * w1_stride + (size_t)wave * (32 * BITS);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t h = (hw[k] >> (lane & 31)) & 1u;
+                const uint32_t v = (uint32_t)use_hint<G2HI>((int32_t)h, acc[k]);
+                if constexpr (G2HI) {
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // lane ^ 1
+                    if (!(lane & 1)) dst[32 * k + (lane >> 1)] = (uint8_t)(v | (nb << 4));
+                } else {
+                    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+                    const uint32_t pair = (lane & 1) ? 0u : (v | (n1 << 6));                                      // 12 bits in even lanes
+                    const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pair, 0x4E, 0xF, 0xF, false);  // lane ^ 2
+                    if (!(lane & 3)) {
+                        const uint32_t q24 = pair | (n2 << 12);
+                        uint8_t* d = dst + 48 * k + 3 * (lane >> 2);
+                        d[0] = (uint8_t)q24; d[1] = (uint8_t)(q24 >> 8); d[2] = (uint8_t)(q24 >> 16);
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -363,6 +479,23 @@ int launch_use_hint_w1(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* w, 
         hipLaunchKernelGGL((k_use_hint_w1<true>), grid, block, 0, s, w, hmask, w1, p->k, w1_stride, n_ops);
     else
         hipLaunchKernelGGL((k_use_hint_w1<false>), grid, block, 0, s, w, hmask, w1, p->k, w1_stride, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_hat, const uint8_t* sigs, const int32_t* c,
+                       const int32_t* t1, const uint32_t* key_idx, const uint32_t* hmask, uint8_t* w1, size_t w1_stride,
+                       int32_t* znorm, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    dim3 grid(grid_for(ctx, n_ops, 1, 12));
+#define MLDSA_VM(KK, LL, GB, G2)                                                                                             \
+    hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2>), grid, dim3(64 * (KK > LL + 1 ? KK : LL + 1)), 0, s, a_hat, sigs,     \
+                       (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, n_ops, ctx->d_fwd_tw, \
+                       ctx->d_inv_tw)
+    if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false);
+    else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true);
+    else MLDSA_VM(8, 7, 19, true);
+#undef MLDSA_VM
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

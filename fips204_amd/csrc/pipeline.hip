@@ -81,8 +81,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
         MLDSA_HIP_CHECK(hipMemsetAsync(w.znorm, 0, n * sizeof(int32_t), s));
-        // 2: (c_tilde, z, h) <- sigDecode(sigma)                         ml_dsa.rs:368-376
-        STAGE("sig_unpack_z", launch_sig_unpack_z(ctx, p, sg, w.z, w.znorm, n, s));
+        // 2: (c_tilde, z, h) <- sigDecode(sigma): hints here, z inside k_verify_main      ml_dsa.rs:368-376
         STAGE("hint_unpack", launch_hint_unpack(ctx, p, sg, w.hmask, w.hvalid, n, s));
         // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
         STAGE("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
@@ -91,10 +90,9 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, s));
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
         STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
-        // 9: w'_approx <- invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))   ml_dsa.rs:407-416
-        STAGE("verify_arith", launch_verify_arith(ctx, set, w.a_hat, w.z, w.c, t1 + key_base * (size_t)p->k * N, kidx, w.wp, n, s));
-        // 10: w1' <- UseHint(h, w'_approx); w1Encode                       ml_dsa.rs:420-428
-        STAGE("use_hint_w1", launch_use_hint_w1(ctx, p, w.wp, w.hmask, w.mu_w1 + 64, mw, n, s));
+        // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
+        STAGE("verify_main", launch_verify_main(ctx, p, w.a_hat, sg, w.c, t1 + key_base * (size_t)p->k * N, kidx, w.hmask,
+                                                w.mu_w1 + 64, mw, w.znorm, n, s));
         // 12: c_tilde' <- H(mu || w1Encode(w1'), lambda/4)                 ml_dsa.rs:429-431
         STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, w.ctilde_p, 64, n, s));
         // 13: [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]      ml_dsa.rs:434-436
