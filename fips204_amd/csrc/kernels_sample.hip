@@ -46,17 +46,28 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // Flush: lane row `r` holds take[r] dwords that continue stream r's polynomial at
-// coefficient n[r].  Two streams per iteration (half-wave each, <= 32 dwords per row).
-__device__ __forceinline__ void flush_rows(const uint32_t* stage, int32_t* __restrict__ out, size_t wave_base,
+// coefficient n[r].  Two streams per iteration (half-wave each, <= 32 dwords per row).  The
+// per-row (n, take) pairs go through a 64-word LDS table so that every LDS read of a batch of
+// 8 iterations is independent and can be in flight together (one wait per batch).
+__device__ __forceinline__ void flush_rows(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
                                            int take, int n, int lane) {
+    meta[lane] = ((uint32_t)n << 8) | (uint32_t)take;
     wave_lds_sync();
     const int half = lane >> 5, l5 = lane & 31;
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        const int row = 2 * i + half;
-        const int c_r = __shfl(take, row);
-        const int n_r = __shfl(n, row);
-        if (l5 < c_r) out[(wave_base + row) * N + n_r + l5] = (int32_t)stage[row * STAGE_STRIDE + l5];
+#pragma unroll 1
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+        uint32_t m[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = 2 * (i0 + u) + half;
+            m[u] = meta[row];
+            v[u] = stage[row * STAGE_STRIDE + l5];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = 2 * (i0 + u) + half;
+            if (l5 < (int)(m[u] & 0xFFu)) out[(wave_base + row) * N + (m[u] >> 8) + l5] = (int32_t)v[u];
+        }
     }
     wave_lds_sync();
 }
@@ -70,8 +81,10 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restr
                                                           const uint32_t* __restrict__ key_idx,
                                                           int32_t* __restrict__ a_hat, size_t n_ops) {
     __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    __shared__ uint32_t meta_lds[SWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
+    uint32_t* meta = meta_lds + wave * 64;
     uint32_t* my = stage + lane * STAGE_STRIDE;
     const size_t g = (size_t)blockIdx.x * (64 * SWAVES) + threadIdx.x;
     const size_t wave_base = g - lane;
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restr
                 cnt += (z < (uint32_t)Q) ? 1 : 0;
             });
             const int take = min(cnt, N - n);
-            flush_rows(stage, a_hat, wave_base, take, n, lane);
+            flush_rows(stage, meta, a_hat, wave_base, take, n, lane);
             n += take;
         });
     }
@@ -128,8 +141,10 @@ template <int ETA>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restrict__ rho_prime, size_t rho_stride,
                                                           int32_t* __restrict__ s12, int polys_per_op, size_t n_ops) {
     __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    __shared__ uint32_t meta_lds[SWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
+    uint32_t* meta = meta_lds + wave * 64;
     uint32_t* my = stage + lane * STAGE_STRIDE;
     const size_t g = (size_t)blockIdx.x * (64 * SWAVES) + threadIdx.x;
     const size_t wave_base = g - lane;
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
                 }
             });
             const int take = min(cnt, N - n);
-            flush_rows(stage, s12, wave_base, take, n, lane);
+            flush_rows(stage, meta, s12, wave_base, take, n, lane);
             n += take;
         });
     }
