@@ -4,6 +4,8 @@
 // Intermediates live in one context-owned workspace that grows on demand (sized for HBM:
 // a 65536-op chunk of ML-DSA-87 needs ~4.5 GiB, mostly A_hat; fixed per-kernel latencies are
 // amortised over whole-batch launches).
+#include <cstdlib>
+
 #include "ctx.h"
 
 namespace mldsa {
@@ -182,8 +184,8 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
 // Signer::try_sign_* -> sign_internal (ml_dsa.rs:153-337) with the rejection loop re-batched:
 // every round runs one loop iteration for all unfinished ops, then compacts the active list.
 namespace {
-constexpr size_t SPEC_TARGET_SLOTS = 32768;  // keep at least this many candidate slots per round
-constexpr int SPEC_MAX = 32;                 // candidates per op per round (0.8^32 < 0.1 % all-fail)
+constexpr size_t SPEC_TARGET_SLOTS = 65536;  // upper bound of candidate slots per speculative round (workspace size)
+constexpr int SPEC_MAX = 64;                 // candidates per op per round (0.8^32 < 0.1 % all-fail)
 
 struct SignWs {
     int32_t *a_hat, *y, *w, *cs1, *cs2, *ct0, *c, *done, *ctx_bad, *accept;
@@ -234,6 +236,11 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     TRY(ensure_workspace(ctx, SignWs(nullptr, p, chunk).bytes));
     uint32_t *h_count = nullptr;
     MLDSA_HIP_CHECK(hipHostMalloc((void **)&h_count, sizeof(uint32_t)));
+    // tuning knobs (experiments): slots per round to aim for, candidates per op per round
+    size_t spec_target = 32768;
+    int spec_max = 32;
+    if (const char *e = getenv("MLDSA_SPEC_TARGET")) { size_t v = (size_t)atol(e); if (v >= 1 && v <= SPEC_TARGET_SLOTS) spec_target = v; }
+    if (const char *e = getenv("MLDSA_SPEC_MAX")) { int v = atoi(e); if (v >= 1 && v <= 64) spec_max = v; }
     int rc = MLDSA_OK;
 #define TRYC(expr) do { rc = (expr); if (rc != MLDSA_OK) goto out; } while (0)
 #define STAGEC(name, expr) do { { ProfScope _ps(ctx, s, name); rc = (expr); } if (rc != MLDSA_OK) goto out; } while (0)
@@ -263,9 +270,9 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         while (m > 0) {  // 10: while (z, h) = bottom                          ml_dsa.rs:212
             // candidates per op this round (1 while the active set fills the GPU)
             int spec = 1;
-            if (m * 2 <= SPEC_TARGET_SLOTS) {
-                const size_t sp = SPEC_TARGET_SLOTS / m;
-                spec = sp > (size_t)SPEC_MAX ? SPEC_MAX : (int)sp;
+            if (m * 2 <= spec_target) {
+                const size_t sp = spec_target / m;
+                spec = sp > (size_t)spec_max ? spec_max : (int)sp;
             }
             const size_t ns = m * (size_t)spec;
             if (ctx->prof_on) ctx->prof_sign_slots += ns;
