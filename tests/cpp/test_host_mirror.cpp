@@ -1,0 +1,131 @@
+// GPU test of the C++ host mirror (fips204_amd/host/fips204_hip.hpp).  Reads like the reference's
+// own tests: src/lib.rs:497-552 (smoke_test per parameter set), tests/integration.rs:79-119
+// (test_44_no_verif), tests/messages.rs:10-21 (fixed vector; xi / rnd and the expected hex are
+// passed on the command line by tests/test_gpu_cpp_host.py, which also checks them against the
+// golden fixture).
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../fips204_amd/host/fips204_hip.hpp"
+
+using namespace fips204_hip;
+
+#define ASSERT(cond) do { if (!(cond)) { std::fprintf(stderr, "ASSERT FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); std::exit(1); } } while (0)
+
+// deterministic replay RNG, like TestRng of tests/nist_vectors/mod.rs:23-52
+struct CountingRng {
+    uint8_t next = 1;
+    bool try_fill_bytes(uint8_t* out, size_t n) {
+        for (size_t i = 0; i < n; i++) out[i] = (uint8_t)(next * 131u + (uint8_t)i * 7u);
+        next++;
+        return true;
+    }
+};
+struct FailingRng {
+    bool try_fill_bytes(uint8_t*, size_t) { return false; }
+};
+
+static std::vector<uint8_t> from_hex(const std::string& h) {
+    std::vector<uint8_t> v(h.size() / 2);
+    for (size_t i = 0; i < v.size(); i++) v[i] = (uint8_t)std::stoul(h.substr(2 * i, 2), nullptr, 16);
+    return v;
+}
+static std::string to_hex(const uint8_t* p, size_t n) {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (size_t i = 0; i < n; i++) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); }
+    return s;
+}
+
+template <class P>
+static void smoke_test(int expect_pk0) {  // src/lib.rs:497-552
+    CountingRng rng;
+    const std::vector<uint8_t> message1 = {0, 1, 2, 3, 4, 5, 6, 7}, message2 = {7, 7, 7, 7, 7, 7, 7, 7};
+    for (int i = 0; i < 4; i++) {
+        auto [pk, sk] = P::KG::try_keygen_with_rng(rng);
+        auto sig = sk.try_sign_with_rng(rng, message1, {});
+        ASSERT(pk.verify(message1, sig, {}));
+        ASSERT(!pk.verify(message2, sig, {}));
+        ASSERT(P::PublicKey::try_from_bytes(pk.into_bytes()).verify(message1, sig, {}));  // SerDes round trip
+    }
+    auto [pk, sk] = P::KG::keygen_from_seed([] { std::array<uint8_t, 32> a; a.fill(0x11); return a; }());
+    std::array<uint8_t, 32> seed12; seed12.fill(12);
+    auto sig = sk.try_sign_with_seed(seed12, message1, {});
+    ASSERT(pk.verify(message1, sig, {}));
+    ASSERT(!pk.verify(message1, sig, std::vector<uint8_t>(257, 0)));              // lib.rs:527
+    bool threw = false;
+    try { (void)sk.try_sign_with_seed(seed12, message1, std::vector<uint8_t>(257, 0)); } catch (const Error&) { threw = true; }
+    ASSERT(threw);                                                                 // lib.rs:528
+    ASSERT(pk.into_bytes()[0] == expect_pk0);                                      // lib.rs:543-545
+    FailingRng bad;
+    threw = false;
+    try { (void)P::KG::try_keygen_with_rng(bad); } catch (const Error&) { threw = true; }
+    ASSERT(threw);                                                                 // ml_dsa.rs:41
+}
+
+static void test_44_no_verif() {  // tests/integration.rs:79-119
+    using P = ml_dsa_44;
+    CountingRng rng;
+    const std::vector<uint8_t> msg = {0, 1, 2, 3, 4, 5, 6, 7}, ctx = {0};
+    auto [pk, sk] = P::KG::try_keygen_with_rng(rng);
+    auto sig = sk.try_sign_with_rng(rng, msg, ctx);
+    ASSERT(pk.verify(msg, sig, ctx));
+    for (int i = 0; i < 8; i++) {
+        auto bad = msg; bad[i] ^= 0x08;
+        ASSERT(!pk.verify(bad, sig, ctx));
+    }
+    for (int i = 0; i < 8; i++) {
+        auto skb = sk.into_bytes(); skb[70 + i * 10] ^= 0x08;
+        auto sig2 = P::PrivateKey::try_from_bytes(skb).try_sign_with_rng(rng, msg, ctx);
+        ASSERT(!pk.verify(msg, sig2, ctx));
+    }
+    for (int i = 0; i < 8; i++) {
+        auto pkb = pk.into_bytes(); pkb[i * 10] ^= 0x08;
+        ASSERT(!P::PublicKey::try_from_bytes(pkb).verify(msg, sig, ctx));
+    }
+    for (int i = 0; i < 8; i++) {
+        auto s2 = sig; s2[i * 10] ^= 0x08;
+        ASSERT(!pk.verify(msg, s2, ctx));
+    }
+}
+
+int main(int argc, char** argv) {
+    smoke_test<ml_dsa_44>(197);
+    smoke_test<ml_dsa_65>(177);
+    smoke_test<ml_dsa_87>(16);
+    test_44_no_verif();
+    if (argc >= 3) {  // tests/messages.rs:10-21 with xi, rnd from ChaCha8Rng::seed_from_u64(123)
+        using P = ml_dsa_44;
+        std::array<uint8_t, 32> xi{}, rnd{};
+        auto a = from_hex(argv[1]), b = from_hex(argv[2]);
+        ASSERT(a.size() == 32 && b.size() == 32);
+        std::memcpy(xi.data(), a.data(), 32);
+        std::memcpy(rnd.data(), b.data(), 32);
+        auto [pk, sk] = P::KG::keygen_from_seed(xi);
+        auto sig = sk.try_sign_with_seed(rnd, {'a', 's', 'd', 'f'}, {});
+        ASSERT(pk.verify({'a', 's', 'd', 'f'}, sig, {}));
+        auto skb = sk.into_bytes(); auto pkb = pk.into_bytes();
+        std::printf("sk %s\nsig %s\npk %s\n", to_hex(skb.data(), skb.size()).c_str(), to_hex(sig.data(), sig.size()).c_str(),
+                    to_hex(pkb.data(), pkb.size()).c_str());
+    }
+    // a small batch through the *_many calls: 3 keys, 12 ops, one corrupted signature
+    {
+        using P = ml_dsa_65;
+        std::vector<std::array<uint8_t, 32>> xi(3), rnd(12);
+        for (int i = 0; i < 3; i++) xi[i].fill((uint8_t)(40 + i));
+        for (int i = 0; i < 12; i++) rnd[i].fill((uint8_t)i);
+        auto ks = P::keygen_many(xi);
+        auto pks = P::PublicKeys::try_from_bytes(ks.first);
+        auto sks = P::PrivateKeys::try_from_bytes(ks.second);
+        std::vector<uint32_t> kidx(12);
+        std::vector<std::vector<uint8_t>> msgs(12), ctxs(12);
+        for (int i = 0; i < 12; i++) { kidx[i] = (uint32_t)(i % 3); msgs[i].assign((size_t)(i * 37), (uint8_t)i); ctxs[i].assign((size_t)(i % 4), 9); }
+        auto sigs = P::sign_many(sks, kidx, msgs, ctxs, rnd);
+        sigs[5][100] ^= 1;
+        auto ok = P::verify_many(pks, kidx, msgs, sigs, ctxs);
+        for (int i = 0; i < 12; i++) ASSERT(ok[i] == (i != 5));
+    }
+    std::printf("OK\n");
+    return 0;
+}

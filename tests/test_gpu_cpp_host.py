@@ -1,0 +1,26 @@
+"""Builds and runs the C++ host-mirror test (tests/cpp/test_host_mirror.cpp) on the GPU and checks
+its messages.rs output against the reference's golden hex (tests/messages.rs:18-20)."""
+import os
+import subprocess
+
+import pytest
+
+from chacha8rng import ChaCha8Rng
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_host_mirror(tmp_path, ref_hex):
+    exe = tmp_path / "test_host_mirror"
+    libdir = os.path.join(ROOT, "fips204_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp"), "-o", str(exe),
+                           f"-L{libdir}", "-lmldsa_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    rng = ChaCha8Rng(123)
+    xi, rnd = rng.fill_bytes(32), rng.fill_bytes(32)
+    out = subprocess.run([str(exe), xi.hex(), rnd.hex()], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = dict(ln.split(" ", 1) for ln in out.stdout.splitlines() if " " in ln)
+    v = ref_hex["messages_rs"]
+    assert lines["sk"] == v["sk"] and lines["sig"] == v["sig"] and lines["pk"] == v["pk"]
+    assert out.stdout.strip().endswith("OK")
