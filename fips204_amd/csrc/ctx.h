@@ -92,7 +92,6 @@ int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t c
 
 
 // ---- launchers (kernels_codec.hip) ----
-int launch_sig_unpack_z(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, int32_t *z, int32_t *znorm, size_t n_ops, hipStream_t);
 int launch_hint_unpack(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, uint32_t *hmask, int32_t *hvalid, size_t n_ops, hipStream_t);
 int launch_use_hint_w1(mldsa_ctx *, const mldsa_params *, const int32_t *w, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, size_t n_ops, hipStream_t);
 int launch_verify_main(mldsa_ctx *, const mldsa_params *, const int32_t *a_hat, const uint8_t *sigs, const int32_t *c, const int32_t *t1,
@@ -110,11 +109,6 @@ int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs
 int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, size_t n_ops, hipStream_t);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
-int launch_sign_cs(mldsa_ctx *, int set, const int32_t *c, const uint32_t *act, const uint32_t *key_idx, const int32_t *s1,
-                   const int32_t *s2, const int32_t *t0, int32_t *cs1, int32_t *cs2, int32_t *ct0, size_t n_slots, hipStream_t);
-int launch_sign_finish(mldsa_ctx *, const mldsa_params *, const int32_t *y, const int32_t *w, const int32_t *cs1, const int32_t *cs2,
-                       const int32_t *ct0, const uint8_t *ctilde, const uint32_t *slot_op, uint16_t *kappa, int32_t *done,
-                       uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept, size_t n_slots, hipStream_t);
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,
                      const uint32_t *slot_op, const uint32_t *key_idx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
                      uint16_t *kappa, int32_t *done, uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept,

@@ -64,42 +64,6 @@ __device__ __forceinline__ int32_t use_hint(int32_t h, int32_t r) {
 }
 
 // ------------------------------------------------------------------------------------
-// sig_decode part 1 (encodings.rs:312-321 -> bit_unpack, conversion.rs:227-262): z[j] =
-// gamma1 - (c-bit fields), one wave per polynomial, plus the verifier's norm test
-// ||z||inf < gamma1 - beta (ml_dsa.rs:434) as a per-op maximum.
-template <int GB>
-__global__ __launch_bounds__(CBLOCK) void k_sig_unpack_z(const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
-                                                         int l, int32_t* __restrict__ z, int32_t* __restrict__ znorm,
-                                                         size_t n_ops) {
-    constexpr int CB = GB + 1;
-    const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6);
-    const size_t n_waves = (size_t)gridDim.x * CWAVES;
-    const size_t n_polys = n_ops * (size_t)l;
-    for (size_t p = wave; p < n_polys; p += n_waves) {
-        const size_t op = p / l;
-        const int j = (int)(p % l);
-        const uint8_t* src = sigs + op * sig_len + ctilde_len + (size_t)j * (32 * CB);
-        int32_t mx = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = 64 * k + lane;
-            const int bo = i * CB;
-            const uint32_t v = (load_le32(src + (bo >> 3)) >> (bo & 7)) & ((1u << CB) - 1u);
-            const int32_t c = (1 << GB) - (int32_t)v;
-            z[p * N + i] = c;
-            const int32_t a = c < 0 ? -c : c;
-            mx = a > mx ? a : mx;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const int32_t o = __shfl_xor(mx, m);
-            mx = o > mx ? o : mx;
-        }
-        if (lane == 0) atomicMax(&znorm[op], mx);
-    }
-}
-
 // sig_decode part 2: hint_bit_unpack (conversion.rs:340-414), one op per lane.  Output: a
 // 256-bit mask per hint polynomial and a validity flag (0 = the reference returns Err).
 __global__ __launch_bounds__(CBLOCK) void k_hint_unpack(const uint8_t* __restrict__ sigs, size_t sig_len, int hint_off,
@@ -450,17 +414,6 @@ __global__ __launch_bounds__(CBLOCK) void k_verify_verdict(const uint8_t* __rest
 
 // ------------------------------------------------------------------------- launchers
 static inline unsigned lane_blocks(size_t n) { return (unsigned)((n + CBLOCK - 1) / CBLOCK); }
-
-int launch_sig_unpack_z(mldsa_ctx* ctx, const mldsa_params* p, const uint8_t* sigs, int32_t* z, int32_t* znorm, size_t n_ops,
-                        hipStream_t s) {
-    dim3 grid(grid_for(ctx, n_ops * (size_t)p->l, CWAVES, 8)), block(CBLOCK);
-    if (p->gamma1 == (1 << 17))
-        hipLaunchKernelGGL((k_sig_unpack_z<17>), grid, block, 0, s, sigs, (size_t)p->sig_len, p->ctilde_len, p->l, z, znorm, n_ops);
-    else
-        hipLaunchKernelGGL((k_sig_unpack_z<19>), grid, block, 0, s, sigs, (size_t)p->sig_len, p->ctilde_len, p->l, z, znorm, n_ops);
-    MLDSA_HIP_CHECK(hipGetLastError());
-    return MLDSA_OK;
-}
 
 int launch_hint_unpack(mldsa_ctx*, const mldsa_params* p, const uint8_t* sigs, uint32_t* hmask, int32_t* hvalid, size_t n_ops,
                        hipStream_t s) {

@@ -9,7 +9,6 @@ namespace mldsa {
 
 constexpr int GWAVES = 4;
 constexpr int GBLOCK = 64 * GWAVES;
-constexpr int32_t C13_MONT2 = 6346488;       // 2^13 * 2^64 mod q:  x -> x * 2^13 * 2^32 (ml_dsa.rs:108-113)
 
 // `bits`-wide little-endian field starting at bit offset `bo`; never reads past the field
 __device__ __forceinline__ uint32_t load_bits(const uint8_t* p, int bo, int bits) {
@@ -53,54 +52,6 @@ __global__ __launch_bounds__(GBLOCK) void k_unpack_ntt(const uint8_t* __restrict
     }
 }
 
-// ------------------------------------------------------------------------------------
-// One block per slot: c_hat = ntt(c); then every polynomial of the key's s1_hat (L), s2_hat
-// (K) and t0_hat (K): inv_ntt(c_hat o v_hat_mont)  (ml_dsa.rs:240-260, 288-295).
-template <int K, int L>
-__global__ __launch_bounds__(64 * K) void k_sign_cs(const int32_t* __restrict__ c, const uint32_t* __restrict__ act,
-                                                    const uint32_t* __restrict__ key_idx,
-                                                    const int32_t* __restrict__ s1, const int32_t* __restrict__ s2,
-                                                    const int32_t* __restrict__ t0, int32_t* __restrict__ cs1,
-                                                    int32_t* __restrict__ cs2, int32_t* __restrict__ ct0, size_t n_slots,
-                                                    const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab) {
-    __shared__ int4 chat[64];
-    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * K) tw_lds[i] = fwd_tab[i];
-    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * K) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
-    __syncthreads();
-    const LdsTw ftw{tw_lds, lane};
-    const LdsTw itw{tw_lds + FWD_TW * 64, lane};
-    for (size_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
-        const size_t op = act ? act[slot] : slot;
-        const size_t key = key_idx ? key_idx[op] : op;
-        if (wave == 0) {
-            int32_t r[4];
-            load_strided(r, c + slot * N, lane);
-            ntt_fwd_wave(r, ftw, lane);
-            chat[lane] = make_int4(r[0], r[1], r[2], r[3]);
-        }
-        __syncthreads();
-        const int4 cv = chat[lane];
-        for (int p = wave; p < L + 2 * K; p += K) {
-            const int32_t* src;
-            int32_t* dst;
-            if (p < L) { src = s1 + (key * L + p) * (size_t)N; dst = cs1 + (slot * L + p) * (size_t)N; }
-            else if (p < L + K) { src = s2 + (key * K + (p - L)) * (size_t)N; dst = cs2 + (slot * K + (p - L)) * (size_t)N; }
-            else { src = t0 + (key * K + (p - L - K)) * (size_t)N; dst = ct0 + (slot * K + (p - L - K)) * (size_t)N; }
-            int32_t v[4], r[4];
-            load_packed(v, src, lane);
-            r[0] = mont_mul(cv.x, v[0]);
-            r[1] = mont_mul(cv.y, v[1]);
-            r[2] = mont_mul(cv.z, v[2]);
-            r[3] = mont_mul(cv.w, v[3]);
-            ntt_inv_wave(r, itw, lane, F_MONT);
-            store_strided(r, dst, lane);
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------ high_low.rs pieces
 template <bool G2HI>
 __device__ __forceinline__ void decompose_s(int32_t rp, int32_t& r1, int32_t& r0) {  // high_low.rs:66-96, rp canonical
@@ -123,160 +74,6 @@ struct Coef4 { int32_t v[4]; };
 __device__ __forceinline__ Coef4 ld4(const int32_t* p, int u) {
     const int4 t = reinterpret_cast<const int4*>(p)[u];
     return Coef4{{t.x, t.y, t.z, t.w}};
-}
-
-// hint bit of one coefficient: make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0))  (ml_dsa.rs:298-306)
-template <bool G2HI>
-__device__ __forceinline__ int hint_bit(int32_t w, int32_t cs2, int32_t ct0) {
-    const int32_t r = reduce32(w - cs2 + ct0);
-    int32_t a1, a0, b1, b0;
-    decompose_s<G2HI>(caddq(r), a1, a0);
-    decompose_s<G2HI>(freeze(r + (Q - ct0)), b1, b0);
-    return a1 != b1;
-}
-
-// ------------------------------------------------------------------------------------
-// Tail of one rejection-loop iteration for one slot (one 256-thread block):
-//   z = y + cs1, r0 = LowBits(w - cs2), ct0, h = MakeHint(..)        ml_dsa.rs:262-306
-//   accept iff ||z|| < gamma1 - beta, ||r0|| < gamma2 - beta, ||ct0|| < gamma2, #h <= omega
-//   (the reference tests these in two stages, ml_dsa.rs:277-283 and 312-319; both stages
-//    end in the same `kappa += L; continue`, so one combined test is equivalent)
-//   accepted: sigma = sigEncode(c_tilde, z mod+- q, h) (encodings.rs:238-276), done[op] = 1
-//   rejected: kappa[op] += L
-template <bool G2HI>
-__global__ __launch_bounds__(256) void k_sign_finish(const int32_t* __restrict__ y, const int32_t* __restrict__ w,
-                                                     const int32_t* __restrict__ cs1, const int32_t* __restrict__ cs2,
-                                                     const int32_t* __restrict__ ct0, const uint8_t* __restrict__ ctilde,
-                                                     const uint32_t* __restrict__ act, uint16_t* __restrict__ kappa,
-                                                     int32_t* __restrict__ done, uint8_t* __restrict__ sigs,
-                                                     int spec, uint8_t* __restrict__ stage, size_t stage_stride,
-                                                     int32_t* __restrict__ accept,
-                                                     int k, int l, int gb, int beta, int omega, int ctilde_len,
-                                                     size_t sig_len) {
-    constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
-    __shared__ int32_t red[4][4];
-    __shared__ int32_t cnt[8];
-    __shared__ int32_t verdict;
-    const size_t slot = blockIdx.x;
-    const size_t op = act[slot];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int32_t gamma1 = 1 << gb;
-    const int32_t* yp = y + slot * (size_t)l * N;
-    const int32_t* wp = w + slot * (size_t)k * N;
-    const int32_t* c1p = cs1 + slot * (size_t)l * N;
-    const int32_t* c2p = cs2 + slot * (size_t)k * N;
-    const int32_t* t0p = ct0 + slot * (size_t)k * N;
-
-    // ---- pass 1: norms and hint weight
-    int32_t zmax = 0, r0max = 0, t0max = 0, hsum = 0;
-    for (int u = t; u < l * 64; u += 256) {
-        const Coef4 a = ld4(yp, u), b = ld4(c1p, u);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int32_t zc = center(a.v[i] + b.v[i]);  // partial_reduce32 then center_mod (ml_dsa.rs:264, helpers.rs:138)
-            zc = zc < 0 ? -zc : zc;
-            zmax = zc > zmax ? zc : zmax;
-        }
-    }
-    for (int u = t; u < k * 64; u += 256) {
-        const Coef4 a = ld4(wp, u), b = ld4(c2p, u), c = ld4(t0p, u);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int32_t r1, r0;
-            decompose_s<G2HI>(freeze(a.v[i] - b.v[i]), r1, r0);  // low_bits(partial_reduce32(w - cs2)), ml_dsa.rs:270
-            r0 = r0 < 0 ? -r0 : r0;
-            r0max = r0 > r0max ? r0 : r0max;
-            int32_t tc = center(c.v[i]);
-            tc = tc < 0 ? -tc : tc;
-            t0max = tc > t0max ? tc : t0max;
-            hsum += hint_bit<G2HI>(a.v[i], b.v[i], c.v[i]);
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        int32_t o;
-        o = __shfl_xor(zmax, m); zmax = o > zmax ? o : zmax;
-        o = __shfl_xor(r0max, m); r0max = o > r0max ? o : r0max;
-        o = __shfl_xor(t0max, m); t0max = o > t0max ? o : t0max;
-        hsum += __shfl_xor(hsum, m);
-    }
-    if (lane == 0) { red[wave][0] = zmax; red[wave][1] = r0max; red[wave][2] = t0max; red[wave][3] = hsum; }
-    __syncthreads();
-    if (t == 0) {
-        int32_t a = 0, b = 0, c = 0, h = 0;
-        for (int i = 0; i < 4; i++) {
-            a = red[i][0] > a ? red[i][0] : a;
-            b = red[i][1] > b ? red[i][1] : b;
-            c = red[i][2] > c ? red[i][2] : c;
-            h += red[i][3];
-        }
-        const int ok = (a < gamma1 - beta) && (b < GAMMA2 - beta) && (c < GAMMA2) && (h <= omega);
-        verdict = ok;
-        if (spec == 1) {
-            if (ok) done[op] = 1;
-            else kappa[op] = (uint16_t)(kappa[op] + l);  // ml_dsa.rs:281 / 316 (u16 arithmetic)
-        } else {
-            accept[slot] = ok;  // speculative candidate: k_resolve keeps the first accepted kappa of the op
-        }
-    }
-    __syncthreads();
-    if (!verdict) return;
-
-    // ---- pass 2: sigEncode
-    uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
-    const int cb = gb + 1;
-    if (t < ctilde_len) sig[t] = ctilde[slot * 64 + t];
-    // z: BitPack(z mod+- q, gamma1 - 1, gamma1): field = gamma1 - z, cb bits, 4 fields per thread
-    for (int u = t; u < l * 64; u += 256) {
-        const Coef4 a = ld4(yp, u), b = ld4(c1p, u);
-        uint64_t lo = 0;
-        uint32_t hi = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint64_t f = (uint64_t)(uint32_t)(gamma1 - center(a.v[i] + b.v[i]));
-            const int sh = i * cb;
-            lo |= f << sh;
-            if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
-        }
-        const int nbytes = cb / 2;  // 4 * cb / 8 = 9 or 10
-        uint8_t* dst = sig + ctilde_len + (size_t)(u >> 6) * (32 * cb) + (size_t)(u & 63) * nbytes;
-        for (int i = 0; i < 8; i++) dst[i] = (uint8_t)(lo >> (8 * i));
-        for (int i = 8; i < nbytes; i++) dst[i] = (uint8_t)(hi >> (8 * (i - 8)));
-    }
-    // h: HintBitPack (conversion.rs:277-328).  wave wv packs hint polynomials wv, wv + 4
-    uint8_t* hy = sig + ctilde_len + (size_t)l * (32 * cb);
-    if (t < omega + k) hy[t] = 0;
-    __syncthreads();
-    uint32_t bits[2] = {0, 0};
-    int rank[2] = {0, 0};
-    for (int pi = 0; pi < 2; pi++) {
-        const int i = wave + 4 * pi;
-        if (i >= k) break;
-        const Coef4 a = ld4(wp + i * N, lane), b = ld4(c2p + i * N, lane), c = ld4(t0p + i * N, lane);
-        uint32_t hb = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) hb |= (uint32_t)hint_bit<G2HI>(a.v[j], b.v[j], c.v[j]) << j;
-        int mine = __popc(hb), incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        bits[pi] = hb;
-        rank[pi] = incl - mine;
-        if (lane == 63) cnt[i] = incl;
-    }
-    __syncthreads();
-    for (int pi = 0; pi < 2; pi++) {
-        const int i = wave + 4 * pi;
-        if (i >= k) break;
-        int base = 0;
-        for (int j = 0; j < i; j++) base += cnt[j];
-        int r = base + rank[pi];
-        for (int j = 0; j < 4; j++)
-            if (bits[pi] & (1u << j)) hy[r++] = (uint8_t)(4 * lane + j);
-        if (lane == 0) hy[omega + i] = (uint8_t)(base + cnt[i]);
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -587,34 +384,6 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
     if (n_keys == 0) return MLDSA_OK;
     hipLaunchKernelGGL(k_unpack_ntt, dim3(grid_for(ctx, n_keys * (size_t)polys_per_key, GWAVES, 8)), dim3(GBLOCK), 0, s, src,
                        key_stride, poly_off, bits, b, scale, out, polys_per_key, n_keys, ctx->d_fwd_tw);
-    MLDSA_HIP_CHECK(hipGetLastError());
-    return MLDSA_OK;
-}
-
-int launch_sign_cs(mldsa_ctx* ctx, int set, const int32_t* c, const uint32_t* act, const uint32_t* key_idx, const int32_t* s1,
-                   const int32_t* s2, const int32_t* t0, int32_t* cs1, int32_t* cs2, int32_t* ct0, size_t n_slots, hipStream_t s) {
-    if (n_slots == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_slots, 1, 12));
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_sign_cs<4, 4>), grid, dim3(64 * 4), 0, s, c, act, key_idx, s1, s2, t0, cs1, cs2, ct0, n_slots, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_sign_cs<6, 5>), grid, dim3(64 * 6), 0, s, c, act, key_idx, s1, s2, t0, cs1, cs2, ct0, n_slots, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else hipLaunchKernelGGL((k_sign_cs<8, 7>), grid, dim3(64 * 8), 0, s, c, act, key_idx, s1, s2, t0, cs1, cs2, ct0, n_slots, ctx->d_fwd_tw, ctx->d_inv_tw);
-    MLDSA_HIP_CHECK(hipGetLastError());
-    return MLDSA_OK;
-}
-
-int launch_sign_finish(mldsa_ctx*, const mldsa_params* p, const int32_t* y, const int32_t* w, const int32_t* cs1,
-                       const int32_t* cs2, const int32_t* ct0, const uint8_t* ctilde, const uint32_t* act, uint16_t* kappa,
-                       int32_t* done, uint8_t* sigs, int spec, uint8_t* stage, size_t stage_stride, int32_t* accept,
-                       size_t n_slots, hipStream_t s) {
-    if (n_slots == 0) return MLDSA_OK;
-    const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
-    dim3 grid((unsigned)n_slots), block(256);
-    if (p->gamma2 == (Q - 1) / 32)
-        hipLaunchKernelGGL((k_sign_finish<true>), grid, block, 0, s, y, w, cs1, cs2, ct0, ctilde, act, kappa, done, sigs, spec, stage,
-                           stage_stride, accept, p->k, p->l, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len);
-    else
-        hipLaunchKernelGGL((k_sign_finish<false>), grid, block, 0, s, y, w, cs1, cs2, ct0, ctilde, act, kappa, done, sigs, spec, stage,
-                           stage_stride, accept, p->k, p->l, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -42,16 +42,14 @@ struct Carver {
 };
 
 struct VerifyWs {
-    int32_t *a_hat, *z, *c, *wp, *znorm, *hvalid, *ctx_bad;
+    int32_t *a_hat, *c, *znorm, *hvalid, *ctx_bad;
     uint32_t *hmask;
     uint8_t *mu_w1, *ctilde_p;
     size_t bytes;
     VerifyWs(void *base, const mldsa_params *p, size_t n) {
         Carver cv(base);
         a_hat = cv.take<int32_t>(n * p->k * p->l * N);
-        z = cv.take<int32_t>(n * p->l * N);
         c = cv.take<int32_t>(n * N);
-        wp = cv.take<int32_t>(n * p->k * N);
         znorm = cv.take<int32_t>(n);
         hvalid = cv.take<int32_t>(n);
         ctx_bad = cv.take<int32_t>(n);
@@ -113,7 +111,7 @@ int pk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, ui
     MLDSA_HIP_CHECK(hipMemcpy2DAsync(rho, 32, pk, (size_t)p->pk_len, 32, n, hipMemcpyDeviceToDevice, s));
     TRY(launch_shake256_2(ctx, 64, pk, (size_t)p->pk_len, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, tr, 64, n, s));  // tr = H(pk)
     // t1_d2_hat_mont = ntt(t1) * 2^13 * 2^32  (ml_dsa.rs:492-495)
-    TRY(launch_unpack_ntt(ctx, pk, (size_t)p->pk_len, 32, 10, -1, 6346488, t1, p->k, n, s));
+    TRY(launch_unpack_ntt(ctx, pk, (size_t)p->pk_len, 32, 10, -1, 6346488 /* 2^13 * 2^64 mod q */, t1, p->k, n, s));
     return MLDSA_OK;
 }
 
@@ -185,10 +183,9 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
 // every round runs one loop iteration for all unfinished ops, then compacts the active list.
 namespace {
 constexpr size_t SPEC_TARGET_SLOTS = 65536;  // upper bound of candidate slots per speculative round (workspace size)
-constexpr int SPEC_MAX = 64;                 // candidates per op per round (0.8^32 < 0.1 % all-fail)
 
 struct SignWs {
-    int32_t *a_hat, *y, *w, *cs1, *cs2, *ct0, *c, *done, *ctx_bad, *accept;
+    int32_t *a_hat, *y, *w, *c, *done, *ctx_bad, *accept;
     uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage;
     uint16_t *kappa, *slot_kappa;
     uint32_t *act0, *act1, *slot_op, *counter;
@@ -200,9 +197,6 @@ struct SignWs {
         a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
         y = cv.take<int32_t>(ns * (size_t)p->l * N);
         w = cv.take<int32_t>(ns * (size_t)p->k * N);
-        cs1 = cv.take<int32_t>(ns * (size_t)p->l * N);
-        cs2 = cv.take<int32_t>(ns * (size_t)p->k * N);
-        ct0 = cv.take<int32_t>(ns * (size_t)p->k * N);
         c = cv.take<int32_t>(ns * (size_t)N);
         done = cv.take<int32_t>(n);
         ctx_bad = cv.take<int32_t>(n);
@@ -240,7 +234,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     size_t spec_target = 32768;
     int spec_max = 32;
     if (const char *e = getenv("MLDSA_SPEC_TARGET")) { size_t v = (size_t)atol(e); if (v >= 1 && v <= SPEC_TARGET_SLOTS) spec_target = v; }
-    if (const char *e = getenv("MLDSA_SPEC_MAX")) { int v = atoi(e); if (v >= 1 && v <= 64) spec_max = v; }
+    if (const char *e = getenv("MLDSA_SPEC_MAX")) { int v = atoi(e); if (v >= 1 && v <= 64) spec_max = v; }  // k_resolve scans one wave of candidates
     int rc = MLDSA_OK;
 #define TRYC(expr) do { rc = (expr); if (rc != MLDSA_OK) goto out; } while (0)
 #define STAGEC(name, expr) do { { ProfScope _ps(ctx, s, name); rc = (expr); } if (rc != MLDSA_OK) goto out; } while (0)

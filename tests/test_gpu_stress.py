@@ -1,0 +1,107 @@
+"""GPU stress / edge-case parity for the op-level API: multi-chunk batches, message lengths around
+the SHAKE256 rate boundaries, maximum ctx, identity key mapping, rejection-loop speculation paths."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sets():
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    hp = HotPath(0)
+    yield {s: MlDsa(s, hotpath=hp) for s in (44, 65, 87)}
+    hp.close()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_message_and_ctx_length_edges_vs_oracle(sets, pset):
+    """mu = H(tr | 0 | len(ctx) | ctx | M): lengths that put the pad byte at every position class of
+    the 136-byte rate (64 + 2 + |ctx| + |M| = 135, 136, 137, 271, 272, 273 ...), empty message, ctx 255."""
+    m = sets[pset]
+    rng = np.random.default_rng(900 + pset)
+    pk_o, sk_o = orc.keygen_from_seed(pset, bytes(range(32)))
+    pks = m.public_keys_from_bytes([orc.pk_into_bytes(pset, pk_o)])
+    sks = m.private_keys_from_bytes([orc.sk_into_bytes(pset, sk_o)])
+    cases = []
+    for total in (66, 67, 135, 136, 137, 138, 271, 272, 273, 407, 408, 409, 1000):
+        for clen in (0, 1, 255):
+            mlen = total - 66 - clen
+            if mlen >= 0:
+                cases.append((mlen, clen))
+    msgs = [rng.integers(0, 256, a, dtype=np.uint8).tobytes() for a, _ in cases]
+    ctxs = [rng.integers(0, 256, b, dtype=np.uint8).tobytes() for _, b in cases]
+    rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in cases]
+    sig = host(m.try_sign_with_seed(sks, msgs, rnd, ctxs=ctxs))
+    for i in range(len(cases)):
+        assert sig[i].tobytes() == orc.sign_internal(pset, sk_o, msgs[i], rnd[i], ctx=ctxs[i], mode=0), cases[i]
+    assert m.verify(pks, msgs, torch.from_numpy(sig).cuda(), ctxs=ctxs).all()
+    # pre-hash domain separation (mode 2): msg = OID | PH(M), must differ from pure mode
+    sig2 = host(m.try_sign_with_seed(sks, msgs[:3], rnd[:3], ctxs=ctxs[:3], mode=2))
+    for i in range(3):
+        assert sig2[i].tobytes() == orc.sign_internal(pset, sk_o, msgs[i], rnd[i], ctx=ctxs[i], mode=2)
+    assert m.verify(pks, msgs[:3], torch.from_numpy(sig2).cuda(), ctxs=ctxs[:3], mode=2).all()
+    assert not m.verify(pks, msgs[:3], torch.from_numpy(sig2).cuda(), ctxs=ctxs[:3], mode=0).any()
+
+
+def test_identity_key_mapping_and_multichunk(sets):
+    """key_idx = None with one key per op, and a batch larger than one pipeline chunk (65536 ops):
+    verdicts must match a known corruption pattern."""
+    m = sets[44]
+    g = torch.Generator(device="cuda").manual_seed(17)
+    n = 70001  # > CHUNK_OPS
+    xi = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    pk, sk = m.keygen_from_seed(xi)
+    pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+    msgs = [i.to_bytes(8, "little") for i in range(n)]
+    rnd = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")  # deterministic variant
+    sig = m.try_sign_with_seed(sks, msgs, rnd)                      # key_idx None: op i uses key i
+    bad = np.zeros(n, dtype=bool)
+    bad[::97] = True
+    sig_h = host(sig).copy()
+    sig_h[bad, 40] ^= 0x10
+    got = m.verify(pks, msgs, torch.from_numpy(sig_h).cuda())
+    assert np.array_equal(got, ~bad)
+    # spot-check signatures against the oracle on both sides of the chunk boundary
+    skh = host(sk)
+    for i in (0, 1, 65535, 65536, 70000):
+        want = orc.sign_internal(44, orc.sk_try_from_bytes(44, skh[i].tobytes()), msgs[i], bytes(32), mode=0)
+        assert host(sig)[i].tobytes() == want, i
+
+
+@pytest.mark.parametrize("n_ops", [1, 2, 63, 64, 65, 1000, 40000])
+def test_sign_speculation_regimes_match_oracle(sets, n_ops):
+    """active-set sizes that start in different speculation regimes (spec = 32 ... 1)"""
+    m = sets[65]
+    rng = np.random.default_rng(n_ops)
+    pk_o, sk_o = orc.keygen_from_seed(65, bytes([7] * 32))
+    sks = m.private_keys_from_bytes([orc.sk_into_bytes(65, sk_o)])
+    pks = m.public_keys_from_bytes([orc.pk_into_bytes(65, pk_o)])
+    msgs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_ops)]
+    rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_ops)]
+    sig = m.try_sign_with_seed(sks, msgs, rnd)
+    sig_h = host(sig)
+    for i in sorted(set([0, n_ops // 2, n_ops - 1] + list(range(0, n_ops, max(1, n_ops // 12))))):
+        assert sig_h[i].tobytes() == orc.sign_internal(65, sk_o, msgs[i], rnd[i], mode=0), i
+    assert m.verify(pks, msgs, sig).all()
+
+
+def test_hint_weight_and_z_bound_rejections(sets, acvp_sigver):
+    """the ACVP 'too many hints' / 'z too large' signatures stay rejected inside a large mixed batch"""
+    g = [x for x in acvp_sigver["testGroups"] if x["parameterSet"] == "ML-DSA-87"][0]
+    m = sets[87]
+    pks = m.public_keys_from_bytes([bytes.fromhex(g["pk"])])
+    tests = g["tests"] * 300  # 4500 ops
+    msgs = [bytes.fromhex(t["message"]) for t in tests]
+    sigs = [bytes.fromhex(t["signature"]) for t in tests]
+    got = m.verify(pks, msgs, sigs, mode=1)
+    assert got.tolist() == [t["testPassed"] for t in tests]
