@@ -77,20 +77,21 @@ __device__ __forceinline__ Coef4 ld4(const int32_t* p, int u) {
 }
 
 // ------------------------------------------------------------------------------------
-// Fused tail of one rejection-loop iteration (ml_dsa.rs:240-336), one K-wave block per slot,
-// one wave per polynomial, nothing but c, y, w and the key's polynomials read from memory:
-//   (c_hat = ntt(c) is computed by k_ntt just before)
+// Fused tail of one rejection-loop iteration (ml_dsa.rs:243-336): ONE WAVE PER SLOT, looping over
+// the slot's polynomials, so there are no block barriers and no cross-wave reductions:
 //   z_j  = y_j + inv_ntt(c_hat o s1_hat_j)            ||z||  <  gamma1 - beta ?
 //   r_i  = w_i - inv_ntt(c_hat o s2_hat_i)            ||LowBits(r)|| < gamma2 - beta ?
 //   -- only if both hold (about 1 slot in 5):
 //   ct0_i = inv_ntt(c_hat o t0_hat_i)                 ||ct0|| < gamma2 ?
 //   h_i  = MakeHint(-ct0_i, r_i + ct0_i)              weight(h) <= omega ?
-//   -- only if accepted: sigEncode(c_tilde, z mod+- q, h)
-// The reference's two `continue` stages (ml_dsa.rs:280, 312) are kept as two stages here, so
-// the K inverse NTTs of ct0 run only when the first test passes.
+// (c_hat = ntt(c) comes from k_ntt.)  sigEncode (encodings.rs:238-276) is written EAGERLY while the
+// polynomials stream through: z bytes in stage 1, hint bytes in stage 2.  If the attempt is then
+// rejected the bytes are garbage, but the op's next attempt rewrites every byte, and only an
+// accepted attempt sets done[] / accept[] -- so the signature buffer of a finished op always holds
+// the accepted attempt.  The reference's two `continue` stages (ml_dsa.rs:280, 312) stay two stages.
 template <int K, int L, bool G2HI>
-__global__ __launch_bounds__(64 * K, 6) void k_sign_tail(
-    const int32_t* __restrict__ c, const int32_t* __restrict__ y, const int32_t* __restrict__ w,
+__global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
+    const int32_t* __restrict__ c_hat, const int32_t* __restrict__ y, const int32_t* __restrict__ w,
     const uint8_t* __restrict__ ctilde, const uint32_t* __restrict__ slot_op, const uint32_t* __restrict__ key_idx,
     const int32_t* __restrict__ s1, const int32_t* __restrict__ s2, const int32_t* __restrict__ t0,
     uint16_t* __restrict__ kappa, int32_t* __restrict__ done, uint8_t* __restrict__ sigs, int spec,
@@ -98,51 +99,72 @@ __global__ __launch_bounds__(64 * K, 6) void k_sign_tail(
     int ctilde_len, size_t sig_len, size_t n_slots, const Twiddle* __restrict__ inv_tab) {
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     __shared__ Twiddle tw_lds[INV_TW * 64];
-    __shared__ int32_t xpose[K][N];  // per-wave transpose buffer: strided -> 4 consecutive per lane
-    __shared__ int32_t red[K][3];
-    __shared__ int32_t cnt[K];
+    __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
+    __shared__ int32_t rr_lds[GWAVES][K][N]; // r_i = w_i - cs2_i, kept for the hint stage
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * K) tw_lds[i] = inv_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = inv_tab[i];
     __syncthreads();
     const LdsTw itw{tw_lds, lane};
     const int32_t gamma1 = 1 << gb;
     const int cb = gb + 1;
+    const size_t wid = (size_t)blockIdx.x * GWAVES + wave, n_waves = (size_t)gridDim.x * GWAVES;
 
-    for (size_t slot = blockIdx.x; slot < n_slots; slot += gridDim.x) {
+    for (size_t slot = wid; slot < n_slots; slot += n_waves) {
         const size_t op = slot_op[slot];
         const size_t key = key_idx ? key_idx[op] : op;
-        // issue every load of stage 1 first, so their latency hides under ntt(c)
-        int32_t v1[4] = {0, 0, 0, 0}, yy[4] = {0, 0, 0, 0}, v2[4], ww[4];
-        if (wave < L) {
-            load_packed(v1, s1 + (key * L + wave) * (size_t)N, lane);
-            load_strided(yy, y + (slot * L + wave) * (size_t)N, lane);
-        }
-        load_packed(v2, s2 + (key * K + wave) * (size_t)N, lane);
-        load_strided(ww, w + (slot * K + wave) * (size_t)N, lane);
-        const int4 cv = reinterpret_cast<const int4*>(c + slot * N)[lane];  // c_hat (k_ntt ran on c just before)
-        // ---- stage 1: z (waves < L) and r = w - cs2 (all waves); coefficient 64 k + lane in reg k
-        int32_t zc[4] = {0, 0, 0, 0}, rr[4];
+        uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
+        const int4 cv = reinterpret_cast<const int4*>(c_hat + slot * N)[lane];
+        if (lane < ctilde_len) sig[lane] = ctilde[slot * 64 + lane];
+        // ---- stage 1a: z
         int32_t zmax = 0, r0max = 0;
-        if (wave < L) {
-            int32_t r[4];
-            r[0] = mont_mul(cv.x, v1[0]); r[1] = mont_mul(cv.y, v1[1]); r[2] = mont_mul(cv.z, v1[2]); r[3] = mont_mul(cv.w, v1[3]);
+#pragma unroll 1
+        for (int j = 0; j < L; j++) {
+            int32_t v[4], yy[4], r[4];
+            load_packed(v, s1 + (key * L + j) * (size_t)N, lane);
+            load_strided(yy, y + (slot * L + j) * (size_t)N, lane);
+            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
             ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                zc[k] = center(yy[k] + r[k]);  // z mod+- q (ml_dsa.rs:264, 334)
-                const int32_t a = zc[k] < 0 ? -zc[k] : zc[k];
+                const int32_t zc = center(yy[k] + r[k]);  // z mod+- q (ml_dsa.rs:264, 334)
+                xpose[wave][64 * k + lane] = zc;
+                const int32_t a = zc < 0 ? -zc : zc;
                 zmax = a > zmax ? a : zmax;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int4 z4 = reinterpret_cast<const int4*>(&xpose[wave][0])[lane];
+            const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
+            uint64_t lo = 0;
+            uint32_t hi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {  // BitPack(z, gamma1 - 1, gamma1): field = gamma1 - z
+                const uint64_t f = (uint64_t)(uint32_t)(gamma1 - zz[i]);
+                const int sh = i * cb;
+                lo |= f << sh;
+                if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
+            }
+            const int nbytes = cb / 2;
+            uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * cb) + (size_t)lane * nbytes;
+            for (int i = 0; i < 8; i++) dst[i] = (uint8_t)(lo >> (8 * i));
+            for (int i = 8; i < nbytes; i++) dst[i] = (uint8_t)(hi >> (8 * (i - 8)));
+            __builtin_amdgcn_wave_barrier();
         }
-        {
-            int32_t r[4];
-            r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
+        // ---- stage 1b: r = w - cs2, LowBits
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            int32_t v[4], ww[4], r[4];
+            load_packed(v, s2 + (key * K + i) * (size_t)N, lane);
+            load_strided(ww, w + (slot * K + i) * (size_t)N, lane);
+            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
             ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                rr[k] = freeze(ww[k] - r[k]);  // w - cs2, canonical
+                const int32_t rr = freeze(ww[k] - r[k]);  // w - cs2, canonical
+                rr_lds[wave][i][64 * k + lane] = rr;
                 int32_t r1, r0;
-                decompose_s<G2HI>(rr[k], r1, r0);
+                decompose_s<G2HI>(rr, r1, r0);
                 r0 = r0 < 0 ? -r0 : r0;
                 r0max = r0 > r0max ? r0 : r0max;
             }
@@ -153,49 +175,47 @@ __global__ __launch_bounds__(64 * K, 6) void k_sign_tail(
             o = __shfl_xor(zmax, m); zmax = o > zmax ? o : zmax;
             o = __shfl_xor(r0max, m); r0max = o > r0max ? o : r0max;
         }
-        if (lane == 0) { red[wave][0] = zmax; red[wave][1] = r0max; }
-        __syncthreads();
-        int32_t za = 0, ra = 0;
-#pragma unroll
-        for (int i = 0; i < K; i++) { za = red[i][0] > za ? red[i][0] : za; ra = red[i][1] > ra ? red[i][1] : ra; }
-        bool ok = (za < gamma1 - beta) && (ra < GAMMA2 - beta);  // ml_dsa.rs:280
-        // ---- stage 2: ct0, hints
-        uint32_t hb = 0;
+        bool ok = (zmax < gamma1 - beta) && (r0max < GAMMA2 - beta);  // ml_dsa.rs:280 (wave-uniform)
+        // ---- stage 2: ct0, hints (HintBitPack, conversion.rs:277-328, written as they are found)
         if (ok) {
-            int32_t v[4], r[4];
-            load_packed(v, t0 + (key * K + wave) * (size_t)N, lane);
-            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-            ntt_inv_wave(r, itw, lane, F_MONT);
-            int32_t tmax = 0, hcount = 0;
+            uint8_t* hy = sig + ctilde_len + (size_t)L * (32 * cb);
+            for (int i = lane; i < omega + K; i += 64) hy[i] = 0;
+            int32_t tmax = 0;
+            int index = 0;  // running count of hints, wave-uniform
+#pragma unroll 1
+            for (int i = 0; i < K; i++) {
+                int32_t v[4], r[4];
+                load_packed(v, t0 + (key * K + i) * (size_t)N, lane);
+                r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+                ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int32_t tc = center(r[k]);
-                tc = tc < 0 ? -tc : tc;
-                tmax = tc > tmax ? tc : tmax;
-                // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
-                int32_t a1, a0, b1, b0;
-                decompose_s<G2HI>(freeze(rr[k] + r[k]), a1, a0);
-                decompose_s<G2HI>(rr[k], b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q)
-                const uint32_t h = a1 != b1;
-                hb |= h << k;
-                hcount += (int32_t)h;
+                for (int k = 0; k < 4; k++) {
+                    int32_t tc = center(r[k]);
+                    tc = tc < 0 ? -tc : tc;
+                    tmax = tc > tmax ? tc : tmax;
+                    // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
+                    const int32_t rr = rr_lds[wave][i][64 * k + lane];
+                    int32_t a1, a0, b1, b0;
+                    decompose_s<G2HI>(freeze(rr + r[k]), a1, a0);
+                    decompose_s<G2HI>(rr, b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q)
+                    const bool h = a1 != b1;
+                    const unsigned long long mask = __ballot(h);
+                    if (h) {
+                        const int rank = index + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (rank < omega) hy[rank] = (uint8_t)(64 * k + lane);
+                    }
+                    index += __popcll(mask);
+                }
+                if (lane == 0) hy[omega + i] = (uint8_t)(index < 255 ? index : 255);
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 const int32_t o = __shfl_xor(tmax, m);
                 tmax = o > tmax ? o : tmax;
-                hcount += __shfl_xor(hcount, m);
             }
-            if (lane == 0) { red[wave][2] = tmax; cnt[wave] = hcount; }
+            ok = (tmax < GAMMA2) && (index <= omega);  // ml_dsa.rs:312-315
         }
-        __syncthreads();
-        if (ok) {
-            int32_t ta = 0, hs = 0;
-#pragma unroll
-            for (int i = 0; i < K; i++) { ta = red[i][2] > ta ? red[i][2] : ta; hs += cnt[i]; }
-            ok = (ta < GAMMA2) && (hs <= omega);  // ml_dsa.rs:312-315
-        }
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             if (spec == 1) {
                 if (ok) done[op] = 1;
                 else kappa[op] = (uint16_t)(kappa[op] + L);  // ml_dsa.rs:281 / 316
@@ -203,52 +223,6 @@ __global__ __launch_bounds__(64 * K, 6) void k_sign_tail(
                 accept[slot] = ok ? 1 : 0;
             }
         }
-        if (ok) {
-            // ---- sigEncode (encodings.rs:238-276)
-            uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
-            if ((int)threadIdx.x < ctilde_len) sig[threadIdx.x] = ctilde[slot * 64 + threadIdx.x];
-            if (wave < L) {
-                // transpose z to 4 consecutive coefficients per lane, then BitPack(z, gamma1 - 1, gamma1)
-#pragma unroll
-                for (int k = 0; k < 4; k++) xpose[wave][64 * k + lane] = zc[k];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int4 z4 = reinterpret_cast<const int4*>(&xpose[wave][0])[lane];
-                const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
-                uint64_t lo = 0;
-                uint32_t hi = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint64_t f = (uint64_t)(uint32_t)(gamma1 - zz[i]);
-                    const int sh = i * cb;
-                    lo |= f << sh;
-                    if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
-                }
-                const int nbytes = cb / 2;
-                uint8_t* dst = sig + ctilde_len + (size_t)wave * (32 * cb) + (size_t)lane * nbytes;
-                for (int i = 0; i < 8; i++) dst[i] = (uint8_t)(lo >> (8 * i));
-                for (int i = 8; i < nbytes; i++) dst[i] = (uint8_t)(hi >> (8 * (i - 8)));
-            }
-            // HintBitPack (conversion.rs:277-328): positions in increasing order, running index
-            uint8_t* hy = sig + ctilde_len + (size_t)L * (32 * cb);
-            if ((int)threadIdx.x < omega + K) hy[threadIdx.x] = 0;
-            __syncthreads();
-            int base = 0;
-            for (int j = 0; j < wave; j++) base += cnt[j];
-            int before = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned long long mask = __ballot((hb >> k) & 1u);
-                if ((hb >> k) & 1u) {
-                    const int rank = base + before + __popcll(mask & ((1ull << lane) - 1ull));
-                    hy[rank] = (uint8_t)(64 * k + lane);
-                }
-                before += __popcll(mask);
-            }
-            if (lane == 0) hy[omega + wave] = (uint8_t)(base + cnt[wave]);
-        }
-        __syncthreads();
     }
 }
 
@@ -394,9 +368,9 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
                      size_t n_slots, hipStream_t s) {
     if (n_slots == 0) return MLDSA_OK;
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
-    dim3 grid(grid_for(ctx, n_slots, 1, 12));
+    dim3 grid(grid_for(ctx, n_slots, GWAVES, 6));
 #define MLDSA_TAIL(KK, LL, G2)                                                                                              \
-    hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * KK), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
+    hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
                        done, sigs, spec, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
                        n_slots, ctx->d_inv_tw)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
