@@ -106,7 +106,8 @@ int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs
                           const int32_t *znorm, const int32_t *hvalid, const int32_t *ctx_bad, uint8_t *ok, size_t n_ops, hipStream_t);
 
 // ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
-int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, size_t n_ops, hipStream_t);
+int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
+                  size_t w1_stride, size_t n_ops, hipStream_t);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,

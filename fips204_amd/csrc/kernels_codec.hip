@@ -9,6 +9,7 @@
 #include "ctx.h"
 #include "keccak.h"
 #include "ntt_wave.h"
+#include "rounding.h"
 
 namespace mldsa {
 
@@ -27,40 +28,6 @@ __device__ __forceinline__ void wave_lds_sync_c() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ------------------------------------------------------------------ high_low.rs on device
-
-// decompose (high_low.rs:66-96) for canonical r in [0, q); G2HI = (gamma2 == (q-1)/32)
-template <bool G2HI>
-__device__ __forceinline__ void decompose(int32_t rp, int32_t& r1, int32_t& r0) {
-    constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
-    int32_t x = (rp + 127) >> 7;
-    if constexpr (!G2HI) {
-        x = (x * 11275 + (1 << 23)) >> 24;
-        x ^= ((43 - x) >> 31) & x;
-    } else {
-        x = (x * 1025 + (1 << 21)) >> 22;
-        x &= 15;
-    }
-    int32_t y = rp - x * 2 * GAMMA2;
-    y -= (((Q - 1) / 2 - y) >> 31) & Q;
-    r1 = x;
-    r0 = y;
-}
-
-// use_hint (high_low.rs:155-192), r canonical
-template <bool G2HI>
-__device__ __forceinline__ int32_t use_hint(int32_t h, int32_t r) {
-    int32_t r1, r0;
-    decompose<G2HI>(r, r1, r0);
-    if (h == 0) return r1;
-    if constexpr (!G2HI) {
-        if (r0 > 0) return r1 == 43 ? 0 : r1 + 1;
-        return r1 == 0 ? 43 : r1 - 1;
-    } else {
-        return r0 > 0 ? (r1 + 1) & 15 : (r1 - 1) & 15;
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -221,19 +188,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
             for (int k = 0; k < 4; k++) {
                 const uint32_t h = (hw[k] >> (lane & 31)) & 1u;
                 const uint32_t v = (uint32_t)use_hint<G2HI>((int32_t)h, acc[k]);
-                if constexpr (G2HI) {
-                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // lane ^ 1
-                    if (!(lane & 1)) dst[32 * k + (lane >> 1)] = (uint8_t)(v | (nb << 4));
-                } else {
-                    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // lane ^ 1
-                    const uint32_t pair = (lane & 1) ? 0u : (v | (n1 << 6));                                      // 12 bits in even lanes
-                    const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pair, 0x4E, 0xF, 0xF, false);  // lane ^ 2
-                    if (!(lane & 3)) {
-                        const uint32_t q24 = pair | (n2 << 12);
-                        uint8_t* d = dst + 48 * k + 3 * (lane >> 2);
-                        d[0] = (uint8_t)q24; d[1] = (uint8_t)(q24 >> 8); d[2] = (uint8_t)(q24 >> 16);
-                    }
-                }
+                pack_w1_strided<G2HI>(v, k, dst, lane);
             }
         }
         __syncthreads();

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "ctx.h"
+#include "rounding.h"
 
 namespace mldsa {
 
@@ -154,11 +155,14 @@ __global__ __launch_bounds__(BLOCK) void k_infinity_norm(const int32_t *__restri
 // HBM traffic per op = algorithmic bytes: (K*L + L + 1 + K) KiB in, K KiB out.
 // With HAS_C = false the kernel is the signer's w = inv_ntt(A_hat * ntt(y)) (ml_dsa.rs:218-222);
 // a_idx then maps a compacted slot to the op whose A_hat it uses.
-template <int K, int L, bool HAS_C>
+// W1 = 1 / 2 additionally emits w1Encode(HighBits(w)) (6-bit / 4-bit fields) per op: the signer's
+// commitment bytes (ml_dsa.rs:225-232), so no separate pass re-reads w.
+template <int K, int L, bool HAS_C, int W1 = 0>
 __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
-    int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab) {
+    int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
+    uint8_t *__restrict__ w1 = nullptr, size_t w1_stride = 0) {
     constexpr int W = K > L + 1 ? K : L + 1;
     constexpr int NIN = HAS_C ? L + 1 : L;  // polynomials transformed in phase 1
     __shared__ int4 lds[(L + 1) * 64];
@@ -220,6 +224,12 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
             for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
             ntt_inv_wave(acc, itw, lane, F_MONT2);
             store_strided(acc, w_out + (op * K + wave) * (size_t)N, lane);
+            if constexpr (W1 != 0) {
+                constexpr bool G2HI = W1 == 2;
+                uint8_t *dst = w1 + op * w1_stride + (size_t)wave * (32 * (G2HI ? 4 : 6));
+#pragma unroll
+                for (int k = 0; k < 4; k++) pack_w1_strided<G2HI>((uint32_t)use_hint<G2HI>(0, acc[k]), k, dst, lane);
+            }
         }
         __syncthreads();
     }
@@ -301,17 +311,22 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
     return MLDSA_OK;
 }
 
-// w[slot] = inv_ntt(A_hat[a_idx[slot]] * ntt(y[slot]))   (ml_dsa.rs:218-222)
-int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, size_t n_ops,
-                  hipStream_t s) {
+// w[slot] = inv_ntt(A_hat[a_idx[slot]] * ntt(y[slot]))   (ml_dsa.rs:218-222); with w1 != nullptr also
+// w1Encode(HighBits(w)) (ml_dsa.rs:225-232)
+int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
+                  size_t w1_stride, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, 1, 12));
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, false>), grid, dim3(64 * 5), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, false>), grid, dim3(64 * 6), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, false>), grid, dim3(64 * 8), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+#define MLDSA_SW(KK, LL, WW, W1M)                                                                                              \
+    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M>), grid, dim3(64 * WW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
+                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride)
+    if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 5, 1); else MLDSA_SW(4, 4, 5, 0); }
+    else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 6, 2); else MLDSA_SW(6, 5, 6, 0); }
+    else if (set == MLDSA_87) { if (w1) MLDSA_SW(8, 7, 8, 2); else MLDSA_SW(8, 7, 8, 0); }
     else return set_error(MLDSA_ERR_PARAM, "sign_w: unknown parameter set");
+#undef MLDSA_SW
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

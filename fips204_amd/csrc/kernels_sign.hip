@@ -4,6 +4,7 @@
 // wave per polynomial; the NTT work goes through ntt_wave.h.
 #include "ctx.h"
 #include "keccak.h"
+#include "rounding.h"
 
 namespace mldsa {
 
@@ -50,24 +51,6 @@ __global__ __launch_bounds__(GBLOCK) void k_unpack_ntt(const uint8_t* __restrict
         for (int k = 0; k < 4; k++) r[k] = mont_mul(r[k], scale);
         store_packed(r, out + p * N, lane);
     }
-}
-
-// ------------------------------------------------------------------ high_low.rs pieces
-template <bool G2HI>
-__device__ __forceinline__ void decompose_s(int32_t rp, int32_t& r1, int32_t& r0) {  // high_low.rs:66-96, rp canonical
-    constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
-    int32_t x = (rp + 127) >> 7;
-    if constexpr (!G2HI) {
-        x = (x * 11275 + (1 << 23)) >> 24;
-        x ^= ((43 - x) >> 31) & x;
-    } else {
-        x = (x * 1025 + (1 << 21)) >> 22;
-        x &= 15;
-    }
-    int32_t y = rp - x * 2 * GAMMA2;
-    y -= (((Q - 1) / 2 - y) >> 31) & Q;
-    r1 = x;
-    r0 = y;
 }
 
 struct Coef4 { int32_t v[4]; };
@@ -164,7 +147,7 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
                 const int32_t rr = freeze(ww[k] - r[k]);  // w - cs2, canonical
                 rr_lds[wave][i][64 * k + lane] = rr;
                 int32_t r1, r0;
-                decompose_s<G2HI>(rr, r1, r0);
+                decompose<G2HI>(rr, r1, r0);
                 r0 = r0 < 0 ? -r0 : r0;
                 r0max = r0 > r0max ? r0 : r0max;
             }
@@ -196,8 +179,8 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
                     // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
                     const int32_t rr = rr_lds[wave][i][64 * k + lane];
                     int32_t a1, a0, b1, b0;
-                    decompose_s<G2HI>(freeze(rr + r[k]), a1, a0);
-                    decompose_s<G2HI>(rr, b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q)
+                    decompose<G2HI>(freeze(rr + r[k]), a1, a0);
+                    decompose<G2HI>(rr, b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q)
                     const bool h = a1 != b1;
                     const unsigned long long mask = __ballot(h);
                     if (h) {

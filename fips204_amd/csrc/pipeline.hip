@@ -168,7 +168,7 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
         TRY(launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s));                // :85
         MLDSA_HIP_CHECK(hipMemcpy2DAsync(w.s1c, (size_t)p->l * N * 4, w.s1s2, (size_t)(p->l + p->k) * N * 4,
                                          (size_t)p->l * N * 4, n, hipMemcpyDeviceToDevice, s));
-        TRY(launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1c, w.as1, n, s));                 // :86-88 inv_ntt(A * ntt(s1))
+        TRY(launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1c, w.as1, nullptr, 0, n, s));                 // :86-88 inv_ntt(A * ntt(s1))
         TRY(launch_keygen_encode(ctx, p, w.s1s2, w.as1, pko, sko, n, s));                   // :88-92, pk/sk encode
         MLDSA_HIP_CHECK(hipMemcpy2DAsync(pko, pkl, w.hbuf, 128, 32, n, hipMemcpyDeviceToDevice, s));        // rho
         MLDSA_HIP_CHECK(hipMemcpy2DAsync(sko, skl, w.hbuf, 128, 32, n, hipMemcpyDeviceToDevice, s));        // rho
@@ -274,9 +274,8 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
             // 11: y <- ExpandMask(rho'', kappa)                               :215
             STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, s));
             // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-            STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, w.slot_op, w.y, w.w, ns, s));
-            // 13-15: w1 <- HighBits(w); c_tilde <- H(mu || w1Encode(w1))      :225-234
-            STAGEC("high_bits_w1", launch_use_hint_w1(ctx, p, w.w, nullptr, w.w1, (size_t)p->w1_len, ns, s));
+            STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, w.slot_op, w.y, w.w, w.w1, (size_t)p->w1_len, ns, s));
+            // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
             STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
                                    w.ctilde, 64, ns, s));
             // 16: c <- SampleInBall(c_tilde)                                  :237
