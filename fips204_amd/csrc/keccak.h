@@ -130,6 +130,17 @@ __device__ __forceinline__ uint32_t load_le32(const uint8_t* p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
+// `bits`-wide little-endian field at bit offset `bo` of an arbitrarily aligned byte string, fetched
+// with two ALIGNED dword loads (consecutive lanes read overlapping 8-byte windows: coalesced).
+// May read up to 7 bytes past the field: only for fields that are followed by more data.
+__device__ __forceinline__ uint32_t load_field_aligned(const uint8_t* base, int bo, int bits) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(base) + (uintptr_t)(bo >> 3);
+    const uint32_t* a4 = reinterpret_cast<const uint32_t*>(addr & ~(uintptr_t)3);
+    const int sh = (int)((addr & 3) << 3) + (bo & 7);
+    const uint64_t d = ((uint64_t)a4[1] << 32) | a4[0];
+    return (uint32_t)(d >> sh) & ((1u << bits) - 1u);
+}
+
 // absorb NW 8-byte words from (unaligned) memory into state words 0..NW-1 of a fresh state
 template <int NW>
 __device__ __forceinline__ void absorb_words(KeccakState& s, const uint8_t* p) {

@@ -122,16 +122,12 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
     for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
         int4 av[L];
         int4 tv = make_int4(0, 0, 0, 0);
-        uint32_t hw[4] = {0, 0, 0, 0};
         if (wave < K) {
             const int4* ap = reinterpret_cast<const int4*>(a_hat + ((op * K + wave) * (size_t)L) * N);
 #pragma unroll
             for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
             const size_t key = key_idx ? key_idx[op] : op;
             tv = reinterpret_cast<const int4*>(t1 + (key * K + wave) * (size_t)N)[lane];
-            // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5)
-#pragma unroll
-            for (int k = 0; k < 4; k++) hw[k] = hmask[(op * K + wave) * 8 + 2 * k + (lane >> 5)];
         }
         if (wave <= L) {
             int32_t r[4];
@@ -140,8 +136,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
                 int32_t mx = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int bo = (64 * k + lane) * CB;
-                    const uint32_t v = (load_le32(src + (bo >> 3)) >> (bo & 7)) & ((1u << CB) - 1u);
+                    const uint32_t v = load_field_aligned(src, (64 * k + lane) * CB, CB);  // hints follow z: over-read is in-buffer
                     r[k] = (1 << GB) - (int32_t)v;
                     const int32_t a = r[k] < 0 ? -r[k] : r[k];
                     mx = a > mx ? a : mx;
@@ -180,6 +175,11 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
             acc[3] -= mont_mul(cv.w, tv.w);
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
+            // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5); issued before the inverse
+            // NTT so the (L2-resident) loads complete under it without occupying registers in phase 1
+            uint32_t hw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hw[k] = hmask[(op * K + wave) * 8 + 2 * k + (lane >> 5)];
             ntt_inv_wave(acc, itw, lane, F_MONT2);
             // acc[k] = w'[64 k + lane], canonical.  UseHint, then pack BITS-bit fields: coefficient
             // pairs (4-bit) / quads (6-bit) sit in adjacent lanes of the same register.
