@@ -1,0 +1,105 @@
+// Device-side building blocks shared by the sampler kernels (kernels_sample.hip) and the fused
+// verify kernel (kernels_fused.hip): compile-time loops, static access to the squeezed block,
+// lane-private LDS staging rows and their cooperative, coalesced flush.
+#pragma once
+#include <type_traits>
+
+#include "field.h"
+#include "keccak.h"
+
+namespace mldsa {
+
+constexpr int SWAVES = 4;         // waves per block for the sampler kernels
+constexpr int STAGE_STRIDE = 33;  // dwords per lane row (odd: conflict-free), capacity 32
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+// 32-bit word W (compile time) of the sponge state
+template <int W>
+__device__ __forceinline__ uint32_t state_word(const KeccakState& s) {
+    if constexpr (W & 1) return s.hi[W / 2]; else return s.lo[W / 2];
+}
+
+// 32 bits of the squeezed block starting at byte B (compile time)
+template <int B>
+__device__ __forceinline__ uint32_t block_bits(const KeccakState& s) {
+    constexpr int W = B / 4, SH = (B % 4) * 8;
+    if constexpr (SH == 0) return state_word<W>(s);
+    else if constexpr (W + 1 < 50) return __builtin_amdgcn_alignbit(state_word<W + 1>(s), state_word<W>(s), SH);
+    else return state_word<W>(s) >> SH;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Flush: lane row `r` holds take[r] dwords that continue stream r's polynomial at
+// coefficient n[r].  Two streams per iteration (half-wave each, <= 32 dwords per row).  The
+// per-row (n, take) pairs go through a 64-word LDS table so that every LDS read of a batch of
+// 8 iterations is independent and can be in flight together (one wait per batch).
+__device__ __forceinline__ void flush_rows(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
+                                           int take, int n, int lane) {
+    meta[lane] = ((uint32_t)n << 8) | (uint32_t)take;
+    wave_lds_sync();
+    const int half = lane >> 5, l5 = lane & 31;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+        uint32_t m[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = 2 * (i0 + u) + half;
+            m[u] = meta[row];
+            v[u] = stage[row * STAGE_STRIDE + l5];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = 2 * (i0 + u) + half;
+            if (l5 < (int)(m[u] & 0xFFu)) out[(wave_base + row) * N + (m[u] >> 8) + l5] = (int32_t)v[u];
+        }
+    }
+    wave_lds_sync();
+}
+
+
+// RejNTTPoly (hashing.rs:111-146) for the lane's stream: `st` holds the absorbed, padded seed.
+// Squeezes SHAKE128 blocks until the lane has its 256 coefficients (wave-uniform loop: every lane
+// keeps permuting until the whole wave is done, extra output is dropped) and flushes 28-candidate
+// half blocks through the staging rows to out[(wave_base + lane) * 256 + ...].
+__device__ __forceinline__ void rej_ntt_poly_lane(KeccakState& st, uint32_t* stage, uint32_t* meta, uint32_t* my,
+                                                  int32_t* __restrict__ out, size_t wave_base, int lane, bool valid) {
+    int n = valid ? 0 : N;
+    while (__any(n < N)) {
+        keccak_f1600(st);
+        static_for<0, 2>([&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            int cnt = 0;
+            static_for<0, 28>([&](auto cc) {  // 28 candidates per half block: bytes 84 H + 3 C
+                constexpr int C = decltype(cc)::value;
+                const uint32_t z = block_bits<84 * H + 3 * C>(st) & 0x7FFFFFu;  // coeff_from_three_bytes, conversion.rs:40-61
+                my[cnt] = z;
+                cnt += (z < (uint32_t)Q) ? 1 : 0;
+            });
+            const int take = min(cnt, N - n);
+            flush_rows(stage, meta, out, wave_base, take, n, lane);
+            n += take;
+        });
+    }
+}
+
+// absorbed + padded SHAKE128 state of stream (rho, s, r)   (hashing.rs:236: rho || s || r)
+__device__ __forceinline__ void expand_a_seed(KeccakState& st, const uint8_t* rho, int s_idx, int r_idx) {
+    keccak_zero(st);
+    absorb_words<4>(st, rho);
+    st.lo[4] = (uint32_t)s_idx | ((uint32_t)r_idx << 8) | (0x1Fu << 16);
+    st.hi[SHAKE128_RATE / 8 - 1] = 0x80000000u;
+}
+
+}  // namespace mldsa
