@@ -163,6 +163,69 @@ def usable_cores():
     return n
 
 
+class SeamKernel:
+    """One seam-level primitive of the hot path on its own (SURVEY.md 8d per-kernel figures):
+    ntt / inv_ntt (2 048 B per polynomial), mat_vec_mul65 (41 984 B per op), expand_a65 (30 752 B
+    written per op; Keccak-bound), expand_mask65 ((66 + 1024) * L per op; Keccak-bound)."""
+
+    def __init__(self, hp, name, batch, rank):
+        self.hp, self.name_, self.rank = hp, name, rank
+        g = torch.Generator(device="cuda").manual_seed(204 + rank)
+        self.dtype = "int32"
+        self.unit = "polys/s"
+        if name in ("ntt", "inv_ntt"):
+            self.batch = batch or 393216  # config-3 size: 65 536 ops x 6 polys
+            self.bytes_per_op = 2048
+            self.n_sets = 3               # 3 x 403 MB in + out buffers: nothing survives in the 256 MiB Infinity Cache
+            self.inputs = [torch.randint(0, Q, (self.batch, 256), dtype=torch.int32, device="cuda", generator=g) for _ in range(self.n_sets)]
+            self.out = torch.empty_like(self.inputs[0])
+            fn = hp.ntt if name == "ntt" else hp.inv_ntt
+            self.call = lambda i: fn(self.inputs[i % self.n_sets], out=self.out)
+            self.kernel = "k_" + name
+        elif name == "mat_vec_mul65":
+            self.batch = batch or 16384
+            self.unit = "ops/s"
+            self.bytes_per_op = 1024 * (30 + 5 + 6)
+            self.n_sets = 2
+            self.inputs = [(torch.randint(0, Q, (self.batch, 6, 5, 256), dtype=torch.int32, device="cuda", generator=g),
+                            torch.randint(0, Q, (self.batch, 5, 256), dtype=torch.int32, device="cuda", generator=g)) for _ in range(self.n_sets)]
+            self.call = lambda i: hp.mat_vec_mul(65, *self.inputs[i % self.n_sets])
+            self.kernel = "k_mat_vec_mul<6,5>"
+        elif name == "expand_a65":
+            self.batch = batch or 65536
+            self.unit = "ops/s"
+            self.bytes_per_op = 32 + 1024 * 30
+            self.n_sets = 1
+            self.rho = torch.randint(0, 256, (self.batch, 32), dtype=torch.uint8, device="cuda", generator=g)
+            self.call = lambda i: hp.expand_a(65, self.rho)
+            self.kernel = "k_expand_a<6,5>"
+        elif name == "expand_mask65":
+            self.batch = batch or 65536
+            self.unit = "ops/s"
+            self.bytes_per_op = (66 + 1024) * 5
+            self.n_sets = 1
+            self.rho = torch.randint(0, 256, (self.batch, 64), dtype=torch.uint8, device="cuda", generator=g)
+            self.kappa = torch.zeros(self.batch, dtype=torch.int16, device="cuda")
+            self.call = lambda i: hp.expand_mask(65, self.rho, self.kappa)
+            self.kernel = "k_expand_mask<19>"
+        else:
+            raise SystemExit(f"unknown seam kernel {name!r}")
+        self.name = f"{name} batch={self.batch} (seam-level primitive, inputs resident in HBM)"
+        self.metric = f"{name} {self.unit} per GPU (batched); % HBM roofline"
+
+    def step(self, i):
+        self.call(i)
+
+    def kernel_launches_per_step(self):
+        return 1
+
+    def check(self):
+        pass  # parity of every seam primitive is covered by tests/test_gpu_poly.py / test_gpu_samplers.py
+
+    def cpu_baseline(self, budget_s=0):
+        return None
+
+
 def _shake(tag, i, width):
     import hashlib
     return hashlib.shake_256(tag + i.to_bytes(width, "little")).digest(32)
@@ -296,6 +359,8 @@ def make_workload(name, hp, batch, rank):
     for kind in ("verify", "sign"):
         if name.startswith(kind) and name[len(kind):].isdigit():
             return WholeOp(hp, int(name[len(kind):]), kind, batch or 65536, rank)
+    if name in ("ntt", "inv_ntt", "mat_vec_mul65", "expand_a65", "expand_mask65"):
+        return SeamKernel(hp, name, batch, rank)
     raise SystemExit(f"unknown workload {name!r}")
 
 
@@ -376,7 +441,9 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
                                 "achieved_GBs": wl.bytes_per_op * value / world / 1e9,
                                 "frac_of_peak": wl.bytes_per_op * value / world / 1e9 / HBM_PEAK_GBS}
     if world == 1 and cpu_baseline:
-        line["cpu_baseline"] = wl.cpu_baseline()
+        cb = wl.cpu_baseline()
+        if cb:
+            line["cpu_baseline"] = cb
     del wl
     torch.cuda.empty_cache()
     return line

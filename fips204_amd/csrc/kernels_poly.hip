@@ -23,9 +23,13 @@ __global__ __launch_bounds__(BLOCK) void k_ntt(const int32_t *__restrict__ in, i
     const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
     FwdTw tw;
     load_fwd_tw(tw, tab, lane);
+    // software prefetch: the next polynomial's loads are in flight while this one is transformed
+    // (1 KiB per wave in flight is too little to cover HBM latency at 32 waves per CU)
+    int32_t nxt[4] = {0, 0, 0, 0};
+    if (wave < n_polys) load_strided(nxt, in + wave * N, lane);
     for (size_t p = wave; p < n_polys; p += n_waves) {
-        int32_t r[4];
-        load_strided(r, in + p * N, lane);
+        int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+        if (p + n_waves < n_polys) load_strided(nxt, in + (p + n_waves) * N, lane);
 #pragma unroll
         for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
         ntt_fwd_wave(r, tw, lane);
@@ -41,9 +45,11 @@ __global__ __launch_bounds__(BLOCK) void k_inv_ntt(const int32_t *__restrict__ i
     const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
     InvTw tw;
     load_inv_tw(tw, tab, lane);
+    int32_t nxt[4] = {0, 0, 0, 0};
+    if (wave < n_polys) load_packed(nxt, in + wave * N, lane);
     for (size_t p = wave; p < n_polys; p += n_waves) {
-        int32_t r[4];
-        load_packed(r, in + p * N, lane);
+        int32_t r[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+        if (p + n_waves < n_polys) load_packed(nxt, in + (p + n_waves) * N, lane);
 #pragma unroll
         for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
         ntt_inv_wave(r, tw, lane, F_MONT);

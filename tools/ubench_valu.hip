@@ -11,8 +11,14 @@
 
 constexpr int ILP = 8;
 
+__device__ unsigned long long g_clk[2];  // sum of s_memtime deltas, sum of s_memrealtime deltas (block 0, wave 0)
+
+#define CLK_BEGIN unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#define CLK_END if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = __builtin_amdgcn_s_memtime() - t0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+
 #define DEFINE_KERNEL(NAME, ASM)                                                        \
     __global__ __launch_bounds__(256) void NAME(uint32_t* out, int iters) {             \
+        CLK_BEGIN                                                                       \
         uint32_t a[ILP];                                                                \
         uint32_t b = threadIdx.x * 2654435761u + 12345u, c = blockIdx.x * 40503u + 7u;  \
         for (int j = 0; j < ILP; j++) a[j] = threadIdx.x + j * 977u + 1u;               \
@@ -23,6 +29,7 @@ constexpr int ILP = 8;
         uint32_t s = 0;                                                                 \
         for (int j = 0; j < ILP; j++) s += a[j];                                        \
         out[blockIdx.x * 256 + threadIdx.x] = s;                                        \
+        CLK_END                                                                         \
     }
 
 DEFINE_KERNEL(k_add, "v_add_u32 %0, %0, %1")
@@ -49,6 +56,7 @@ DEFINE_KERNEL(k_swizzle, "ds_swizzle_b32 %0, %0 offset:swizzle(BITMASK_PERM,\"00
 
 // 64-bit multiply-add (one instruction produces a 64-bit result)
 __global__ __launch_bounds__(256) void k_mad_u64(uint32_t* out, int iters) {
+    CLK_BEGIN
     uint64_t a[ILP];
     uint32_t b = threadIdx.x * 2654435761u + 12345u;
     for (int j = 0; j < ILP; j++) a[j] = threadIdx.x + j * 977u + 1u;
@@ -62,6 +70,7 @@ __global__ __launch_bounds__(256) void k_mad_u64(uint32_t* out, int iters) {
     uint32_t s = 0;
     for (int j = 0; j < ILP; j++) s += (uint32_t)a[j] + (uint32_t)(a[j] >> 32);
     out[blockIdx.x * 256 + threadIdx.x] = s;
+    CLK_END
 }
 
 typedef void (*kern_t)(uint32_t*, int);
@@ -72,7 +81,7 @@ int main() {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, dev));
     const int n_cu = prop.multiProcessorCount;
-    const int blocks = n_cu * 8, iters = 2048;
+    const int blocks = n_cu * 8, iters = 16384;  // ~2 ms per kernel so the clock reading settles
     uint32_t* out;
     CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     hipEvent_t e0, e1;
@@ -88,7 +97,7 @@ int main() {
         {"ds_bpermute_b32(+wait)", k_bpermute}, {"ds_swizzle_b32(+wait)", k_swizzle},
     };
     printf("device: %s, %d CUs, clock %d MHz\n", prop.name, n_cu, prop.clockRate / 1000);
-    printf("%-28s %12s %16s %18s\n", "instruction", "ms", "Glane-ops/s", "cyc/wave-instr/SIMD@2.4GHz");
+    printf("%-28s %12s %16s %18s %10s %14s\n", "instruction", "ms", "Glane-ops/s", "cyc/instr@2.4GHz", "clock MHz", "cyc/instr@clk");
     for (auto& t : tests) {
         hipLaunchKernelGGL(t.k, dim3(blocks), dim3(256), 0, 0, out, 64);  // warm-up
         CHECK(hipDeviceSynchronize());
@@ -105,7 +114,11 @@ int main() {
         double wave_instrs_per_simd = (double)blocks * 4 /*waves per block*/ * iters * ILP / (n_cu * 4.0);
         double cyc = best * 1e-3 * 2.4e9 / wave_instrs_per_simd;
         double glops = (double)blocks * 256 * iters * ILP / (best * 1e-3) / 1e9;
-        printf("%-28s %12.3f %16.1f %18.2f\n", t.name, best, glops, cyc);
+        unsigned long long clk[2] = {0, 0};
+        CHECK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
+        // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+        double mhz = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0;
+        printf("%-28s %12.3f %16.1f %18.2f %10.0f %14.2f\n", t.name, best, glops, cyc, mhz, cyc * mhz / 2400.0);
     }
     return 0;
 }
