@@ -390,7 +390,9 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world)
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / wl.kernel_launches_per_step()
+    # single-kernel workloads: average launch duration over the back-to-back launches of the timed region
+    # (first start event -> last end event; per-step pairs would add the host's record-to-launch latency)
+    kern_ms = ev[0][0].elapsed_time(ev[-1][1]) / steps / wl.kernel_launches_per_step()
     total_ops = wl.batch * world * steps
     value = total_ops / dt
     stages = None
