@@ -80,9 +80,12 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_inv_tw, i.size() * sizeof(Twiddle));
     if (e == hipSuccess) e = hipMemcpy(ctx->d_fwd_tw, f.data(), f.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_inv_tw, i.data(), i.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
-        return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload", e);
+        return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
     }
     *out = ctx;
     return MLDSA_OK;
@@ -95,6 +98,9 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
         (void)hipFree(ctx->ws);
     }
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
     delete ctx;

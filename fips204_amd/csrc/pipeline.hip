@@ -81,15 +81,31 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
         MLDSA_HIP_CHECK(hipMemsetAsync(w.znorm, 0, n * sizeof(int32_t), s));
-        // 2: (c_tilde, z, h) <- sigDecode(sigma): hints here, z inside k_verify_main      ml_dsa.rs:368-376
-        STAGE("hint_unpack", launch_hint_unpack(ctx, p, sg, w.hmask, w.hvalid, n, s));
-        // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
-        STAGE("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
-                      w.mu_w1, mw, w.ctx_bad, n, s));
-        // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
-        STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, s));
+        // fork: the small lane-per-op kernels are latency-bound (1-2 Keccak-f per op, <= 1 wave per SIMD) and
+        // independent of ExpandA, so they run on the context's second stream underneath it
+        hipStream_t aux = ctx->aux_stream;
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(aux, ctx->fork_ev, 0));
+        {
+            // 2: (c_tilde, z, h) <- sigDecode(sigma): hints here, z inside k_verify_main      ml_dsa.rs:368-376
+            ProfScope ps(ctx, aux, "hint_unpack");
+            TRY(launch_hint_unpack(ctx, p, sg, w.hmask, w.hvalid, n, aux));
+        }
+        {
+            // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
+            ProfScope ps(ctx, aux, "mu");
+            TRY(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
+                          w.mu_w1, mw, w.ctx_bad, n, aux));
+        }
+        {
+            // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
+            ProfScope ps(ctx, aux, "sample_in_ball");
+            TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, aux));
+        }
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, aux));
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
         STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
         // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
         STAGE("verify_main", launch_verify_main(ctx, p, w.a_hat, sg, w.c, t1 + key_base * (size_t)p->k * N, kidx, w.hmask,
                                                 w.mu_w1 + 64, mw, w.znorm, n, s));
