@@ -106,6 +106,7 @@ class VerifyArith:
             t1 = torch.randint(0, Q, (batch, self.k, 256), dtype=torch.int32, device="cuda", generator=g)
             self.inputs.append((a, z, c, t1))
         self.out = torch.empty((batch, self.k, 256), dtype=torch.int32, device="cuda")
+        self._calls = None
         self.kernel = f"k_verify_arith<{self.k},{self.l}>"
         self.name = f"ml_dsa_{pset} batch={batch} verify arithmetic (NTT/INTT + pointwise kernels only, inputs resident in HBM)"
         self.unit = "verifies/s"
@@ -113,8 +114,18 @@ class VerifyArith:
         self.dtype = "int32"
 
     def step(self, i):
-        a, z, c, t1 = self.inputs[i % self.n_sets]
-        self.hp.verify_arith(self.pset, a, z, c, t1, out=self.out)
+        # the kernel runs ~25 us: go through a pre-bound C call so the host keeps the stream's queue full
+        if self._calls is None:
+            import ctypes as C
+            import functools
+            lib, h = self.hp.lib, self.hp._h
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self._calls = [functools.partial(lib.mldsa_verify_arith, h, self.pset, C.c_void_p(a.data_ptr()), C.c_void_p(z.data_ptr()),
+                                             C.c_void_p(c.data_ptr()), C.c_void_p(t1.data_ptr()), C.c_void_p(self.out.data_ptr()),
+                                             self.batch, stream) for a, z, c, t1 in self.inputs]
+        rc = self._calls[i % self.n_sets]()
+        if rc != 0:
+            raise RuntimeError(f"mldsa_verify_arith failed: {rc}")
 
     def kernel_launches_per_step(self):
         return 1
@@ -377,22 +388,22 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
 
     # timed region: exactly K steps, barrier + synchronize on both sides; HIP events on the launch
     # stream give the dominant kernel's average duration for the roofline
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(steps):
-        ev[i][0].record()
         wl.step(warmup + i)
-        ev[i][1].record()
+    ev1.record()
     torch.cuda.synchronize()
     barrier(world)
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world)
 
     # single-kernel workloads: average launch duration over the back-to-back launches of the timed region
-    # (first start event -> last end event; per-step pairs would add the host's record-to-launch latency)
-    kern_ms = ev[0][0].elapsed_time(ev[-1][1]) / steps / wl.kernel_launches_per_step()
+    # (HIP events on the launch stream, first launch -> last completion)
+    kern_ms = ev0.elapsed_time(ev1) / steps / wl.kernel_launches_per_step()
     total_ops = wl.batch * world * steps
     value = total_ops / dt
     stages = None
