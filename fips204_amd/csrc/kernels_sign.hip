@@ -98,13 +98,21 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
         uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
         const int4 cv = reinterpret_cast<const int4*>(c_hat + slot * N)[lane];
         if (lane < ctilde_len) sig[lane] = ctilde[slot * 64 + lane];
-        // ---- stage 1a: z
+        // ---- stage 1a: z   (software-pipelined: the next polynomial's loads are issued before this one's inverse NTT)
         int32_t zmax = 0, r0max = 0;
+        int32_t nv[4], ny[4];
+        load_packed(nv, s1 + (key * L) * (size_t)N, lane);
+        load_strided(ny, y + (slot * L) * (size_t)N, lane);
 #pragma unroll 1
         for (int j = 0; j < L; j++) {
-            int32_t v[4], yy[4], r[4];
-            load_packed(v, s1 + (key * L + j) * (size_t)N, lane);
-            load_strided(yy, y + (slot * L + j) * (size_t)N, lane);
+            int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, yy[4] = {ny[0], ny[1], ny[2], ny[3]}, r[4];
+            if (j + 1 < L) {
+                load_packed(nv, s1 + (key * L + j + 1) * (size_t)N, lane);
+                load_strided(ny, y + (slot * L + j + 1) * (size_t)N, lane);
+            } else {  // first polynomial of stage 1b
+                load_packed(nv, s2 + (key * K) * (size_t)N, lane);
+                load_strided(ny, w + (slot * K) * (size_t)N, lane);
+            }
             r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
             ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
@@ -137,9 +145,11 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
         // ---- stage 1b: r = w - cs2, LowBits
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
-            int32_t v[4], ww[4], r[4];
-            load_packed(v, s2 + (key * K + i) * (size_t)N, lane);
-            load_strided(ww, w + (slot * K + i) * (size_t)N, lane);
+            int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, ww[4] = {ny[0], ny[1], ny[2], ny[3]}, r[4];
+            if (i + 1 < K) {
+                load_packed(nv, s2 + (key * K + i + 1) * (size_t)N, lane);
+                load_strided(ny, w + (slot * K + i + 1) * (size_t)N, lane);
+            }
             r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
             ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
