@@ -83,7 +83,6 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
-    for (int k = 0; k < 8 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->sub_ev[k], hipEventDisableTiming);
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
@@ -101,8 +100,6 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
-    for (hipEvent_t e : ctx->sub_ev)
-        if (e) (void)hipEventDestroy(e);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);

@@ -21,7 +21,7 @@ struct mldsa_ctx {
     // second stream: the small latency-bound lane-per-op kernels of verify (hint unpack, mu,
     // SampleInBall) run here, concurrently with the VALU-bound ExpandA on the caller's stream
     hipStream_t aux_stream = nullptr;
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr, sub_ev[8] = {};
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     // optional per-stage timing: HIP event pairs recorded on the launch stream, resolved
     // only when the caller asks for the report (no synchronisation in the timed region)
     bool prof_on = false;

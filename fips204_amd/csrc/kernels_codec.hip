@@ -118,9 +118,6 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
     __syncthreads();
     const LdsTw ftw{tw_lds, lane};
     const LdsTw itw{tw_lds + FWD_TW * 64, lane};
-    // this kernel mostly waits on HBM; when it shares the chip with the VALU-bound ExpandA of the next
-    // sub-batch its waves should win issue arbitration so that their loads go out promptly
-    __builtin_amdgcn_s_setprio(3);
 
     for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
         int4 av[L];

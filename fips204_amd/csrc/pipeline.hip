@@ -102,30 +102,13 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
             ProfScope ps(ctx, aux, "sample_in_ball");
             TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, aux));
         }
-        // 5: A_hat <- ExpandA(rho) on the caller's stream, sub-batch by sub-batch          ml_dsa.rs:406
-        // 9-10: verify_main(b) on the second stream as soon as ExpandA(b) is done, i.e. under ExpandA(b + 1):
-        //       ExpandA is VALU-bound, verify_main mostly waits on HBM and runs at raised wave priority
-        {
-            const char *e4 = getenv("MLDSA_VERIFY_NSUB");
-            const size_t n_sub = e4 ? (size_t)atoi(e4) : (n >= 32768 ? 4 : 1);
-            const size_t per = (n + n_sub - 1) / n_sub;
-            for (size_t b = 0; b < n_sub; b++) {
-                const size_t so = b * per;
-                if (so >= n) break;
-                const size_t sn = (n - so) < per ? (n - so) : per;
-                const uint32_t *skidx = kidx ? kidx + so : nullptr;
-                const size_t skb = kidx ? key_base : key_base + so;
-                STAGE("expand_a", launch_expand_a(ctx, set, rho + skb * 32, 32, skidx, w.a_hat + so * (size_t)(p->k * p->l) * N, sn, s));
-                MLDSA_HIP_CHECK(hipEventRecord(ctx->sub_ev[b], s));
-                MLDSA_HIP_CHECK(hipStreamWaitEvent(aux, ctx->sub_ev[b], 0));
-                ProfScope ps(ctx, aux, "verify_main");
-                TRY(launch_verify_main(ctx, p, w.a_hat + so * (size_t)(p->k * p->l) * N, sg + so * (size_t)p->sig_len,
-                                       w.c + so * (size_t)N, t1 + skb * (size_t)p->k * N, skidx, w.hmask + so * (size_t)p->k * 8,
-                                       w.mu_w1 + 64 + so * mw, mw, w.znorm + so, sn, aux));
-            }
-        }
         MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, aux));
+        // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
+        STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
+        // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
+        STAGE("verify_main", launch_verify_main(ctx, p, w.a_hat, sg, w.c, t1 + key_base * (size_t)p->k * N, kidx, w.hmask,
+                                                w.mu_w1 + 64, mw, w.znorm, n, s));
         // 12: c_tilde' <- H(mu || w1Encode(w1'), lambda/4)                 ml_dsa.rs:429-431
         STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, w.ctilde_p, 64, n, s));
         // 13: [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]      ml_dsa.rs:434-436
