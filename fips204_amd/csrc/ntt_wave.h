@@ -181,7 +181,7 @@ __device__ __forceinline__ void ntt_inv_wave(int32_t r[4], const TW& tw, int lan
     bf_gs(r[0], r[2], ZI1);
     bf_gs(r[1], r[3], ZI1);
 #pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = freeze(mont_mul(r[k], f));
+    for (int k = 0; k < 4; k++) r[k] = caddq(mont_mul(r[k], f));  // mont_mul lands in (-q, q): only the conditional +q of full_reduce32 is left
 }
 
 // coalesced I/O in the two layouts
