@@ -83,6 +83,11 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
+    for (int l = 0; l < MLDSA_SIGN_MAX_LANES; l++) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_lane_count, MLDSA_SIGN_MAX_LANES * sizeof(uint32_t));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
@@ -101,6 +106,11 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (int l = 0; l < MLDSA_SIGN_MAX_LANES; l++) {
+        if (ctx->lane_ev[l]) (void)hipEventDestroy(ctx->lane_ev[l]);
+        if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
+    }
+    if (ctx->h_lane_count) (void)hipHostFree(ctx->h_lane_count);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
     delete ctx;

@@ -10,6 +10,8 @@
 #include "../../include/mldsa_hip.h"
 #include "ntt_wave.h"
 
+#define MLDSA_SIGN_MAX_LANES 8
+
 struct mldsa_ctx {
     int device = 0;
     int n_cu = 256;
@@ -22,6 +24,10 @@ struct mldsa_ctx {
     // SampleInBall) run here, concurrently with the VALU-bound ExpandA on the caller's stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // sign: sub-batches of one call run their rejection loops on these streams, out of phase
+    hipStream_t lane_stream[MLDSA_SIGN_MAX_LANES] = {};
+    hipEvent_t lane_ev[MLDSA_SIGN_MAX_LANES] = {};
+    uint32_t *h_lane_count = nullptr;  // pinned host: unfinished ops per lane after a round
     // optional per-stage timing: HIP event pairs recorded on the launch stream, resolved
     // only when the caller asks for the report (no synchronisation in the timed region)
     bool prof_on = false;

@@ -299,9 +299,14 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
     const int n_blocks = total / SHAKE256_RATE + 1;
     KeccakState st;
     keccak_zero(st);
-    for (int blk = 0; blk < n_blocks; blk++) {
+    // The wave's 64 x 34 dwords of one rate block: element e = 64 i + lane -> (row, word).  All 34
+    // loads of a block are issued back to back, and those of block b+1 are issued before the
+    // permutation of block b, so their latency hides under it (the hash chain of one op is serial
+    // and the kernel often runs a single wave per SIMD).
+    uint32_t pre[34];
+    auto issue = [&](int blk) {
         const int base = blk * SHAKE256_RATE;
-        // cooperative fill: element e = 64 i + lane -> (row, word)
+#pragma unroll
         for (int i = 0; i < 34; i++) {
             const int e = 64 * i + lane;
             const int row = e / 34, wd = e - row * 34;
@@ -315,7 +320,17 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
                     v = ALIGNED ? *reinterpret_cast<const uint32_t*>(src) : load_le32(src);
                 }
             }
-            tile[row * H_STRIDE + wd] = v;
+            pre[i] = v;
+        }
+    };
+    issue(0);
+    for (int blk = 0; blk < n_blocks; blk++) {
+        const int base = blk * SHAKE256_RATE;
+#pragma unroll
+        for (int i = 0; i < 34; i++) {
+            const int e = 64 * i + lane;
+            const int row = e / 34, wd = e - row * 34;
+            tile[row * H_STRIDE + wd] = pre[i];
         }
         wave_lds_sync_c();
         static_for_c<0, 17>([&](auto wc) {
@@ -336,6 +351,7 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
         });
         if (blk == n_blocks - 1) st.hi[16] ^= 0x80000000u;
         wave_lds_sync_c();
+        if (blk + 1 < n_blocks) issue(blk + 1);
         keccak_f1600(st);
     }
     if (!valid) return;

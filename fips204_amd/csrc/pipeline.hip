@@ -196,19 +196,25 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
 
 // ------------------------------------------------------------------------------------
 // Signer::try_sign_* -> sign_internal (ml_dsa.rs:153-337) with the rejection loop re-batched:
-// every round runs one loop iteration for all unfinished ops, then compacts the active list.
+// every round runs one loop iteration for all unfinished ops of a sub-batch, then compacts its
+// active list.  Sub-batches run on several streams ("lanes") at different phases of the loop,
+// so the short, latency-bound late rounds of one lane fill the machine under the wide early
+// rounds of another; a lane that finishes takes the next sub-batch of the call.
 namespace {
-constexpr size_t SPEC_TARGET_SLOTS = 65536;  // upper bound of candidate slots per speculative round (workspace size)
+constexpr size_t SIGN_CHUNK_OPS = 65536;     // ops resident per call pass (workspace size), all lanes together
+constexpr size_t SPEC_TARGET_SLOTS = 65536;  // upper bound of candidate slots per speculative round, all lanes together
 
 struct SignWs {
     int32_t *a_hat, *y, *w, *c, *done, *ctx_bad, *accept;
     uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage;
     uint16_t *kappa, *slot_kappa;
     uint32_t *act0, *act1, *slot_op, *counter;
-    size_t bytes, stage_stride;
-    SignWs(void *base, const mldsa_params *p, size_t n) {
+    size_t bytes = 0, stage_stride = 0;
+    SignWs() = default;
+    // n = ops of the sub-batch, spec_slots = cap of candidate slots in a speculative round
+    SignWs(void *base, const mldsa_params *p, size_t n, size_t spec_slots) {
         Carver cv(base);
-        const size_t ns = n > SPEC_TARGET_SLOTS ? n : SPEC_TARGET_SLOTS;  // slots per round
+        const size_t ns = n > spec_slots ? n : spec_slots;  // slots per round
         stage_stride = ((size_t)p->sig_len + 15) & ~(size_t)15;
         a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
         y = cv.take<int32_t>(ns * (size_t)p->l * N);
@@ -221,19 +227,35 @@ struct SignWs {
         rho_pp = cv.take<uint8_t>(n * 64);
         w1 = cv.take<uint8_t>(ns * (size_t)p->w1_len);
         ctilde = cv.take<uint8_t>(ns * 64);
-        stage = cv.take<uint8_t>(SPEC_TARGET_SLOTS * stage_stride);
+        stage = cv.take<uint8_t>(spec_slots * stage_stride);
         kappa = cv.take<uint16_t>(n);
         slot_kappa = cv.take<uint16_t>(ns);
         act0 = cv.take<uint32_t>(n);
         act1 = cv.take<uint32_t>(n);
         slot_op = cv.take<uint32_t>(ns);
         counter = cv.take<uint32_t>(64);
-        bytes = cv.off + 256;
+        bytes = (cv.off + 511) & ~(size_t)255;
     }
 };
-}  // namespace
 
-constexpr size_t SIGN_CHUNK_OPS = 65536;
+struct SignLane {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    volatile uint32_t *h_count = nullptr;
+    SignWs w;
+    size_t o = 0, n = 0, m = 0;
+    uint32_t *act = nullptr, *act_next = nullptr;
+    bool live = false, in_round = false;
+};
+
+int env_int(const char *name, long lo, long hi, long dflt) {
+    if (const char *e = getenv(name)) {
+        const long v = atol(e);
+        if (v >= lo && v <= hi) return (int)v;
+    }
+    return (int)dflt;
+}
+}  // namespace
 
 int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
                const int32_t *s1, const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs,
@@ -242,85 +264,151 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sign: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
-    const size_t chunk = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
-    TRY(ensure_workspace(ctx, SignWs(nullptr, p, chunk).bytes));
-    uint32_t *h_count = nullptr;
-    MLDSA_HIP_CHECK(hipHostMalloc((void **)&h_count, sizeof(uint32_t)));
-    // tuning knobs (experiments): slots per round to aim for, candidates per op per round
-    size_t spec_target = 32768;
-    int spec_max = 32;
-    if (const char *e = getenv("MLDSA_SPEC_TARGET")) { size_t v = (size_t)atol(e); if (v >= 1 && v <= SPEC_TARGET_SLOTS) spec_target = v; }
-    if (const char *e = getenv("MLDSA_SPEC_MAX")) { int v = atoi(e); if (v >= 1 && v <= 64) spec_max = v; }  // k_resolve scans one wave of candidates
+    // lanes: sub-batches of at least MIN_LANE_OPS ops each (a narrower lane only adds launches)
+    constexpr size_t MIN_LANE_OPS = 2048;
+    int n_lanes = env_int("MLDSA_SIGN_LANES", 1, MLDSA_SIGN_MAX_LANES, 1);
+    while (n_lanes > 1 && (n_ops + n_lanes - 1) / n_lanes < MIN_LANE_OPS) n_lanes--;
+    const size_t resident = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
+    const size_t lane_ops = (resident + n_lanes - 1) / n_lanes;
+    // candidate slots per speculative round and candidates per op per round, per lane
+    const size_t spec_target = (size_t)env_int("MLDSA_SPEC_TARGET", 1, SPEC_TARGET_SLOTS, 32768) / n_lanes;
+    const int spec_max = env_int("MLDSA_SPEC_MAX", 1, 64, 32);  // k_resolve scans one wave of candidates
+    const size_t lane_bytes = SignWs(nullptr, p, lane_ops, spec_target).bytes;
+    TRY(ensure_workspace(ctx, lane_bytes * n_lanes));
+
+    SignLane lanes[MLDSA_SIGN_MAX_LANES];
+    size_t next_op = 0;
     int rc = MLDSA_OK;
-#define TRYC(expr) do { rc = (expr); if (rc != MLDSA_OK) goto out; } while (0)
-#define STAGEC(name, expr) do { { ProfScope _ps(ctx, s, name); rc = (expr); } if (rc != MLDSA_OK) goto out; } while (0)
-#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rc = set_error(MLDSA_ERR_DEVICE, #expr, _e); goto out; } } while (0)
-    for (size_t o = 0; o < n_ops; o += chunk) {
-        const size_t n = (n_ops - o) < chunk ? (n_ops - o) : chunk;
-        SignWs w(ctx->ws, p, chunk);
+#define TRYC(expr) do { rc = (expr); if (rc != MLDSA_OK) return rc; } while (0)
+#define STAGEC(name, expr) do { { ProfScope _ps(ctx, st, name); rc = (expr); } if (rc != MLDSA_OK) return rc; } while (0)
+#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, #expr, _e); } while (0)
+
+    // steps 1-8 of Algorithm 7 for the next sub-batch, on the lane's stream
+    auto start_sub_batch = [&](SignLane &L) -> int {
+        hipStream_t st = L.st;
+        L.o = next_op;
+        L.n = (n_ops - next_op) < lane_ops ? (n_ops - next_op) : lane_ops;
+        next_op += L.n;
+        const SignWs &w = L.w;
+        const size_t o = L.o, n = L.n;
+        const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
+        const size_t key_base = key_idx ? 0 : o;
+        HIPC(hipMemsetAsync(sigs + o * (size_t)p->sig_len, 0, n * (size_t)p->sig_len, st));
+        // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
+        STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, st));
+        // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
+        STAGEC("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
+                               w.rnd_mu + 32, 96, w.ctx_bad, n, st));
+        HIPC(hipMemcpy2DAsync(w.rnd_mu, 96, rnd + o * 32, 32, 32, n, hipMemcpyDeviceToDevice, st));
+        // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
+        STAGEC("rho_pp_hash", launch_shake256_2(ctx, 64, cap_k + key_base * 32, 32, 32, kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, st));
+        // 8: kappa <- 0; active = all ops with a legal ctx
+        HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), st));
+        TRYC(launch_init_active(ctx, n, w.ctx_bad, w.done, w.kappa, status ? status + o : nullptr, w.act0, w.counter, st));
+        HIPC(hipMemcpyAsync((void *)L.h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipEventRecord(L.ev, st));
+        L.act = w.act0;
+        L.act_next = w.act1;
+        L.live = true;
+        L.in_round = false;
+        return MLDSA_OK;
+    };
+
+    // one pass of the rejection loop (steps 10-33) for the lane's L.m unfinished ops
+    auto enqueue_round = [&](SignLane &L) -> int {
+        hipStream_t st = L.st;
+        const SignWs &w = L.w;
+        const size_t o = L.o, m = L.m;
         const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
         const size_t key_base = key_idx ? 0 : o;
         uint8_t *sg = sigs + o * (size_t)p->sig_len;
-        HIPC(hipMemsetAsync(sg, 0, n * (size_t)p->sig_len, s));
-        // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
-        STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
-        // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
-        STAGEC("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
-                       w.rnd_mu + 32, 96, w.ctx_bad, n, s));
-        HIPC(hipMemcpy2DAsync(w.rnd_mu, 96, rnd + o * 32, 32, 32, n, hipMemcpyDeviceToDevice, s));
-        // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
-        STAGEC("rho_pp_hash", launch_shake256_2(ctx, 64, cap_k + key_base * 32, 32, 32, kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
-        // 8: kappa <- 0; active = all ops with a legal ctx
-        HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
-        TRYC(launch_init_active(ctx, n, w.ctx_bad, w.done, w.kappa, status ? status + o : nullptr, w.act0, w.counter, s));
-        HIPC(hipMemcpyAsync(h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIPC(hipStreamSynchronize(s));
-        size_t m = *h_count;
-        uint32_t *act = w.act0, *act_next = w.act1;
-        while (m > 0) {  // 10: while (z, h) = bottom                          ml_dsa.rs:212
-            // candidates per op this round (1 while the active set fills the GPU)
-            int spec = 1;
-            if (m * 2 <= spec_target) {
-                const size_t sp = spec_target / m;
-                spec = sp > (size_t)spec_max ? spec_max : (int)sp;
-            }
-            const size_t ns = m * (size_t)spec;
-            if (ctx->prof_on) ctx->prof_sign_slots += ns;
-            STAGEC("make_slots", launch_make_slots(ctx, act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, s));
-            // 11: y <- ExpandMask(rho'', kappa)                               :215
-            STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, s));
-            // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-            STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, w.slot_op, w.y, w.w, w.w1, (size_t)p->w1_len, ns, s));
-            // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
-            STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
-                                   w.ctilde, 64, ns, s));
-            // 16: c <- SampleInBall(c_tilde)                                  :237
-            STAGEC("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns, s));
-            // 17: c_hat <- NTT(c), in place                                   :240
-            STAGEC("ntt_c", launch_ntt(ctx, w.c, w.c, ns, s));
-            // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
-            STAGEC("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1 + key_base * (size_t)p->l * N,
-                                                 s2 + key_base * (size_t)p->k * N, t0 + key_base * (size_t)p->k * N, w.kappa, w.done, sg,
-                                                 spec, w.stage, w.stage_stride, w.accept, ns, s));
-            if (spec > 1)
-                STAGEC("resolve", launch_resolve(ctx, p, act, m, spec, w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa, s));
-            HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), s));
-            STAGEC("compact", launch_compact(ctx, act, m, w.done, act_next, w.counter, s));
-            HIPC(hipMemcpyAsync(h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIPC(hipStreamSynchronize(s));
-            m = *h_count;
-            uint32_t *tmp = act; act = act_next; act_next = tmp;
+        // candidates per op this round (1 while the active set is wide)
+        int spec = 1;
+        if (m * 2 <= spec_target) {
+            const size_t sp = spec_target / m;
+            spec = sp > (size_t)spec_max ? spec_max : (int)sp;
         }
-    }
-out:
-    // y, rho'', cs1/cs2 are secret-dependent: clear them (the reference zeroizes on drop, types.rs:19)
-    (void)hipMemsetAsync(ctx->ws, 0, ctx->ws_bytes, s);
-    (void)hipStreamSynchronize(s);
-    (void)hipHostFree(h_count);
-    return rc;
+        const size_t ns = m * (size_t)spec;
+        if (ctx->prof_on) ctx->prof_sign_slots += ns;
+        STAGEC("make_slots", launch_make_slots(ctx, L.act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, st));
+        // 11: y <- ExpandMask(rho'', kappa)                               :215
+        STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, st));
+        // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
+        STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, w.slot_op, w.y, w.w, w.w1, (size_t)p->w1_len, ns, st));
+        // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
+        STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len,
+                                                0, 0, w.ctilde, 64, ns, st));
+        // 16: c <- SampleInBall(c_tilde)                                  :237
+        STAGEC("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns, st));
+        // 17: c_hat <- NTT(c), in place                                   :240
+        STAGEC("ntt_c", launch_ntt(ctx, w.c, w.c, ns, st));
+        // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
+        STAGEC("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1 + key_base * (size_t)p->l * N,
+                                             s2 + key_base * (size_t)p->k * N, t0 + key_base * (size_t)p->k * N, w.kappa, w.done, sg,
+                                             spec, w.stage, w.stage_stride, w.accept, ns, st));
+        if (spec > 1)
+            STAGEC("resolve", launch_resolve(ctx, p, L.act, m, spec, w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa, st));
+        HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), st));
+        STAGEC("compact", launch_compact(ctx, L.act, m, w.done, L.act_next, w.counter, st));
+        HIPC(hipMemcpyAsync((void *)L.h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPC(hipEventRecord(L.ev, st));
+        L.in_round = true;
+        return MLDSA_OK;
+    };
+
+    auto run = [&]() -> int {
+        // inputs may have been produced on the caller's stream
+        HIPC(hipEventRecord(ctx->fork_ev, s));
+        for (int i = 0; i < n_lanes; i++) {
+            SignLane &L = lanes[i];
+            L.st = ctx->lane_stream[i];
+            L.ev = ctx->lane_ev[i];
+            L.h_count = ctx->h_lane_count + i;
+            L.w = SignWs(static_cast<uint8_t *>(ctx->ws) + lane_bytes * i, p, lane_ops, spec_target);
+            HIPC(hipStreamWaitEvent(L.st, ctx->fork_ev, 0));
+            if (next_op < n_ops) TRYC(start_sub_batch(L));
+        }
+        int n_live = 0;
+        for (int i = 0; i < n_lanes; i++) n_live += lanes[i].live;
+        while (n_live > 0) {  // 10: while (z, h) = bottom                      ml_dsa.rs:212
+            bool progressed = false;
+            for (int i = 0; i < n_lanes; i++) {
+                SignLane &L = lanes[i];
+                if (!L.live) continue;
+                const hipError_t q = hipEventQuery(L.ev);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "sign: lane event", q);
+                progressed = true;
+                L.m = *L.h_count;
+                if (L.in_round) { uint32_t *t = L.act; L.act = L.act_next; L.act_next = t; }
+                if (L.m > 0) {
+                    TRYC(enqueue_round(L));
+                } else if (next_op < n_ops) {
+                    TRYC(start_sub_batch(L));
+                } else {
+                    L.live = false;
+                    n_live--;
+                }
+            }
+            if (!progressed) {
+                // nothing finished yet: block on the first live lane instead of spinning on the queries
+                for (int i = 0; i < n_lanes; i++)
+                    if (lanes[i].live) { HIPC(hipEventSynchronize(lanes[i].ev)); break; }
+            }
+        }
+        return MLDSA_OK;
+    };
+    rc = run();
 #undef TRYC
 #undef STAGEC
 #undef HIPC
+    // join every lane (also on the error path), then clear y, rho'', cs1/cs2: they are
+    // secret-dependent (the reference zeroizes on drop, types.rs:19)
+    for (int i = 0; i < n_lanes; i++)
+        if (lanes[i].st) (void)hipStreamSynchronize(lanes[i].st);
+    (void)hipMemsetAsync(ctx->ws, 0, ctx->ws_bytes, s);
+    (void)hipStreamSynchronize(s);
+    return rc;
 }
 
 }  // namespace mldsa
