@@ -271,7 +271,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     const size_t resident = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
     const size_t lane_ops = (resident + n_lanes - 1) / n_lanes;
     // candidate slots per speculative round and candidates per op per round, per lane
-    const size_t spec_target = (size_t)env_int("MLDSA_SPEC_TARGET", 1, SPEC_TARGET_SLOTS, 32768) / n_lanes;
+    const size_t spec_target = (size_t)env_int("MLDSA_SPEC_TARGET", 1, SPEC_TARGET_SLOTS, 65536) / n_lanes;
     const int spec_max = env_int("MLDSA_SPEC_MAX", 1, 64, 32);  // k_resolve scans one wave of candidates
     const size_t lane_bytes = SignWs(nullptr, p, lane_ops, spec_target).bytes;
     TRY(ensure_workspace(ctx, lane_bytes * n_lanes));

@@ -95,6 +95,29 @@ def test_sign_speculation_regimes_match_oracle(sets, n_ops):
     assert m.verify(pks, msgs, sig).all()
 
 
+@pytest.mark.parametrize("lanes,target,spec_max", [(1, 65536, 32), (3, 65536, 32), (4, 4096, 7), (8, 1, 1), (2, 65536, 64)])
+def test_sign_schedule_knobs_do_not_change_signatures(sets, monkeypatch, lanes, target, spec_max):
+    """The rejection loop's scheduling (stream lanes, candidate slots per round, candidates per op)
+    is invisible in the output: the first accepted kappa wins, exactly as in ml_dsa.rs:212-336."""
+    m = sets[44]
+    n_ops = 9001
+    rng = np.random.default_rng(5)
+    pk_o, sk_o = orc.keygen_from_seed(44, bytes([3] * 32))
+    sks = m.private_keys_from_bytes([orc.sk_into_bytes(44, sk_o)])
+    msgs = [rng.integers(0, 256, 20, dtype=np.uint8).tobytes() for _ in range(n_ops)]
+    rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_ops)]
+    for k in ("MLDSA_SIGN_LANES", "MLDSA_SPEC_TARGET", "MLDSA_SPEC_MAX"):
+        monkeypatch.delenv(k, raising=False)
+    base = host(m.try_sign_with_seed(sks, msgs, rnd)).copy()
+    monkeypatch.setenv("MLDSA_SIGN_LANES", str(lanes))
+    monkeypatch.setenv("MLDSA_SPEC_TARGET", str(target))
+    monkeypatch.setenv("MLDSA_SPEC_MAX", str(spec_max))
+    got = host(m.try_sign_with_seed(sks, msgs, rnd))
+    assert np.array_equal(got, base)
+    for i in (0, 4500, 9000):
+        assert base[i].tobytes() == orc.sign_internal(44, sk_o, msgs[i], rnd[i], mode=0), i
+
+
 def test_hint_weight_and_z_bound_rejections(sets, acvp_sigver):
     """the ACVP 'too many hints' / 'z too large' signatures stay rejected inside a large mixed batch"""
     g = [x for x in acvp_sigver["testGroups"] if x["parameterSet"] == "ML-DSA-87"][0]
