@@ -404,9 +404,14 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
 #undef HIPC
     // join every lane (also on the error path), then clear y, rho'', cs1/cs2: they are
     // secret-dependent (the reference zeroizes on drop, types.rs:19)
+    // (A_hat = ExpandA(rho) is public and is the first and largest carve of each lane: skipped.)
     for (int i = 0; i < n_lanes; i++)
         if (lanes[i].st) (void)hipStreamSynchronize(lanes[i].st);
-    (void)hipMemsetAsync(ctx->ws, 0, ctx->ws_bytes, s);
+    for (int i = 0; i < n_lanes; i++) {
+        uint8_t *lane_base = static_cast<uint8_t *>(ctx->ws) + lane_bytes * i;
+        uint8_t *secrets = lanes[i].st ? reinterpret_cast<uint8_t *>(lanes[i].w.y) : lane_base;
+        (void)hipMemsetAsync(secrets, 0, (size_t)(lane_base + lane_bytes - secrets), s);
+    }
     (void)hipStreamSynchronize(s);
     return rc;
 }
