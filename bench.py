@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 Q = 8380417
+KECCAK_PEAK_GPERMS = 9.26  # measured: tools/ubench_valu.hip k_keccak, 8 waves/SIMD (profiles/r01_ubench_valu.txt)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured-achievable
 SETS = {44: dict(k=4, l=4, gamma1=1 << 17, tau=39), 65: dict(k=6, l=5, gamma1=1 << 19, tau=49),
         87: dict(k=8, l=7, gamma1=1 << 19, tau=60)}
@@ -288,8 +289,12 @@ class WholeOp:
             "verify_arith": 1024 * (kl + self.l + 1 + 2 * self.k),
             "sign_w": 1024 * (kl + self.l + self.k),
             "expand_mask": 66 * self.l + 1024 * self.l,
-            "sign_tail": 1024 * (1 + 2 * self.l + 3 * self.k),
+            # A_hat + signature bytes + c + t1 row block + hint masks in, w1 bytes out
+            "verify_main": 1024 * (kl + 1 + self.k) + p.sig_len + 32 * self.k + p.w1_len,
         }
+        # Keccak-f[1600] permutations per unit of the SHAKE-bound stages (5 SHAKE128 blocks per A_hat
+        # polynomial, 5 SHAKE256 blocks per mask polynomial): their ceiling is integer-ALU issue
+        self.stage_perms = {"expand_a": 5 * kl, "expand_mask": 5 * self.l}
         self.name = (f"ml_dsa_{pset} batch={batch} whole {kind} on FIPS 204 wire formats, GPU ExpandA"
                      + ("/ExpandMask + rejection-loop re-batch" if kind == "sign" else "")
                      + ", 32-byte messages, inputs resident in HBM")
@@ -450,6 +455,23 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
                                     f"~{perms} permutations per op; the HBM-bound kernel of the path is reported under "
                                     "also.verify_arith44 (BASELINE config 2)")
         line["keccak_permutations_per_s"] = perms * value / world
+        # every modelled stage against the ceiling that bounds it: HBM peak for the polynomial-streaming
+        # kernels, the measured Keccak-f[1600] issue ceiling (tools/ubench_valu.hip k_keccak at 8 waves/SIMD,
+        # profiles/r01_ubench_valu.txt) for the SHAKE-bound samplers
+        by_stage = {}
+        n_slots = slots["calls"] if slots else None
+        for st_name, st in stages.items():
+            per_round = st_name in ("expand_mask", "sign_w", "sign_tail")
+            units = n_slots if (wl.kind == "sign" and per_round) else wl.batch * steps
+            if st_name in wl.stage_perms:
+                ach = wl.stage_perms[st_name] * units / (st["ms"] * 1e-3) / 1e9
+                by_stage[st_name] = {"bound": "valu", "achieved": ach, "peak": KECCAK_PEAK_GPERMS,
+                                     "unit": "G Keccak-f[1600]/s", "frac": ach / KECCAK_PEAK_GPERMS}
+            elif st_name in wl.stage_bytes:
+                ach = wl.stage_bytes[st_name] * units / (st["ms"] * 1e-3) / 1e9
+                by_stage[st_name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": ach / HBM_PEAK_GBS}
+        line["roofline_by_stage"] = by_stage
         line["whole_op_hbm"] = {"algorithmic_bytes_per_op": wl.bytes_per_op,
                                 "achieved_GBs": wl.bytes_per_op * value / world / 1e9,
                                 "frac_of_peak": wl.bytes_per_op * value / world / 1e9 / HBM_PEAK_GBS}

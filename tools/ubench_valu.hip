@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "../fips204_amd/csrc/keccak.h"
+
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 constexpr int ILP = 8;
@@ -75,6 +77,17 @@ __global__ __launch_bounds__(256) void k_mad_u64(uint32_t* out, int iters) {
 
 typedef void (*kern_t)(uint32_t*, int);
 
+// Keccak-f[1600] alone, one state per lane exactly as the samplers run it: the integer-ALU ceiling of
+// every SHAKE-driven kernel (ExpandA, ExpandMask, SampleInBall, the hashes).
+__global__ __launch_bounds__(256) void k_keccak(uint32_t* out, int perms) {
+    mldsa::KeccakState st;
+    for (int i = 0; i < 25; i++) { st.lo[i] = threadIdx.x * 31u + i; st.hi[i] = blockIdx.x * 17u + i; }
+    for (int p = 0; p < perms; p++) mldsa::keccak_f1600(st);
+    uint32_t s = 0;
+    for (int i = 0; i < 25; i++) s ^= st.lo[i] ^ st.hi[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 int main() {
     int dev = 0;
     CHECK(hipSetDevice(dev));
@@ -119,6 +132,23 @@ int main() {
         // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
         double mhz = clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0;
         printf("%-28s %12.3f %16.1f %18.2f %10.0f %14.2f\n", t.name, best, glops, cyc, mhz, cyc * mhz / 2400.0);
+    }
+    for (int bpc : {1, 2, 4, 8}) {  // 1, 2, 4, 8 waves per SIMD
+        const int kb = n_cu * bpc, perms = 256;
+        hipLaunchKernelGGL(k_keccak, dim3(kb), dim3(256), 0, 0, out, 4);
+        CHECK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+            CHECK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_keccak, dim3(kb), dim3(256), 0, 0, out, perms);
+            CHECK(hipEventRecord(e1, 0));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        printf("keccak_f1600 lane-per-state, %d waves/SIMD: %.3f ms, %.2f G permutations/s, %.2f us per permutation per wave\n", bpc, best,
+               (double)kb * 256 * perms / (best * 1e-3) / 1e9, best * 1e3 / perms);
     }
     return 0;
 }
