@@ -19,7 +19,7 @@ template <int K, int L>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restrict__ rho, size_t rho_stride,
                                                           const uint32_t* __restrict__ key_idx,
                                                           int32_t* __restrict__ a_hat, size_t n_ops) {
-    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
     __shared__ uint32_t meta_lds[SWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
                                                              int32_t* __restrict__ y, int l, size_t n_ops) {
     constexpr int CB = GB + 1;
     constexpr uint32_t MASK = (1u << CB) - 1u;
-    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
     uint32_t* my = stage + lane * STAGE_STRIDE;
@@ -136,13 +136,13 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
     }
     // bit buffer; everything below is lane-uniform and resolves at compile time
     uint64_t acc = 0;
-    int nbits = 0, n = 0;
+    int nbits = 0, n = 0, carry = 0;  // n = coefficients already stored (multiple of 4), carry < 4 wait in the row
 #pragma unroll
     for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(st);
         static_for<0, 2>([&](auto hc) {
             constexpr int H = decltype(hc)::value;
-            int cnt = 0;
+            int cnt = carry;
             static_for<0, 17>([&](auto wc) {
                 constexpr int W = 17 * H + decltype(wc)::value;
                 if (n + cnt < N) {  // the reference squeezes 640 bytes but unpacks only 32*c (hashing.rs:297-301)
@@ -159,19 +159,26 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
                     }
                 }
             });
-            if (cnt > 0) {
-                // uniform counts: every row has cnt dwords continuing at coefficient n
+            // uniform counts: every row holds cnt coefficients continuing at n; store the multiple-of-4
+            // part as dwordx4 (8 lanes per row, 8 rows per store), keep the rest for the next flush
+            const int fc = (n + cnt == N) ? cnt : (cnt & ~3);
+            if (fc > 0) {
                 wave_lds_sync();
-                const int half = lane >> 5, l5 = lane & 31;
-#pragma unroll 4
-                for (int i = 0; i < 32; i++) {
-                    const int row = 2 * i + half;
-                    if (l5 < cnt && wave_base + row < n_streams)
-                        y[(wave_base + row) * N + n + l5] = (int32_t)stage[row * STAGE_STRIDE + l5];
+                const int grp = lane >> 3, j4 = (lane & 7) * 4;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int row = 8 * i + grp;
+                    if (j4 < fc && wave_base + row < n_streams) {
+                        const uint32_t* src = stage + row * STAGE_STRIDE + j4;
+                        *reinterpret_cast<int4*>(y + (wave_base + row) * N + n + j4) =
+                            make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
+                    }
                 }
                 wave_lds_sync();
+                if (cnt > fc) keep_leftover(my, fc);
             }
-            n += cnt;
+            carry = cnt - fc;
+            n += fc;
         });
     }
 }

@@ -69,27 +69,64 @@ __device__ __forceinline__ void flush_rows(uint32_t* stage, uint32_t* meta, int3
 }
 
 
+// Flush in 16-byte pieces: lane row `r` holds fc[r] dwords (a multiple of 4) that continue stream
+// r's polynomial at coefficient n[r] (a multiple of 4).  Eight lanes serve one row, so one
+// iteration stores 8 rows x 32 coefficients with one dwordx4 store per lane: 8 iterations per
+// flush instead of 32.  Rows keep up to 3 left-over coefficients for the next flush (the caller
+// moves them to the front of its row).
+__device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
+                                            int fc, int n, int lane) {
+    meta[lane] = ((uint32_t)n << 8) | (uint32_t)fc;
+    wave_lds_sync();
+    const int grp = lane >> 3, j4 = (lane & 7) * 4;
+    uint32_t m[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = meta[8 * i + grp];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = 8 * i + grp;
+        if (j4 < (int)(m[i] & 0xFFu)) {
+            const uint32_t* src = stage + row * STAGE_STRIDE + j4;
+            const int4 v = make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
+            *reinterpret_cast<int4*>(out + (wave_base + row) * N + (m[i] >> 8) + j4) = v;
+        }
+    }
+    wave_lds_sync();
+}
+
+// after flush_rows4: move the (at most 3) unflushed coefficients my[fc .. fc + 2] to the row front
+__device__ __forceinline__ void keep_leftover(uint32_t* my, int fc) {
+    const uint32_t a = my[fc], b = my[fc + 1], c = my[fc + 2];
+    my[0] = a;
+    my[1] = b;
+    my[2] = c;
+}
+
 // RejNTTPoly (hashing.rs:111-146) for the lane's stream: `st` holds the absorbed, padded seed.
 // Squeezes SHAKE128 blocks until the lane has its 256 coefficients (wave-uniform loop: every lane
 // keeps permuting until the whole wave is done, extra output is dropped) and flushes 28-candidate
 // half blocks through the staging rows to out[(wave_base + lane) * 256 + ...].
 __device__ __forceinline__ void rej_ntt_poly_lane(KeccakState& st, uint32_t* stage, uint32_t* meta, uint32_t* my,
                                                   int32_t* __restrict__ out, size_t wave_base, int lane, bool valid) {
-    int n = valid ? 0 : N;
+    int n = valid ? 0 : N;  // coefficients already in `out` (a multiple of 4)
+    int carry = 0;          // accepted coefficients waiting in my[0 .. carry), < 4
     while (__any(n < N)) {
         keccak_f1600(st);
         static_for<0, 2>([&](auto hc) {
             constexpr int H = decltype(hc)::value;
-            int cnt = 0;
+            int cnt = carry;
             static_for<0, 28>([&](auto cc) {  // 28 candidates per half block: bytes 84 H + 3 C
                 constexpr int C = decltype(cc)::value;
                 const uint32_t z = block_bits<84 * H + 3 * C>(st) & 0x7FFFFFu;  // coeff_from_three_bytes, conversion.rs:40-61
                 my[cnt] = z;
                 cnt += (z < (uint32_t)Q) ? 1 : 0;
             });
-            const int take = min(cnt, N - n);
-            flush_rows(stage, meta, out, wave_base, take, n, lane);
-            n += take;
+            const int have = min(cnt, N - n);
+            const int fc = (n + have == N) ? have : (have & ~3);  // N and n are multiples of 4, so fc is too
+            flush_rows4(stage, meta, out, wave_base, fc, n, lane);
+            keep_leftover(my, fc);
+            carry = have - fc;
+            n += fc;
         });
     }
 }
