@@ -6,6 +6,7 @@
 // h256_xof call sites of src/ml_dsa.rs (mu, rho'', c_tilde, tr, keygen seed expansion).
 #include <type_traits>
 
+#include <cstdlib>
 #include "ctx.h"
 #include "keccak.h"
 #include "ntt_wave.h"
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
     const int32_t* __restrict__ a_hat, const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
     const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint32_t* __restrict__ key_idx,
     const uint32_t* __restrict__ hmask, uint8_t* __restrict__ w1, size_t w1_stride, int32_t* __restrict__ znorm,
-    size_t n_ops, const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab) {
+    int32_t zbound, size_t n_ops, const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab) {
     constexpr int W = K > L + 1 ? K : L + 1;
     constexpr int CB = GB + 1;
     constexpr int BITS = G2HI ? 4 : 6;
@@ -141,12 +142,9 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
                     const int32_t a = r[k] < 0 ? -r[k] : r[k];
                     mx = a > mx ? a : mx;
                 }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) {
-                    const int32_t o = __shfl_xor(mx, m);
-                    mx = o > mx ? o : mx;
-                }
-                if (lane == 0) atomicMax(&znorm[op], mx);
+                // ||z||inf >= gamma1 - beta (ml_dsa.rs:434) as a flag: one ballot instead of a cross-lane
+                // max reduction; znorm[] is zeroed by the pipeline, every writer stores the same value
+                if (__ballot(mx >= zbound) != 0ull && lane == 0) znorm[op] = 0x7fffffff;
             } else {
                 load_strided(r, c + op * (size_t)N, lane);
             }
@@ -411,10 +409,10 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
                        const int32_t* t1, const uint32_t* key_idx, const uint32_t* hmask, uint8_t* w1, size_t w1_stride,
                        int32_t* znorm, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, 12));
+    dim3 grid(grid_for(ctx, n_ops, 1, getenv("MLDSA_XB") ? atoi(getenv("MLDSA_XB")) : 12));
 #define MLDSA_VM(KK, LL, GB, G2)                                                                                             \
     hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2>), grid, dim3(64 * (KK > LL + 1 ? KK : LL + 1)), 0, s, a_hat, sigs,     \
-                       (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, n_ops, ctx->d_fwd_tw, \
+                       (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, ctx->d_fwd_tw, \
                        ctx->d_inv_tw)
     if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false);
     else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true);
