@@ -54,7 +54,10 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # MLDSA_BENCH_FORCE_DIST=1: take the RCCL path even with one rank (to exercise it on a 1-GPU box)
+    global _DIST
+    _DIST = world > 1 or (os.environ.get("MLDSA_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if _DIST:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -66,14 +69,17 @@ def dist_setup(n_gpus):
     return rank, local_rank, world
 
 
+_DIST = False
+
+
 def barrier(world):
-    if world > 1:
+    if _DIST:
         import torch.distributed as dist
         dist.barrier()
 
 
 def max_over_ranks(x, world):
-    if world == 1:
+    if not _DIST:
         return x
     import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -503,6 +509,10 @@ def main():
         line["also"] = also
     if rank == 0:
         print(json.dumps(line))
+    if _DIST:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
