@@ -100,21 +100,44 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
         uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
         const int4 cv = reinterpret_cast<const int4*>(c_hat + slot * N)[lane];
         if (lane < ctilde_len) sig[lane] = ctilde[slot * 64 + lane];
-        // ---- stage 1a: z   (software-pipelined: the next polynomial's loads are issued before this one's inverse NTT)
+        // ---- stage 1, most selective test first: r = w - cs2 with ||LowBits(r)||inf (rejects ~2 of 3 attempts),
+        // then z = y + cs1 with ||z||inf (rejects ~1 of 3); software-pipelined: the next polynomial's loads are
+        // issued before this one's inverse NTT.  Both tests feed the same `continue` (ml_dsa.rs:280).
         int32_t zmax = 0, r0max = 0;
         bool ok = true;  // wave-uniform
         int32_t nv[4], ny[4];
-        load_packed(nv, s1 + (key * L) * (size_t)N, lane);
-        load_strided(ny, y + (slot * L) * (size_t)N, lane);
+        load_packed(nv, s2 + (key * K) * (size_t)N, lane);
+        load_strided(ny, w + (slot * K) * (size_t)N, lane);
 #pragma unroll 1
-        for (int j = 0; j < L; j++) {
+        for (int i = 0; i < K; i++) {
+            int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, ww[4] = {ny[0], ny[1], ny[2], ny[3]}, r[4];
+            if (i + 1 < K) {
+                load_packed(nv, s2 + (key * K + i + 1) * (size_t)N, lane);
+                load_strided(ny, w + (slot * K + i + 1) * (size_t)N, lane);
+            } else {  // first polynomial of the z loop
+                load_packed(nv, s1 + (key * L) * (size_t)N, lane);
+                load_strided(ny, y + (slot * L) * (size_t)N, lane);
+            }
+            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+            ntt_inv_wave(r, itw, lane, F_MONT);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int32_t rr = freeze(ww[k] - r[k]);  // w - cs2, canonical
+                rr_lds[wave][i][64 * k + lane] = rr;      // kept for the hint stage
+                int32_t r1, r0;
+                decompose<G2HI>(rr, r1, r0);
+                r0 = r0 < 0 ? -r0 : r0;
+                r0max = r0 > r0max ? r0 : r0max;
+            }
+            // stop at the first polynomial that rejects the attempt: the rest cannot change the outcome
+            if (__ballot(r0max >= GAMMA2 - beta) != 0ull) { ok = false; break; }
+        }
+#pragma unroll 1
+        for (int j = 0; ok && j < L; j++) {
             int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, yy[4] = {ny[0], ny[1], ny[2], ny[3]}, r[4];
             if (j + 1 < L) {
                 load_packed(nv, s1 + (key * L + j + 1) * (size_t)N, lane);
                 load_strided(ny, y + (slot * L + j + 1) * (size_t)N, lane);
-            } else {  // first polynomial of stage 1b
-                load_packed(nv, s2 + (key * K) * (size_t)N, lane);
-                load_strided(ny, w + (slot * K) * (size_t)N, lane);
             }
             r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
             ntt_inv_wave(r, itw, lane, F_MONT);
@@ -125,8 +148,6 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
                 const int32_t a = zc < 0 ? -zc : zc;
                 zmax = a > zmax ? a : zmax;
             }
-            // ||z||inf >= gamma1 - beta rejects the attempt (ml_dsa.rs:280): stop at the first polynomial that
-            // shows it -- the rest of the attempt cannot change the outcome (wave-uniform branch)
             if (__ballot(zmax >= gamma1 - beta) != 0ull) { ok = false; break; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -147,27 +168,6 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
             for (int i = 0; i < 8; i++) dst[i] = (uint8_t)(lo >> (8 * i));
             for (int i = 8; i < nbytes; i++) dst[i] = (uint8_t)(hi >> (8 * (i - 8)));
             __builtin_amdgcn_wave_barrier();
-        }
-        // ---- stage 1b: r = w - cs2, LowBits
-#pragma unroll 1
-        for (int i = 0; ok && i < K; i++) {
-            int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, ww[4] = {ny[0], ny[1], ny[2], ny[3]}, r[4];
-            if (i + 1 < K) {
-                load_packed(nv, s2 + (key * K + i + 1) * (size_t)N, lane);
-                load_strided(ny, w + (slot * K + i + 1) * (size_t)N, lane);
-            }
-            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-            ntt_inv_wave(r, itw, lane, F_MONT);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int32_t rr = freeze(ww[k] - r[k]);  // w - cs2, canonical
-                rr_lds[wave][i][64 * k + lane] = rr;
-                int32_t r1, r0;
-                decompose<G2HI>(rr, r1, r0);
-                r0 = r0 < 0 ? -r0 : r0;
-                r0max = r0 > r0max ? r0 : r0max;
-            }
-            if (__ballot(r0max >= GAMMA2 - beta) != 0ull) ok = false;  // ||LowBits(w - cs2)||inf, ml_dsa.rs:280
         }
         // ---- stage 2: ct0, hints (HintBitPack, conversion.rs:277-328, written as they are found)
         if (ok) {
