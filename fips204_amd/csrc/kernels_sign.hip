@@ -2,6 +2,7 @@
 // of the rejection loop of sign_internal (src/ml_dsa.rs:212-330), sig_encode, and the
 // keygen tail (power2round, pk / sk encode).  Everything is integer, element-wise or one
 // wave per polynomial; the NTT work goes through ntt_wave.h.
+#include <cstdlib>
 #include "ctx.h"
 #include "keccak.h"
 #include "rounding.h"
@@ -86,17 +87,27 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
     __shared__ int32_t rr_lds[GWAVES][K][N]; // r_i = w_i - cs2_i, kept for the hint stage
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: slot indices and row pointers stay scalar
     for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = inv_tab[i];
     __syncthreads();
     const LdsTw itw{tw_lds, lane};
     const int32_t gamma1 = 1 << gb;
     const int cb = gb + 1;
-    const size_t wid = (size_t)blockIdx.x * GWAVES + wave, n_waves = (size_t)gridDim.x * GWAVES;
+    const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES, n_slots32 = (uint32_t)n_slots;
 
-    for (size_t slot = wid; slot < n_slots; slot += n_waves) {
-        const size_t op = slot_op[slot];
-        const size_t key = key_idx ? key_idx[op] : op;
+    // op / key of the next slot are fetched one slot ahead (two dependent loads off the critical path)
+    uint32_t op_next = 0, key_next = 0;
+    if (wid < n_slots32) {
+        op_next = slot_op[wid];
+        key_next = key_idx ? key_idx[op_next] : op_next;
+    }
+    for (uint32_t slot32 = wid; slot32 < n_slots32; slot32 += n_waves) {
+        const size_t slot = slot32, op = op_next, key = key_next;
+        if (slot32 + n_waves < n_slots32) {
+            op_next = slot_op[slot32 + n_waves];
+            key_next = key_idx ? key_idx[op_next] : op_next;
+        }
         uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
         const int4 cv = reinterpret_cast<const int4*>(c_hat + slot * N)[lane];
         if (lane < ctilde_len) sig[lane] = ctilde[slot * 64 + lane];
@@ -361,7 +372,7 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
                      size_t n_slots, hipStream_t s) {
     if (n_slots == 0) return MLDSA_OK;
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
-    dim3 grid(grid_for(ctx, n_slots, GWAVES, 6));
+    dim3 grid(grid_for(ctx, n_slots, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
 #define MLDSA_TAIL(KK, LL, G2)                                                                                              \
     hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
                        done, sigs, spec, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
