@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
             ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int32_t rr = freeze(ww[k] - r[k]);  // w - cs2, canonical
+                const int32_t rr = caddq(ww[k] - r[k]);  // w - cs2, canonical (both operands are in [0, q))
                 rr_lds[wave][i][64 * k + lane] = rr;      // kept for the hint stage
                 int32_t r1, r0;
                 decompose<G2HI>(rr, r1, r0);
@@ -154,7 +154,10 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
             ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int32_t zc = center(yy[k] + r[k]);  // z mod+- q (ml_dsa.rs:264, 334)
+                // z mod+- q (ml_dsa.rs:264, 334): y in (-gamma1, gamma1], cs1 in [0, q), so one conditional
+                // subtraction lands in (-q/2, q/2]
+                const int32_t zs = yy[k] + r[k];
+                const int32_t zc = zs - ((((Q / 2) - zs) >> 31) & Q);
                 xpose[wave][64 * k + lane] = zc;
                 const int32_t a = zc < 0 ? -zc : zc;
                 zmax = a > zmax ? a : zmax;
@@ -194,13 +197,14 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
                 ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    int32_t tc = center(r[k]);
+                    int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);  // center_mod of a canonical value
                     tc = tc < 0 ? -tc : tc;
                     tmax = tc > tmax ? tc : tmax;
                     // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
                     const int32_t rr = rr_lds[wave][i][64 * k + lane];
                     int32_t a1, a0, b1, b0;
-                    decompose<G2HI>(freeze(rr + r[k]), a1, a0);
+                    const int32_t sum = rr + r[k] - Q;  // both in [0, q)
+                    decompose<G2HI>(caddq(sum), a1, a0);
                     decompose<G2HI>(rr, b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q)
                     const bool h = a1 != b1;
                     const unsigned long long mask = __ballot(h);
