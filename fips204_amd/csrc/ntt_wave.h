@@ -34,6 +34,7 @@ constexpr int INV_TW = 14;  // levels s = 0..6, two butterflies per lane
 // inverse level (-ZETA_TABLE_MONT[1]).
 constexpr int32_t ZF1 = 25847, ZF2 = 5771523, ZF3 = 7861508;
 constexpr int32_t ZI1 = -25847;
+constexpr int64_t RINV_MOD_Q = 8265825;  // (2^32)^-1 mod q
 
 // Twiddle providers.  FwdTw / InvTw keep the lane's twiddles in registers (standalone NTT
 // kernels: a wave loops over many polynomials); LdsTw reads them from a block-shared LDS copy
@@ -178,10 +179,16 @@ __device__ __forceinline__ void ntt_inv_wave(int32_t r[4], const TW& tw, int lan
     bf_gs(r[0], r[1], tw.get(12));
     bf_gs(r[2], r[3], tw.get(13));
     xchg_hi<32>(r, lane);
-    bf_gs(r[0], r[2], ZI1);
-    bf_gs(r[1], r[3], ZI1);
+    // last level with the 1/256 scaling folded in: a' = (a + b) f, b' = (a - b) (zeta f); f is a
+    // constant at every call site, so zf folds at compile time.  mont_mul lands in (-q, q): only the
+    // conditional +q of full_reduce32 is left.
+    const int32_t zf = (int32_t)((((int64_t)ZI1 * f) % Q) * RINV_MOD_Q % Q);  // ZI1 * f * 2^-32 mod q
 #pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = caddq(mont_mul(r[k], f));  // mont_mul lands in (-q, q): only the conditional +q of full_reduce32 is left
+    for (int k = 0; k < 2; k++) {
+        const int32_t a = r[k], b = r[k + 2];
+        r[k] = caddq(mont_mul(a + b, f));
+        r[k + 2] = caddq(mont_mul(a - b, zf));
+    }
 }
 
 // coalesced I/O in the two layouts
