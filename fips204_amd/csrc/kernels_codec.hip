@@ -182,12 +182,13 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
             // acc[k] = w'[64 k + lane], canonical.  UseHint, then pack BITS-bit fields: coefficient
             // pairs (4-bit) / quads (6-bit) sit in adjacent lanes of the same register.
             uint8_t* dst = w1 + op * w1_stride + (size_t)wave * (32 * BITS);
+            uint32_t v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t h = (hw[k] >> (lane & 31)) & 1u;
-                const uint32_t v = (uint32_t)use_hint<G2HI>((int32_t)h, acc[k]);
-                pack_w1_strided<G2HI>(v, k, dst, lane);
+                v[k] = (uint32_t)use_hint<G2HI>((int32_t)h, acc[k]);
             }
+            pack_w1_strided<G2HI>(v, dst, lane);
         }
         __syncthreads();
     }

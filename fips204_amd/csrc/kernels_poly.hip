@@ -233,8 +233,10 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
             if constexpr (W1 != 0) {
                 constexpr bool G2HI = W1 == 2;
                 uint8_t *dst = w1 + op * w1_stride + (size_t)wave * (32 * (G2HI ? 4 : 6));
+                uint32_t hb[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) pack_w1_strided<G2HI>((uint32_t)use_hint<G2HI>(0, acc[k]), k, dst, lane);
+                for (int k = 0; k < 4; k++) hb[k] = (uint32_t)use_hint<G2HI>(0, acc[k]);
+                pack_w1_strided<G2HI>(hb, dst, lane);
             }
         }
         __syncthreads();

@@ -38,22 +38,39 @@ __device__ __forceinline__ int32_t use_hint(int32_t h, int32_t r) {
     }
 }
 
-// simple_bit_pack of w1 (4 bits per coefficient for gamma2 = (q-1)/32, 6 bits otherwise) when lane
-// holds coefficient 64 k + lane in v: coefficient pairs (4-bit) / quads (6-bit) sit in adjacent
-// lanes, so the bytes are assembled with DPP quad permutes.  `dst` = first byte of the polynomial.
+// simple_bit_pack of w1 (encodings.rs:338-360: 4 bits per coefficient for gamma2 = (q-1)/32, 6 bits
+// otherwise) for a polynomial in the strided register layout: v[k] = field of coefficient 64 k + lane.
+// `dst` = first byte of the polynomial's 32 * bits bytes (4-byte aligned for the 4-bit form).
 template <bool G2HI>
-__device__ __forceinline__ void pack_w1_strided(uint32_t v, int k, uint8_t* dst, int lane) {
+__device__ __forceinline__ void pack_w1_strided(const uint32_t v[4], uint8_t* dst, int lane) {
     if constexpr (G2HI) {
-        const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // lane ^ 1
-        if (!(lane & 1)) dst[32 * k + (lane >> 1)] = (uint8_t)(v | (nb << 4));
+        // 8 adjacent lanes make one dword (8 nibbles): OR-butterfly over lane ^ 1, lane ^ 2 and the mirror
+        // of the 8-lane half row; afterwards every lane of the group holds dword 8 k + (lane >> 3) of
+        // register k, and lanes 8 m + k (k < 4) store the polynomial's 128 bytes with ONE dword store
+        uint32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = v[k] << (4 * (lane & 7));
+            x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // quad_perm:[1,0,3,2]
+            x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+            x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);  // row_half_mirror
+            d[k] = x;
+        }
+        const int k = lane & 3;
+        const uint32_t mine = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
+        if (!(lane & 4)) reinterpret_cast<uint32_t*>(dst)[8 * k + (lane >> 3)] = mine;
     } else {
-        const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // lane ^ 1
-        const uint32_t pair = (lane & 1) ? 0u : (v | (n1 << 6));                                         // 12 bits in even lanes
-        const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pair, 0x4E, 0xF, 0xF, false);  // lane ^ 2
-        if (!(lane & 3)) {
-            const uint32_t q24 = pair | (n2 << 12);
-            uint8_t* d = dst + 48 * k + 3 * (lane >> 2);
-            d[0] = (uint8_t)q24; d[1] = (uint8_t)(q24 >> 8); d[2] = (uint8_t)(q24 >> 16);
+        // coefficient quads sit in adjacent lanes: 4 x 6 bits = 3 bytes, assembled with DPP quad permutes
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[k], 0xB1, 0xF, 0xF, false);  // lane ^ 1
+            const uint32_t pair = (lane & 1) ? 0u : (v[k] | (n1 << 6));                                       // 12 bits in even lanes
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pair, 0x4E, 0xF, 0xF, false);   // lane ^ 2
+            if (!(lane & 3)) {
+                const uint32_t q24 = pair | (n2 << 12);
+                uint8_t* d = dst + 48 * k + 3 * (lane >> 2);
+                d[0] = (uint8_t)q24; d[1] = (uint8_t)(q24 >> 8); d[2] = (uint8_t)(q24 >> 16);
+            }
         }
     }
 }
