@@ -226,6 +226,18 @@ class SeamKernel:
             self.kappa = torch.zeros(self.batch, dtype=torch.int16, device="cuda")
             self.call = lambda i: hp.expand_mask(65, self.rho, self.kappa)
             self.kernel = "k_expand_mask<19>"
+        elif name in ("keygen44", "keygen65", "keygen87"):
+            # KeyGen::keygen_from_seed (ml_dsa.rs:31-150) as one pipeline: xi -> pk, sk wire bytes
+            from fips204_amd.ml_dsa import MlDsa
+            pset = int(name[-2:])
+            ml = MlDsa(pset, hotpath=hp)
+            self.batch = batch or 65536
+            self.unit = "keys/s"
+            self.bytes_per_op = 32 + ml.PK_LEN + ml.SK_LEN  # 3 904 / 6 016 / 7 520
+            self.n_sets = 1
+            self.xi = torch.randint(0, 256, (self.batch, 32), dtype=torch.uint8, device="cuda", generator=g)
+            self.call = lambda i: ml.keygen_from_seed(self.xi)
+            self.kernel = "keygen_batch (ExpandA + ExpandS + NTT/mat-vec + encode pipeline)"
         else:
             raise SystemExit(f"unknown seam kernel {name!r}")
         self.name = f"{name} batch={self.batch} (seam-level primitive, inputs resident in HBM)"
@@ -381,7 +393,7 @@ def make_workload(name, hp, batch, rank):
     for kind in ("verify", "sign"):
         if name.startswith(kind) and name[len(kind):].isdigit():
             return WholeOp(hp, int(name[len(kind):]), kind, batch or 65536, rank)
-    if name in ("ntt", "inv_ntt", "mat_vec_mul65", "expand_a65", "expand_mask65"):
+    if name in ("ntt", "inv_ntt", "mat_vec_mul65", "expand_a65", "expand_mask65", "keygen44", "keygen65", "keygen87"):
         return SeamKernel(hp, name, batch, rank)
     raise SystemExit(f"unknown workload {name!r}")
 
