@@ -116,8 +116,9 @@ int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs
                           const int32_t *znorm, const int32_t *hvalid, const int32_t *ctx_bad, uint8_t *ok, size_t n_ops, hipStream_t);
 
 // ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
+// y_polys_per_op: distance between consecutive ops' y vectors in polynomials (0 = L, contiguous)
 int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
-                  size_t w1_stride, size_t n_ops, hipStream_t);
+                  size_t w1_stride, size_t n_ops, hipStream_t, size_t y_polys_per_op = 0);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,
@@ -131,8 +132,8 @@ int launch_resolve(mldsa_ctx *, const mldsa_params *, const uint32_t *act, size_
 int launch_compact(mldsa_ctx *, const uint32_t *act_in, size_t n, const int32_t *done, uint32_t *act_out, uint32_t *counter, hipStream_t);
 int launch_init_active(mldsa_ctx *, size_t n, const int32_t *ctx_bad, int32_t *done, uint16_t *kappa, int32_t *status,
                        uint32_t *act_out, uint32_t *counter, hipStream_t);
-int launch_keygen_encode(mldsa_ctx *, const mldsa_params *, const int32_t *s1s2, const int32_t *as1, uint8_t *pk, uint8_t *sk,
-                         size_t n_keys, hipStream_t);
+int launch_keygen_encode(mldsa_ctx *, const mldsa_params *, const int32_t *s1s2, const int32_t *as1, const uint8_t *seeds,
+                         uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t);
 
 // ---- op-level pipelines (pipeline.hip) ----
 int pk_expand_batch(mldsa_ctx *, int set, const uint8_t *pk, uint8_t *rho, uint8_t *tr, int32_t *t1, size_t n, hipStream_t);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
     int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
-    uint8_t *__restrict__ w1 = nullptr, size_t w1_stride = 0) {
+    uint8_t *__restrict__ w1 = nullptr, size_t w1_stride = 0, size_t z_polys_per_op = L) {
     constexpr int W = K > L + 1 ? K : L + 1;
     constexpr int NIN = HAS_C ? L + 1 : L;  // polynomials transformed in phase 1
     __shared__ int4 lds[(L + 1) * 64];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
         }
         if (wave < NIN) {
             int32_t r[4];
-            const int32_t *src = (wave < L) ? z + (op * L + wave) * (size_t)N : c + op * (size_t)N;
+            const int32_t *src = (wave < L) ? z + (op * z_polys_per_op + wave) * (size_t)N : c + op * (size_t)N;
             load_strided(r, src, lane);
 #pragma unroll
             for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
@@ -322,14 +322,14 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 // w[slot] = inv_ntt(A_hat[a_idx[slot]] * ntt(y[slot]))   (ml_dsa.rs:218-222); with w1 != nullptr also
 // w1Encode(HighBits(w)) (ml_dsa.rs:225-232)
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
-                  size_t w1_stride, size_t n_ops, hipStream_t s) {
+                  size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, 1, 12));
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
 #define MLDSA_SW(KK, LL, WW, W1M)                                                                                              \
     hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M>), grid, dim3(64 * WW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
-                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride)
+                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL)
     if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 5, 1); else MLDSA_SW(4, 4, 5, 0); }
     else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 6, 2); else MLDSA_SW(6, 5, 6, 0); }
     else if (set == MLDSA_87) { if (w1) MLDSA_SW(8, 7, 8, 2); else MLDSA_SW(8, 7, 8, 0); }

@@ -57,7 +57,7 @@ __device__ __forceinline__ bool half_byte(uint32_t b, int32_t& out) {
 template <int ETA>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restrict__ rho_prime, size_t rho_stride,
                                                           int32_t* __restrict__ s12, int polys_per_op, size_t n_ops) {
-    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE];
+    __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
     __shared__ uint32_t meta_lds[SWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
@@ -77,16 +77,17 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
         st.lo[8] = r | (0x1Fu << 16);  // hashing.rs:260/266: rho' || r || 0  (then pad)
         st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
     }
-    int n = valid ? 0 : N;
+    int n = valid ? 0 : N;  // coefficients already in s12 (a multiple of 4)
+    int carry = 0;          // accepted coefficients waiting in my[0 .. carry), < 4
     while (__any(n < N)) {
         keccak_f1600(st);
-        // 136 bytes = 34 words; 4 words (32 half-bytes) per flush, last group has 2 words
-        static_for<0, 9>([&](auto gc) {
+        // 136 bytes = 34 words; 3 words (24 half-bytes) per flush so that carry + candidates fit a row
+        static_for<0, 12>([&](auto gc) {
             constexpr int G = decltype(gc)::value;
-            constexpr int NW = (G == 8) ? 2 : 4;
-            int cnt = 0;
+            constexpr int NW = (G == 11) ? 1 : 3;
+            int cnt = carry;
             static_for<0, NW>([&](auto wc) {
-                constexpr int W = 4 * G + decltype(wc)::value;
+                constexpr int W = 3 * G + decltype(wc)::value;
                 const uint32_t w = state_word<W>(st);
 #pragma unroll
                 for (int k = 0; k < 8; k++) {  // low nibble of each byte first (hashing.rs:177-180)
@@ -96,9 +97,12 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
                     cnt += ok ? 1 : 0;
                 }
             });
-            const int take = min(cnt, N - n);
-            flush_rows(stage, meta, s12, wave_base, take, n, lane);
-            n += take;
+            const int have = min(cnt, N - n);
+            const int fc = (n + have == N) ? have : (have & ~3);
+            flush_rows4(stage, meta, s12, wave_base, fc, n, lane);
+            keep_leftover(my, fc);
+            carry = have - fc;
+            n += fc;
         });
     }
 }

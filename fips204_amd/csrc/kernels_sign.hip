@@ -323,7 +323,9 @@ __device__ __forceinline__ void store_fields(uint8_t* dst, const uint32_t f[4], 
 }
 
 // polys: s1s2[key][L + K] (ExpandS output), as1[key][K] = inv_ntt(A * ntt(s1)) canonical
+// seeds[key] = rho (32) | rho' (64) | K (32): rho opens pk and sk, K follows in sk (encodings.rs:27-31, 118-121)
 __global__ __launch_bounds__(GBLOCK) void k_keygen_encode(const int32_t* __restrict__ s1s2, const int32_t* __restrict__ as1,
+                                                          const uint8_t* __restrict__ seeds,
                                                           uint8_t* __restrict__ pk, uint8_t* __restrict__ sk, int k, int l,
                                                           int eta, size_t pk_len, size_t sk_len, size_t n_keys) {
     const int lane = threadIdx.x & 63;
@@ -335,6 +337,12 @@ __global__ __launch_bounds__(GBLOCK) void k_keygen_encode(const int32_t* __restr
         const size_t key = p / per_key;
         const int j = (int)(p % per_key);
         uint8_t* skp = sk + key * sk_len;
+        if (j == 0 && lane < 32) {
+            const uint8_t r = seeds[key * 128 + lane];
+            pk[key * pk_len + lane] = r;
+            skp[lane] = r;
+            skp[32 + lane] = seeds[key * 128 + 96 + lane];
+        }
         if (j < l + k) {  // skEncode: BitPack(s, eta, eta): field = eta - s   (encodings.rs:118-134)
             const Coef4 s = ld4(s1s2 + (key * (l + k) + j) * (size_t)N, lane);
             uint32_t f[4];
@@ -424,11 +432,11 @@ int launch_init_active(mldsa_ctx*, size_t n, const int32_t* ctx_bad, int32_t* do
     return MLDSA_OK;
 }
 
-int launch_keygen_encode(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s1s2, const int32_t* as1, uint8_t* pk, uint8_t* sk,
-                         size_t n_keys, hipStream_t s) {
+int launch_keygen_encode(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s1s2, const int32_t* as1, const uint8_t* seeds,
+                         uint8_t* pk, uint8_t* sk, size_t n_keys, hipStream_t s) {
     if (n_keys == 0) return MLDSA_OK;
     hipLaunchKernelGGL(k_keygen_encode, dim3(grid_for(ctx, n_keys * (size_t)(p->l + 2 * p->k), GWAVES, 8)), dim3(GBLOCK), 0, s, s1s2,
-                       as1, pk, sk, p->k, p->l, p->eta, (size_t)p->pk_len, (size_t)p->sk_len, n_keys);
+                       as1, seeds, pk, sk, p->k, p->l, p->eta, (size_t)p->pk_len, (size_t)p->sk_len, n_keys);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -152,13 +152,12 @@ int sk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, ui
 namespace {
 struct KeygenWs {
     uint8_t *hbuf;
-    int32_t *s1s2, *s1c, *a_hat, *as1;
+    int32_t *s1s2, *a_hat, *as1;
     size_t bytes;
     KeygenWs(void *base, const mldsa_params *p, size_t n) {
         Carver cv(base);
         hbuf = cv.take<uint8_t>(n * 128);
         s1s2 = cv.take<int32_t>(n * (size_t)(p->l + p->k) * N);
-        s1c = cv.take<int32_t>(n * (size_t)p->l * N);
         a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
         as1 = cv.take<int32_t>(n * (size_t)p->k * N);
         bytes = cv.off + 256;
@@ -178,18 +177,14 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
         KeygenWs w(ctx->ws, p, chunk);
         uint8_t *pko = pk + o * pkl, *sko = sk + o * skl;
         // 1: (rho, rho', K) <- H(xi || k || l, 128)                          ml_dsa.rs:68-74
-        TRY(launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
-                              w.hbuf, 128, n, s));
-        TRY(launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
-        TRY(launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s));                // :85
-        MLDSA_HIP_CHECK(hipMemcpy2DAsync(w.s1c, (size_t)p->l * N * 4, w.s1s2, (size_t)(p->l + p->k) * N * 4,
-                                         (size_t)p->l * N * 4, n, hipMemcpyDeviceToDevice, s));
-        TRY(launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1c, w.as1, nullptr, 0, n, s));                 // :86-88 inv_ntt(A * ntt(s1))
-        TRY(launch_keygen_encode(ctx, p, w.s1s2, w.as1, pko, sko, n, s));                   // :88-92, pk/sk encode
-        MLDSA_HIP_CHECK(hipMemcpy2DAsync(pko, pkl, w.hbuf, 128, 32, n, hipMemcpyDeviceToDevice, s));        // rho
-        MLDSA_HIP_CHECK(hipMemcpy2DAsync(sko, skl, w.hbuf, 128, 32, n, hipMemcpyDeviceToDevice, s));        // rho
-        MLDSA_HIP_CHECK(hipMemcpy2DAsync(sko + 32, skl, w.hbuf + 96, 128, 32, n, hipMemcpyDeviceToDevice, s));  // K
-        TRY(launch_shake256_2(ctx, 64, pko, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, sko + 64, skl, n, s));  // tr = H(pk), :99-101
+        STAGE("seed_hash", launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
+                                             w.hbuf, 128, n, s));
+        STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
+        STAGE("expand_a", launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s));                // :85
+        // :86-88 inv_ntt(A * ntt(s1)); s1 is read in place from the (s1, s2) rows ExpandS wrote
+        STAGE("sign_w", launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1s2, w.as1, nullptr, 0, n, s, (size_t)(p->l + p->k)));
+        STAGE("keygen_encode", launch_keygen_encode(ctx, p, w.s1s2, w.as1, w.hbuf, pko, sko, n, s));  // :88-92, pk/sk encode incl. rho, K
+        STAGE("tr_hash", launch_shake256_2(ctx, 64, pko, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, sko + 64, skl, n, s));  // tr = H(pk), :99-101
     }
     return MLDSA_OK;
 }
