@@ -87,6 +87,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming);
     }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_lane_count, MLDSA_SIGN_MAX_LANES * sizeof(uint32_t));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
@@ -111,6 +112,7 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
         if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
     }
     if (ctx->h_lane_count) (void)hipHostFree(ctx->h_lane_count);
+    if (ctx->ws_ev) (void)hipEventDestroy(ctx->ws_ev);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
     delete ctx;
@@ -159,6 +161,7 @@ int mldsa_stream_sync(void *stream) {
 // ------------------------------------------------------------------ per-stage timing
 int mldsa_profile_enable(mldsa_ctx *ctx, int on) {
     REQUIRE(ctx, "mldsa_profile_enable: NULL ctx");
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
     ctx->prof_on = on != 0;
     ctx->prof_used = 0;
     ctx->prof_sign_slots = 0;
@@ -167,6 +170,7 @@ int mldsa_profile_enable(mldsa_ctx *ctx, int on) {
 
 int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len) {
     REQUIRE(ctx && buf && buf_len > 2, "mldsa_profile_report: bad argument");
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
     MLDSA_HIP_CHECK(hipDeviceSynchronize());
     struct Acc { const char *name; double ms; size_t calls; };
     std::vector<Acc> acc;
@@ -282,6 +286,7 @@ int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
     REQUIRE(params_of(set), "mldsa_verify: unknown parameter set");
     REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_verify: bad mode");
     REQUIRE(ctx && (n_ops == 0 || (rho && tr && t1_d2_hat_mont && msg_off && sigs && ok)), "mldsa_verify: NULL pointer");
+    OpGuard guard(ctx, (hipStream_t)stream);
     return verify_batch(ctx, set, mode, rho, tr, t1_d2_hat_mont, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
                         (hipStream_t)stream);
 }
@@ -304,6 +309,7 @@ int mldsa_sk_expand(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, ui
 int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, void *stream) {
     REQUIRE(params_of(set), "mldsa_keygen: unknown parameter set");
     REQUIRE(ctx && (n_keys == 0 || (xi && pk && sk)), "mldsa_keygen: NULL pointer");
+    OpGuard guard(ctx, (hipStream_t)stream);
     return keygen_batch(ctx, set, xi, pk, sk, n_keys, (hipStream_t)stream);
 }
 
@@ -315,6 +321,7 @@ int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_sign: bad mode");
     REQUIRE(ctx && (n_ops == 0 || (rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont && msg_off && rnd && sigs)),
             "mldsa_sign: NULL pointer");
+    OpGuard guard(ctx, (hipStream_t)stream);
     return sign_batch(ctx, set, mode, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, key_idx, msgs, msg_off, ctxs,
                       ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream);
 }

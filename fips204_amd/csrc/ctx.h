@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,13 @@ struct mldsa_ctx {
     hipStream_t lane_stream[MLDSA_SIGN_MAX_LANES] = {};
     hipEvent_t lane_ev[MLDSA_SIGN_MAX_LANES] = {};
     uint32_t *h_lane_count = nullptr;  // pinned host: unfinished ops per lane after a round
+    // The op-level calls share the workspace and the helper streams: they serialise here.  The mutex
+    // covers the host side of a call; ws_ev orders the device side when the next call comes on another
+    // stream (device-side wait, no host synchronisation).
+    std::mutex op_mutex;
+    hipEvent_t ws_ev = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_busy = false;
     // optional per-stage timing: HIP event pairs recorded on the launch stream, resolved
     // only when the caller asks for the report (no synchronisation in the timed region)
     bool prof_on = false;
@@ -56,6 +64,21 @@ inline unsigned grid_for(const mldsa_ctx *ctx, size_t units, unsigned units_per_
     if (need < 1) need = 1;
     return (unsigned)(need < cap ? need : cap);
 }
+
+// RAII guard of one op-level call (capi.hip)
+struct OpGuard {
+    mldsa_ctx *c;
+    hipStream_t s;
+    std::unique_lock<std::mutex> lk;
+    OpGuard(mldsa_ctx *ctx, hipStream_t stream) : c(ctx), s(stream), lk(ctx->op_mutex) {
+        if (c->ws_busy && c->ws_stream != s) (void)hipStreamWaitEvent(s, c->ws_ev, 0);
+    }
+    ~OpGuard() {
+        (void)hipEventRecord(c->ws_ev, s);
+        c->ws_stream = s;
+        c->ws_busy = true;
+    }
+};
 
 // RAII stage marker used by pipeline.hip: records an event pair around one kernel launch
 struct ProfScope {

@@ -20,6 +20,14 @@
  *  - Return value: 0 = MLDSA_OK, negative = error (never aborts).  A failed signature
  *    verification is ok[i] = 0, not an error (src/lib.rs:368-370, ml_dsa.rs:368-376).
  *  - Randomness is always supplied by the caller (src/traits.rs:228-232).
+ *  - Threads and streams.  The reference's functions are re-entrant and its keys Send + Sync.  Here
+ *    the seam-level primitives keep no state in the context and may be called from any thread on
+ *    any stream.  The op-level calls (mldsa_keygen / mldsa_sign / mldsa_verify) share the context's
+ *    workspace: they may also be called from any thread on any stream, and the context serialises
+ *    them (a mutex on the host side, a device-side event wait when consecutive calls use different
+ *    streams -- never a host synchronisation).  For op-level calls that should overlap on the device,
+ *    use one context per stream.  mldsa_sign returns after its last rejection round completed;
+ *    everything else is asynchronous on `stream`.
  */
 #ifndef MLDSA_HIP_H
 #define MLDSA_HIP_H

@@ -118,6 +118,81 @@ def test_sign_schedule_knobs_do_not_change_signatures(sets, monkeypatch, lanes, 
         assert base[i].tobytes() == orc.sign_internal(44, sk_o, msgs[i], rnd[i], mode=0), i
 
 
+def _verify_job(m, pset, seed, n_ops):
+    """keys / messages / signatures (from the oracle, a few corrupted) and the expected verdicts"""
+    rng = np.random.default_rng(seed)
+    pk_o, sk_o = orc.keygen_from_seed(pset, bytes(rng.integers(0, 256, 32, dtype=np.uint8)))
+    pks = m.public_keys_from_bytes([orc.pk_into_bytes(pset, pk_o)])
+    base_msgs = [rng.integers(0, 256, 24, dtype=np.uint8).tobytes() for _ in range(8)]
+    base_sigs = [orc.sign_internal(pset, sk_o, mm, bytes(32), mode=0) for mm in base_msgs]
+    msgs = [base_msgs[i % 8] for i in range(n_ops)]
+    want = np.ones(n_ops, dtype=bool)
+    sigs = []
+    for i in range(n_ops):
+        sg = bytearray(base_sigs[i % 8])
+        if i % 5 == 3:
+            sg[100 + i % 64] ^= 1 << (i % 8)
+            want[i] = False
+        sigs.append(bytes(sg))
+    return pks, msgs, sigs, want
+
+
+def test_one_context_two_streams_and_two_threads(sets):
+    """include/mldsa_hip.h threading contract: op-level calls on one context may come from several host
+    threads and several streams; the context serialises their use of its workspace."""
+    import threading
+    jobs = {pset: _verify_job(sets[pset], pset, pset, 3000 + pset) for pset in (44, 65)}
+    # (a) two streams, alternating calls, nothing synchronised in between
+    st = {44: torch.cuda.Stream(), 65: torch.cuda.Stream()}
+    torch.cuda.synchronize()
+    # (the convenience wrapper synchronises; the device-level entry does not)
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    staged = {}
+    for pset in (44, 65):
+        pks, msgs, sigs, _ = jobs[pset]
+        mb, mo = _cat_with_offsets(msgs, "cuda")
+        sg = torch.frombuffer(bytearray(b"".join(sigs)), dtype=torch.uint8).cuda().view(len(sigs), -1)
+        kidx = torch.zeros(len(sigs), dtype=torch.int32, device="cuda")
+        staged[pset] = (pks, mb, mo, sg, kidx)
+    torch.cuda.synchronize()
+    oks = {44: [], 65: []}
+    for rep in range(4):
+        for pset in (44, 65):
+            pks, mb, mo, sg, kidx = staged[pset]
+            ok = torch.zeros(sg.shape[0], dtype=torch.uint8, device="cuda")
+            with torch.cuda.stream(st[pset]):
+                sets[pset].verify_device(pks, mb, mo, sg, ok, sg.shape[0], key_idx=kidx)
+            oks[pset].append(ok)
+    torch.cuda.synchronize()
+    for pset in (44, 65):
+        for ok in oks[pset]:
+            assert np.array_equal(ok.cpu().numpy().astype(bool), jobs[pset][3]), pset
+
+    # (b) two host threads, each on its own stream, hammering the same context (ctypes drops the GIL)
+    errors = []
+
+    def worker(pset):
+        try:
+            pks, mb, mo, sg, kidx = staged[pset]
+            s = torch.cuda.Stream()
+            for _ in range(6):
+                ok = torch.zeros(sg.shape[0], dtype=torch.uint8, device="cuda")
+                with torch.cuda.stream(s):
+                    sets[pset].verify_device(pks, mb, mo, sg, ok, sg.shape[0], key_idx=kidx)
+                s.synchronize()
+                if not np.array_equal(ok.cpu().numpy().astype(bool), jobs[pset][3]):
+                    errors.append(pset)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(p,)) for p in (44, 65)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
 def test_hint_weight_and_z_bound_rejections(sets, acvp_sigver):
     """the ACVP 'too many hints' / 'z too large' signatures stay rejected inside a large mixed batch"""
     g = [x for x in acvp_sigver["testGroups"] if x["parameterSet"] == "ML-DSA-87"][0]
