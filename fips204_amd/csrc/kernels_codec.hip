@@ -410,7 +410,7 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
                        const int32_t* t1, const uint32_t* key_idx, const uint32_t* hmask, uint8_t* w1, size_t w1_stride,
                        int32_t* znorm, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, getenv("MLDSA_XB") ? atoi(getenv("MLDSA_XB")) : 12));
+    dim3 grid(grid_for(ctx, n_ops, 1, 12));
 #define MLDSA_VM(KK, LL, GB, G2)                                                                                             \
     hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2>), grid, dim3(64 * (KK > LL + 1 ? KK : LL + 1)), 0, s, a_hat, sigs,     \
                        (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, ctx->d_fwd_tw, \
