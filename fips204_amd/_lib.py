@@ -60,6 +60,8 @@ _SIGNATURES = {
     "mldsa_sk_expand": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mldsa_keygen": [_P, _I, _P, _P, _P, _SZ, _P],
     "mldsa_sign": [_P, _I, _I] + [_P] * 14 + [_SZ, _P],
+    "mldsa_verify_cached_a": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_sign_cached_a": [_P, _I, _I] + [_P] * 14 + [_SZ, _P],
 }
 _RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p}
 

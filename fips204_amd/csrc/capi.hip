@@ -326,4 +326,30 @@ int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
                       ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream);
 }
 
+int mldsa_verify_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *tr,
+                          const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                          const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                          const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_verify_cached_a: unknown parameter set");
+    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_verify_cached_a: bad mode");
+    REQUIRE(ctx && (n_ops == 0 || (a_hat && tr && t1_d2_hat_mont && msg_off && sigs && ok)), "mldsa_verify_cached_a: NULL pointer");
+    OpGuard guard(ctx, (hipStream_t)stream);
+    return verify_batch(ctx, set, mode, nullptr, tr, t1_d2_hat_mont, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
+                        (hipStream_t)stream, a_hat);
+}
+
+int mldsa_sign_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *cap_k,
+                        const uint8_t *tr, const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont,
+                        const int32_t *t_0_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                        const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                        const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream) {
+    REQUIRE(params_of(set), "mldsa_sign_cached_a: unknown parameter set");
+    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_sign_cached_a: bad mode");
+    REQUIRE(ctx && (n_ops == 0 || (a_hat && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont && msg_off && rnd && sigs)),
+            "mldsa_sign_cached_a: NULL pointer");
+    OpGuard guard(ctx, (hipStream_t)stream);
+    return sign_batch(ctx, set, mode, nullptr, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, key_idx, msgs, msg_off, ctxs,
+                      ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream, a_hat);
+}
+
 }  // extern "C"

@@ -129,7 +129,7 @@ int launch_hint_unpack(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, u
 int launch_use_hint_w1(mldsa_ctx *, const mldsa_params *, const int32_t *w, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, size_t n_ops, hipStream_t);
 int launch_verify_main(mldsa_ctx *, const mldsa_params *, const int32_t *a_hat, const uint8_t *sigs, const int32_t *c, const int32_t *t1,
                        const uint32_t *key_idx, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, int32_t *znorm, size_t n_ops,
-                       hipStream_t);
+                       hipStream_t, bool a_by_key = false);
 int launch_mu(mldsa_ctx *, const uint8_t *tr, size_t tr_stride, const uint32_t *key_idx, int mode, const uint8_t *msgs,
               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, uint8_t *mu, size_t mu_stride, int32_t *ctx_bad,
               size_t n_ops, hipStream_t);
@@ -149,7 +149,7 @@ int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const 
                      uint16_t *kappa, int32_t *done, uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept,
                      size_t n_slots, hipStream_t);
 int launch_make_slots(mldsa_ctx *, const uint32_t *act, size_t m, int spec, const uint16_t *kappa, int l, uint32_t *slot_op,
-                      uint16_t *slot_kappa, hipStream_t);
+                      uint16_t *slot_kappa, hipStream_t, const uint32_t *key_idx = nullptr, uint32_t *slot_key = nullptr);
 int launch_resolve(mldsa_ctx *, const mldsa_params *, const uint32_t *act, size_t m, int spec, const int32_t *accept,
                    const uint8_t *stage, size_t stage_stride, uint8_t *sigs, int32_t *done, uint16_t *kappa, hipStream_t);
 int launch_compact(mldsa_ctx *, const uint32_t *act_in, size_t n, const int32_t *done, uint32_t *act_out, uint32_t *counter, hipStream_t);
@@ -163,13 +163,15 @@ int pk_expand_batch(mldsa_ctx *, int set, const uint8_t *pk, uint8_t *rho, uint8
 int sk_expand_batch(mldsa_ctx *, int set, const uint8_t *sk, uint8_t *rho, uint8_t *cap_k, uint8_t *tr, int32_t *s1, int32_t *s2,
                     int32_t *t0, size_t n, hipStream_t);
 int keygen_batch(mldsa_ctx *, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t);
+// a_hat_keys != nullptr: per-key A_hat supplied by the caller (ExpandA is skipped)
 int sign_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1,
                const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off,
                const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops,
-               hipStream_t);
+               hipStream_t, const int32_t *a_hat_keys = nullptr);
 int ensure_workspace(mldsa_ctx *, size_t bytes);
 int verify_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1_d2_hat_mont,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
-                 const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t);
+                 const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t,
+                 const int32_t *a_hat_keys = nullptr);
 
 }  // namespace mldsa

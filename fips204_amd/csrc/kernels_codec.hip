@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
     const int32_t* __restrict__ a_hat, const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
     const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint32_t* __restrict__ key_idx,
     const uint32_t* __restrict__ hmask, uint8_t* __restrict__ w1, size_t w1_stride, int32_t* __restrict__ znorm,
-    int32_t zbound, size_t n_ops, const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab) {
+    int32_t zbound, size_t n_ops, const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab, int a_by_key) {
     constexpr int W = K > L + 1 ? K : L + 1;
     constexpr int CB = GB + 1;
     constexpr int BITS = G2HI ? 4 : 6;
@@ -124,10 +124,11 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
         int4 av[L];
         int4 tv = make_int4(0, 0, 0, 0);
         if (wave < K) {
-            const int4* ap = reinterpret_cast<const int4*>(a_hat + ((op * K + wave) * (size_t)L) * N);
+            const size_t key = key_idx ? key_idx[op] : op;
+            const size_t aop = a_by_key ? key : op;  // per-key A_hat kept by the caller, or the op's own ExpandA output
+            const int4* ap = reinterpret_cast<const int4*>(a_hat + ((aop * K + wave) * (size_t)L) * N);
 #pragma unroll
             for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
-            const size_t key = key_idx ? key_idx[op] : op;
             tv = reinterpret_cast<const int4*>(t1 + (key * K + wave) * (size_t)N)[lane];
         }
         if (wave <= L) {
@@ -408,13 +409,13 @@ int launch_use_hint_w1(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* w, 
 
 int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_hat, const uint8_t* sigs, const int32_t* c,
                        const int32_t* t1, const uint32_t* key_idx, const uint32_t* hmask, uint8_t* w1, size_t w1_stride,
-                       int32_t* znorm, size_t n_ops, hipStream_t s) {
+                       int32_t* znorm, size_t n_ops, hipStream_t s, bool a_by_key) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, 1, 12));
 #define MLDSA_VM(KK, LL, GB, G2)                                                                                             \
     hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2>), grid, dim3(64 * (KK > LL + 1 ? KK : LL + 1)), 0, s, a_hat, sigs,     \
                        (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, ctx->d_fwd_tw, \
-                       ctx->d_inv_tw)
+                       ctx->d_inv_tw, a_by_key ? 1 : 0)
     if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false);
     else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true);
     else MLDSA_VM(8, 7, 19, true);

@@ -241,11 +241,13 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
 // ml_dsa.rs:212-330 would have produced (all earlier candidates were rejected).
 __global__ __launch_bounds__(256) void k_make_slots(const uint32_t* __restrict__ act, size_t m, int spec,
                                                     const uint16_t* __restrict__ kappa, int l,
-                                                    uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa) {
+                                                    uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa,
+                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key) {
     const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (sidx >= m * (size_t)spec) return;
     const uint32_t op = act[sidx / spec];
     slot_op[sidx] = op;
+    if (slot_key) slot_key[sidx] = key_idx ? key_idx[op] : op;  // row of a per-key A_hat table
     slot_kappa[sidx] = (uint16_t)(kappa[op] + (uint32_t)(sidx % spec) * l);
 }
 
@@ -398,10 +400,11 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
 }
 
 int launch_make_slots(mldsa_ctx*, const uint32_t* act, size_t m, int spec, const uint16_t* kappa, int l, uint32_t* slot_op,
-                      uint16_t* slot_kappa, hipStream_t s) {
+                      uint16_t* slot_kappa, hipStream_t s, const uint32_t* key_idx, uint32_t* slot_key) {
     if (m == 0) return MLDSA_OK;
     const size_t n = m * (size_t)spec;
-    hipLaunchKernelGGL(k_make_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act, m, spec, kappa, l, slot_op, slot_kappa);
+    hipLaunchKernelGGL(k_make_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act, m, spec, kappa, l, slot_op, slot_kappa, key_idx,
+                       slot_key);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -46,9 +46,9 @@ struct VerifyWs {
     uint32_t *hmask;
     uint8_t *mu_w1, *ctilde_p;
     size_t bytes;
-    VerifyWs(void *base, const mldsa_params *p, size_t n) {
+    VerifyWs(void *base, const mldsa_params *p, size_t n, bool own_a_hat) {
         Carver cv(base);
-        a_hat = cv.take<int32_t>(n * p->k * p->l * N);
+        a_hat = cv.take<int32_t>(own_a_hat ? n * p->k * p->l * N : 0);
         c = cv.take<int32_t>(n * N);
         znorm = cv.take<int32_t>(n);
         hvalid = cv.take<int32_t>(n);
@@ -67,16 +67,18 @@ struct VerifyWs {
 // verify_internal (ml_dsa.rs:351-437) for n_ops independent (key, message, signature) triples
 int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
-                 const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t s) {
+                 const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t s,
+                 const int32_t *a_hat_keys) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "verify: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
     const size_t chunk = n_ops < CHUNK_OPS ? n_ops : CHUNK_OPS;
-    TRY(ensure_workspace(ctx, VerifyWs(nullptr, p, chunk).bytes));
+    TRY(ensure_workspace(ctx, VerifyWs(nullptr, p, chunk, a_hat_keys == nullptr).bytes));
     const size_t mw = (size_t)(64 + p->w1_len);
+    const size_t kl_coeffs = (size_t)(p->k * p->l) * N;
     for (size_t o = 0; o < n_ops; o += chunk) {
         const size_t n = (n_ops - o) < chunk ? (n_ops - o) : chunk;
-        VerifyWs w(ctx->ws, p, chunk);
+        VerifyWs w(ctx->ws, p, chunk, a_hat_keys == nullptr);
         const uint8_t *sg = sigs + o * (size_t)p->sig_len;
         const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
@@ -104,11 +106,14 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         }
         MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, aux));
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
-        STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
+        // (skipped when the caller keeps A_hat with its keys: the optimisation the reference's benches/README.md
+        //  names as missing; the rows are then looked up by key instead of by op)
+        if (!a_hat_keys) STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
         // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
-        STAGE("verify_main", launch_verify_main(ctx, p, w.a_hat, sg, w.c, t1 + key_base * (size_t)p->k * N, kidx, w.hmask,
-                                                w.mu_w1 + 64, mw, w.znorm, n, s));
+        STAGE("verify_main", launch_verify_main(ctx, p, a_hat_keys ? a_hat_keys + key_base * kl_coeffs : w.a_hat, sg, w.c,
+                                                t1 + key_base * (size_t)p->k * N, kidx, w.hmask, w.mu_w1 + 64, mw, w.znorm, n, s,
+                                                a_hat_keys != nullptr));
         // 12: c_tilde' <- H(mu || w1Encode(w1'), lambda/4)                 ml_dsa.rs:429-431
         STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, w.ctilde_p, 64, n, s));
         // 13: [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]      ml_dsa.rs:434-436
@@ -203,15 +208,15 @@ struct SignWs {
     int32_t *a_hat, *y, *w, *c, *done, *ctx_bad, *accept;
     uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage;
     uint16_t *kappa, *slot_kappa;
-    uint32_t *act0, *act1, *slot_op, *counter;
+    uint32_t *act0, *act1, *slot_op, *slot_key, *counter;
     size_t bytes = 0, stage_stride = 0;
     SignWs() = default;
     // n = ops of the sub-batch, spec_slots = cap of candidate slots in a speculative round
-    SignWs(void *base, const mldsa_params *p, size_t n, size_t spec_slots) {
+    SignWs(void *base, const mldsa_params *p, size_t n, size_t spec_slots, bool own_a_hat) {
         Carver cv(base);
         const size_t ns = n > spec_slots ? n : spec_slots;  // slots per round
         stage_stride = ((size_t)p->sig_len + 15) & ~(size_t)15;
-        a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
+        a_hat = cv.take<int32_t>(own_a_hat ? n * (size_t)(p->k * p->l) * N : 0);
         y = cv.take<int32_t>(ns * (size_t)p->l * N);
         w = cv.take<int32_t>(ns * (size_t)p->k * N);
         c = cv.take<int32_t>(ns * (size_t)N);
@@ -228,6 +233,7 @@ struct SignWs {
         act0 = cv.take<uint32_t>(n);
         act1 = cv.take<uint32_t>(n);
         slot_op = cv.take<uint32_t>(ns);
+        slot_key = cv.take<uint32_t>(ns);
         counter = cv.take<uint32_t>(64);
         bytes = (cv.off + 511) & ~(size_t)255;
     }
@@ -255,7 +261,7 @@ int env_int(const char *name, long lo, long hi, long dflt) {
 int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
                const int32_t *s1, const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs,
                const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-               int32_t *status, size_t n_ops, hipStream_t s) {
+               int32_t *status, size_t n_ops, hipStream_t s, const int32_t *a_hat_keys) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sign: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
@@ -268,7 +274,9 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     // candidate slots per speculative round and candidates per op per round, per lane
     const size_t spec_target = (size_t)env_int("MLDSA_SPEC_TARGET", 1, SPEC_TARGET_SLOTS, 65536) / n_lanes;
     const int spec_max = env_int("MLDSA_SPEC_MAX", 1, 64, 32);  // k_resolve scans one wave of candidates
-    const size_t lane_bytes = SignWs(nullptr, p, lane_ops, spec_target).bytes;
+    const bool own_a = a_hat_keys == nullptr;
+    const size_t kl_coeffs = (size_t)(p->k * p->l) * N;
+    const size_t lane_bytes = SignWs(nullptr, p, lane_ops, spec_target, own_a).bytes;
     TRY(ensure_workspace(ctx, lane_bytes * n_lanes));
 
     SignLane lanes[MLDSA_SIGN_MAX_LANES];
@@ -290,7 +298,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         const size_t key_base = key_idx ? 0 : o;
         HIPC(hipMemsetAsync(sigs + o * (size_t)p->sig_len, 0, n * (size_t)p->sig_len, st));
         // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
-        STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, st));
+        if (own_a) STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, st));
         // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
         STAGEC("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
                                w.rnd_mu + 32, 96, w.ctx_bad, n, st));
@@ -325,11 +333,13 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         }
         const size_t ns = m * (size_t)spec;
         if (ctx->prof_on) ctx->prof_sign_slots += ns;
-        STAGEC("make_slots", launch_make_slots(ctx, L.act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, st));
+        STAGEC("make_slots", launch_make_slots(ctx, L.act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, st, kidx,
+                                               own_a ? nullptr : w.slot_key));
         // 11: y <- ExpandMask(rho'', kappa)                               :215
         STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, st));
         // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-        STAGEC("sign_w", launch_sign_w(ctx, set, w.a_hat, w.slot_op, w.y, w.w, w.w1, (size_t)p->w1_len, ns, st));
+        STAGEC("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys + key_base * kl_coeffs, own_a ? w.slot_op : w.slot_key,
+                                       w.y, w.w, w.w1, (size_t)p->w1_len, ns, st));
         // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
         STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len,
                                                 0, 0, w.ctilde, 64, ns, st));
@@ -359,7 +369,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
             L.st = ctx->lane_stream[i];
             L.ev = ctx->lane_ev[i];
             L.h_count = ctx->h_lane_count + i;
-            L.w = SignWs(static_cast<uint8_t *>(ctx->ws) + lane_bytes * i, p, lane_ops, spec_target);
+            L.w = SignWs(static_cast<uint8_t *>(ctx->ws) + lane_bytes * i, p, lane_ops, spec_target, own_a);
             HIPC(hipStreamWaitEvent(L.st, ctx->fork_ev, 0));
             if (next_op < n_ops) TRYC(start_sub_batch(L));
         }

@@ -90,12 +90,19 @@ class MlDsa:
             res &= ~wrong_len
         return res
 
+    def expand_a_for_keys(self, keys):
+        """A_hat = ExpandA(rho) of every key of a PublicKeys / PrivateKeys batch: the `cap_a_hat`
+        pre-compute the reference lists as an open optimisation (benches/README.md:4-8).  Pass the result
+        as `a_hat=` to verify_device / sign_device to skip the per-operation ExpandA."""
+        return self.hp.expand_a(self.pset, keys.rho.contiguous())
+
     def verify_device(self, pks, msg_buf, msg_off, sigs, ok, n_ops, ctx_buf=None, ctx_off=None, key_idx=None,
-                      mode=MODE_PURE):
+                      mode=MODE_PURE, a_hat=None):
         """Same, everything already resident in HBM (what bench.py times)."""
         null = C.c_void_p(0)
-        _lib.check(self.lib.mldsa_verify(
-            self.hp._h, self.pset, mode, _ptr(pks.rho), _ptr(pks.tr), _ptr(pks.t1_d2_hat_mont),
+        fn, first = (self.lib.mldsa_verify, pks.rho) if a_hat is None else (self.lib.mldsa_verify_cached_a, a_hat)
+        _lib.check(fn(
+            self.hp._h, self.pset, mode, _ptr(first), _ptr(pks.tr), _ptr(pks.t1_d2_hat_mont),
             _ptr(key_idx) if key_idx is not None else null, _ptr(msg_buf), _ptr(msg_off),
             _ptr(ctx_buf) if ctx_buf is not None else null, _ptr(ctx_off) if ctx_off is not None else null,
             _ptr(sigs), _ptr(ok), n_ops, _stream()))
@@ -178,10 +185,11 @@ class MlDsa:
         return sigs[:n_ops]
 
     def sign_device(self, sks, msg_buf, msg_off, rnd, sigs, n_ops, ctx_buf=None, ctx_off=None, key_idx=None,
-                    mode=MODE_PURE, status=None):
+                    mode=MODE_PURE, status=None, a_hat=None):
         null = C.c_void_p(0)
-        _lib.check(self.lib.mldsa_sign(
-            self.hp._h, self.pset, mode, _ptr(sks.rho), _ptr(sks.cap_k), _ptr(sks.tr), _ptr(sks.s_1_hat_mont),
+        fn, first = (self.lib.mldsa_sign, sks.rho) if a_hat is None else (self.lib.mldsa_sign_cached_a, a_hat)
+        _lib.check(fn(
+            self.hp._h, self.pset, mode, _ptr(first), _ptr(sks.cap_k), _ptr(sks.tr), _ptr(sks.s_1_hat_mont),
             _ptr(sks.s_2_hat_mont), _ptr(sks.t_0_hat_mont), _ptr(key_idx) if key_idx is not None else null,
             _ptr(msg_buf), _ptr(msg_off), _ptr(ctx_buf) if ctx_buf is not None else null,
             _ptr(ctx_off) if ctx_off is not None else null, _ptr(rnd), _ptr(sigs),

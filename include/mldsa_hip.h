@@ -201,6 +201,25 @@ int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
                const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream);
 
+/* ---- A_hat kept with the keys --------------------------------------------------------
+ * The reference re-derives A_hat = ExpandA(rho) inside every sign and verify (src/ml_dsa.rs:181,
+ * 406) and names "the cap_a_hat pre-compute ... put into both PublicKey and PrivateKey structs"
+ * as an open optimisation (benches/README.md:4-8).  These two entry points are that
+ * optimisation: identical to mldsa_verify / mldsa_sign (same arguments, same results, bit for
+ * bit) except that ExpandA is skipped and row key_idx[op] (or row op when key_idx is NULL) of
+ * `a_hat` is used instead.  a_hat[n_keys][K][L][256] = mldsa_expand_a(set, rho of the keys), any
+ * representative mldsa_expand_a produces; `rho` may then be NULL.  bench.py reports them as
+ * separate workloads (verify65_cached_a, sign65_cached_a), never as the headline. */
+int mldsa_verify_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *tr,
+                          const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                          const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                          const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream);
+int mldsa_sign_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *cap_k,
+                        const uint8_t *tr, const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont,
+                        const int32_t *t_0_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                        const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                        const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,6 +193,52 @@ def test_one_context_two_streams_and_two_threads(sets):
     assert not errors, errors
 
 
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_cached_a_hat_entry_points_are_bit_identical(sets, pset):
+    """mldsa_verify_cached_a / mldsa_sign_cached_a (A_hat kept with the keys, benches/README.md:4-8) give
+    exactly the results of the per-op ExpandA path, with and without a key index."""
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    m = sets[pset]
+    g = torch.Generator(device="cuda").manual_seed(pset)
+    n_keys, n_ops = 5, 700
+    xi = torch.randint(0, 256, (n_keys, 32), dtype=torch.uint8, device="cuda", generator=g)
+    pk, sk = m.keygen_from_seed(xi)
+    pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+    a_pk, a_sk = m.expand_a_for_keys(pks), m.expand_a_for_keys(sks)
+    assert torch.equal(a_pk, a_sk)
+    msgs = [bytes([i & 255, i >> 8]) * 9 for i in range(n_ops)]
+    mb, mo = _cat_with_offsets(msgs, "cuda")
+    rnd = torch.randint(0, 256, (n_ops, 32), dtype=torch.uint8, device="cuda", generator=g)
+    kidx = (torch.arange(n_ops, device="cuda") % n_keys).to(torch.int32)
+    sig0 = torch.empty((n_ops, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    sig1 = torch.empty_like(sig0)
+    m.sign_device(sks, mb, mo, rnd, sig0, n_ops, key_idx=kidx)
+    m.sign_device(sks, mb, mo, rnd, sig1, n_ops, key_idx=kidx, a_hat=a_sk)
+    assert torch.equal(sig0, sig1)
+    bad = sig0.clone()
+    bad[::7, 50] ^= 4
+    want = np.ones(n_ops, dtype=bool)
+    want[::7] = False
+    for a in (None, a_pk):
+        ok = torch.zeros(n_ops, dtype=torch.uint8, device="cuda")
+        m.verify_device(pks, mb, mo, bad, ok, n_ops, key_idx=kidx, a_hat=a)
+        assert np.array_equal(host(ok).astype(bool), want)
+    # identity mapping (key_idx = NULL): op i uses key i and A_hat row i
+    sig2 = torch.empty((n_keys, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    sig3 = torch.empty_like(sig2)
+    mb5, mo5 = _cat_with_offsets(msgs[:n_keys], "cuda")
+    m.sign_device(sks, mb5, mo5, rnd[:n_keys].contiguous(), sig2, n_keys)
+    m.sign_device(sks, mb5, mo5, rnd[:n_keys].contiguous(), sig3, n_keys, a_hat=a_sk)
+    assert torch.equal(sig2, sig3)
+    ok = torch.zeros(n_keys, dtype=torch.uint8, device="cuda")
+    m.verify_device(pks, mb5, mo5, sig3, ok, n_keys, a_hat=a_pk)
+    assert host(ok).all()
+    skh = host(sk)
+    for i in (0, 4):
+        want_sig = orc.sign_internal(pset, orc.sk_try_from_bytes(pset, skh[i].tobytes()), msgs[i], host(rnd)[i].tobytes(), mode=0)
+        assert host(sig3)[i].tobytes() == want_sig
+
+
 def test_hint_weight_and_z_bound_rejections(sets, acvp_sigver):
     """the ACVP 'too many hints' / 'z too large' signatures stay rejected inside a large mixed batch"""
     g = [x for x in acvp_sigver["testGroups"] if x["parameterSet"] == "ML-DSA-87"][0]
