@@ -94,47 +94,52 @@ __global__ __launch_bounds__(CBLOCK) void k_use_hint_w1(const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------
-// Whole-verify arithmetic in one kernel (ml_dsa.rs:368-372, 407-428): one block per op,
-//   phase 1: wave j < L unpacks z[j] straight from the signature bytes into NTT registers
-//            (bit_unpack, conversion.rs:227-262; also the ||z||inf test of ml_dsa.rs:434),
-//            wave L transforms c; results to LDS
-//   phase 2: wave i < K: A_hat[i] o z_hat - c_hat o t1_hat[i] -> inverse NTT -> UseHint
-//            (high_low.rs:155-192) -> w1Encode (encodings.rs:338-360) -> packed bytes
+// Whole-verify arithmetic in one kernel (ml_dsa.rs:368-372, 407-428), ONE WAVE PER OPERATION (the
+// structure of k_verify_arith: no barriers, lane-private LDS rows, next A_hat row requested under the
+// current row's inverse NTT):
+//   forward: z[j] is unpacked straight from the signature bytes into NTT registers (bit_unpack,
+//            conversion.rs:227-262; with the ||z||inf test of ml_dsa.rs:434), then c; results to LDS
+//   rows:    A_hat[i] o z_hat - c_hat o t1_hat[i] -> inverse NTT -> UseHint (high_low.rs:155-192)
+//            -> w1Encode (encodings.rs:338-360) -> packed bytes
 // so neither z, w' nor w1' ever exist as int32 polynomials in HBM.
+constexpr int VW = 4;  // waves (= ops in flight) per block
 template <int K, int L, int GB, bool G2HI>
-__global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
+__global__ __launch_bounds__(64 * VW) void k_verify_main(
     const int32_t* __restrict__ a_hat, const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
     const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint32_t* __restrict__ key_idx,
     const uint32_t* __restrict__ hmask, uint8_t* __restrict__ w1, size_t w1_stride, int32_t* __restrict__ znorm,
     int32_t zbound, size_t n_ops, const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab, int a_by_key) {
-    constexpr int W = K > L + 1 ? K : L + 1;
     constexpr int CB = GB + 1;
     constexpr int BITS = G2HI ? 4 : 6;
-    __shared__ int4 lds[(L + 1) * 64];
+    __shared__ int4 zh[VW][L + 1][64];
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * W) tw_lds[i] = fwd_tab[i];
-    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * W) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * VW) tw_lds[i] = fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * VW) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
     __syncthreads();
     const LdsTw ftw{tw_lds, lane};
     const LdsTw itw{tw_lds + FWD_TW * 64, lane};
+    const uint32_t wid = blockIdx.x * VW + wave, n_waves = gridDim.x * VW;
 
-    for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
+    for (size_t op = wid; op < n_ops; op += n_waves) {
+        const size_t key = key_idx ? key_idx[op] : op;
+        const size_t aop = a_by_key ? key : op;  // per-key A_hat kept by the caller, or the op's own ExpandA output
+        const int4* arow = reinterpret_cast<const int4*>(a_hat + (aop * K * (size_t)L) * N);
+        const int4* trow = reinterpret_cast<const int4*>(t1 + (key * K) * (size_t)N);
         int4 av[L];
-        int4 tv = make_int4(0, 0, 0, 0);
-        if (wave < K) {
-            const size_t key = key_idx ? key_idx[op] : op;
-            const size_t aop = a_by_key ? key : op;  // per-key A_hat kept by the caller, or the op's own ExpandA output
-            const int4* ap = reinterpret_cast<const int4*>(a_hat + ((aop * K + wave) * (size_t)L) * N);
 #pragma unroll
-            for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
-            tv = reinterpret_cast<const int4*>(t1 + (key * K + wave) * (size_t)N)[lane];
-        }
-        if (wave <= L) {
+        for (int j = 0; j < L; j++) av[j] = arow[j * 64 + lane];
+        int4 tv = trow[lane];
+        // ---- forward transforms: z[0..L) from the signature bytes, then c
+        const uint8_t* zsrc = sigs + op * sig_len + ctilde_len;
+        bool zbad = false;
+#pragma unroll 1
+        for (int j = 0; j <= L; j++) {
+            asm volatile("" ::: "memory");  // keep the LDS twiddle reads at their point of use
             int32_t r[4];
-            if (wave < L) {
-                const uint8_t* src = sigs + op * sig_len + ctilde_len + (size_t)wave * (32 * CB);
+            if (j < L) {
+                const uint8_t* src = zsrc + (size_t)j * (32 * CB);
                 int32_t mx = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -143,46 +148,51 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
                     const int32_t a = r[k] < 0 ? -r[k] : r[k];
                     mx = a > mx ? a : mx;
                 }
-                // ||z||inf >= gamma1 - beta (ml_dsa.rs:434) as a flag: one ballot instead of a cross-lane
-                // max reduction; znorm[] is zeroed by the pipeline, every writer stores the same value
-                if (__ballot(mx >= zbound) != 0ull && lane == 0) znorm[op] = 0x7fffffff;
+                zbad |= mx >= zbound;
             } else {
                 load_strided(r, c + op * (size_t)N, lane);
             }
             ntt_fwd_wave(r, ftw, lane);
-            if (wave == L) {
+            if (j == L) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) r[k] = mont_mul(r[k], 1);  // c_hat * 2^-32
             }
-            lds[wave * 64 + lane] = make_int4(r[0], r[1], r[2], r[3]);
+            zh[wave][j][lane] = make_int4(r[0], r[1], r[2], r[3]);
         }
-        __syncthreads();
-        if (wave < K) {
+        // ||z||inf >= gamma1 - beta (ml_dsa.rs:434) as a flag; znorm[] is zeroed by the pipeline
+        if (__ballot(zbad) != 0ull && lane == 0) znorm[op] = 0x7fffffff;
+        // ---- rows
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            asm volatile("" ::: "memory");
             int32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < L; j++) {
-                const int4 zv = lds[j * 64 + lane];
+                const int4 zv = zh[wave][j][lane];
                 acc[0] += mont_mul(av[j].x, zv.x);
                 acc[1] += mont_mul(av[j].y, zv.y);
                 acc[2] += mont_mul(av[j].z, zv.z);
                 acc[3] += mont_mul(av[j].w, zv.w);
             }
-            const int4 cv = lds[L * 64 + lane];
+            const int4 cv = zh[wave][L][lane];
             acc[0] -= mont_mul(cv.x, tv.x);
             acc[1] -= mont_mul(cv.y, tv.y);
             acc[2] -= mont_mul(cv.z, tv.z);
             acc[3] -= mont_mul(cv.w, tv.w);
+            if (i + 1 < K) {  // next row: in flight during this row's inverse transform
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
-            // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5); issued before the inverse
-            // NTT so the (L2-resident) loads complete under it without occupying registers in phase 1
+                for (int j = 0; j < L; j++) av[j] = arow[((i + 1) * L + j) * 64 + lane];
+                tv = trow[(i + 1) * 64 + lane];
+            }
+            // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5)
             uint32_t hw[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) hw[k] = hmask[(op * K + wave) * 8 + 2 * k + (lane >> 5)];
+            for (int k = 0; k < 4; k++) hw[k] = hmask[(op * K + i) * 8 + 2 * k + (lane >> 5)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
             ntt_inv_wave(acc, itw, lane, F_MONT2);
-            // acc[k] = w'[64 k + lane], canonical.  UseHint, then pack BITS-bit fields: coefficient
-            // pairs (4-bit) / quads (6-bit) sit in adjacent lanes of the same register.
-            uint8_t* dst = w1 + op * w1_stride + (size_t)wave * (32 * BITS);
+            // acc[k] = w'[64 k + lane], canonical.  UseHint, then pack BITS-bit fields.
+            uint8_t* dst = w1 + op * w1_stride + (size_t)i * (32 * BITS);
             uint32_t v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -191,7 +201,6 @@ __global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_main(
             }
             pack_w1_strided<G2HI>(v, dst, lane);
         }
-        __syncthreads();
     }
 }
 
@@ -411,11 +420,11 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
                        const int32_t* t1, const uint32_t* key_idx, const uint32_t* hmask, uint8_t* w1, size_t w1_stride,
                        int32_t* znorm, size_t n_ops, hipStream_t s, bool a_by_key) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, 12));
+    dim3 grid(grid_for(ctx, n_ops, VW, 16));
 #define MLDSA_VM(KK, LL, GB, G2)                                                                                             \
-    hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2>), grid, dim3(64 * (KK > LL + 1 ? KK : LL + 1)), 0, s, a_hat, sigs,     \
-                       (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, ctx->d_fwd_tw, \
-                       ctx->d_inv_tw, a_by_key ? 1 : 0)
+    hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2>), grid, dim3(64 * VW), 0, s, a_hat, sigs,                               \
+                       (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, \
+                       ctx->d_fwd_tw, ctx->d_inv_tw, a_by_key ? 1 : 0)
     if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false);
     else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true);
     else MLDSA_VM(8, 7, 19, true);

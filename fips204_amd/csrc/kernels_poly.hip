@@ -150,96 +150,105 @@ __global__ __launch_bounds__(BLOCK) void k_infinity_norm(const int32_t *__restri
 // -------------------------------------------------------------------------------------
 // Fused verify-arithmetic unit (ml_dsa.rs:407-416):
 //   w' = inv_ntt( A_hat * ntt(z)  -  ntt(c) o t1_d2_hat_mont )
-// One workgroup per operation, one wave per polynomial: W = max(L + 1, K) waves.
-//   phase 1: wave j < L transforms z[j], wave L transforms c; results go to LDS (1 KiB each)
-//   phase 2: wave i < K streams row i of A_hat from HBM (L coalesced 1-KiB reads, issued
-//            before phase 1 so their latency hides under the transforms), multiplies with
-//            z_hat from LDS, subtracts c_hat o t1[i], and runs the inverse NTT in place.
+// ONE WAVE PER OPERATION: the wave runs the L (+1) forward transforms one after the other and keeps
+// z_hat (and c_hat) in lane-private LDS rows -- each lane reads back only what it wrote, so there is
+// no barrier anywhere in the loop -- then walks the K rows of A_hat: row i + 1 is requested as soon
+// as row i has been multiplied, so its HBM latency hides under row i's inverse NTT (row 0 is
+// requested before the forward transforms).  Four waves (= four ops in flight) share the block's
+// twiddle copy.  (A workgroup-per-op layout with one wave per polynomial and two barriers per op
+// was 6-8 % slower at batch 65 536: this one streams at 95 % of the bandwidth the box delivers for
+// the 6:1 read:write mix, profiles/r01_ubench_hbm.txt.)
 // Domain bookkeeping: products mont_mul(a, z_hat) carry a factor 2^-32, so c_hat is stored
 // as c_hat * 2^-32 (then mont_mul(c_hat', t1 * 2^32) carries the same factor) and the
 // inverse NTT finishes with F_MONT2 = 256^-1 * 2^64.
 // HBM traffic per op = algorithmic bytes: (K*L + L + 1 + K) KiB in, K KiB out.
 // With HAS_C = false the kernel is the signer's w = inv_ntt(A_hat * ntt(y)) (ml_dsa.rs:218-222);
-// a_idx then maps a compacted slot to the op whose A_hat it uses.
+// a_idx then maps a candidate slot to the A_hat it uses.
 // W1 = 1 / 2 additionally emits w1Encode(HighBits(w)) (6-bit / 4-bit fields) per op: the signer's
 // commitment bytes (ml_dsa.rs:225-232), so no separate pass re-reads w.
+constexpr int AW = 4;  // waves per block
 template <int K, int L, bool HAS_C, int W1 = 0>
-__global__ __launch_bounds__(64 * (K > L + 1 ? K : L + 1)) void k_verify_arith(
+__global__ __launch_bounds__(64 * AW) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
     int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
-    uint8_t *__restrict__ w1 = nullptr, size_t w1_stride = 0, size_t z_polys_per_op = L) {
-    constexpr int W = K > L + 1 ? K : L + 1;
-    constexpr int NIN = HAS_C ? L + 1 : L;  // polynomials transformed in phase 1
-    __shared__ int4 lds[(L + 1) * 64];
-    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];  // block-shared twiddles, read at the point of use
+    uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op) {
+    constexpr int NZ = HAS_C ? L + 1 : L;
+    __shared__ int4 zh[AW][NZ][64];
+    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * W) tw_lds[i] = fwd_tab[i];
-    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * W) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * AW) tw_lds[i] = fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * AW) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
     __syncthreads();
     const LdsTw ftw{tw_lds, lane};
     const LdsTw itw{tw_lds + FWD_TW * 64, lane};
+    const uint32_t wid = blockIdx.x * AW + wave, n_waves = gridDim.x * AW;
 
-    for (size_t op = blockIdx.x; op < n_ops; op += gridDim.x) {
-        // issue this wave's row of A_hat and its t1 row early
+    for (size_t op = wid; op < n_ops; op += n_waves) {
+        const size_t aop = a_idx ? a_idx[op] : op;
+        const size_t key = HAS_C ? (key_idx ? key_idx[op] : op) : 0;
+        const int4 *arow = reinterpret_cast<const int4 *>(a_hat + (aop * K * (size_t)L) * N);
+        // row 0 of A_hat (and of t1) is requested before the transforms
         int4 av[L];
         int4 tv = make_int4(0, 0, 0, 0);
-        if (wave < K) {
-            const size_t aop = a_idx ? a_idx[op] : op;
-            const int4 *ap = reinterpret_cast<const int4 *>(a_hat + ((aop * K + wave) * (size_t)L) * N);
 #pragma unroll
-            for (int j = 0; j < L; j++) av[j] = ap[j * 64 + lane];
-            if constexpr (HAS_C) {
-                const size_t key = key_idx ? key_idx[op] : op;  // t1 belongs to the key, not to the op
-                tv = reinterpret_cast<const int4 *>(t1 + (key * K + wave) * (size_t)N)[lane];
-            }
-        }
-        if (wave < NIN) {
-            int32_t r[4];
-            const int32_t *src = (wave < L) ? z + (op * z_polys_per_op + wave) * (size_t)N : c + op * (size_t)N;
-            load_strided(r, src, lane);
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = reduce32(r[k]);
+        for (int j = 0; j < L; j++) av[j] = arow[j * 64 + lane];
+        if constexpr (HAS_C) tv = reinterpret_cast<const int4 *>(t1 + (key * K) * (size_t)N)[lane];
+        // ---- forward transforms, next polynomial loaded one ahead
+        int32_t nr[4];
+        load_strided(nr, z + (op * z_polys_per_op) * (size_t)N, lane);
+#pragma unroll 1
+        for (int j = 0; j < NZ; j++) {
+            asm volatile("" ::: "memory");  // keep the LDS twiddle reads at their point of use (no hoisting into registers)
+            int32_t r[4] = {reduce32(nr[0]), reduce32(nr[1]), reduce32(nr[2]), reduce32(nr[3])};
+            if (j + 1 < L) load_strided(nr, z + (op * z_polys_per_op + j + 1) * (size_t)N, lane);
+            else if (HAS_C && j + 1 == L) load_strided(nr, c + op * (size_t)N, lane);
             ntt_fwd_wave(r, ftw, lane);
-            if (wave == L) {
+            if (HAS_C && j == L) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) r[k] = mont_mul(r[k], 1);  // c_hat * 2^-32
             }
-            lds[wave * 64 + lane] = make_int4(r[0], r[1], r[2], r[3]);
+            zh[wave][j][lane] = make_int4(r[0], r[1], r[2], r[3]);
         }
-        __syncthreads();
-        if (wave < K) {
+        // ---- rows
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            asm volatile("" ::: "memory");
             int32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < L; j++) {
-                int4 zv = lds[j * 64 + lane];
+                const int4 zv = zh[wave][j][lane];
                 acc[0] += mont_mul(av[j].x, zv.x);
                 acc[1] += mont_mul(av[j].y, zv.y);
                 acc[2] += mont_mul(av[j].z, zv.z);
                 acc[3] += mont_mul(av[j].w, zv.w);
             }
             if constexpr (HAS_C) {
-                int4 cv = lds[L * 64 + lane];
+                const int4 cv = zh[wave][L][lane];
                 acc[0] -= mont_mul(cv.x, tv.x);
                 acc[1] -= mont_mul(cv.y, tv.y);
                 acc[2] -= mont_mul(cv.z, tv.z);
                 acc[3] -= mont_mul(cv.w, tv.w);
             }
+            if (i + 1 < K) {  // next row: in flight during this row's inverse transform
+#pragma unroll
+                for (int j = 0; j < L; j++) av[j] = arow[((i + 1) * L + j) * 64 + lane];
+                if constexpr (HAS_C) tv = reinterpret_cast<const int4 *>(t1 + (key * K + i + 1) * (size_t)N)[lane];
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
             ntt_inv_wave(acc, itw, lane, F_MONT2);
-            store_strided(acc, w_out + (op * K + wave) * (size_t)N, lane);
+            store_strided(acc, w_out + (op * K + i) * (size_t)N, lane);
             if constexpr (W1 != 0) {
                 constexpr bool G2HI = W1 == 2;
-                uint8_t *dst = w1 + op * w1_stride + (size_t)wave * (32 * (G2HI ? 4 : 6));
+                uint8_t *dst = w1 + op * w1_stride + (size_t)i * (32 * (G2HI ? 4 : 6));
                 uint32_t hb[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) hb[k] = (uint32_t)use_hint<G2HI>(0, acc[k]);
                 pack_w1_strided<G2HI>(hb, dst, lane);
             }
         }
-        __syncthreads();
     }
 }
 
@@ -309,11 +318,12 @@ static unsigned tune_blocks_per_cu(unsigned dflt) {
 int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t *z, const int32_t *c, const int32_t *t1,
                         const uint32_t *key_idx, int32_t *w, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, tune_blocks_per_cu(12)));
     const uint32_t *no_idx = nullptr;
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), grid, dim3(64 * 5), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), grid, dim3(64 * 6), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), grid, dim3(64 * 8), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw);
+    dim3 gw(grid_for(ctx, n_ops, AW, tune_blocks_per_cu(16)));
+    uint8_t *nw1 = nullptr;
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7);
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -324,15 +334,15 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
                   size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op) {
     if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(grid_for(ctx, n_ops, 1, 12));
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
-#define MLDSA_SW(KK, LL, WW, W1M)                                                                                              \
-    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M>), grid, dim3(64 * WW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
+    dim3 gw(grid_for(ctx, n_ops, AW, 16));
+#define MLDSA_SW(KK, LL, W1M)                                                                                                    \
+    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
                        ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL)
-    if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 5, 1); else MLDSA_SW(4, 4, 5, 0); }
-    else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 6, 2); else MLDSA_SW(6, 5, 6, 0); }
-    else if (set == MLDSA_87) { if (w1) MLDSA_SW(8, 7, 8, 2); else MLDSA_SW(8, 7, 8, 0); }
+    if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
+    else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 2); else MLDSA_SW(6, 5, 0); }
+    else if (set == MLDSA_87) { if (w1) MLDSA_SW(8, 7, 2); else MLDSA_SW(8, 7, 0); }
     else return set_error(MLDSA_ERR_PARAM, "sign_w: unknown parameter set");
 #undef MLDSA_SW
     MLDSA_HIP_CHECK(hipGetLastError());
