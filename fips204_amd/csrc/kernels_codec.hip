@@ -103,8 +103,8 @@ __global__ __launch_bounds__(CBLOCK) void k_use_hint_w1(const int32_t* __restric
 //            -> w1Encode (encodings.rs:338-360) -> packed bytes
 // so neither z, w' nor w1' ever exist as int32 polynomials in HBM.
 constexpr int VW = 4;  // waves (= ops in flight) per block
-template <int K, int L, int GB, bool G2HI>
-__global__ __launch_bounds__(64 * VW) void k_verify_main(
+template <int K, int L, int GB, bool G2HI, int MINW>
+__global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW))) void k_verify_main(
     const int32_t* __restrict__ a_hat, const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
     const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint32_t* __restrict__ key_idx,
     const uint32_t* __restrict__ hmask, uint8_t* __restrict__ w1, size_t w1_stride, int32_t* __restrict__ znorm,
@@ -421,13 +421,13 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
                        int32_t* znorm, size_t n_ops, hipStream_t s, bool a_by_key) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, VW, 16));
-#define MLDSA_VM(KK, LL, GB, G2)                                                                                             \
-    hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2>), grid, dim3(64 * VW), 0, s, a_hat, sigs,                               \
+#define MLDSA_VM(KK, LL, GB, G2, MW)                                                                                           \
+    hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2, MW>), grid, dim3(64 * VW), 0, s, a_hat, sigs,                               \
                        (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, \
                        ctx->d_fwd_tw, ctx->d_inv_tw, a_by_key ? 1 : 0)
-    if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false);
-    else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true);
-    else MLDSA_VM(8, 7, 19, true);
+    if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false, 5);
+    else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true, 4);
+    else MLDSA_VM(8, 7, 19, true, 4);
 #undef MLDSA_VM
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
