@@ -314,6 +314,11 @@ class WholeOp:
         # Keccak-f[1600] permutations per unit of the SHAKE-bound stages (5 SHAKE128 blocks per A_hat
         # polynomial, 5 SHAKE256 blocks per mask polynomial): their ceiling is integer-ALU issue
         self.stage_perms = {"expand_a": 5 * kl, "expand_mask": 5 * self.l}
+        if cached_a:
+            # the n_keys A_hat tables (n_keys * K * L KiB, 30 MB for 1 024 ML-DSA-65 keys) are re-read from
+            # L2 / Infinity Cache, not from HBM: they are not algorithmic HBM bytes of these workloads
+            self.stage_bytes["verify_main"] -= 1024 * kl
+            self.stage_bytes["sign_w"] -= 1024 * kl
         self.name = (f"ml_dsa_{pset} batch={batch} whole {kind} on FIPS 204 wire formats, "
                      + (f"A_hat KEPT WITH THE {n_keys} KEYS (no per-op ExpandA: not the reference's per-op cost, reported separately)"
                         if cached_a else "GPU ExpandA")
