@@ -119,8 +119,9 @@ int launch_verify_arith(mldsa_ctx *, int set, const int32_t *, const int32_t *, 
 // ---- launchers (kernels_sample.hip) ----
 int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride, const uint32_t *key_idx, int32_t *a_hat, size_t n_ops, hipStream_t);
 int launch_expand_s(mldsa_ctx *, int set, const uint8_t *rho_prime, size_t rho_stride, int32_t *s12, size_t n_ops, hipStream_t);
+// yrisk (optional): one byte per polynomial, 1 = some |y| >= gamma1 - 2 beta (see k_sign_tail)
 int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, int kappa_by_slot,
-                       const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t);
+                       const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t, uint8_t *yrisk = nullptr);
 int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t ct_stride, int32_t *c, size_t n_ops, hipStream_t);
 
 
@@ -141,13 +142,13 @@ int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs
 // ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
 // y_polys_per_op: distance between consecutive ops' y vectors in polynomials (0 = L, contiguous)
 int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
-                  size_t w1_stride, size_t n_ops, hipStream_t, size_t y_polys_per_op = 0);
+                  size_t w1_stride, size_t n_ops, hipStream_t, size_t y_polys_per_op = 0, uint8_t *wrisk = nullptr);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,
                      const uint32_t *slot_op, const uint32_t *key_idx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
                      uint16_t *kappa, int32_t *done, uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept,
-                     size_t n_slots, hipStream_t);
+                     size_t n_slots, hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr);
 int launch_make_slots(mldsa_ctx *, const uint32_t *act, size_t m, int spec, const uint16_t *kappa, int l, uint32_t *slot_op,
                       uint16_t *slot_kappa, hipStream_t, const uint32_t *key_idx = nullptr, uint32_t *slot_key = nullptr);
 int launch_resolve(mldsa_ctx *, const mldsa_params *, const uint32_t *act, size_t m, int spec, const int32_t *accept,

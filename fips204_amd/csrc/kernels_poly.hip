@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
     int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
-    uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op) {
+    uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op, uint8_t *__restrict__ wrisk, int32_t risk_bound) {
     constexpr int NZ = HAS_C ? L + 1 : L;
     __shared__ int4 zh[AW][NZ][64];
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
             zh[wave][j][lane] = make_int4(r[0], r[1], r[2], r[3]);
         }
         // ---- rows
+        uint32_t risk = 0;
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             asm volatile("" ::: "memory");
@@ -244,10 +245,22 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
                 constexpr bool G2HI = W1 == 2;
                 uint8_t *dst = w1 + op * w1_stride + (size_t)i * (32 * (G2HI ? 4 : 6));
                 uint32_t hb[4];
+                bool near = false;
 #pragma unroll
-                for (int k = 0; k < 4; k++) hb[k] = (uint32_t)use_hint<G2HI>(0, acc[k]);
+                for (int k = 0; k < 4; k++) {
+                    int32_t r1, r0;
+                    decompose<G2HI>(acc[k], r1, r0);  // HighBits = r1 (high_low.rs:104-111)
+                    hb[k] = (uint32_t)r1;
+                    near |= (r0 < 0 ? -r0 : r0) >= risk_bound;
+                }
                 pack_w1_strided<G2HI>(hb, dst, lane);
+                // bit i: some |LowBits(w_i)| >= gamma2 - 2 beta.  Only such a polynomial can fail the signer's
+                // ||LowBits(w - c s2)|| < gamma2 - beta test (||c s2|| <= beta), see k_sign_tail
+                if (__ballot(near) != 0ull) risk |= 1u << i;
             }
+        }
+        if constexpr (W1 != 0) {
+            if (wrisk && lane == 0) wrisk[op] = (uint8_t)risk;
         }
     }
 }
@@ -321,9 +334,9 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
     const uint32_t *no_idx = nullptr;
     dim3 gw(grid_for(ctx, n_ops, AW, tune_blocks_per_cu(16)));
     uint8_t *nw1 = nullptr;
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7);
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0);
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -332,14 +345,16 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 // w[slot] = inv_ntt(A_hat[a_idx[slot]] * ntt(y[slot]))   (ml_dsa.rs:218-222); with w1 != nullptr also
 // w1Encode(HighBits(w)) (ml_dsa.rs:225-232)
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
-                  size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op) {
+                  size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op, uint8_t *wrisk) {
     if (n_ops == 0) return MLDSA_OK;
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
+    const mldsa_params *pp = params_of(set);
+    const int32_t risk_bound = pp ? pp->gamma2 - 2 * pp->beta : 0;
     dim3 gw(grid_for(ctx, n_ops, AW, 16));
 #define MLDSA_SW(KK, LL, W1M)                                                                                                    \
     hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
-                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL)
+                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound)
     if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
     else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 2); else MLDSA_SW(6, 5, 0); }
     else if (set == MLDSA_87) { if (w1) MLDSA_SW(8, 7, 2); else MLDSA_SW(8, 7, 0); }

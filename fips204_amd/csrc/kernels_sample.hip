@@ -115,7 +115,8 @@ template <int GB>  // gamma1 = 2^GB, GB = 17 or 19
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __restrict__ rho_pp, size_t rho_stride,
                                                              const uint16_t* __restrict__ kappa, int kappa_by_slot,
                                                              const uint32_t* __restrict__ op_idx,
-                                                             int32_t* __restrict__ y, int l, size_t n_ops) {
+                                                             int32_t* __restrict__ y, int l, size_t n_ops,
+                                                             uint8_t* __restrict__ yrisk, int32_t risk_bound) {
     constexpr int CB = GB + 1;
     constexpr uint32_t MASK = (1u << CB) - 1u;
     __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
     // bit buffer; everything below is lane-uniform and resolves at compile time
     uint64_t acc = 0;
     int nbits = 0, n = 0, carry = 0;  // n = coefficients already stored (multiple of 4), carry < 4 wait in the row
+    int32_t ymax = 0;
 #pragma unroll
     for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(st);
@@ -155,7 +157,9 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         if (nbits >= CB && n + cnt < N) {
-                            my[cnt] = (uint32_t)((1 << GB) - (int32_t)((uint32_t)acc & MASK));
+                            const int32_t yv = (1 << GB) - (int32_t)((uint32_t)acc & MASK);
+                            my[cnt] = (uint32_t)yv;
+                            ymax = max(ymax, yv < 0 ? -yv : yv);
                             cnt++;
                             acc >>= CB;
                             nbits -= CB;
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
             n += fc;
         });
     }
+    if (yrisk && valid) yrisk[g] = ymax >= risk_bound ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -279,13 +284,13 @@ int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_st
 }
 
 int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_stride, const uint16_t* kappa, int kappa_by_slot,
-                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s) {
+                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s, uint8_t* yrisk) {
     if (n_ops == 0) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
     dim3 grid(stream_blocks(n_ops * (size_t)p->l)), block(64 * SWAVES);
-    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops);
-    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops);
+    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, yrisk, p->gamma1 - 2 * p->beta);
+    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, yrisk, p->gamma1 - 2 * p->beta);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

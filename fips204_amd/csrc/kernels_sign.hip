@@ -72,9 +72,10 @@ __device__ __forceinline__ Coef4 ld4(const int32_t* p, int u) {
 // polynomials stream through: z bytes in stage 1, hint bytes in stage 2.  If the attempt is then
 // rejected the bytes are garbage, but the op's next attempt rewrites every byte, and only an
 // accepted attempt sets done[] / accept[] -- so the signature buffer of a finished op always holds
-// the accepted attempt.  The reference's two `continue` stages (ml_dsa.rs:280, 312) stay two stages,
-// and inside stage 1 the wave leaves at the FIRST polynomial whose norm rejects the attempt
-// (about 8 of the 11 inverse NTTs of stage 1 are run on average for ML-DSA-65).
+// the accepted attempt.  The reference's two `continue` stages (ml_dsa.rs:280, 312) stay two stages;
+// stage 1 first transforms only the polynomials that CAN reject (flags from sign_w / ExpandMask, see
+// below), the more selective LowBits test first, and leaves at the first rejection: a rejected
+// ML-DSA-65 attempt costs about 1.5 of the 11 inverse NTTs of stage 1.
 template <int K, int L, bool G2HI>
 __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     const int32_t* __restrict__ c_hat, const int32_t* __restrict__ y, const int32_t* __restrict__ w,
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     const int32_t* __restrict__ s1, const int32_t* __restrict__ s2, const int32_t* __restrict__ t0,
     uint16_t* __restrict__ kappa, int32_t* __restrict__ done, uint8_t* __restrict__ sigs, int spec,
     uint8_t* __restrict__ stage, size_t stage_stride, int32_t* __restrict__ accept, int gb, int beta, int omega,
-    int ctilde_len, size_t sig_len, size_t n_slots, const Twiddle* __restrict__ inv_tab) {
+    int ctilde_len, size_t sig_len, size_t n_slots, const Twiddle* __restrict__ inv_tab,
+    const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk) {
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
@@ -97,91 +99,114 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES, n_slots32 = (uint32_t)n_slots;
 
     // op / key of the next slot are fetched one slot ahead (two dependent loads off the critical path)
-    uint32_t op_next = 0, key_next = 0;
+    // ... and so are its risk flags (which polynomials stage 1 has to transform, see below)
+    auto risk_flags = [&](uint32_t sl, uint32_t& rr, uint32_t& zr) {
+        rr = wrisk ? (uint32_t)wrisk[sl] : (1u << K) - 1u;
+        zr = (1u << L) - 1u;
+        if (yrisk) {
+            zr = 0;
+#pragma unroll
+            for (int j = 0; j < L; j++) zr |= (yrisk[(size_t)sl * L + j] ? 1u : 0u) << j;
+        }
+    };
+    uint32_t op_next = 0, key_next = 0, rrisk_next = 0, zrisk_next = 0;
     if (wid < n_slots32) {
         op_next = slot_op[wid];
         key_next = key_idx ? key_idx[op_next] : op_next;
+        risk_flags(wid, rrisk_next, zrisk_next);
     }
     for (uint32_t slot32 = wid; slot32 < n_slots32; slot32 += n_waves) {
         const size_t slot = slot32, op = op_next, key = key_next;
+        const uint32_t r_risky = rrisk_next, z_risky = zrisk_next;
         if (slot32 + n_waves < n_slots32) {
             op_next = slot_op[slot32 + n_waves];
             key_next = key_idx ? key_idx[op_next] : op_next;
+            risk_flags(slot32 + n_waves, rrisk_next, zrisk_next);
         }
         uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
         const int4 cv = reinterpret_cast<const int4*>(c_hat + slot * N)[lane];
         if (lane < ctilde_len) sig[lane] = ctilde[slot * 64 + lane];
-        // ---- stage 1, most selective test first: r = w - cs2 with ||LowBits(r)||inf (rejects ~2 of 3 attempts),
-        // then z = y + cs1 with ||z||inf (rejects ~1 of 3); software-pipelined: the next polynomial's loads are
-        // issued before this one's inverse NTT.  Both tests feed the same `continue` (ml_dsa.rs:280).
-        int32_t zmax = 0, r0max = 0;
+        // ---- stage 1.  ||c s1||inf and ||c s2||inf are at most beta = tau * eta, so a polynomial of w whose
+        // LowBits all stay below gamma2 - 2 beta cannot fail ||LowBits(w - c s2)||inf < gamma2 - beta, and a
+        // polynomial of y below gamma1 - 2 beta cannot fail ||y + c s1||inf < gamma1 - beta (ml_dsa.rs:280; with
+        // |low| < gamma2 the decomposition of w - c s2 keeps the high part of w).  sign_w and ExpandMask flag the
+        // few polynomials that are NOT below those margins (about 1 in 3 of w, 1 in 6 of y for ML-DSA-65):
+        // pass 0 transforms only those -- the more selective LowBits test first -- and leaves at the first
+        // rejection; pass 1 computes the remaining r_i and z_j for the attempts that survived (1 in 5), which
+        // need them for the hints and the signature bytes.
         bool ok = true;  // wave-uniform
-        int32_t nv[4], ny[4];
-        load_packed(nv, s2 + (key * K) * (size_t)N, lane);
-        load_strided(ny, w + (slot * K) * (size_t)N, lane);
+        // work list of a pass: bit i < K = r_i (s2 / w), bit K + j = z_j (s1 / y), walked from the low end with the
+        // next polynomial's loads issued before the current inverse NTT
+        uint32_t todo = (1u << (K + L)) - 1u;
+        const uint32_t risky = (r_risky & ((1u << K) - 1u)) | (z_risky << K);
+        auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
+            const bool is_r = idx < K;
+            const int32_t* sp = is_r ? s2 + (key * K + idx) * (size_t)N : s1 + (key * L + (idx - K)) * (size_t)N;
+            const int32_t* xp = is_r ? w + (slot * K + idx) * (size_t)N : y + (slot * L + (idx - K)) * (size_t)N;
+            load_packed(v, sp, lane);
+            load_strided(x, xp, lane);
+        };
 #pragma unroll 1
-        for (int i = 0; i < K; i++) {
-            int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, ww[4] = {ny[0], ny[1], ny[2], ny[3]}, r[4];
-            if (i + 1 < K) {
-                load_packed(nv, s2 + (key * K + i + 1) * (size_t)N, lane);
-                load_strided(ny, w + (slot * K + i + 1) * (size_t)N, lane);
-            } else {  // first polynomial of the z loop
-                load_packed(nv, s1 + (key * L) * (size_t)N, lane);
-                load_strided(ny, y + (slot * L) * (size_t)N, lane);
-            }
-            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-            ntt_inv_wave(r, itw, lane, F_MONT);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int32_t rr = caddq(ww[k] - r[k]);  // w - cs2, canonical (both operands are in [0, q))
-                rr_lds[wave][i][64 * k + lane] = rr;      // kept for the hint stage
-                int32_t r1, r0;
-                decompose<G2HI>(rr, r1, r0);
-                r0 = r0 < 0 ? -r0 : r0;
-                r0max = r0 > r0max ? r0 : r0max;
-            }
-            // stop at the first polynomial that rejects the attempt: the rest cannot change the outcome
-            if (__ballot(r0max >= GAMMA2 - beta) != 0ull) { ok = false; break; }
-        }
+        for (int pass = 0; pass < 2 && ok; pass++) {
+            uint32_t work = pass == 0 ? (risky & todo) : todo;
+            todo &= ~work;
+            int cur = work ? __ffs((int)work) - 1 : -1;
+            int32_t nv[4] = {0, 0, 0, 0}, nx[4] = {0, 0, 0, 0};
+            if (cur >= 0) issue_loads(cur, nv, nx);
 #pragma unroll 1
-        for (int j = 0; ok && j < L; j++) {
-            int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, yy[4] = {ny[0], ny[1], ny[2], ny[3]}, r[4];
-            if (j + 1 < L) {
-                load_packed(nv, s1 + (key * L + j + 1) * (size_t)N, lane);
-                load_strided(ny, y + (slot * L + j + 1) * (size_t)N, lane);
-            }
-            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-            ntt_inv_wave(r, itw, lane, F_MONT);
+            while (cur >= 0) {
+                work &= work - 1u;
+                const int nxt = work ? __ffs((int)work) - 1 : -1;
+                const int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, x[4] = {nx[0], nx[1], nx[2], nx[3]};
+                if (nxt >= 0) issue_loads(nxt, nv, nx);
+                int32_t r[4];
+                r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+                ntt_inv_wave(r, itw, lane, F_MONT);
+                bool bad = false;
+                if (cur < K) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                // z mod+- q (ml_dsa.rs:264, 334): y in (-gamma1, gamma1], cs1 in [0, q), so one conditional
-                // subtraction lands in (-q/2, q/2]
-                const int32_t zs = yy[k] + r[k];
-                const int32_t zc = zs - ((((Q / 2) - zs) >> 31) & Q);
-                xpose[wave][64 * k + lane] = zc;
-                const int32_t a = zc < 0 ? -zc : zc;
-                zmax = a > zmax ? a : zmax;
-            }
-            if (__ballot(zmax >= gamma1 - beta) != 0ull) { ok = false; break; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int4 z4 = reinterpret_cast<const int4*>(&xpose[wave][0])[lane];
-            const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
-            uint64_t lo = 0;
-            uint32_t hi = 0;
+                    for (int k = 0; k < 4; k++) {
+                        const int32_t rr = caddq(x[k] - r[k]);     // w - cs2, canonical (both operands are in [0, q))
+                        rr_lds[wave][cur][64 * k + lane] = rr;      // kept for the hint stage
+                        int32_t r1, r0;
+                        decompose<G2HI>(rr, r1, r0);
+                        bad |= (r0 < 0 ? -r0 : r0) >= GAMMA2 - beta;
+                    }
+                    if (__ballot(bad) != 0ull) { ok = false; break; }
+                } else {
+                    const int j = cur - K;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {  // BitPack(z, gamma1 - 1, gamma1): field = gamma1 - z
-                const uint64_t f = (uint64_t)(uint32_t)(gamma1 - zz[i]);
-                const int sh = i * cb;
-                lo |= f << sh;
-                if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
+                    for (int k = 0; k < 4; k++) {
+                        // z mod+- q (ml_dsa.rs:264, 334): y in (-gamma1, gamma1], cs1 in [0, q), so one conditional
+                        // subtraction lands in (-q/2, q/2]
+                        const int32_t zs = x[k] + r[k];
+                        const int32_t zc = zs - ((((Q / 2) - zs) >> 31) & Q);
+                        xpose[wave][64 * k + lane] = zc;
+                        bad |= (zc < 0 ? -zc : zc) >= gamma1 - beta;
+                    }
+                    if (__ballot(bad) != 0ull) { ok = false; break; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int4 z4 = reinterpret_cast<const int4*>(&xpose[wave][0])[lane];
+                    const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
+                    uint64_t lo = 0;
+                    uint32_t hi = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {  // BitPack(z, gamma1 - 1, gamma1): field = gamma1 - z
+                        const uint64_t f = (uint64_t)(uint32_t)(gamma1 - zz[t]);
+                        const int sh = t * cb;
+                        lo |= f << sh;
+                        if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
+                    }
+                    const int nbytes = cb / 2;
+                    uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * cb) + (size_t)lane * nbytes;
+                    for (int t = 0; t < 8; t++) dst[t] = (uint8_t)(lo >> (8 * t));
+                    for (int t = 8; t < nbytes; t++) dst[t] = (uint8_t)(hi >> (8 * (t - 8)));
+                    __builtin_amdgcn_wave_barrier();
+                }
+                cur = nxt;
             }
-            const int nbytes = cb / 2;
-            uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * cb) + (size_t)lane * nbytes;
-            for (int i = 0; i < 8; i++) dst[i] = (uint8_t)(lo >> (8 * i));
-            for (int i = 8; i < nbytes; i++) dst[i] = (uint8_t)(hi >> (8 * (i - 8)));
-            __builtin_amdgcn_wave_barrier();
         }
         // ---- stage 2: ct0, hints (HintBitPack, conversion.rs:277-328, written as they are found)
         if (ok) {
@@ -383,14 +408,14 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
 int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde,
                      const uint32_t* slot_op, const uint32_t* key_idx, const int32_t* s1, const int32_t* s2, const int32_t* t0,
                      uint16_t* kappa, int32_t* done, uint8_t* sigs, int spec, uint8_t* stage, size_t stage_stride, int32_t* accept,
-                     size_t n_slots, hipStream_t s) {
+                     size_t n_slots, hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk) {
     if (n_slots == 0) return MLDSA_OK;
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
     dim3 grid(grid_for(ctx, n_slots, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
 #define MLDSA_TAIL(KK, LL, G2)                                                                                              \
     hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
                        done, sigs, spec, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
-                       n_slots, ctx->d_inv_tw)
+                       n_slots, ctx->d_inv_tw, wrisk, yrisk)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_TAIL(6, 5, true);
     else MLDSA_TAIL(8, 7, true);

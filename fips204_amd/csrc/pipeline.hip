@@ -206,7 +206,7 @@ constexpr size_t SPEC_TARGET_SLOTS = 65536;  // upper bound of candidate slots p
 
 struct SignWs {
     int32_t *a_hat, *y, *w, *c, *done, *ctx_bad, *accept;
-    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage;
+    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage, *wrisk, *yrisk;
     uint16_t *kappa, *slot_kappa;
     uint32_t *act0, *act1, *slot_op, *slot_key, *counter;
     size_t bytes = 0, stage_stride = 0;
@@ -227,6 +227,8 @@ struct SignWs {
         rho_pp = cv.take<uint8_t>(n * 64);
         w1 = cv.take<uint8_t>(ns * (size_t)p->w1_len);
         ctilde = cv.take<uint8_t>(ns * 64);
+        wrisk = cv.take<uint8_t>(ns);
+        yrisk = cv.take<uint8_t>(ns * (size_t)p->l);
         stage = cv.take<uint8_t>(spec_slots * stage_stride);
         kappa = cv.take<uint16_t>(n);
         slot_kappa = cv.take<uint16_t>(ns);
@@ -336,10 +338,10 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         STAGEC("make_slots", launch_make_slots(ctx, L.act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, st, kidx,
                                                own_a ? nullptr : w.slot_key));
         // 11: y <- ExpandMask(rho'', kappa)                               :215
-        STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, st));
+        STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, st, w.yrisk));
         // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
         STAGEC("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys + key_base * kl_coeffs, own_a ? w.slot_op : w.slot_key,
-                                       w.y, w.w, w.w1, (size_t)p->w1_len, ns, st));
+                                       w.y, w.w, w.w1, (size_t)p->w1_len, ns, st, 0, w.wrisk));
         // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
         STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len,
                                                 0, 0, w.ctilde, 64, ns, st));
@@ -350,7 +352,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
         STAGEC("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1 + key_base * (size_t)p->l * N,
                                              s2 + key_base * (size_t)p->k * N, t0 + key_base * (size_t)p->k * N, w.kappa, w.done, sg,
-                                             spec, w.stage, w.stage_stride, w.accept, ns, st));
+                                             spec, w.stage, w.stage_stride, w.accept, ns, st, w.wrisk, w.yrisk));
         if (spec > 1)
             STAGEC("resolve", launch_resolve(ctx, p, L.act, m, spec, w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa, st));
         HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), st));
