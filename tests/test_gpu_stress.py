@@ -239,6 +239,32 @@ def test_cached_a_hat_entry_points_are_bit_identical(sets, pset):
         assert host(sig3)[i].tobytes() == want_sig
 
 
+@pytest.mark.parametrize("pset,n_ops", [(44, 6000), (65, 4000), (87, 3000)])
+def test_every_signature_of_a_batch_matches_the_oracle(sets, pset, n_ops):
+    """Not a sample: all signatures of a few-thousand-op batch (several keys, hedged rnd) are compared
+    byte for byte with the oracle, so a wrong accept / reject of any single candidate -- e.g. in the
+    margin shortcut of k_sign_tail -- would show as a different kappa."""
+    import os
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    m = sets[pset]
+    rng = np.random.default_rng(1000 + pset)
+    n_keys = 7
+    keys = [orc.keygen_from_seed(pset, bytes(rng.integers(0, 256, 32, dtype=np.uint8))) for _ in range(n_keys)]
+    sks = m.private_keys_from_bytes([orc.sk_into_bytes(pset, k[1]) for k in keys])
+    msgs = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_ops)]
+    rnds = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_ops)]
+    kidx_h = (np.arange(n_ops) * 5 % n_keys).astype(np.uint32)
+    mb, mo = _cat_with_offsets(msgs, "cuda")
+    rnd = torch.frombuffer(bytearray(b"".join(rnds)), dtype=torch.uint8).cuda().view(n_ops, 32)
+    kidx = torch.from_numpy(kidx_h.view(np.int32)).cuda()
+    sig = torch.empty((n_ops, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    m.sign_device(sks, mb, mo, rnd, sig, n_ops, key_idx=kidx)
+    got = host(sig)
+    want = orc.sign_batch_mt(pset, [k[1] for k in keys], kidx_h, msgs, rnds, n_threads=min(16, os.cpu_count() or 1))
+    bad = [i for i in range(n_ops) if got[i].tobytes() != want[i]]
+    assert not bad, (len(bad), bad[:5])
+
+
 def test_hint_weight_and_z_bound_rejections(sets, acvp_sigver):
     """the ACVP 'too many hints' / 'z too large' signatures stay rejected inside a large mixed batch"""
     g = [x for x in acvp_sigver["testGroups"] if x["parameterSet"] == "ML-DSA-87"][0]
