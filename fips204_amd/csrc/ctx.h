@@ -117,7 +117,9 @@ int launch_verify_arith(mldsa_ctx *, int set, const int32_t *, const int32_t *, 
 
 
 // ---- launchers (kernels_sample.hip) ----
-int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride, const uint32_t *key_idx, int32_t *a_hat, size_t n_ops, hipStream_t);
+// pack24: write A_hat as 24-bit fields, 768 bytes per polynomial (the pipelines' private form, sampler_dev.h)
+int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride, const uint32_t *key_idx, int32_t *a_hat, size_t n_ops, hipStream_t,
+                    bool pack24 = false);
 int launch_expand_s(mldsa_ctx *, int set, const uint8_t *rho_prime, size_t rho_stride, int32_t *s12, size_t n_ops, hipStream_t);
 // yrisk (optional): one byte per polynomial, 1 = some |y| >= gamma1 - 2 beta (see k_sign_tail)
 int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, int kappa_by_slot,
@@ -130,7 +132,7 @@ int launch_hint_unpack(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, u
 int launch_use_hint_w1(mldsa_ctx *, const mldsa_params *, const int32_t *w, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, size_t n_ops, hipStream_t);
 int launch_verify_main(mldsa_ctx *, const mldsa_params *, const int32_t *a_hat, const uint8_t *sigs, const int32_t *c, const int32_t *t1,
                        const uint32_t *key_idx, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, int32_t *znorm, size_t n_ops,
-                       hipStream_t, bool a_by_key = false);
+                       hipStream_t, bool a_by_key = false, bool a_packed = false);
 int launch_mu(mldsa_ctx *, const uint8_t *tr, size_t tr_stride, const uint32_t *key_idx, int mode, const uint8_t *msgs,
               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, uint8_t *mu, size_t mu_stride, int32_t *ctx_bad,
               size_t n_ops, hipStream_t);
@@ -142,7 +144,8 @@ int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs
 // ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
 // y_polys_per_op: distance between consecutive ops' y vectors in polynomials (0 = L, contiguous)
 int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
-                  size_t w1_stride, size_t n_ops, hipStream_t, size_t y_polys_per_op = 0, uint8_t *wrisk = nullptr);
+                  size_t w1_stride, size_t n_ops, hipStream_t, size_t y_polys_per_op = 0, uint8_t *wrisk = nullptr,
+                  bool a_packed = false);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,

@@ -8,6 +8,7 @@
 
 #include <cstdlib>
 #include "ctx.h"
+#include "sampler_dev.h"
 #include "keccak.h"
 #include "ntt_wave.h"
 #include "rounding.h"
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(CBLOCK) void k_use_hint_w1(const int32_t* __restric
 //            -> w1Encode (encodings.rs:338-360) -> packed bytes
 // so neither z, w' nor w1' ever exist as int32 polynomials in HBM.
 constexpr int VW = 4;  // waves (= ops in flight) per block
-template <int K, int L, int GB, bool G2HI, int MINW>
+template <int K, int L, int GB, bool G2HI, int MINW, bool APACK>
 __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW))) void k_verify_main(
     const int32_t* __restrict__ a_hat, const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
     const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint32_t* __restrict__ key_idx,
@@ -125,9 +126,15 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
     for (size_t op = wid; op < n_ops; op += n_waves) {
         const size_t key = key_idx ? key_idx[op] : op;
         const size_t aop = a_by_key ? key : op;  // per-key A_hat kept by the caller, or the op's own ExpandA output
-        const int4* arow = reinterpret_cast<const int4*>(a_hat + (aop * K * (size_t)L) * N);
+        // APACK: A_hat in the pipelines' 24-bit form (768 bytes per polynomial, three dwords per lane)
+        using ARow = std::conditional_t<APACK, Packed3, int4>;
+        const ARow* arow = APACK ? reinterpret_cast<const ARow*>(reinterpret_cast<const uint32_t*>(a_hat) + (aop * K * (size_t)L) * PACKED_POLY_DWORDS)
+                                 : reinterpret_cast<const ARow*>(a_hat + (aop * K * (size_t)L) * N);
+        auto coeffs = [](const ARow& v) -> int4 {
+            if constexpr (APACK) return unpack24(v); else return v;
+        };
         const int4* trow = reinterpret_cast<const int4*>(t1 + (key * K) * (size_t)N);
-        int4 av[L];
+        ARow av[L];
 #pragma unroll
         for (int j = 0; j < L; j++) av[j] = arow[j * 64 + lane];
         int4 tv = trow[lane];
@@ -169,10 +176,11 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
 #pragma unroll
             for (int j = 0; j < L; j++) {
                 const int4 zv = zh[wave][j][lane];
-                acc[0] += mont_mul(av[j].x, zv.x);
-                acc[1] += mont_mul(av[j].y, zv.y);
-                acc[2] += mont_mul(av[j].z, zv.z);
-                acc[3] += mont_mul(av[j].w, zv.w);
+                const int4 a4 = coeffs(av[j]);
+                acc[0] += mont_mul(a4.x, zv.x);
+                acc[1] += mont_mul(a4.y, zv.y);
+                acc[2] += mont_mul(a4.z, zv.z);
+                acc[3] += mont_mul(a4.w, zv.w);
             }
             const int4 cv = zh[wave][L][lane];
             acc[0] -= mont_mul(cv.x, tv.x);
@@ -418,16 +426,18 @@ int launch_use_hint_w1(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* w, 
 
 int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_hat, const uint8_t* sigs, const int32_t* c,
                        const int32_t* t1, const uint32_t* key_idx, const uint32_t* hmask, uint8_t* w1, size_t w1_stride,
-                       int32_t* znorm, size_t n_ops, hipStream_t s, bool a_by_key) {
+                       int32_t* znorm, size_t n_ops, hipStream_t s, bool a_by_key, bool a_packed) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, VW, 16));
-#define MLDSA_VM(KK, LL, GB, G2, MW)                                                                                           \
-    hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2, MW>), grid, dim3(64 * VW), 0, s, a_hat, sigs,                               \
+#define MLDSA_VM2(KK, LL, GB, G2, MW, AP)                                                                                    \
+    hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2, MW, AP>), grid, dim3(64 * VW), 0, s, a_hat, sigs,                       \
                        (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, \
                        ctx->d_fwd_tw, ctx->d_inv_tw, a_by_key ? 1 : 0)
+#define MLDSA_VM(KK, LL, GB, G2, MW) do { if (a_packed) MLDSA_VM2(KK, LL, GB, G2, MW, true); else MLDSA_VM2(KK, LL, GB, G2, MW, false); } while (0)
     if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false, 5);
     else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true, 4);
     else MLDSA_VM(8, 7, 19, true, 4);
+#undef MLDSA_VM2
 #undef MLDSA_VM
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;

@@ -7,7 +7,10 @@
 // to_mont, add_vector_ntt, infinity_norm) of the reference.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "ctx.h"
+#include "sampler_dev.h"
 #include "rounding.h"
 
 namespace mldsa {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(BLOCK) void k_infinity_norm(const int32_t *__restri
 // W1 = 1 / 2 additionally emits w1Encode(HighBits(w)) (6-bit / 4-bit fields) per op: the signer's
 // commitment bytes (ml_dsa.rs:225-232), so no separate pass re-reads w.
 constexpr int AW = 4;  // waves per block
-template <int K, int L, bool HAS_C, int W1 = 0>
+template <int K, int L, bool HAS_C, int W1 = 0, bool APACK = false>
 __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
@@ -188,9 +191,15 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     for (size_t op = wid; op < n_ops; op += n_waves) {
         const size_t aop = a_idx ? a_idx[op] : op;
         const size_t key = HAS_C ? (key_idx ? key_idx[op] : op) : 0;
-        const int4 *arow = reinterpret_cast<const int4 *>(a_hat + (aop * K * (size_t)L) * N);
+        // APACK: A_hat in the pipelines' 24-bit form (768 bytes per polynomial, three dwords per lane)
+        using ARow = std::conditional_t<APACK, Packed3, int4>;
+        const ARow *arow = APACK ? reinterpret_cast<const ARow *>(reinterpret_cast<const uint32_t *>(a_hat) + (aop * K * (size_t)L) * PACKED_POLY_DWORDS)
+                                 : reinterpret_cast<const ARow *>(a_hat + (aop * K * (size_t)L) * N);
+        auto coeffs = [](const ARow &v) -> int4 {
+            if constexpr (APACK) return unpack24(v); else return v;
+        };
         // row 0 of A_hat (and of t1) is requested before the transforms
-        int4 av[L];
+        ARow av[L];
         int4 tv = make_int4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < L; j++) av[j] = arow[j * 64 + lane];
@@ -220,10 +229,11 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
 #pragma unroll
             for (int j = 0; j < L; j++) {
                 const int4 zv = zh[wave][j][lane];
-                acc[0] += mont_mul(av[j].x, zv.x);
-                acc[1] += mont_mul(av[j].y, zv.y);
-                acc[2] += mont_mul(av[j].z, zv.z);
-                acc[3] += mont_mul(av[j].w, zv.w);
+                const int4 a4 = coeffs(av[j]);
+                acc[0] += mont_mul(a4.x, zv.x);
+                acc[1] += mont_mul(a4.y, zv.y);
+                acc[2] += mont_mul(a4.z, zv.z);
+                acc[3] += mont_mul(a4.w, zv.w);
             }
             if constexpr (HAS_C) {
                 const int4 cv = zh[wave][L][lane];
@@ -345,20 +355,22 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 // w[slot] = inv_ntt(A_hat[a_idx[slot]] * ntt(y[slot]))   (ml_dsa.rs:218-222); with w1 != nullptr also
 // w1Encode(HighBits(w)) (ml_dsa.rs:225-232)
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
-                  size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op, uint8_t *wrisk) {
+                  size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op, uint8_t *wrisk, bool a_packed) {
     if (n_ops == 0) return MLDSA_OK;
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
     const mldsa_params *pp = params_of(set);
     const int32_t risk_bound = pp ? pp->gamma2 - 2 * pp->beta : 0;
     dim3 gw(grid_for(ctx, n_ops, AW, 16));
-#define MLDSA_SW(KK, LL, W1M)                                                                                                    \
-    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
+#define MLDSA_SW2(KK, LL, W1M, AP)                                                                                               \
+    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M, AP>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
                        ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound)
+#define MLDSA_SW(KK, LL, W1M) do { if (a_packed) MLDSA_SW2(KK, LL, W1M, true); else MLDSA_SW2(KK, LL, W1M, false); } while (0)
     if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
     else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 2); else MLDSA_SW(6, 5, 0); }
     else if (set == MLDSA_87) { if (w1) MLDSA_SW(8, 7, 2); else MLDSA_SW(8, 7, 0); }
     else return set_error(MLDSA_ERR_PARAM, "sign_w: unknown parameter set");
+#undef MLDSA_SW2
 #undef MLDSA_SW
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;

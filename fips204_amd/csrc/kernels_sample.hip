@@ -15,7 +15,7 @@ namespace mldsa {
 // ExpandA (hashing.rs:225-239) = K*L x RejNTTPoly (hashing.rs:111-146):
 // stream (op, r, s): SHAKE128(rho || s || r); 3 bytes -> 23-bit candidate, keep if < q
 // (coeff_from_three_bytes, conversion.rs:40-61).  Output A_hat[op][r][s], canonical [0, q).
-template <int K, int L>
+template <int K, int L, bool PACK24>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restrict__ rho, size_t rho_stride,
                                                           const uint32_t* __restrict__ key_idx,
                                                           int32_t* __restrict__ a_hat, size_t n_ops) {
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restr
 
     KeccakState st;
     expand_a_seed(st, rho + (key_idx ? key_idx[op] : op) * rho_stride, sidx, r);
-    rej_ntt_poly_lane(st, stage, meta, my, a_hat, wave_base, lane, valid);
+    rej_ntt_poly_lane<PACK24>(st, stage, meta, my, a_hat, wave_base, lane, valid);
 }
 
 // ------------------------------------------------------------------------------------
@@ -259,14 +259,20 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
 static inline unsigned stream_blocks(size_t n_streams) { return (unsigned)((n_streams + 64 * SWAVES - 1) / (64 * SWAVES)); }
 
 int launch_expand_a(mldsa_ctx*, int set, const uint8_t* rho, size_t rho_stride, const uint32_t* key_idx, int32_t* a_hat,
-                    size_t n_ops, hipStream_t s) {
+                    size_t n_ops, hipStream_t s, bool pack24) {
     if (n_ops == 0) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_a: unknown parameter set");
     dim3 grid(stream_blocks(n_ops * (size_t)(p->k * p->l))), block(64 * SWAVES);
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_expand_a<4, 4>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_expand_a<6, 5>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);
-    else hipLaunchKernelGGL((k_expand_a<8, 7>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);
+#define MLDSA_EA(KK, LL)                                                                                                          \
+    do {                                                                                                                          \
+        if (pack24) hipLaunchKernelGGL((k_expand_a<KK, LL, true>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);     \
+        else hipLaunchKernelGGL((k_expand_a<KK, LL, false>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);          \
+    } while (0)
+    if (set == MLDSA_44) MLDSA_EA(4, 4);
+    else if (set == MLDSA_65) MLDSA_EA(6, 5);
+    else MLDSA_EA(8, 7);
+#undef MLDSA_EA
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

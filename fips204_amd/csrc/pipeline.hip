@@ -108,12 +108,12 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
         // (skipped when the caller keeps A_hat with its keys: the optimisation the reference's benches/README.md
         //  names as missing; the rows are then looked up by key instead of by op)
-        if (!a_hat_keys) STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s));
+        if (!a_hat_keys) STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s, true));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
         // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
         STAGE("verify_main", launch_verify_main(ctx, p, a_hat_keys ? a_hat_keys + key_base * kl_coeffs : w.a_hat, sg, w.c,
                                                 t1 + key_base * (size_t)p->k * N, kidx, w.hmask, w.mu_w1 + 64, mw, w.znorm, n, s,
-                                                a_hat_keys != nullptr));
+                                                a_hat_keys != nullptr, a_hat_keys == nullptr));
         // 12: c_tilde' <- H(mu || w1Encode(w1'), lambda/4)                 ml_dsa.rs:429-431
         STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, w.ctilde_p, 64, n, s));
         // 13: [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]      ml_dsa.rs:434-436
@@ -185,9 +185,9 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
         STAGE("seed_hash", launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
                                              w.hbuf, 128, n, s));
         STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
-        STAGE("expand_a", launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s));                // :85
+        STAGE("expand_a", launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s, true));          // :85 (24-bit form)
         // :86-88 inv_ntt(A * ntt(s1)); s1 is read in place from the (s1, s2) rows ExpandS wrote
-        STAGE("sign_w", launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1s2, w.as1, nullptr, 0, n, s, (size_t)(p->l + p->k)));
+        STAGE("sign_w", launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1s2, w.as1, nullptr, 0, n, s, (size_t)(p->l + p->k), nullptr, true));
         STAGE("keygen_encode", launch_keygen_encode(ctx, p, w.s1s2, w.as1, w.hbuf, pko, sko, n, s));  // :88-92, pk/sk encode incl. rho, K
         STAGE("tr_hash", launch_shake256_2(ctx, 64, pko, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, sko + 64, skl, n, s));  // tr = H(pk), :99-101
     }
@@ -300,7 +300,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         const size_t key_base = key_idx ? 0 : o;
         HIPC(hipMemsetAsync(sigs + o * (size_t)p->sig_len, 0, n * (size_t)p->sig_len, st));
         // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
-        if (own_a) STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, st));
+        if (own_a) STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, st, true));
         // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
         STAGEC("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
                                w.rnd_mu + 32, 96, w.ctx_bad, n, st));
@@ -341,7 +341,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, st, w.yrisk));
         // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
         STAGEC("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys + key_base * kl_coeffs, own_a ? w.slot_op : w.slot_key,
-                                       w.y, w.w, w.w1, (size_t)p->w1_len, ns, st, 0, w.wrisk));
+                                       w.y, w.w, w.w1, (size_t)p->w1_len, ns, st, 0, w.wrisk, own_a));
         // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
         STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len,
                                                 0, 0, w.ctilde, 64, ns, st));

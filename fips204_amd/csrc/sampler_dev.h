@@ -74,6 +74,14 @@ __device__ __forceinline__ void flush_rows(uint32_t* stage, uint32_t* meta, int3
 // iteration stores 8 rows x 32 coefficients with one dwordx4 store per lane: 8 iterations per
 // flush instead of 32.  Rows keep up to 3 left-over coefficients for the next flush (the caller
 // moves them to the front of its row).
+// PACK24: the stream's coefficients (all < 2^23) are stored as 24-bit little-endian fields, 768 bytes per
+// polynomial instead of 1024: four coefficients = three dwords, so a flush piece is one dwordx3 store.
+// The A_hat the op-level pipelines keep for themselves uses this form (a quarter less HBM traffic in
+// the kernels that stream it); the seam-level mldsa_expand_a keeps the reference's int32 layout.
+struct Packed3 { uint32_t a, b, c; };
+constexpr int PACKED_POLY_DWORDS = 192;  // 256 * 24 bits
+
+template <bool PACK24 = false>
 __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
                                             int fc, int n, int lane) {
     meta[lane] = ((uint32_t)n << 8) | (uint32_t)fc;
@@ -87,11 +95,24 @@ __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int
         const int row = 8 * i + grp;
         if (j4 < (int)(m[i] & 0xFFu)) {
             const uint32_t* src = stage + row * STAGE_STRIDE + j4;
-            const int4 v = make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
-            *reinterpret_cast<int4*>(out + (wave_base + row) * N + (m[i] >> 8) + j4) = v;
+            if constexpr (PACK24) {
+                const uint32_t c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+                Packed3 v{c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8)};
+                uint32_t* o = reinterpret_cast<uint32_t*>(out) + (wave_base + row) * PACKED_POLY_DWORDS + (((m[i] >> 8) + j4) >> 2) * 3;
+                *reinterpret_cast<Packed3*>(o) = v;
+            } else {
+                const int4 v = make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
+                *reinterpret_cast<int4*>(out + (wave_base + row) * N + (m[i] >> 8) + j4) = v;
+            }
         }
     }
     wave_lds_sync();
+}
+
+// four 24-bit fields (three dwords of a PACK24 polynomial) -> coefficients
+__device__ __forceinline__ int4 unpack24(const Packed3& p) {
+    return make_int4((int)(p.a & 0xFFFFFFu), (int)(__builtin_amdgcn_alignbit(p.b, p.a, 24) & 0xFFFFFFu),
+                     (int)(__builtin_amdgcn_alignbit(p.c, p.b, 16) & 0xFFFFFFu), (int)(p.c >> 8));
 }
 
 // after flush_rows4: move the (at most 3) unflushed coefficients my[fc .. fc + 2] to the row front
@@ -106,6 +127,7 @@ __device__ __forceinline__ void keep_leftover(uint32_t* my, int fc) {
 // Squeezes SHAKE128 blocks until the lane has its 256 coefficients (wave-uniform loop: every lane
 // keeps permuting until the whole wave is done, extra output is dropped) and flushes 28-candidate
 // half blocks through the staging rows to out[(wave_base + lane) * 256 + ...].
+template <bool PACK24 = false>
 __device__ __forceinline__ void rej_ntt_poly_lane(KeccakState& st, uint32_t* stage, uint32_t* meta, uint32_t* my,
                                                   int32_t* __restrict__ out, size_t wave_base, int lane, bool valid) {
     int n = valid ? 0 : N;  // coefficients already in `out` (a multiple of 4)
@@ -123,7 +145,7 @@ __device__ __forceinline__ void rej_ntt_poly_lane(KeccakState& st, uint32_t* sta
             });
             const int have = min(cnt, N - n);
             const int fc = (n + have == N) ? have : (have & ~3);  // N and n are multiples of 4, so fc is too
-            flush_rows4(stage, meta, out, wave_base, fc, n, lane);
+            flush_rows4<PACK24>(stage, meta, out, wave_base, fc, n, lane);
             keep_leftover(my, fc);
             carry = have - fc;
             n += fc;
