@@ -488,6 +488,9 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
         line["roofline"]["note"] = ("whole ops are integer-ALU-bound (Keccak-f[1600]), not HBM-bound: "
                                     f"~{perms} permutations per op; the HBM-bound kernel of the path is reported under "
                                     "also.verify_arith44 (BASELINE config 2)")
+        line["roofline"]["note"] += ("; algorithmic bytes are SURVEY 8d's int32-polynomial counts: the pipelines keep A_hat as 24-bit "
+                                     "fields and candidates of one op share its rows through L2, so the PMC traffic of "
+                                     "sign_w / verify_main is below them")
         line["keccak_permutations_per_s"] = perms * value / world
         # every modelled stage against the ceiling that bounds it: HBM peak for the polynomial-streaming
         # kernels, the measured Keccak-f[1600] issue ceiling (tools/ubench_valu.hip k_keccak at 8 waves/SIMD,
