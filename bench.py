@@ -401,7 +401,69 @@ class WholeOp:
                            f"restatement with per-op ExpandA, {dt:.1f} s")
 
 
+class MixedStream:
+    """BASELINE config[4] on one GPU: a stream of ML-DSA-44 / 65 / 87 work -- per step and parameter set
+    keygen of B/8 keys, B signatures under those keys, B verifications -- issued back to back on one
+    context.  value = (keys + signatures + verifications) per second."""
+
+    def __init__(self, hp, batch, rank):
+        from fips204_amd.ml_dsa import MlDsa, _cat_with_offsets
+        self.hp, self.batch, self.rank = hp, batch or 16384, rank
+        self.unit = "ops/s"
+        self.dtype = "int32"
+        self.n_sets = 1
+        self.kernel = "keygen + sign + verify pipelines of the three parameter sets"
+        g = torch.Generator(device="cuda").manual_seed(4465 + rank)
+        B, nk = self.batch, max(1, self.batch // 8)
+        self.sets = []
+        for pset in (44, 65, 87):
+            ml = MlDsa(pset, hotpath=hp)
+            xi = torch.randint(0, 256, (nk, 32), dtype=torch.uint8, device="cuda", generator=g)
+            msgs = [_shake(b"mldsa-bench-mixed" + bytes([pset]), rank * B + i, 8) for i in range(B)]
+            mb, mo = _cat_with_offsets(msgs, ml.device)
+            rnd = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device="cuda", generator=g)
+            kidx = (torch.arange(B, device="cuda") % nk).to(torch.int32)
+            sig = torch.empty((B, ml.SIG_LEN), dtype=torch.uint8, device="cuda")
+            ok = torch.zeros(B, dtype=torch.uint8, device="cuda")
+            self.sets.append(dict(ml=ml, xi=xi, mb=mb, mo=mo, rnd=rnd, kidx=kidx, sig=sig, ok=ok, msgs=msgs))
+        self.ops_per_step = 3 * (nk + 2 * B)
+        p = [s["ml"] for s in self.sets]
+        self.bytes_per_op = sum(nk * (32 + m.PK_LEN + m.SK_LEN) + B * (m.SK_LEN + 64 + m.SIG_LEN) + B * (m.PK_LEN + m.SIG_LEN + 33)
+                                for m in p) / self.ops_per_step
+        self.name = (f"mixed ml_dsa_44/65/87 stream: per set keygen x{nk} + sign x{B} + verify x{B} per step, one context, "
+                     "wire formats resident in HBM")
+        self.metric = "mixed ML-DSA-44/65/87 keygen+sign+verify ops/sec per GPU (batched); % HBM roofline"
+
+    def step(self, i):
+        for s in self.sets:
+            ml = s["ml"]
+            pk, sk = ml.keygen_from_seed(s["xi"])
+            pks, sks = ml.public_keys_from_bytes(pk), ml.private_keys_from_bytes(sk)
+            ml.sign_device(sks, s["mb"], s["mo"], s["rnd"], s["sig"], self.batch, key_idx=s["kidx"])
+            ml.verify_device(pks, s["mb"], s["mo"], s["sig"], s["ok"], self.batch, key_idx=s["kidx"])
+            s["pk"], s["sk"] = pk, sk
+
+    def kernel_launches_per_step(self):
+        return 1
+
+    def check(self):
+        from oracle import oracle as orc
+        self.step(0)
+        torch.cuda.synchronize()
+        for s in self.sets:
+            ml = s["ml"]
+            assert bool(s["ok"].all()), "mixed stream: a GPU signature did not verify"
+            sk0 = orc.sk_try_from_bytes(ml.pset, s["sk"][0].cpu().numpy().tobytes())
+            want = orc.sign_internal(ml.pset, sk0, s["msgs"][0], s["rnd"][0].cpu().numpy().tobytes(), mode=0)
+            assert s["sig"][0].cpu().numpy().tobytes() == want, "mixed stream: GPU signature differs from the oracle"
+
+    def cpu_baseline(self, budget_s=0):
+        return None
+
+
 def make_workload(name, hp, batch, rank):
+    if name == "mixed":
+        return MixedStream(hp, batch, rank)
     if name.startswith("verify_arith"):
         pset = int(name[len("verify_arith"):])
         return VerifyArith(hp, pset, batch or 4096, rank)
@@ -443,7 +505,7 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
     # single-kernel workloads: average launch duration over the back-to-back launches of the timed region
     # (HIP events on the launch stream, first launch -> last completion)
     kern_ms = ev0.elapsed_time(ev1) / steps / wl.kernel_launches_per_step()
-    total_ops = wl.batch * world * steps
+    total_ops = getattr(wl, "ops_per_step", wl.batch) * world * steps
     value = total_ops / dt
     stages = None
     if whole:
@@ -452,7 +514,7 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
     if rank != 0:
         return None
 
-    alg_bytes = wl.bytes_per_op * wl.batch
+    alg_bytes = wl.bytes_per_op * getattr(wl, "ops_per_step", wl.batch)
     if whole:
         # dominant kernel = the stage with the largest share of device time; its average launch
         # duration comes from the event pairs recorded inside the timed region

@@ -265,6 +265,39 @@ def test_every_signature_of_a_batch_matches_the_oracle(sets, pset, n_ops):
     assert not bad, (len(bad), bad[:5])
 
 
+def test_mixed_parameter_set_stream(sets):
+    """BASELINE config 5 as a parity case: ML-DSA-44 / 65 / 87 keygen -> sign -> verify issued back to back
+    on one context with no synchronisation in between; all signatures verify and match the oracle."""
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    n_ops, n_keys = 600, 6
+    runs = []
+    for rep in range(2):
+        for pset in (87, 44, 65):
+            m = sets[pset]
+            g = torch.Generator(device="cuda").manual_seed(100 * rep + pset)
+            xi = torch.randint(0, 256, (n_keys, 32), dtype=torch.uint8, device="cuda", generator=g)
+            msgs = [bytes([pset, rep, i & 255, i >> 8]) * 5 for i in range(n_ops)]
+            mb, mo = _cat_with_offsets(msgs, "cuda")
+            rnd = torch.randint(0, 256, (n_ops, 32), dtype=torch.uint8, device="cuda", generator=g)
+            kidx = (torch.arange(n_ops, device="cuda") % n_keys).to(torch.int32)
+            pk, sk = m.keygen_from_seed(xi)
+            pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+            sig = torch.empty((n_ops, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+            ok = torch.zeros(n_ops, dtype=torch.uint8, device="cuda")
+            m.sign_device(sks, mb, mo, rnd, sig, n_ops, key_idx=kidx)
+            m.verify_device(pks, mb, mo, sig, ok, n_ops, key_idx=kidx)
+            runs.append((pset, xi, msgs, rnd, sk, sig, ok))
+    torch.cuda.synchronize()
+    for pset, xi, msgs, rnd, sk, sig, ok in runs:
+        assert host(ok).all(), pset
+        skh, sgh, rh, xh = host(sk), host(sig), host(rnd), host(xi)
+        for i in (0, 7, n_ops - 1):
+            ki = i % n_keys
+            pk_o, sk_o = orc.keygen_from_seed(pset, xh[ki].tobytes())
+            assert skh[ki].tobytes() == orc.sk_into_bytes(pset, sk_o)
+            assert sgh[i].tobytes() == orc.sign_internal(pset, sk_o, msgs[i], rh[i].tobytes(), mode=0), (pset, i)
+
+
 def test_hint_weight_and_z_bound_rejections(sets, acvp_sigver):
     """the ACVP 'too many hints' / 'z too large' signatures stay rejected inside a large mixed batch"""
     g = [x for x in acvp_sigver["testGroups"] if x["parameterSet"] == "ML-DSA-87"][0]
