@@ -153,7 +153,7 @@ int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const 
                      uint16_t *kappa, int32_t *done, uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept,
                      size_t n_slots, hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr);
 int launch_make_slots(mldsa_ctx *, const uint32_t *act, size_t m, int spec, const uint16_t *kappa, int l, uint32_t *slot_op,
-                      uint16_t *slot_kappa, hipStream_t, const uint32_t *key_idx = nullptr, uint32_t *slot_key = nullptr);
+                      uint16_t *slot_kappa, hipStream_t, const uint32_t *key_idx, uint32_t *slot_key, uint32_t *counter);
 int launch_resolve(mldsa_ctx *, const mldsa_params *, const uint32_t *act, size_t m, int spec, const int32_t *accept,
                    const uint8_t *stage, size_t stage_stride, uint8_t *sigs, int32_t *done, uint16_t *kappa, hipStream_t);
 int launch_compact(mldsa_ctx *, const uint32_t *act_in, size_t n, const int32_t *done, uint32_t *act_out, uint32_t *counter, hipStream_t);

@@ -267,8 +267,10 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
 __global__ __launch_bounds__(256) void k_make_slots(const uint32_t* __restrict__ act, size_t m, int spec,
                                                     const uint16_t* __restrict__ kappa, int l,
                                                     uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa,
-                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key) {
+                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key,
+                                                    uint32_t* __restrict__ counter) {
     const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (sidx == 0) *counter = 0;  // k_compact of this round counts the survivors from zero
     if (sidx >= m * (size_t)spec) return;
     const uint32_t op = act[sidx / spec];
     slot_op[sidx] = op;
@@ -425,11 +427,11 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
 }
 
 int launch_make_slots(mldsa_ctx*, const uint32_t* act, size_t m, int spec, const uint16_t* kappa, int l, uint32_t* slot_op,
-                      uint16_t* slot_kappa, hipStream_t s, const uint32_t* key_idx, uint32_t* slot_key) {
+                      uint16_t* slot_kappa, hipStream_t s, const uint32_t* key_idx, uint32_t* slot_key, uint32_t* counter) {
     if (m == 0) return MLDSA_OK;
     const size_t n = m * (size_t)spec;
     hipLaunchKernelGGL(k_make_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act, m, spec, kappa, l, slot_op, slot_kappa, key_idx,
-                       slot_key);
+                       slot_key, counter);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

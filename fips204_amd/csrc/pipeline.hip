@@ -336,7 +336,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         const size_t ns = m * (size_t)spec;
         if (ctx->prof_on) ctx->prof_sign_slots += ns;
         STAGEC("make_slots", launch_make_slots(ctx, L.act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, st, kidx,
-                                               own_a ? nullptr : w.slot_key));
+                                               own_a ? nullptr : w.slot_key, w.counter));
         // 11: y <- ExpandMask(rho'', kappa)                               :215
         STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, st, w.yrisk));
         // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
@@ -355,7 +355,6 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
                                              spec, w.stage, w.stage_stride, w.accept, ns, st, w.wrisk, w.yrisk));
         if (spec > 1)
             STAGEC("resolve", launch_resolve(ctx, p, L.act, m, spec, w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa, st));
-        HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), st));
         STAGEC("compact", launch_compact(ctx, L.act, m, w.done, L.act_next, w.counter, st));
         HIPC(hipMemcpyAsync((void *)L.h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPC(hipEventRecord(L.ev, st));
