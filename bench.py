@@ -38,7 +38,22 @@ SETS = {44: dict(k=4, l=4, gamma1=1 << 17, tau=39), 65: dict(k=6, l=5, gamma1=1 
         87: dict(k=8, l=7, gamma1=1 << 19, tau=60)}
 
 
-def parse():
+# the reference's own published single-core figures (benches/README.md:16-26; i7-7700K @ 4.2 GHz, Rust 1.81,
+# RUSTFLAGS="-C target-cpu=native" cargo bench), printed beside the CPU baseline measured here
+REFERENCE_PUBLISHED = {
+    "source": "/root/reference/benches/README.md:16-26 (Intel i7-7700K @ 4.20 GHz, one core, Oct 2024)",
+    "keygen_us": {44: 104.89, 65: 194.80, 87: 290.24},
+    "sign_us": {44: 226.32, 65: 352.89, 87: 385.05},
+    "verify_us": {44: 21.016, 65: 27.996, 87: 36.468},
+    "note": ("the published verify time is inconsistent with the published keygen time of the same crate: keygen (about 190 "
+             "Keccak-f incl. ExpandA) takes 194.8 us but verify (159 Keccak-f incl. the same ExpandA, ml_dsa.rs:406) 28.0 us; "
+             "benches/benchmark.rs:58-60 verifies one constant (pk, msg, sig) triple with a mismatching ctx in a closure the "
+             "compiler can hoist the loop-invariant ExpandA(rho) out of.  Per clock the oracle timed here is on par with the "
+             "published keygen (318 us at 2.1 GHz vs 194.8 us at 4.2-4.5 GHz)."),
+}
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -47,44 +62,42 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="ops per GPU (0 = the workload's BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra config[1] / config[2] objects of the default run")
-    return ap.parse_args()
+    ap.add_argument("--backend", default=os.environ.get("MLDSA_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend of the N > 1 run: nccl (= RCCL) or gloo (CPU rendezvous; lets several ranks "
+                         "share one GPU for a functional check on a 1-GPU box)")
+    ap.add_argument("--graphs", type=int, default=-1, help="override MLDSA_OPT_GRAPHS (hipGraph replay) of the context: 0 / 1")
+    return ap.parse_args(argv)
 
 
-def dist_setup(n_gpus):
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def dist_setup(args):
+    """One process per GPU.  Launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment) or by this script's own parent (main(): --gpus N without that environment)."""
+    from fips204_amd import multi_gpu
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # MLDSA_BENCH_FORCE_DIST=1: take the RCCL path even with one rank (to exercise it on a 1-GPU box)
-    global _DIST
-    _DIST = world > 1 or (os.environ.get("MLDSA_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
-    if _DIST:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
-    return rank, local_rank, world
-
-
-_DIST = False
+    if world != args.gpus and "RANK" in os.environ:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    if world > 1 and n_dev < world and args.backend == "nccl":
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPUs visible (RCCL needs one GPU per rank; "
+                         "--backend gloo shares GPUs for a functional check)")
+    dev = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev)
+    rank, _, world = multi_gpu.init_process_group(args.backend if world > 1 else None, device_index=dev)
+    return rank, dev, world
 
 
 def barrier(world):
-    if _DIST:
-        import torch.distributed as dist
-        dist.barrier()
+    from fips204_amd import multi_gpu
+    multi_gpu.barrier()
 
 
 def max_over_ranks(x, world):
-    if not _DIST:
+    from fips204_amd import multi_gpu
+    if not multi_gpu.is_distributed():
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return multi_gpu.max_over_ranks(x, "cuda" if dist.get_backend() == "nccl" else "cpu")
 
 
 # ----------------------------------------------------------------------- workloads
@@ -268,15 +281,18 @@ class WholeOp:
     SHAKE256("mldsa-bench-rnd" | i_le64); empty ctx, external interface.  A_hat is re-derived
     from rho inside every op (no cross-op reuse), like the reference (ml_dsa.rs:181, 406)."""
 
-    def __init__(self, hp, pset, kind, batch, rank, cached_a=False):
+    def __init__(self, hp, pset, kind, batch, rank, cached_a=False, world=1):
+        from fips204_amd import multi_gpu
         from fips204_amd.ml_dsa import MlDsa, _cat_with_offsets
         self.cached_a = cached_a
-        self.hp, self.pset, self.kind, self.batch, self.rank = hp, pset, kind, batch, rank
+        self.hp, self.pset, self.kind, self.batch, self.rank, self.world = hp, pset, kind, batch, rank, world
         self.ml = ml = MlDsa(pset, hotpath=hp)
         p = ml.params
         self.k, self.l = p.k, p.l
         n_keys = min(batch, 1024)
-        base = rank * batch  # global op index of this rank's first op (weak scaling: distinct data per rank)
+        # the job is batch * world ops, contiguous slices per rank (weak scaling: distinct data per rank)
+        base, n_mine = multi_gpu.shard(batch * world, rank, world)
+        assert n_mine == batch
         xi = [_shake(b"mldsa-bench-key" + bytes([pset]), base + i, 4) for i in range(n_keys)]
         self.msgs = [_shake(b"mldsa-bench-msg", base + i, 8) for i in range(batch)]
         self.rnd_host = [_shake(b"mldsa-bench-rnd", base + i, 8) for i in range(batch)]
@@ -290,6 +306,7 @@ class WholeOp:
         self.sigs = torch.empty((batch, ml.SIG_LEN), dtype=torch.uint8, device="cuda")
         self.ok = torch.zeros(batch, dtype=torch.uint8, device="cuda")
         self.status = torch.zeros(batch, dtype=torch.int32, device="cuda")
+        hp.reserve(pset, 2, batch)  # MLDSA_OP_SIGN: the largest workspace of the three pipelines
         ml.sign_device(self.sks, self.msg_buf, self.msg_off, self.rnd, self.sigs, batch, key_idx=self.key_idx, status=self.status)
         torch.cuda.synchronize()
         self.n_sets = 1
@@ -302,14 +319,19 @@ class WholeOp:
             self.bytes_per_op = p.sk_len + 32 + 32 + p.sig_len          # whole sign
             self.unit = "signs/s"
             self.metric = f"ML-DSA-{pset} signs/sec per GPU (batched); % HBM roofline"
-        # algorithmic bytes per unit of each stage's kernel (DESIGN.md "Kernels")
+        # Bytes each stage's kernel is OBLIGED to move per unit (DESIGN.md "Kernels").  The pipelines keep their own
+        # A_hat as 24-bit fields: 768 bytes per polynomial, written once by expand_a and read once by verify_main;
+        # sign_w needs an op's A_hat once per ROUND (its speculative candidates share the rows), so its A_hat term is
+        # counted per op-round, the y / w / w1 terms per candidate slot (see run_one).
+        self.a_poly_bytes = 768
         self.stage_bytes = {
-            "expand_a": 32 + 1024 * kl,
+            "expand_a": 32 + self.a_poly_bytes * kl,
             "verify_arith": 1024 * (kl + self.l + 1 + 2 * self.k),
-            "sign_w": 1024 * (kl + self.l + self.k),
+            "sign_w": 1024 * (self.l + self.k) + p.w1_len + 1,              # per candidate slot: y in, w + w1 + risk flag out
+            "sign_w_per_op_round": self.a_poly_bytes * kl,                  # per unfinished op and round: A_hat in
             "expand_mask": 66 * self.l + 1024 * self.l,
             # A_hat + signature bytes + c + t1 row block + hint masks in, w1 bytes out
-            "verify_main": 1024 * (kl + 1 + self.k) + p.sig_len + 32 * self.k + p.w1_len,
+            "verify_main": self.a_poly_bytes * kl + 1024 * (1 + self.k) + p.sig_len + 32 * self.k + p.w1_len,
         }
         # Keccak-f[1600] permutations per unit of the SHAKE-bound stages (5 SHAKE128 blocks per A_hat
         # polynomial, 5 SHAKE256 blocks per mask polynomial): their ceiling is integer-ALU issue
@@ -317,8 +339,8 @@ class WholeOp:
         if cached_a:
             # the n_keys A_hat tables (n_keys * K * L KiB, 30 MB for 1 024 ML-DSA-65 keys) are re-read from
             # L2 / Infinity Cache, not from HBM: they are not algorithmic HBM bytes of these workloads
-            self.stage_bytes["verify_main"] -= 1024 * kl
-            self.stage_bytes["sign_w"] -= 1024 * kl
+            self.stage_bytes["verify_main"] -= self.a_poly_bytes * kl
+            self.stage_bytes["sign_w_per_op_round"] = 0
         self.name = (f"ml_dsa_{pset} batch={batch} whole {kind} on FIPS 204 wire formats, "
                      + (f"A_hat KEPT WITH THE {n_keys} KEYS (no per-op ExpandA: not the reference's per-op cost, reported separately)"
                         if cached_a else "GPU ExpandA")
@@ -401,12 +423,65 @@ class WholeOp:
                            f"restatement with per-op ExpandA, {dt:.1f} s")
 
 
+def measure_h2d_GBs(n_bytes=256 << 20):
+    """PCIe host->device rate of this box from page-locked memory (what bounds the host-fed path)."""
+    h = torch.empty(n_bytes, dtype=torch.uint8, pin_memory=True)
+    d = torch.empty(n_bytes, dtype=torch.uint8, device="cuda")
+    d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        d.copy_(h, non_blocking=True)
+    torch.cuda.synchronize()
+    return 4 * n_bytes / (time.perf_counter() - t0) / 1e9
+
+
+def host_fed(wl, reps=3):
+    """The same batch handed over in HOST memory (mldsa_verify_host / mldsa_sign_host: wire-format keys,
+    page-locked buffers, sub-batches with upload | kernels | download overlapped).  PCIe-inclusive, so it is
+    reported beside `value`, never as `value`."""
+    ml, p, n = wl.ml, wl.ml.params, wl.batch
+    pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t).numpy()
+    keys = pin(wl.pk_bytes if wl.kind == "verify" else wl.sk_bytes)
+    msgs = pin(wl.msg_buf)
+    moff = pin(wl.msg_off).view(np.uint64)
+    kidx = pin(wl.key_idx).view(np.uint32)
+    if wl.kind == "verify":
+        sigs = pin(wl.sigs)
+        ok_out = pin(wl.ok)
+        run = lambda: ml.verify_host(keys, (msgs, moff), sigs, key_idx=kidx, out=ok_out)
+        up, down = p.sig_len + 32 + 8 + 4, 1
+    else:
+        rnd = pin(wl.rnd)
+        outs = (pin(wl.sigs), pin(wl.status))
+        run = lambda: ml.sign_host(keys, (msgs, moff), rnd, key_idx=kidx, out=outs)
+        up, down = 32 + 32 + 8 + 4, p.sig_len + 4
+    res = run()  # warm-up: staging buffers, graphs
+    if wl.kind == "verify":
+        assert bool(res.all()), "host-fed verify rejected a valid signature"
+    else:
+        assert np.array_equal(res[:64], wl.sigs[:64].cpu().numpy()), "host-fed signatures differ from the device-resident path"
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    dt = (time.perf_counter() - t0) / reps
+    h2d = measure_h2d_GBs()
+    bound = h2d * 1e9 / max(up, down)  # full duplex: the busier direction bounds
+    return {"value": n / dt, "unit": wl.unit, "ms_per_batch": dt * 1e3, "bytes_up_per_op": up, "bytes_down_per_op": down,
+            "pcie_GBs_used": n * max(up, down) / dt / 1e9, "pcie_h2d_GBs_measured": h2d, "pcie_bound_ops_per_s": bound,
+            "frac_of_pcie_bound": n / dt / bound,
+            "note": "inputs and outputs in page-locked host memory, wire-format keys uploaded and expanded once per call; "
+                    "includes H2D + kernels + D2H + the host-side call overhead of the ctypes wrapper"}
+
+
 class MixedStream:
     """BASELINE config[4] on one GPU: a stream of ML-DSA-44 / 65 / 87 work -- per step and parameter set
     keygen of B/8 keys, B signatures under those keys, B verifications -- issued back to back on one
-    context.  value = (keys + signatures + verifications) per second."""
+    context, nothing waits for the device (mldsa_sign_async) and every call writes the same buffers each step,
+    so from the second step on the whole stream replays as hipGraphs.  value = (keys + signatures +
+    verifications) per second."""
 
-    def __init__(self, hp, batch, rank):
+    def __init__(self, hp, batch, rank, world=1):
         from fips204_amd.ml_dsa import MlDsa, _cat_with_offsets
         self.hp, self.batch, self.rank = hp, batch or 16384, rank
         self.unit = "ops/s"
@@ -416,8 +491,9 @@ class MixedStream:
         g = torch.Generator(device="cuda").manual_seed(4465 + rank)
         B, nk = self.batch, max(1, self.batch // 8)
         self.sets = []
-        for pset in (44, 65, 87):
+        for pset in (87, 65, 44):  # largest workspace first: reserved once
             ml = MlDsa(pset, hotpath=hp)
+            hp.reserve(pset, 2, B)
             xi = torch.randint(0, 256, (nk, 32), dtype=torch.uint8, device="cuda", generator=g)
             msgs = [_shake(b"mldsa-bench-mixed" + bytes([pset]), rank * B + i, 8) for i in range(B)]
             mb, mo = _cat_with_offsets(msgs, ml.device)
@@ -425,23 +501,27 @@ class MixedStream:
             kidx = (torch.arange(B, device="cuda") % nk).to(torch.int32)
             sig = torch.empty((B, ml.SIG_LEN), dtype=torch.uint8, device="cuda")
             ok = torch.zeros(B, dtype=torch.uint8, device="cuda")
-            self.sets.append(dict(ml=ml, xi=xi, mb=mb, mo=mo, rnd=rnd, kidx=kidx, sig=sig, ok=ok, msgs=msgs))
+            st = torch.zeros(B, dtype=torch.int32, device="cuda")
+            pk = torch.empty((nk, ml.PK_LEN), dtype=torch.uint8, device="cuda")
+            sk = torch.empty((nk, ml.SK_LEN), dtype=torch.uint8, device="cuda")
+            self.sets.append(dict(ml=ml, xi=xi, mb=mb, mo=mo, rnd=rnd, kidx=kidx, sig=sig, ok=ok, st=st, msgs=msgs, pk=pk, sk=sk,
+                                  pks=ml.empty_public_keys(nk), sks=ml.empty_private_keys(nk)))
         self.ops_per_step = 3 * (nk + 2 * B)
         p = [s["ml"] for s in self.sets]
         self.bytes_per_op = sum(nk * (32 + m.PK_LEN + m.SK_LEN) + B * (m.SK_LEN + 64 + m.SIG_LEN) + B * (m.PK_LEN + m.SIG_LEN + 33)
                                 for m in p) / self.ops_per_step
         self.name = (f"mixed ml_dsa_44/65/87 stream: per set keygen x{nk} + sign x{B} + verify x{B} per step, one context, "
-                     "wire formats resident in HBM")
+                     "wire formats resident in HBM, no host wait inside a step")
         self.metric = "mixed ML-DSA-44/65/87 keygen+sign+verify ops/sec per GPU (batched); % HBM roofline"
 
     def step(self, i):
         for s in self.sets:
             ml = s["ml"]
-            pk, sk = ml.keygen_from_seed(s["xi"])
-            pks, sks = ml.public_keys_from_bytes(pk), ml.private_keys_from_bytes(sk)
-            ml.sign_device(sks, s["mb"], s["mo"], s["rnd"], s["sig"], self.batch, key_idx=s["kidx"])
-            ml.verify_device(pks, s["mb"], s["mo"], s["sig"], s["ok"], self.batch, key_idx=s["kidx"])
-            s["pk"], s["sk"] = pk, sk
+            ml.keygen_from_seed(s["xi"], out=(s["pk"], s["sk"]))
+            ml.public_keys_from_bytes(s["pk"], out=s["pks"])
+            ml.private_keys_from_bytes(s["sk"], out=s["sks"])
+            ml.sign_device(s["sks"], s["mb"], s["mo"], s["rnd"], s["sig"], self.batch, key_idx=s["kidx"], status=s["st"], wait=False)
+            ml.verify_device(s["pks"], s["mb"], s["mo"], s["sig"], s["ok"], self.batch, key_idx=s["kidx"])
 
     def kernel_launches_per_step(self):
         return 1
@@ -452,6 +532,7 @@ class MixedStream:
         torch.cuda.synchronize()
         for s in self.sets:
             ml = s["ml"]
+            assert int(s["st"].min()) == 0, "mixed stream: an op was left unfinished by the enqueued rounds"
             assert bool(s["ok"].all()), "mixed stream: a GPU signature did not verify"
             sk0 = orc.sk_try_from_bytes(ml.pset, s["sk"][0].cpu().numpy().tobytes())
             want = orc.sign_internal(ml.pset, sk0, s["msgs"][0], s["rnd"][0].cpu().numpy().tobytes(), mode=0)
@@ -461,74 +542,116 @@ class MixedStream:
         return None
 
 
-def make_workload(name, hp, batch, rank):
+def make_workload(name, hp, batch, rank, world=1):
     if name == "mixed":
-        return MixedStream(hp, batch, rank)
+        return MixedStream(hp, batch, rank, world)
     if name.startswith("verify_arith"):
         pset = int(name[len("verify_arith"):])
         return VerifyArith(hp, pset, batch or 4096, rank)
     for kind in ("verify", "sign"):
         core = name[:-len("_cached_a")] if name.endswith("_cached_a") else name
         if core.startswith(kind) and core[len(kind):].isdigit():
-            return WholeOp(hp, int(core[len(kind):]), kind, batch or 65536, rank, cached_a=name.endswith("_cached_a"))
+            return WholeOp(hp, int(core[len(kind):]), kind, batch or 65536, rank, cached_a=name.endswith("_cached_a"), world=world)
     if name in ("ntt", "inv_ntt", "mat_vec_mul65", "expand_a65", "expand_mask65", "keygen44", "keygen65", "keygen87"):
         return SeamKernel(hp, name, batch, rank)
     raise SystemExit(f"unknown workload {name!r}")
 
 
-def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
-    wl = make_workload(name, hp, args.batch if name == args.workload else 0, rank)
-    if rank == 0:
-        wl.check()
-    for i in range(warmup):
-        wl.step(i)
-    torch.cuda.synchronize()
-    whole = isinstance(wl, WholeOp)
-    if whole:
-        hp.profile_enable(True)  # event pairs around every kernel launch, resolved after the timed region
+def pmc_traffic(name):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (tools/collect_profiles.sh): the dominant
+    kernel's figure, and per stage where collected.  None when the file is absent."""
+    for fn in (f"r02_pmc_{name}.json", f"pmc_{name}.json"):
+        path = os.path.join(ROOT, "profiles", fn)
+        if os.path.exists(path):
+            d = json.load(open(path))
+            return d.get("hbm_bytes_per_launch"), d.get("by_stage", {}), fn
+    return None, {}, None
 
-    # timed region: exactly K steps, barrier + synchronize on both sides; HIP events on the launch
-    # stream give the dominant kernel's average duration for the roofline
+
+def timed_steps(wl, world, steps, first):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks."""
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
     for i in range(steps):
-        wl.step(warmup + i)
+        wl.step(first + i)
     ev1.record()
     torch.cuda.synchronize()
     barrier(world)
     dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt, world)
+    return max_over_ranks(dt, world), ev0.elapsed_time(ev1)
 
-    # single-kernel workloads: average launch duration over the back-to-back launches of the timed region
-    # (HIP events on the launch stream, first launch -> last completion)
-    kern_ms = ev0.elapsed_time(ev1) / steps / wl.kernel_launches_per_step()
-    total_ops = getattr(wl, "ops_per_step", wl.batch) * world * steps
-    value = total_ops / dt
-    stages = None
+
+def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_fed=False):
+    wl = make_workload(name, hp, args.batch if name == args.workload else 0, rank, world)
+    if rank == 0:
+        wl.check()
+    for i in range(warmup):
+        wl.step(i)
+    torch.cuda.synchronize()
+    whole = isinstance(wl, WholeOp)
+    units_per_step = getattr(wl, "ops_per_step", wl.batch)
+
+    # THE timed region: exactly K steps of the product's default path (a signing call whose shape repeats replays as a
+    # hipGraph), barrier + synchronize on both sides, max over ranks -> `value`
+    st0 = hp.stats() if hasattr(hp, "stats") else None
+    dt, ev_ms = timed_steps(wl, world, steps, warmup)
+    kern_ms = ev_ms / steps / wl.kernel_launches_per_step()
+    value = units_per_step * world * steps / dt
+    st1 = hp.stats()
+    launch_mode = {"graph_replays": st1["graph_replays"] - st0["graph_replays"], "direct_calls": st1["direct_calls"] - st0["direct_calls"],
+                   "sign_extra_rounds": st1["sign_extra_rounds"] - st0["sign_extra_rounds"]}
+    # Per-kernel durations: a graph has no place for an event between two of its kernels, so the whole-op workloads
+    # run the SAME K steps once more right away with a HIP event pair around every kernel launch on the launch
+    # stream (the library launches directly while it is being profiled).  The roofline's kernel time comes from there.
+    stages, dt_prof = None, None
     if whole:
+        hp.profile_enable(True)
+        dt_prof, _ = timed_steps(wl, world, steps, warmup + steps)
         stages = hp.profile_report()
         hp.profile_enable(False)
+
+    # the verdict bytes of every rank gathered into the whole job's verdict array (SURVEY 8e), outside `value`
+    gather = None
+    if whole and wl.kind == "verify":
+        from fips204_amd import multi_gpu
+        import torch.distributed as dist
+        on_cpu = multi_gpu.is_distributed() and dist.get_backend() != "nccl"
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        allok = multi_gpu.gather_verdicts(wl.ok.cpu() if on_cpu else wl.ok, wl.batch * world)
+        n_ok = int(allok.sum().item())
+        gather = {"ms": (time.perf_counter() - t0) * 1e3, "verdicts": wl.batch * world, "ok": n_ok,
+                  "collective": "all_gather_into_tensor (RCCL)" if not on_cpu else "all_gather_into_tensor (gloo)"}
+        assert n_ok == wl.batch * world, "a rank reported a failed verification of a valid signature"
     if rank != 0:
         return None
 
-    alg_bytes = wl.bytes_per_op * getattr(wl, "ops_per_step", wl.batch)
+    alg_bytes = wl.bytes_per_op * units_per_step
+    traffic, traffic_by_stage, traffic_file = pmc_traffic(name)
+    slots = op_rounds = None
     if whole:
+        slots = stages.pop("_sign_slots", None)
+        op_rounds = stages.pop("_sign_op_rounds", None)
+
+        def stage_bytes_total(st_name):
+            """algorithmic bytes of all launches of a stage inside the timed region"""
+            per_round = st_name in ("expand_mask", "sign_w", "sign_tail")
+            units = slots["calls"] if (wl.kind == "sign" and per_round and slots) else wl.batch * steps
+            total = wl.stage_bytes[st_name] * units
+            if st_name == "sign_w" and wl.kind == "sign" and op_rounds:
+                total += wl.stage_bytes["sign_w_per_op_round"] * op_rounds["calls"]
+            return total, units
+
         # dominant kernel = the stage with the largest share of device time; its average launch
         # duration comes from the event pairs recorded inside the timed region
         dom = max((k for k in stages if k in wl.stage_bytes), key=lambda k: stages[k]["ms"])
         kern_ms = stages[dom]["ms"] / stages[dom]["calls"]
-        per_round = dom in ("expand_mask", "sign_w", "sign_tail")
-        units_total = stages["_sign_slots"]["calls"] if (wl.kind == "sign" and per_round) else wl.batch * steps
-        alg_bytes = wl.stage_bytes[dom] * units_total / stages[dom]["calls"]
+        alg_bytes = stage_bytes_total(dom)[0] / stages[dom]["calls"]
         wl.kernel = "k_" + dom
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", f"pmc_{name}.json")
-    if os.path.exists(pmc_path):
-        traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
     line = {
         "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
@@ -539,45 +662,63 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
     }
+    if traffic_file:
+        line["roofline"]["traffic_source"] = "profiles/" + traffic_file
+    line["launch_mode"] = launch_mode
+    if gather:
+        line["verdict_gather"] = gather
     if whole:
-        slots = stages.pop("_sign_slots", None)
         total_ms = sum(v["ms"] for v in stages.values())
         line["stage_ms_per_step"] = {k: round(v["ms"] / steps, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
+        line["launch_gap_ms_per_step"] = round(dt / steps * 1e3 - total_ms / steps, 4)
+        line["profiled_pass"] = {"ms_per_step": dt_prof / steps * 1e3, "value": units_per_step * world * steps / dt_prof,
+                                 "note": "the same K steps again with an event pair around every kernel (direct launches): source of "
+                                         "stage_ms_per_step and roofline.kernel_ms"}
         if slots:
             line["sign_iterations_per_signature"] = slots["calls"] / (wl.batch * steps)
         line["device_busy_frac"] = total_ms / (dt * 1e3)
         perms = {"verify": {44: 89, 65: 159, 87: 291}, "sign": {44: 201, 65: 320, 87: 455}}[wl.kind][wl.pset]
         line["roofline"]["note"] = ("whole ops are integer-ALU-bound (Keccak-f[1600]), not HBM-bound: "
                                     f"~{perms} permutations per op; the HBM-bound kernel of the path is reported under "
-                                    "also.verify_arith44 (BASELINE config 2)")
-        line["roofline"]["note"] += ("; algorithmic bytes are SURVEY 8d's int32-polynomial counts: the pipelines keep A_hat as 24-bit "
-                                     "fields and candidates of one op share its rows through L2, so the PMC traffic of "
-                                     "sign_w / verify_main is below them")
+                                    "also.verify_arith44 (BASELINE config 2).  Bytes are those the kernel is obliged to move "
+                                    "(A_hat as the pipelines hold it: 768 B per polynomial)")
         line["keccak_permutations_per_s"] = perms * value / world
         # every modelled stage against the ceiling that bounds it: HBM peak for the polynomial-streaming
         # kernels, the measured Keccak-f[1600] issue ceiling (tools/ubench_valu.hip k_keccak at 8 waves/SIMD,
         # profiles/r01_ubench_valu.txt) for the SHAKE-bound samplers
         by_stage = {}
-        n_slots = slots["calls"] if slots else None
         for st_name, st in stages.items():
-            per_round = st_name in ("expand_mask", "sign_w", "sign_tail")
-            units = n_slots if (wl.kind == "sign" and per_round) else wl.batch * steps
             if st_name in wl.stage_perms:
+                units = slots["calls"] if (wl.kind == "sign" and st_name == "expand_mask" and slots) else wl.batch * steps
                 ach = wl.stage_perms[st_name] * units / (st["ms"] * 1e-3) / 1e9
                 by_stage[st_name] = {"bound": "valu", "achieved": ach, "peak": KECCAK_PEAK_GPERMS,
                                      "unit": "G Keccak-f[1600]/s", "frac": ach / KECCAK_PEAK_GPERMS}
             elif st_name in wl.stage_bytes:
-                ach = wl.stage_bytes[st_name] * units / (st["ms"] * 1e-3) / 1e9
+                model = stage_bytes_total(st_name)[0] / st["calls"]
+                pmc = traffic_by_stage.get(st_name)
+                # the figure credited is never above what the counters saw cross the memory interface
+                moved = min(model, pmc) if pmc else model
+                ach = moved / (st["ms"] / st["calls"] * 1e-3) / 1e9
                 by_stage[st_name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": ach / HBM_PEAK_GBS}
+                                     "frac": ach / HBM_PEAK_GBS, "model_bytes_per_launch": model, "pmc_bytes_per_launch": pmc}
+                if ach > 6400:
+                    by_stage[st_name]["suspect"] = "above what this box streams (6.2-6.4 TB/s): served partly from L2 / Infinity Cache"
         line["roofline_by_stage"] = by_stage
+        if dom in by_stage and by_stage[dom]["bound"] == "hbm":
+            line["roofline"]["achieved"] = by_stage[dom]["achieved"]
+            line["roofline"]["frac"] = by_stage[dom]["frac"]
         line["whole_op_hbm"] = {"algorithmic_bytes_per_op": wl.bytes_per_op,
                                 "achieved_GBs": wl.bytes_per_op * value / world / 1e9,
                                 "frac_of_peak": wl.bytes_per_op * value / world / 1e9 / HBM_PEAK_GBS}
+        pub = REFERENCE_PUBLISHED[f"{wl.kind}_us"][wl.pset]
+        line["reference_published"] = {"value": 1e6 / pub, "unit": wl.unit + " per core", "us_per_op": pub,
+                                       "source": REFERENCE_PUBLISHED["source"], "note": REFERENCE_PUBLISHED["note"]}
     if world == 1 and cpu_baseline:
         cb = wl.cpu_baseline()
         if cb:
             line["cpu_baseline"] = cb
+    if world == 1 and with_host_fed and whole and not wl.cached_a:
+        line["end_to_end_host_fed"] = host_fed(wl)
     del wl
     torch.cuda.empty_cache()
     return line
@@ -585,27 +726,37 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline):
 
 def main():
     args = parse()
-    rank, local_rank, world = dist_setup(args.gpus)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher.  It has not touched the GPU
+        # (importing torch does not), starts N fresh rank processes of this script and relays rank 0's line.
+        from fips204_amd import multi_gpu
+        raise SystemExit(multi_gpu.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    rank, local_rank, world = dist_setup(args)
+    from fips204_amd import multi_gpu
     from fips204_amd.hotpath import HotPath
     hp = HotPath(local_rank)
-    line = run_one(args, hp, rank, world, args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
+    if args.graphs >= 0:
+        hp.set_option(1, args.graphs)
+    default_run = world == 1 and args.workload == "verify65" and not args.no_extras
+    line = run_one(args, hp, rank, world, args.workload, args.steps, args.warmup, not args.no_cpu_baseline,
+                   with_host_fed=default_run or os.environ.get("MLDSA_BENCH_HOST_FED") == "1")
     # the default single-GPU run also carries the other two BASELINE configs as extra objects
     # (same JSON line): config[1] = the HBM-roofline kernel, config[2] = whole sign
-    if world == 1 and args.workload == "verify65" and not args.no_extras:
+    if default_run:
         also = {}
-        for name, st, wu in (("verify_arith44", 50, 5), ("sign65", 3, 1)):
-            sub = run_one(args, hp, rank, world, name, st, wu, False)
-            also[name] = {k: sub[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline") if k in sub}
-            for k in ("stage_ms_per_step", "sign_iterations_per_signature"):
+        for name, st, wu, cb in (("verify_arith44", 50, 5, False), ("sign65", 10, 2, not args.no_cpu_baseline)):
+            sub = run_one(args, hp, rank, world, name, st, wu, cb, with_host_fed=(name == "sign65"))
+            also[name] = {k: sub[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline") if k in sub}
+            for k in ("stage_ms_per_step", "launch_gap_ms_per_step", "sign_iterations_per_signature", "launch_mode", "profiled_pass", "cpu_baseline",
+                      "reference_published", "end_to_end_host_fed", "roofline_by_stage"):
                 if k in sub:
                     also[name][k] = sub[k]
         line["also"] = also
     if rank == 0:
-        print(json.dumps(line))
-    if _DIST:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        line["library_stats"] = hp.stats()
+        print(json.dumps(line), flush=True)
+    hp.close()
+    multi_gpu.finish()
 
 
 if __name__ == "__main__":

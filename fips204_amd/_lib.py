@@ -28,6 +28,16 @@ class Params(C.Structure):
 
 _P, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
 
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_ulonglong) for n in (
+        "graphs_captured", "graph_replays", "direct_calls", "workspace_growths", "sign_extra_rounds")]
+
+
+OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
+OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE, OPT_SIGN_ROUNDS = 1, 2, 3, 4, 5, 6
+ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
+
 # name -> argtypes (all return int unless listed in _RESTYPES)
 _SIGNATURES = {
     "mldsa_ctx_create": [_I, C.POINTER(_P)],
@@ -35,10 +45,18 @@ _SIGNATURES = {
     "mldsa_last_error": [],
     "mldsa_get_params": [_I, C.POINTER(Params)],
     "mldsa_device_count": [],
+    "mldsa_ctx_device": [_P],
+    "mldsa_reserve": [_P, _I, _I, _SZ],
+    "mldsa_set_option": [_P, _I, C.c_long],
+    "mldsa_get_option": [_P, _I],
+    "mldsa_get_stats": [_P, C.POINTER(Stats)],
     "mldsa_profile_enable": [_P, _I],
     "mldsa_profile_report": [_P, C.c_char_p, _SZ],
     "mldsa_malloc": [C.POINTER(_P), _SZ],
+    "mldsa_ctx_malloc": [_P, C.POINTER(_P), _SZ],
     "mldsa_free": [_P],
+    "mldsa_host_alloc": [C.POINTER(_P), _SZ],
+    "mldsa_host_free": [_P],
     "mldsa_memcpy_h2d": [_P, _P, _SZ, _P],
     "mldsa_memcpy_d2h": [_P, _P, _SZ, _P],
     "mldsa_memset": [_P, _I, _SZ, _P],
@@ -55,15 +73,25 @@ _SIGNATURES = {
     "mldsa_expand_s": [_P, _I, _P, _P, _SZ, _P],
     "mldsa_expand_mask": [_P, _I, _P, _P, _P, _SZ, _P],
     "mldsa_sample_in_ball": [_P, _I, _P, _P, _SZ, _P],
-    "mldsa_verify": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    # ctx, set, mode, rho | a_hat, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, stream
+    "mldsa_verify": [_P, _I, _I, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_verify_cached_a": [_P, _I, _I, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mldsa_pk_expand": [_P, _I, _P, _P, _P, _P, _SZ, _P],
     "mldsa_sk_expand": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_pk_into_bytes": [_P, _I, _P, _P, _P, _SZ, _P],
+    "mldsa_sk_into_bytes": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_get_public_key": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mldsa_keygen": [_P, _I, _P, _P, _P, _SZ, _P],
-    "mldsa_sign": [_P, _I, _I] + [_P] * 14 + [_SZ, _P],
-    "mldsa_verify_cached_a": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
-    "mldsa_sign_cached_a": [_P, _I, _I] + [_P] * 14 + [_SZ, _P],
+    # ctx, set, mode, rho | a_hat, K, tr, s1, s2, t0, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, rnd, sigs, status, n_ops, stream
+    "mldsa_sign": [_P, _I, _I] + [_P] * 6 + [_SZ] + [_P] * 8 + [_SZ, _P],
+    "mldsa_sign_async": [_P, _I, _I] + [_P] * 6 + [_SZ] + [_P] * 8 + [_SZ, _P],
+    "mldsa_sign_cached_a": [_P, _I, _I] + [_P] * 6 + [_SZ] + [_P] * 8 + [_SZ, _P],
+    # host-memory variants: ctx, set, mode, keys, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, ...
+    "mldsa_verify_host": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ],
+    "mldsa_sign_host": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ],
+    "mldsa_keygen_host": [_P, _I, _P, _P, _P, _SZ],
 }
-_RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p}
+_RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p, "mldsa_get_option": C.c_long}
 
 _lib = None
 

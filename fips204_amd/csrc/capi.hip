@@ -1,6 +1,7 @@
 // extern "C" entry points of include/mldsa_hip.h: argument validation, context and
 // device-memory helpers.  Kernels live in kernels_*.hip, op-level sequencing in pipeline.hip.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -39,6 +40,20 @@ using namespace mldsa;
 
 #define REQUIRE(cond, msg) \
     do { if (!(cond)) return set_error(MLDSA_ERR_PARAM, msg); } while (0)
+// every entry that takes a context: argument check, then bind the calling thread to the context's device
+#define ENTER(ctx, name)                      \
+    REQUIRE(ctx, name ": NULL context");      \
+    DeviceGuard _dev_guard((ctx)->device)
+
+static bool mode_ok(int mode) { return mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH; }
+
+static long env_long(const char *name, long lo, long hi, long dflt) {
+    if (const char *e = getenv(name)) {
+        const long v = atol(e);
+        if (v >= lo && v <= hi) return v;
+    }
+    return dflt;
+}
 
 extern "C" {
 
@@ -57,13 +72,25 @@ int mldsa_device_count(void) {
     return n;
 }
 
+int mldsa_ctx_device(const mldsa_ctx *ctx) { return ctx ? ctx->device : MLDSA_ERR_PARAM; }
+
 int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     REQUIRE(out, "mldsa_ctx_create: NULL out");
     *out = nullptr;
-    MLDSA_HIP_CHECK(hipSetDevice(device_id));
+    int n_dev = 0;
+    MLDSA_HIP_CHECK(hipGetDeviceCount(&n_dev));
+    REQUIRE(device_id >= 0 && device_id < n_dev, "mldsa_ctx_create: no such device");
+    DeviceGuard guard(device_id);  // the caller's current device is left as it was
     mldsa_ctx *ctx = new (std::nothrow) mldsa_ctx();
     if (!ctx) return set_error(MLDSA_ERR_NOMEM, "mldsa_ctx_create: host allocation failed");
     ctx->device = device_id;
+    // experiment knobs: the environment only sets the initial value of the per-context options
+    ctx->opt_graphs = env_long("MLDSA_GRAPHS", 0, 2, ctx->opt_graphs);
+    ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 65536, ctx->opt_spec_target);
+    ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
+    ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
+    ctx->opt_host_sub_verify = env_long("MLDSA_HOST_SUB_VERIFY", 64, 65536, ctx->opt_host_sub_verify);
+    ctx->opt_host_sub_sign = env_long("MLDSA_HOST_SUB_SIGN", 64, 65536, ctx->opt_host_sub_sign);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cu = prop.multiProcessorCount;
@@ -83,22 +110,26 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
-    for (int l = 0; l < MLDSA_SIGN_MAX_LANES; l++) {
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->lane_ev[l], hipEventDisableTiming);
-    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_lane_count, MLDSA_SIGN_MAX_LANES * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctl, sizeof(RoundCtl));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
     }
+    memset(ctx->h_ctl, 0, sizeof(RoundCtl));
     *out = ctx;
     return MLDSA_OK;
 }
 
 void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (!ctx) return;
+    DeviceGuard guard(ctx->device);
+    (void)hipDeviceSynchronize();
+    drop_graphs(ctx);
+    host_stage_destroy(ctx);
     if (ctx->ws) {
         (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // secrets (y, rho'', s1..) live here: types.rs:19
         (void)hipFree(ctx->ws);
@@ -107,15 +138,80 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
-    for (int l = 0; l < MLDSA_SIGN_MAX_LANES; l++) {
-        if (ctx->lane_ev[l]) (void)hipEventDestroy(ctx->lane_ev[l]);
-        if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
-    }
-    if (ctx->h_lane_count) (void)hipHostFree(ctx->h_lane_count);
+    if (ctx->graph_fork_ev) (void)hipEventDestroy(ctx->graph_fork_ev);
+    if (ctx->graph_join_ev) (void)hipEventDestroy(ctx->graph_join_ev);
+    if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
+    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->ws_ev) (void)hipEventDestroy(ctx->ws_ev);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
     delete ctx;
+}
+
+int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
+    REQUIRE(ctx, "mldsa_set_option: NULL context");
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
+    switch (option) {
+        case MLDSA_OPT_GRAPHS:
+            REQUIRE(value >= 0 && value <= 2, "mldsa_set_option: MLDSA_OPT_GRAPHS is 0, 1 or 2");
+            ctx->opt_graphs = value;
+            return MLDSA_OK;
+        case MLDSA_OPT_SPEC_TARGET:
+            REQUIRE(value >= 1 && value <= 65536, "mldsa_set_option: MLDSA_OPT_SPEC_TARGET out of range");
+            ctx->opt_spec_target = value;
+            return MLDSA_OK;
+        case MLDSA_OPT_SPEC_MAX:
+            REQUIRE(value >= 1 && value <= 64, "mldsa_set_option: MLDSA_OPT_SPEC_MAX out of range");  // k_resolve scans one wave of candidates
+            ctx->opt_spec_max = value;
+            return MLDSA_OK;
+        case MLDSA_OPT_VA_BLOCKS_PER_CU:
+            REQUIRE(value >= 1 && value <= 64, "mldsa_set_option: MLDSA_OPT_VA_BLOCKS_PER_CU out of range");
+            ctx->opt_va_blocks = value;
+            return MLDSA_OK;
+        case MLDSA_OPT_GRAPH_CACHE: {
+            REQUIRE(value >= 1 && value <= 4096, "mldsa_set_option: MLDSA_OPT_GRAPH_CACHE out of range");
+            ctx->opt_graph_cache = value;
+            return MLDSA_OK;
+        }
+        case MLDSA_OPT_SIGN_ROUNDS:
+            REQUIRE(value >= 0 && value <= 64, "mldsa_set_option: MLDSA_OPT_SIGN_ROUNDS out of range");
+            ctx->opt_sign_rounds = value;
+            return MLDSA_OK;
+        default: return set_error(MLDSA_ERR_PARAM, "mldsa_set_option: unknown option");
+    }
+}
+
+long mldsa_get_option(const mldsa_ctx *ctx, int option) {
+    if (!ctx) return MLDSA_ERR_PARAM;
+    switch (option) {
+        case MLDSA_OPT_GRAPHS: return ctx->opt_graphs;
+        case MLDSA_OPT_SPEC_TARGET: return ctx->opt_spec_target;
+        case MLDSA_OPT_SPEC_MAX: return ctx->opt_spec_max;
+        case MLDSA_OPT_VA_BLOCKS_PER_CU: return ctx->opt_va_blocks;
+        case MLDSA_OPT_GRAPH_CACHE: return ctx->opt_graph_cache;
+        case MLDSA_OPT_SIGN_ROUNDS: return ctx->opt_sign_rounds;
+        default: return MLDSA_ERR_PARAM;
+    }
+}
+
+int mldsa_get_stats(mldsa_ctx *ctx, mldsa_stats *out) {
+    REQUIRE(ctx && out, "mldsa_get_stats: NULL pointer");
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
+    *out = ctx->stats;
+    return MLDSA_OK;
+}
+
+int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops) {
+    ENTER(ctx, "mldsa_reserve");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_reserve: unknown parameter set");
+    size_t bytes = 0;
+    if (op == MLDSA_OP_KEYGEN) bytes = keygen_workspace_bytes(p, n_ops);
+    else if (op == MLDSA_OP_SIGN) bytes = sign_workspace_bytes(ctx, p, n_ops, true);
+    else if (op == MLDSA_OP_VERIFY) bytes = verify_workspace_bytes(p, n_ops, true);
+    else return set_error(MLDSA_ERR_PARAM, "mldsa_reserve: unknown operation");
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
+    return n_ops ? ensure_workspace(ctx, bytes) : MLDSA_OK;
 }
 
 int mldsa_malloc(void **dev_ptr, size_t bytes) {
@@ -127,8 +223,27 @@ int mldsa_malloc(void **dev_ptr, size_t bytes) {
     return MLDSA_OK;
 }
 
+int mldsa_ctx_malloc(mldsa_ctx *ctx, void **dev_ptr, size_t bytes) {
+    ENTER(ctx, "mldsa_ctx_malloc");
+    return mldsa_malloc(dev_ptr, bytes);
+}
+
 int mldsa_free(void *dev_ptr) {
     if (dev_ptr) MLDSA_HIP_CHECK(hipFree(dev_ptr));
+    return MLDSA_OK;
+}
+
+int mldsa_host_alloc(void **host_ptr, size_t bytes) {
+    REQUIRE(host_ptr, "mldsa_host_alloc: NULL out");
+    *host_ptr = nullptr;
+    if (bytes == 0) return MLDSA_OK;
+    hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "mldsa_host_alloc", e);
+    return MLDSA_OK;
+}
+
+int mldsa_host_free(void *host_ptr) {
+    if (host_ptr) MLDSA_HIP_CHECK(hipHostFree(host_ptr));
     return MLDSA_OK;
 }
 
@@ -165,11 +280,13 @@ int mldsa_profile_enable(mldsa_ctx *ctx, int on) {
     ctx->prof_on = on != 0;
     ctx->prof_used = 0;
     ctx->prof_sign_slots = 0;
+    ctx->prof_sign_op_rounds = 0;
     return MLDSA_OK;
 }
 
 int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len) {
-    REQUIRE(ctx && buf && buf_len > 2, "mldsa_profile_report: bad argument");
+    REQUIRE(buf && buf_len > 2, "mldsa_profile_report: bad argument");
+    ENTER(ctx, "mldsa_profile_report");
     std::lock_guard<std::mutex> lk(ctx->op_mutex);
     MLDSA_HIP_CHECK(hipDeviceSynchronize());
     struct Acc { const char *name; double ms; size_t calls; };
@@ -192,164 +309,266 @@ int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len) {
         char tmp[96];
         snprintf(tmp, sizeof(tmp), "%s\"_sign_slots\": {\"ms\": 0, \"calls\": %llu}", acc.empty() ? "" : ", ", ctx->prof_sign_slots);
         out += tmp;
+        snprintf(tmp, sizeof(tmp), ", \"_sign_op_rounds\": {\"ms\": 0, \"calls\": %llu}", ctx->prof_sign_op_rounds);
+        out += tmp;
     }
     out += "}";
     if (out.size() + 1 > buf_len) return set_error(MLDSA_ERR_PARAM, "mldsa_profile_report: buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
     ctx->prof_used = 0;
     ctx->prof_sign_slots = 0;
+    ctx->prof_sign_op_rounds = 0;
     return MLDSA_OK;
 }
 
 // ------------------------------------------------------------------ seam-level primitives
 int mldsa_ntt(mldsa_ctx *ctx, const int32_t *w, int32_t *w_hat, size_t n_polys, void *stream) {
-    REQUIRE(ctx && (n_polys == 0 || (w && w_hat)), "mldsa_ntt: NULL pointer");
+    ENTER(ctx, "mldsa_ntt");
+    REQUIRE(n_polys == 0 || (w && w_hat), "mldsa_ntt: NULL pointer");
     return launch_ntt(ctx, w, w_hat, n_polys, (hipStream_t)stream);
 }
 
 int mldsa_inv_ntt(mldsa_ctx *ctx, const int32_t *w_hat, int32_t *w, size_t n_polys, void *stream) {
-    REQUIRE(ctx && (n_polys == 0 || (w && w_hat)), "mldsa_inv_ntt: NULL pointer");
+    ENTER(ctx, "mldsa_inv_ntt");
+    REQUIRE(n_polys == 0 || (w && w_hat), "mldsa_inv_ntt: NULL pointer");
     return launch_inv_ntt(ctx, w_hat, w, n_polys, (hipStream_t)stream);
 }
 
 int mldsa_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n_polys, void *stream) {
-    REQUIRE(ctx && (n_polys == 0 || (in && out)), "mldsa_to_mont: NULL pointer");
+    ENTER(ctx, "mldsa_to_mont");
+    REQUIRE(n_polys == 0 || (in && out), "mldsa_to_mont: NULL pointer");
     return launch_to_mont(ctx, in, out, n_polys, (hipStream_t)stream);
 }
 
 int mldsa_mat_vec_mul(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *u_hat,
                       int32_t *w_hat, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_mat_vec_mul");
     const mldsa_params *p = params_of(set);
     REQUIRE(p, "mldsa_mat_vec_mul: unknown parameter set");
-    REQUIRE(ctx && (n_ops == 0 || (a_hat && u_hat && w_hat)), "mldsa_mat_vec_mul: NULL pointer");
+    REQUIRE(n_ops == 0 || (a_hat && u_hat && w_hat), "mldsa_mat_vec_mul: NULL pointer");
     return launch_mat_vec_mul(ctx, p->k, p->l, a_hat, u_hat, w_hat, n_ops, (hipStream_t)stream);
 }
 
 int mldsa_pointwise_mont(mldsa_ctx *ctx, const int32_t *c_hat, const int32_t *v_hat_mont,
                          int32_t *out, size_t polys_per_op, size_t n_ops, void *stream) {
-    REQUIRE(ctx && (n_ops * polys_per_op == 0 || (c_hat && v_hat_mont && out)), "mldsa_pointwise_mont: NULL pointer");
+    ENTER(ctx, "mldsa_pointwise_mont");
+    REQUIRE(n_ops * polys_per_op == 0 || (c_hat && v_hat_mont && out), "mldsa_pointwise_mont: NULL pointer");
     return launch_pointwise_mont(ctx, c_hat, v_hat_mont, out, polys_per_op, n_ops, (hipStream_t)stream);
 }
 
 int mldsa_add_vector_ntt(mldsa_ctx *ctx, const int32_t *a, const int32_t *b, int32_t *out,
                          size_t n_polys, void *stream) {
-    REQUIRE(ctx && (n_polys == 0 || (a && b && out)), "mldsa_add_vector_ntt: NULL pointer");
+    ENTER(ctx, "mldsa_add_vector_ntt");
+    REQUIRE(n_polys == 0 || (a && b && out), "mldsa_add_vector_ntt: NULL pointer");
     return launch_add(ctx, a, b, out, n_polys, (hipStream_t)stream);
 }
 
 int mldsa_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t polys_per_op, size_t n_ops,
                         int32_t *norms, void *stream) {
-    REQUIRE(ctx && polys_per_op > 0 && (n_ops == 0 || (polys && norms)), "mldsa_infinity_norm: bad argument");
+    ENTER(ctx, "mldsa_infinity_norm");
+    REQUIRE(polys_per_op > 0 && (n_ops == 0 || (polys && norms)), "mldsa_infinity_norm: bad argument");
     return launch_infinity_norm(ctx, polys, polys_per_op, n_ops, norms, (hipStream_t)stream);
 }
 
 int mldsa_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *z,
                        const int32_t *c, const int32_t *t1_d2_hat_mont, int32_t *w_out,
                        size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_verify_arith");
     REQUIRE(params_of(set), "mldsa_verify_arith: unknown parameter set");
-    REQUIRE(ctx && (n_ops == 0 || (a_hat && z && c && t1_d2_hat_mont && w_out)), "mldsa_verify_arith: NULL pointer");
+    REQUIRE(n_ops == 0 || (a_hat && z && c && t1_d2_hat_mont && w_out), "mldsa_verify_arith: NULL pointer");
     return launch_verify_arith(ctx, set, a_hat, z, c, t1_d2_hat_mont, nullptr, w_out, n_ops, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ samplers
 int mldsa_expand_a(mldsa_ctx *ctx, int set, const uint8_t *rho, int32_t *a_hat, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_expand_a");
     REQUIRE(params_of(set), "mldsa_expand_a: unknown parameter set");
-    REQUIRE(ctx && (n_ops == 0 || (rho && a_hat)), "mldsa_expand_a: NULL pointer");
+    REQUIRE(n_ops == 0 || (rho && a_hat), "mldsa_expand_a: NULL pointer");
     return launch_expand_a(ctx, set, rho, 32, nullptr, a_hat, n_ops, (hipStream_t)stream);
 }
 
 int mldsa_expand_s(mldsa_ctx *ctx, int set, const uint8_t *rho_prime, int32_t *s1s2, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_expand_s");
     REQUIRE(params_of(set), "mldsa_expand_s: unknown parameter set");
-    REQUIRE(ctx && (n_ops == 0 || (rho_prime && s1s2)), "mldsa_expand_s: NULL pointer");
+    REQUIRE(n_ops == 0 || (rho_prime && s1s2), "mldsa_expand_s: NULL pointer");
     return launch_expand_s(ctx, set, rho_prime, 64, s1s2, n_ops, (hipStream_t)stream);
 }
 
 int mldsa_expand_mask(mldsa_ctx *ctx, int set, const uint8_t *rho_pp, const uint16_t *kappa, int32_t *y,
                       size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_expand_mask");
     REQUIRE(params_of(set), "mldsa_expand_mask: unknown parameter set");
-    REQUIRE(ctx && (n_ops == 0 || (rho_pp && kappa && y)), "mldsa_expand_mask: NULL pointer");
+    REQUIRE(n_ops == 0 || (rho_pp && kappa && y), "mldsa_expand_mask: NULL pointer");
     return launch_expand_mask(ctx, set, rho_pp, 64, kappa, 0, nullptr, y, n_ops, (hipStream_t)stream);
 }
 
 int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_t *c, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_sample_in_ball");
     const mldsa_params *p = params_of(set);
     REQUIRE(p, "mldsa_sample_in_ball: unknown parameter set");
-    REQUIRE(ctx && (n_ops == 0 || (c_tilde && c)), "mldsa_sample_in_ball: NULL pointer");
+    REQUIRE(n_ops == 0 || (c_tilde && c), "mldsa_sample_in_ball: NULL pointer");
     return launch_sample_in_ball(ctx, set, c_tilde, (size_t)p->ctilde_len, c, n_ops, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ op-level API
+// Shared by mldsa_verify and mldsa_verify_cached_a: reserve, then replay / capture / launch the pipeline.
+static int verify_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *tr,
+                       const int32_t *t1, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off,
+                       const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (n_ops == 0) return MLDSA_OK;
+    OpGuard guard(ctx, s);
+    int rc = ensure_workspace(ctx, verify_workspace_bytes(p, n_ops, a_hat == nullptr));
+    if (rc != MLDSA_OK) return rc;
+    struct { int op, set, mode; const void *rho, *a_hat, *tr, *t1; size_t n_keys; const void *key_idx, *msgs, *msg_off, *ctxs, *ctx_off, *sigs, *ok;
+             size_t n_ops; } key;
+    memset(&key, 0, sizeof(key));
+    key.op = MLDSA_OP_VERIFY; key.set = set; key.mode = mode; key.rho = rho; key.a_hat = a_hat; key.tr = tr; key.t1 = t1; key.n_keys = n_keys;
+    key.key_idx = key_idx; key.msgs = msgs; key.msg_off = msg_off; key.ctxs = ctxs; key.ctx_off = ctx_off; key.sigs = sigs; key.ok = ok;
+    key.n_ops = n_ops;
+    return run_op(ctx, s, MLDSA_OP_VERIFY, &key, sizeof(key), [&](hipStream_t st) {
+        return verify_batch(ctx, set, mode, rho, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, st, a_hat);
+    });
+}
+
 int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr,
-                 const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                 const int32_t *t1_d2_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                  const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                  const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_verify");
     REQUIRE(params_of(set), "mldsa_verify: unknown parameter set");
-    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_verify: bad mode");
-    REQUIRE(ctx && (n_ops == 0 || (rho && tr && t1_d2_hat_mont && msg_off && sigs && ok)), "mldsa_verify: NULL pointer");
-    OpGuard guard(ctx, (hipStream_t)stream);
-    return verify_batch(ctx, set, mode, rho, tr, t1_d2_hat_mont, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
-                        (hipStream_t)stream);
+    REQUIRE(mode_ok(mode), "mldsa_verify: bad mode");
+    REQUIRE(n_ops == 0 || (rho && tr && t1_d2_hat_mont && msg_off && sigs && ok), "mldsa_verify: NULL pointer");
+    REQUIRE(n_ops == 0 || (key_idx ? n_keys > 0 : n_keys >= n_ops), "mldsa_verify: n_keys does not cover the batch");
+    return verify_call(ctx, set, mode, rho, nullptr, tr, t1_d2_hat_mont, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
+                       (hipStream_t)stream);
+}
+
+int mldsa_verify_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *tr,
+                          const int32_t *t1_d2_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
+                          const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                          const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_verify_cached_a");
+    REQUIRE(params_of(set), "mldsa_verify_cached_a: unknown parameter set");
+    REQUIRE(mode_ok(mode), "mldsa_verify_cached_a: bad mode");
+    REQUIRE(n_ops == 0 || (a_hat && tr && t1_d2_hat_mont && msg_off && sigs && ok), "mldsa_verify_cached_a: NULL pointer");
+    REQUIRE(n_ops == 0 || (key_idx ? n_keys > 0 : n_keys >= n_ops), "mldsa_verify_cached_a: n_keys does not cover the batch");
+    return verify_call(ctx, set, mode, nullptr, a_hat, tr, t1_d2_hat_mont, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
+                       (hipStream_t)stream);
 }
 
 int mldsa_pk_expand(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, uint8_t *tr, int32_t *t1_d2_hat_mont,
                     size_t n_keys, void *stream) {
+    ENTER(ctx, "mldsa_pk_expand");
     REQUIRE(params_of(set), "mldsa_pk_expand: unknown parameter set");
-    REQUIRE(ctx && (n_keys == 0 || (pk && rho && tr && t1_d2_hat_mont)), "mldsa_pk_expand: NULL pointer");
+    REQUIRE(n_keys == 0 || (pk && rho && tr && t1_d2_hat_mont), "mldsa_pk_expand: NULL pointer");
     return pk_expand_batch(ctx, set, pk, rho, tr, t1_d2_hat_mont, n_keys, (hipStream_t)stream);
 }
 
 int mldsa_sk_expand(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, uint8_t *cap_k, uint8_t *tr,
                     int32_t *s_1_hat_mont, int32_t *s_2_hat_mont, int32_t *t_0_hat_mont, size_t n_keys, void *stream) {
+    ENTER(ctx, "mldsa_sk_expand");
     REQUIRE(params_of(set), "mldsa_sk_expand: unknown parameter set");
-    REQUIRE(ctx && (n_keys == 0 || (sk && rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont)),
-            "mldsa_sk_expand: NULL pointer");
+    REQUIRE(n_keys == 0 || (sk && rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont), "mldsa_sk_expand: NULL pointer");
     return sk_expand_batch(ctx, set, sk, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, n_keys, (hipStream_t)stream);
 }
 
-int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, void *stream) {
-    REQUIRE(params_of(set), "mldsa_keygen: unknown parameter set");
-    REQUIRE(ctx && (n_keys == 0 || (xi && pk && sk)), "mldsa_keygen: NULL pointer");
-    OpGuard guard(ctx, (hipStream_t)stream);
-    return keygen_batch(ctx, set, xi, pk, sk, n_keys, (hipStream_t)stream);
+int mldsa_pk_into_bytes(mldsa_ctx *ctx, int set, const uint8_t *rho, const int32_t *t1_d2_hat_mont, uint8_t *pk, size_t n_keys,
+                        void *stream) {
+    ENTER(ctx, "mldsa_pk_into_bytes");
+    REQUIRE(params_of(set), "mldsa_pk_into_bytes: unknown parameter set");
+    REQUIRE(n_keys == 0 || (rho && t1_d2_hat_mont && pk), "mldsa_pk_into_bytes: NULL pointer");
+    return pk_into_bytes_batch(ctx, set, rho, t1_d2_hat_mont, pk, n_keys, (hipStream_t)stream);
 }
+
+int mldsa_sk_into_bytes(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
+                        const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont, const int32_t *t_0_hat_mont, uint8_t *sk,
+                        size_t n_keys, void *stream) {
+    ENTER(ctx, "mldsa_sk_into_bytes");
+    REQUIRE(params_of(set), "mldsa_sk_into_bytes: unknown parameter set");
+    REQUIRE(n_keys == 0 || (rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont && sk), "mldsa_sk_into_bytes: NULL pointer");
+    return sk_into_bytes_batch(ctx, set, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, sk, n_keys, (hipStream_t)stream);
+}
+
+int mldsa_get_public_key(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint8_t *tr, const int32_t *s_1_hat_mont,
+                         const int32_t *s_2_hat_mont, uint8_t *pk_rho, uint8_t *pk_tr, int32_t *pk_t1_d2_hat_mont, size_t n_keys,
+                         void *stream) {
+    ENTER(ctx, "mldsa_get_public_key");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_get_public_key: unknown parameter set");
+    REQUIRE(n_keys == 0 || (rho && tr && s_1_hat_mont && s_2_hat_mont && pk_rho && pk_tr && pk_t1_d2_hat_mont),
+            "mldsa_get_public_key: NULL pointer");
+    if (n_keys == 0) return MLDSA_OK;
+    OpGuard guard(ctx, (hipStream_t)stream);
+    int rc = ensure_workspace(ctx, keygen_workspace_bytes(p, n_keys));
+    if (rc != MLDSA_OK) return rc;
+    return get_public_key_batch(ctx, set, rho, tr, s_1_hat_mont, s_2_hat_mont, pk_rho, pk_tr, pk_t1_d2_hat_mont, n_keys, (hipStream_t)stream);
+}
+
+int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, void *stream) {
+    ENTER(ctx, "mldsa_keygen");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_keygen: unknown parameter set");
+    REQUIRE(n_keys == 0 || (xi && pk && sk), "mldsa_keygen: NULL pointer");
+    if (n_keys == 0) return MLDSA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    OpGuard guard(ctx, s);
+    int rc = ensure_workspace(ctx, keygen_workspace_bytes(p, n_keys));
+    if (rc != MLDSA_OK) return rc;
+    struct { int op, set; const void *xi, *pk, *sk; size_t n; } key;
+    memset(&key, 0, sizeof(key));
+    key.op = MLDSA_OP_KEYGEN; key.set = set; key.xi = xi; key.pk = pk; key.sk = sk; key.n = n_keys;
+    return run_op(ctx, s, MLDSA_OP_KEYGEN, &key, sizeof(key), [&](hipStream_t st) { return keygen_batch(ctx, set, xi, pk, sk, n_keys, st); });
+}
+
+static int sign_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,
+                     const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
+                     const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
+                     int32_t *status, size_t n_ops, hipStream_t s, bool async_mode) {
+    const mldsa_params *p = params_of(set);
+    if (n_ops == 0) return MLDSA_OK;
+    OpGuard guard(ctx, s);
+    int rc = ensure_workspace(ctx, sign_workspace_bytes(ctx, p, n_ops, a_hat == nullptr));
+    if (rc != MLDSA_OK) return rc;
+    return sign_batch(ctx, set, mode, rho, cap_k, tr, s1, s2, t0, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, rnd, sigs, status,
+                      n_ops, s, a_hat, async_mode);
+}
+
+#define SIGN_CHECKS(name, first)                                                                                                  \
+    ENTER(ctx, name);                                                                                                             \
+    REQUIRE(params_of(set), name ": unknown parameter set");                                                                      \
+    REQUIRE(mode_ok(mode), name ": bad mode");                                                                                    \
+    REQUIRE(n_ops == 0 || (first && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont && msg_off && rnd && sigs),       \
+            name ": NULL pointer");                                                                                               \
+    REQUIRE(n_ops == 0 || (key_idx ? n_keys > 0 : n_keys >= n_ops), name ": n_keys does not cover the batch")
 
 int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
-               const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont, const int32_t *t_0_hat_mont,
+               const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont, const int32_t *t_0_hat_mont, size_t n_keys,
                const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
                const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream) {
-    REQUIRE(params_of(set), "mldsa_sign: unknown parameter set");
-    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_sign: bad mode");
-    REQUIRE(ctx && (n_ops == 0 || (rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont && msg_off && rnd && sigs)),
-            "mldsa_sign: NULL pointer");
-    OpGuard guard(ctx, (hipStream_t)stream);
-    return sign_batch(ctx, set, mode, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, key_idx, msgs, msg_off, ctxs,
-                      ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream);
+    SIGN_CHECKS("mldsa_sign", rho);
+    return sign_call(ctx, set, mode, rho, nullptr, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, n_keys, key_idx, msgs, msg_off,
+                     ctxs, ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream, false);
 }
 
-int mldsa_verify_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *tr,
-                          const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
-                          const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
-                          const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream) {
-    REQUIRE(params_of(set), "mldsa_verify_cached_a: unknown parameter set");
-    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_verify_cached_a: bad mode");
-    REQUIRE(ctx && (n_ops == 0 || (a_hat && tr && t1_d2_hat_mont && msg_off && sigs && ok)), "mldsa_verify_cached_a: NULL pointer");
-    OpGuard guard(ctx, (hipStream_t)stream);
-    return verify_batch(ctx, set, mode, nullptr, tr, t1_d2_hat_mont, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
-                        (hipStream_t)stream, a_hat);
+int mldsa_sign_async(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
+                     const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont, const int32_t *t_0_hat_mont, size_t n_keys,
+                     const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
+                     const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream) {
+    SIGN_CHECKS("mldsa_sign_async", rho);
+    REQUIRE(n_ops == 0 || status, "mldsa_sign_async: status must not be NULL");
+    return sign_call(ctx, set, mode, rho, nullptr, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, n_keys, key_idx, msgs, msg_off,
+                     ctxs, ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream, true);
 }
 
 int mldsa_sign_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *cap_k,
                         const uint8_t *tr, const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont,
-                        const int32_t *t_0_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                        const int32_t *t_0_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                         const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                         const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream) {
-    REQUIRE(params_of(set), "mldsa_sign_cached_a: unknown parameter set");
-    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_sign_cached_a: bad mode");
-    REQUIRE(ctx && (n_ops == 0 || (a_hat && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont && msg_off && rnd && sigs)),
-            "mldsa_sign_cached_a: NULL pointer");
-    OpGuard guard(ctx, (hipStream_t)stream);
-    return sign_batch(ctx, set, mode, nullptr, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, key_idx, msgs, msg_off, ctxs,
-                      ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream, a_hat);
+    SIGN_CHECKS("mldsa_sign_cached_a", a_hat);
+    return sign_call(ctx, set, mode, nullptr, a_hat, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, n_keys, key_idx, msgs, msg_off,
+                     ctxs, ctx_off, rnd, sigs, status, n_ops, (hipStream_t)stream, false);
 }
 
 }  // extern "C"

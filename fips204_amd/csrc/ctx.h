@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -11,11 +12,40 @@
 #include "../../include/mldsa_hip.h"
 #include "ntt_wave.h"
 
-#define MLDSA_SIGN_MAX_LANES 8
+namespace mldsa {
+// Device-resident control block of the signer's rejection loop (kernels_sign.hip: k_make_slots).
+struct RoundCtl {
+    uint32_t cnt[2];       // unfinished ops entering a round of parity 0 / 1
+    uint32_t m, spec, ns;  // this round: unfinished ops, candidates per op, candidate slots = m * spec
+    uint32_t rounds;       // rounds that found work (statistics)
+    unsigned long long slots_total;  // candidate slots of all rounds of the call (statistics)
+    unsigned long long ops_total;    // sum over the rounds of the unfinished ops entering them (statistics)
+};
+
+// One captured op-level call shape (pipeline.hip "hipGraph replay").
+struct GraphEntry {
+    std::vector<unsigned char> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    unsigned long long last_use = 0;
+};
+struct HostStage;
+}  // namespace mldsa
 
 struct mldsa_ctx {
     int device = 0;
     int n_cu = 256;
+    // tuning knobs (mldsa_set_option)
+    long opt_graphs = 1, opt_spec_target = 65536, opt_spec_max = 32, opt_va_blocks = 16, opt_graph_cache = 24;
+    long opt_sign_rounds = 0;
+    long opt_host_sub_verify = 8192, opt_host_sub_sign = 32768;  // ops per sub-batch of the *_host entry points
+    mldsa_stats stats = {};
+    // hipGraph replay of repeated op-level call shapes
+    std::vector<mldsa::GraphEntry> graphs;
+    unsigned long long graph_tick = 0;
+    // *_host entry points: copy streams, page-locked bounce buffers and device staging (host_api.hip)
+    mldsa::HostStage *host_stage = nullptr;
+    std::mutex host_mutex;  // one *_host call at a time per context (taken before op_mutex)
     mldsa::Twiddle *d_fwd_tw = nullptr;  // [FWD_TW][64]
     mldsa::Twiddle *d_inv_tw = nullptr;  // [INV_TW][64]
     // op-level pipeline workspace (grown on demand, pipeline.hip)
@@ -25,10 +55,11 @@ struct mldsa_ctx {
     // SampleInBall) run here, concurrently with the VALU-bound ExpandA on the caller's stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    // sign: sub-batches of one call run their rejection loops on these streams, out of phase
-    hipStream_t lane_stream[MLDSA_SIGN_MAX_LANES] = {};
-    hipEvent_t lane_ev[MLDSA_SIGN_MAX_LANES] = {};
-    uint32_t *h_lane_count = nullptr;  // pinned host: unfinished ops per lane after a round
+    // graphs of calls made on the legacy default stream run here (that stream cannot be captured)
+    hipStream_t graph_stream = nullptr;
+    hipEvent_t graph_fork_ev = nullptr, graph_join_ev = nullptr;
+    // sign: page-locked copy of the loop's control block, read once after the enqueued rounds
+    mldsa::RoundCtl *h_ctl = nullptr;
     // The op-level calls share the workspace and the helper streams: they serialise here.  The mutex
     // covers the host side of a call; ws_ev orders the device side when the next call comes on another
     // stream (device-side wait, no host synchronisation).
@@ -42,7 +73,9 @@ struct mldsa_ctx {
     std::vector<hipEvent_t> prof_ev;      // 2 events per recorded stage launch
     std::vector<const char *> prof_name;  // stage of pair i
     size_t prof_used = 0;                 // pairs in use
-    unsigned long long prof_sign_slots = 0;  // op-rounds run by mldsa_sign while profiling
+    unsigned long long prof_sign_slots = 0;  // candidate slots run by mldsa_sign while profiling
+    unsigned long long prof_sign_op_rounds = 0;  // sum over rounds of unfinished ops (A_hat is needed once per op and round)
+    unsigned long long last_sign_slots = 0;  // candidate slots of the last synchronous mldsa_sign call
 };
 
 namespace mldsa {
@@ -64,6 +97,23 @@ inline unsigned grid_for(const mldsa_ctx *ctx, size_t units, unsigned units_per_
     if (need < 1) need = 1;
     return (unsigned)(need < cap ? need : cap);
 }
+
+// Every extern "C" entry that touches HIP runs under one of these: the calling thread is bound to the
+// context's device for the duration of the call and its previous device is restored afterwards, so a
+// context created for device N works from any host thread and next to contexts of other devices.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 // RAII guard of one op-level call (capi.hip)
 struct OpGuard {
@@ -106,7 +156,9 @@ struct ProfScope {
 };
 
 // ---- launchers (kernels_poly.hip) ----
-int launch_ntt(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
+// n_dev (where present): the unit count is read from device memory by the kernel (the signer's device-driven rounds);
+// the host-side count then only sizes the grid
+int launch_ntt(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t, const uint32_t *n_dev = nullptr);
 int launch_inv_ntt(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
 int launch_to_mont(mldsa_ctx *, const int32_t *, int32_t *, size_t n_polys, hipStream_t);
 int launch_mat_vec_mul(mldsa_ctx *, int k, int l, const int32_t *, const int32_t *, int32_t *, size_t n_ops, hipStream_t);
@@ -123,8 +175,10 @@ int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride,
 int launch_expand_s(mldsa_ctx *, int set, const uint8_t *rho_prime, size_t rho_stride, int32_t *s12, size_t n_ops, hipStream_t);
 // yrisk (optional): one byte per polynomial, 1 = some |y| >= gamma1 - 2 beta (see k_sign_tail)
 int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, int kappa_by_slot,
-                       const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t, uint8_t *yrisk = nullptr);
-int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t ct_stride, int32_t *c, size_t n_ops, hipStream_t);
+                       const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t, uint8_t *yrisk = nullptr,
+                       const uint32_t *n_dev = nullptr);
+int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t ct_stride, int32_t *c, size_t n_ops, hipStream_t,
+                          const uint32_t *n_dev = nullptr);
 
 
 // ---- launchers (kernels_codec.hip) ----
@@ -135,9 +189,10 @@ int launch_verify_main(mldsa_ctx *, const mldsa_params *, const int32_t *a_hat, 
                        hipStream_t, bool a_by_key = false, bool a_packed = false);
 int launch_mu(mldsa_ctx *, const uint8_t *tr, size_t tr_stride, const uint32_t *key_idx, int mode, const uint8_t *msgs,
               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, uint8_t *mu, size_t mu_stride, int32_t *ctx_bad,
-              size_t n_ops, hipStream_t);
+              size_t n_ops, hipStream_t, const int32_t *key_bad = nullptr);
 int launch_shake256_2(mldsa_ctx *, int out_len, const uint8_t *a, size_t sa, int la, const uint32_t *a_idx, const uint8_t *b, size_t sb,
-                      int lb, uint32_t tail, int tail_len, uint8_t *out, size_t so, size_t n_ops, hipStream_t);
+                      int lb, uint32_t tail, int tail_len, uint8_t *out, size_t so, size_t n_ops, hipStream_t,
+                      const uint32_t *n_dev = nullptr);
 int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, const uint8_t *ctilde_p, size_t cp_stride,
                           const int32_t *znorm, const int32_t *hvalid, const int32_t *ctx_bad, uint8_t *ok, size_t n_ops, hipStream_t);
 
@@ -145,37 +200,64 @@ int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs
 // y_polys_per_op: distance between consecutive ops' y vectors in polynomials (0 = L, contiguous)
 int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
                   size_t w1_stride, size_t n_ops, hipStream_t, size_t y_polys_per_op = 0, uint8_t *wrisk = nullptr,
-                  bool a_packed = false);
+                  bool a_packed = false, const uint32_t *n_dev = nullptr);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
+// the round kernels of the signer: counts come from `ctl` on the device, the *_hint arguments only size the grids
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,
                      const uint32_t *slot_op, const uint32_t *key_idx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
-                     uint16_t *kappa, int32_t *done, uint8_t *sigs, int spec, uint8_t *stage, size_t stage_stride, int32_t *accept,
-                     size_t n_slots, hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr);
-int launch_make_slots(mldsa_ctx *, const uint32_t *act, size_t m, int spec, const uint16_t *kappa, int l, uint32_t *slot_op,
-                      uint16_t *slot_kappa, hipStream_t, const uint32_t *key_idx, uint32_t *slot_key, uint32_t *counter);
-int launch_resolve(mldsa_ctx *, const mldsa_params *, const uint32_t *act, size_t m, int spec, const int32_t *accept,
-                   const uint8_t *stage, size_t stage_stride, uint8_t *sigs, int32_t *done, uint16_t *kappa, hipStream_t);
-int launch_compact(mldsa_ctx *, const uint32_t *act_in, size_t n, const int32_t *done, uint32_t *act_out, uint32_t *counter, hipStream_t);
-int launch_init_active(mldsa_ctx *, size_t n, const int32_t *ctx_bad, int32_t *done, uint16_t *kappa, int32_t *status,
-                       uint32_t *act_out, uint32_t *counter, hipStream_t);
+                     uint16_t *kappa, int32_t *done, uint8_t *sigs, const RoundCtl *ctl, uint8_t *stage, size_t stage_stride,
+                     int32_t *accept, size_t slots_hint, hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr);
+int launch_make_slots(mldsa_ctx *, RoundCtl *ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t *act,
+                      const uint16_t *kappa, int l, uint32_t *slot_op, uint16_t *slot_kappa, const uint32_t *key_idx,
+                      uint32_t *slot_key, size_t slots_hint, hipStream_t);
+int launch_resolve(mldsa_ctx *, const mldsa_params *, const RoundCtl *ctl, const uint32_t *act, const int32_t *accept,
+                   const uint8_t *stage, size_t stage_stride, uint8_t *sigs, int32_t *done, uint16_t *kappa, size_t ops_hint,
+                   hipStream_t);
+int launch_compact(mldsa_ctx *, RoundCtl *ctl, int parity, const uint32_t *act_in, const int32_t *done, uint32_t *act_out,
+                   size_t ops_hint, hipStream_t);
+int launch_init_active(mldsa_ctx *, size_t n, const int32_t *bad_op, int32_t *done, uint16_t *kappa, int32_t *status,
+                       uint32_t *act_out, RoundCtl *ctl, hipStream_t);
+int launch_mark_unfinished(mldsa_ctx *, const RoundCtl *ctl, int parity, const uint32_t *act, int32_t *status, uint8_t *sigs,
+                           size_t sig_len, hipStream_t);
+int launch_sanitize_keys(mldsa_ctx *, const uint32_t *key_idx, size_t n_keys, size_t n_ops, uint32_t *safe, int32_t *bad, hipStream_t);
+int launch_zero(mldsa_ctx *, void *dst, size_t bytes, hipStream_t);
+int launch_copy_rows(mldsa_ctx *, void *dst, size_t dst_stride, const void *src, size_t src_stride, int row_bytes, size_t n_rows,
+                     hipStream_t);
+int launch_key_intt(mldsa_ctx *, const int32_t *src, int polys_per_key, size_t n_keys, int bits, int b, uint8_t *dst, size_t key_stride,
+                    size_t poly_off, int32_t *out32, int out_ppk, int out_off, hipStream_t);
+int launch_t1_hat(mldsa_ctx *, const mldsa_params *, const int32_t *as1, const int32_t *s1s2, int32_t *t1_out, size_t n_keys, hipStream_t);
 int launch_keygen_encode(mldsa_ctx *, const mldsa_params *, const int32_t *s1s2, const int32_t *as1, const uint8_t *seeds,
                          uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t);
 
-// ---- op-level pipelines (pipeline.hip) ----
+// ---- op-level pipelines (pipeline.hip): pure enqueue functions (no allocation, no host wait) unless noted ----
 int pk_expand_batch(mldsa_ctx *, int set, const uint8_t *pk, uint8_t *rho, uint8_t *tr, int32_t *t1, size_t n, hipStream_t);
 int sk_expand_batch(mldsa_ctx *, int set, const uint8_t *sk, uint8_t *rho, uint8_t *cap_k, uint8_t *tr, int32_t *s1, int32_t *s2,
                     int32_t *t0, size_t n, hipStream_t);
+int pk_into_bytes_batch(mldsa_ctx *, int set, const uint8_t *rho, const int32_t *t1, uint8_t *pk, size_t n, hipStream_t);
+int sk_into_bytes_batch(mldsa_ctx *, int set, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1,
+                        const int32_t *s2, const int32_t *t0, uint8_t *sk, size_t n, hipStream_t);
+int get_public_key_batch(mldsa_ctx *, int set, const uint8_t *rho, const uint8_t *tr, const int32_t *s1, const int32_t *s2,
+                         uint8_t *pk_rho, uint8_t *pk_tr, int32_t *pk_t1, size_t n_keys, hipStream_t);
 int keygen_batch(mldsa_ctx *, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t);
-// a_hat_keys != nullptr: per-key A_hat supplied by the caller (ExpandA is skipped)
+// a_hat_keys != nullptr: per-key A_hat supplied by the caller (ExpandA is skipped).
+// sign_batch replays / captures its chunks itself (run_op) and, unless async_mode, waits for the stream.
 int sign_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1,
-               const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off,
-               const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops,
-               hipStream_t, const int32_t *a_hat_keys = nullptr);
-int ensure_workspace(mldsa_ctx *, size_t bytes);
-int verify_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1_d2_hat_mont,
+               const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
+               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
+               int32_t *status, size_t n_ops, hipStream_t, const int32_t *a_hat_keys, bool async_mode);
+int verify_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1_d2_hat_mont, size_t n_keys,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
                  const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t,
                  const int32_t *a_hat_keys = nullptr);
+// workspace: sized before a pipeline is enqueued (growing waits for the device and drops the captured graphs)
+int ensure_workspace(mldsa_ctx *, size_t bytes);
+size_t verify_workspace_bytes(const mldsa_params *, size_t n_ops, bool own_a);
+size_t sign_workspace_bytes(const mldsa_ctx *, const mldsa_params *, size_t n_ops, bool own_a);
+size_t keygen_workspace_bytes(const mldsa_params *, size_t n_keys);
+// hipGraph replay of repeated call shapes: `key` = every value that ends up in a kernel parameter
+int run_op(mldsa_ctx *, hipStream_t, int op, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue);
+void drop_graphs(mldsa_ctx *);
+void host_stage_destroy(mldsa_ctx *);  // host_api.hip
 
 }  // namespace mldsa

@@ -1,0 +1,409 @@
+// Host-memory entry points of include/mldsa_hip.h (mldsa_verify_host / mldsa_sign_host / mldsa_keygen_host):
+// the reference's API works on host slices (src/traits.rs:118-308, 330-362); these calls take host pointers and
+// wire-format keys and stream the batch through the device in sub-batches:
+//
+//     up stream:    H2D(i + 1)            | H2D(i + 2) ...
+//     comp stream:             kernels(i) | kernels(i + 1) ...
+//     down stream:  D2H(i - 1)            | D2H(i) ...
+//
+// Three slots of context-owned device buffers (and page-locked bounce buffers for callers whose memory is
+// pageable) rotate through the three stages; HIP events order the stages, the host thread only waits when it
+// wants a slot back.  The device pointers of a slot never change, so the kernel sequence of a sub-batch is a
+// repeated call shape and replays as a hipGraph (pipeline.hip run_op).
+#include <algorithm>
+#include <cstring>
+
+#include "ctx.h"
+
+namespace mldsa {
+
+namespace {
+constexpr int N_SLOTS = 3;
+// ops per sub-batch (ctx->opt_host_sub_*): verify is PCIe-bound -- small sub-batches keep the pipeline fill and drain
+// short; sign is compute-bound and its rounds are launch-bound on small batches -- large sub-batches
+
+struct Buf {  // a device buffer with an optional page-locked bounce twin, grown on demand
+    uint8_t *dev = nullptr, *pin = nullptr;
+    size_t cap = 0, pin_cap = 0;
+};
+
+struct Slot {
+    Buf sigs, msgs, msg_off, ctxs, ctx_off, key_idx, rnd, out, status, xi, pk, sk;
+    hipEvent_t up_done = nullptr, comp_done = nullptr, down_done = nullptr;
+    bool busy = false;
+    // pending bounce copies back to the caller's pageable memory, done when the slot is reclaimed
+    struct Pending { void *user; const void *pin; size_t bytes; } pend[3];
+    int n_pend = 0;
+};
+}  // namespace
+
+struct HostStage {
+    hipStream_t up = nullptr, comp = nullptr, down = nullptr;
+    Slot slot[N_SLOTS];
+    Buf key_bytes;                          // wire-format keys of the call
+    Buf k_rho, k_capk, k_tr, k_a, k_b, k_c;  // expanded key fields (pk: rho, tr, t1; sk: rho, K, tr, s1, s2, t0)
+    hipEvent_t keys_ready = nullptr;
+};
+
+namespace {
+#define HCHECK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, #expr, _e);          \
+    } while (0)
+#define TRY(expr) do { int _rc = (expr); if (_rc != MLDSA_OK) return _rc; } while (0)
+
+bool is_pinned(const void *p) {
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory is "invalid value" to the runtime: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+int grow_dev(Buf &b, size_t bytes) {
+    if (b.cap >= bytes) return MLDSA_OK;
+    if (b.dev) { HCHECK(hipDeviceSynchronize()); (void)hipMemset(b.dev, 0, b.cap); HCHECK(hipFree(b.dev)); b.dev = nullptr; b.cap = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    if (hipMalloc((void **)&b.dev, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: device staging allocation");
+    b.cap = want;
+    return MLDSA_OK;
+}
+
+int grow_pin(Buf &b, size_t bytes) {
+    if (b.pin_cap >= bytes) return MLDSA_OK;
+    if (b.pin) { HCHECK(hipDeviceSynchronize()); memset(b.pin, 0, b.pin_cap); HCHECK(hipHostFree(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    if (hipHostMalloc((void **)&b.pin, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: page-locked staging allocation");
+    b.pin_cap = want;
+    return MLDSA_OK;
+}
+
+// host -> device on `st`: DMA straight from page-locked caller memory, through the bounce buffer otherwise
+int upload(Buf &b, const void *user, size_t bytes, bool pinned, hipStream_t st) {
+    if (bytes == 0) return grow_dev(b, 1);
+    TRY(grow_dev(b, bytes));
+    const void *src = user;
+    if (!pinned) {
+        TRY(grow_pin(b, bytes));
+        memcpy(b.pin, user, bytes);
+        src = b.pin;
+    }
+    HCHECK(hipMemcpyAsync(b.dev, src, bytes, hipMemcpyHostToDevice, st));
+    return MLDSA_OK;
+}
+
+// device -> host on `st`; pageable destinations are filled from the bounce buffer when the slot is reclaimed
+int download(Slot &sl, Buf &b, void *user, size_t bytes, bool pinned, hipStream_t st) {
+    if (bytes == 0) return MLDSA_OK;
+    void *dst = user;
+    if (!pinned) {
+        TRY(grow_pin(b, bytes));
+        dst = b.pin;
+        sl.pend[sl.n_pend++] = {user, b.pin, bytes};
+    }
+    HCHECK(hipMemcpyAsync(dst, b.dev, bytes, hipMemcpyDeviceToHost, st));
+    return MLDSA_OK;
+}
+
+int reclaim(Slot &sl) {
+    if (!sl.busy) return MLDSA_OK;
+    HCHECK(hipEventSynchronize(sl.down_done));
+    for (int i = 0; i < sl.n_pend; i++) memcpy(sl.pend[i].user, sl.pend[i].pin, sl.pend[i].bytes);
+    sl.n_pend = 0;
+    sl.busy = false;
+    return MLDSA_OK;
+}
+
+int stage_get(mldsa_ctx *ctx, HostStage **out) {
+    if (!ctx->host_stage) {
+        HostStage *hs = new (std::nothrow) HostStage();
+        if (!hs) return set_error(MLDSA_ERR_NOMEM, "host path: allocation failed");
+        hipError_t e = hipStreamCreateWithFlags(&hs->up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&hs->comp, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&hs->down, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&hs->keys_ready, hipEventDisableTiming);
+        for (auto &sl : hs->slot) {
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.up_done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.comp_done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.down_done, hipEventDisableTiming);
+        }
+        ctx->host_stage = hs;
+        if (e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "host path: stream / event setup", e);
+    }
+    *out = ctx->host_stage;
+    return MLDSA_OK;
+}
+
+void free_buf(Buf &b) {
+    if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); }
+    if (b.pin) { memset(b.pin, 0, b.pin_cap); (void)hipHostFree(b.pin); }
+    b = Buf();
+}
+
+// bytes of the [a, b) slice of a concatenated byte-string array
+inline size_t span(const uint64_t *off, size_t a, size_t b) { return (size_t)(off[b] - off[a]); }
+}  // namespace
+
+void host_stage_destroy(mldsa_ctx *ctx) {
+    HostStage *hs = ctx->host_stage;
+    if (!hs) return;
+    for (auto &sl : hs->slot) {
+        for (Buf *b : {&sl.sigs, &sl.msgs, &sl.msg_off, &sl.ctxs, &sl.ctx_off, &sl.key_idx, &sl.rnd, &sl.out, &sl.status, &sl.xi, &sl.pk, &sl.sk})
+            free_buf(*b);
+        if (sl.up_done) (void)hipEventDestroy(sl.up_done);
+        if (sl.comp_done) (void)hipEventDestroy(sl.comp_done);
+        if (sl.down_done) (void)hipEventDestroy(sl.down_done);
+    }
+    for (Buf *b : {&hs->key_bytes, &hs->k_rho, &hs->k_capk, &hs->k_tr, &hs->k_a, &hs->k_b, &hs->k_c}) free_buf(*b);
+    if (hs->keys_ready) (void)hipEventDestroy(hs->keys_ready);
+    if (hs->up) (void)hipStreamDestroy(hs->up);
+    if (hs->comp) (void)hipStreamDestroy(hs->comp);
+    if (hs->down) (void)hipStreamDestroy(hs->down);
+    delete hs;
+    ctx->host_stage = nullptr;
+}
+
+// shared by verify_host and sign_host: upload the per-op inputs of ops [a, b) into slot `sl` on the up stream
+struct OpInputs {
+    const uint32_t *key_idx;
+    const uint8_t *msgs;
+    const uint64_t *msg_off;
+    const uint8_t *ctxs;
+    const uint64_t *ctx_off;
+    bool pin_kidx, pin_msgs, pin_moff, pin_ctxs, pin_coff;
+};
+
+static int upload_op_inputs(HostStage *hs, Slot &sl, const OpInputs &in, size_t a, size_t b) {
+    const size_t n = b - a;
+    if (in.key_idx) TRY(upload(sl.key_idx, in.key_idx + a, n * 4, in.pin_kidx, hs->up));
+    TRY(upload(sl.msg_off, in.msg_off + a, (n + 1) * 8, in.pin_moff, hs->up));
+    TRY(upload(sl.msgs, in.msgs ? in.msgs + in.msg_off[a] : nullptr, in.msgs ? span(in.msg_off, a, b) : 0, in.pin_msgs, hs->up));
+    if (in.ctx_off) {
+        TRY(upload(sl.ctx_off, in.ctx_off + a, (n + 1) * 8, in.pin_coff, hs->up));
+        TRY(upload(sl.ctxs, in.ctxs ? in.ctxs + in.ctx_off[a] : nullptr, in.ctxs ? span(in.ctx_off, a, b) : 0, in.pin_ctxs, hs->up));
+    }
+    return MLDSA_OK;
+}
+
+}  // namespace mldsa
+
+using namespace mldsa;
+
+#define REQUIRE(cond, msg) \
+    do { if (!(cond)) return set_error(MLDSA_ERR_PARAM, msg); } while (0)
+
+extern "C" {
+
+// declared in capi.hip's translation unit as ordinary exports
+int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size_t n_keys, const uint32_t *key_idx,
+                      const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                      const uint8_t *sigs, uint8_t *ok, size_t n_ops) {
+    REQUIRE(ctx, "mldsa_verify_host: NULL context");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_verify_host: unknown parameter set");
+    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_verify_host: bad mode");
+    if (n_ops == 0) return MLDSA_OK;
+    REQUIRE(pk && msg_off && sigs && ok, "mldsa_verify_host: NULL pointer");
+    REQUIRE(key_idx ? n_keys > 0 : n_keys >= n_ops, "mldsa_verify_host: n_keys does not cover the batch");
+    DeviceGuard dg(ctx->device);
+    std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
+    HostStage *hs;
+    TRY(stage_get(ctx, &hs));
+    const size_t pkl = (size_t)p->pk_len, sgl = (size_t)p->sig_len, k = (size_t)p->k;
+    // keys: upload once, expand once (PublicKey::try_from_bytes, ml_dsa.rs:477-498)
+    TRY(upload(hs->key_bytes, pk, n_keys * pkl, is_pinned(pk), hs->up));
+    TRY(grow_dev(hs->k_rho, n_keys * 32));
+    TRY(grow_dev(hs->k_tr, n_keys * 64));
+    TRY(grow_dev(hs->k_a, n_keys * k * 1024));
+    HCHECK(hipEventRecord(hs->keys_ready, hs->up));
+    HCHECK(hipStreamWaitEvent(hs->comp, hs->keys_ready, 0));
+    TRY(mldsa_pk_expand(ctx, set, hs->key_bytes.dev, hs->k_rho.dev, hs->k_tr.dev, reinterpret_cast<int32_t *>(hs->k_a.dev), n_keys, hs->comp));
+    const size_t sub = std::min(n_ops, (size_t)ctx->opt_host_sub_verify);
+    TRY(mldsa_reserve(ctx, set, MLDSA_OP_VERIFY, sub));
+    OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
+    const bool pin_sigs = is_pinned(sigs), pin_ok = is_pinned(ok);
+    int rc = MLDSA_OK;
+    size_t i = 0;
+    for (size_t a = 0; a < n_ops && rc == MLDSA_OK; a += sub, i++) {
+        const size_t b = std::min(n_ops, a + sub), n = b - a;
+        Slot &sl = hs->slot[i % N_SLOTS];
+        rc = [&]() -> int {
+            TRY(reclaim(sl));
+            TRY(upload_op_inputs(hs, sl, in, a, b));
+            TRY(upload(sl.sigs, sigs + a * sgl, n * sgl, pin_sigs, hs->up));
+            TRY(grow_dev(sl.out, n));
+            HCHECK(hipEventRecord(sl.up_done, hs->up));
+            HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
+            // the slice's byte strings start at offset msg_off[a] of the caller's array: hand the kernels a base
+            // pointer that makes the caller's own offsets land in the staging buffer
+            const uint8_t *mbase = sl.msgs.dev - msg_off[a];
+            const uint8_t *cbase = ctx_off ? sl.ctxs.dev - ctx_off[a] : nullptr;
+            const size_t kb = key_idx ? 0 : a;  // identity mapping walks the key table with the batch
+            TRY(mldsa_verify(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_tr.dev + kb * 64,
+                             reinterpret_cast<const int32_t *>(hs->k_a.dev) + kb * k * 256, n_keys - kb,
+                             key_idx ? reinterpret_cast<const uint32_t *>(sl.key_idx.dev) : nullptr, mbase,
+                             reinterpret_cast<const uint64_t *>(sl.msg_off.dev), cbase,
+                             ctx_off ? reinterpret_cast<const uint64_t *>(sl.ctx_off.dev) : nullptr, sl.sigs.dev, sl.out.dev, n, hs->comp));
+            HCHECK(hipEventRecord(sl.comp_done, hs->comp));
+            HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
+            TRY(download(sl, sl.out, ok + a, n, pin_ok, hs->down));
+            HCHECK(hipEventRecord(sl.down_done, hs->down));
+            sl.busy = true;
+            return MLDSA_OK;
+        }();
+    }
+    for (auto &sl : hs->slot) {
+        const int r2 = reclaim(sl);
+        if (rc == MLDSA_OK) rc = r2;
+    }
+    if (rc != MLDSA_OK) (void)hipDeviceSynchronize();
+    return rc;
+}
+
+int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t n_keys, const uint32_t *key_idx,
+                    const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                    const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops) {
+    REQUIRE(ctx, "mldsa_sign_host: NULL context");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_sign_host: unknown parameter set");
+    REQUIRE(mode == MLDSA_MODE_PURE || mode == MLDSA_MODE_INTERNAL || mode == MLDSA_MODE_PREHASH, "mldsa_sign_host: bad mode");
+    if (n_ops == 0) return MLDSA_OK;
+    REQUIRE(sk && msg_off && rnd && sigs, "mldsa_sign_host: NULL pointer");
+    REQUIRE(key_idx ? n_keys > 0 : n_keys >= n_ops, "mldsa_sign_host: n_keys does not cover the batch");
+    DeviceGuard dg(ctx->device);
+    std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
+    HostStage *hs;
+    TRY(stage_get(ctx, &hs));
+    const size_t skl = (size_t)p->sk_len, sgl = (size_t)p->sig_len, k = (size_t)p->k, l = (size_t)p->l;
+    // keys: upload once, expand once (PrivateKey::try_from_bytes, ml_dsa.rs:445-469)
+    TRY(upload(hs->key_bytes, sk, n_keys * skl, is_pinned(sk), hs->up));
+    TRY(grow_dev(hs->k_rho, n_keys * 32));
+    TRY(grow_dev(hs->k_capk, n_keys * 32));
+    TRY(grow_dev(hs->k_tr, n_keys * 64));
+    TRY(grow_dev(hs->k_a, n_keys * l * 1024));
+    TRY(grow_dev(hs->k_b, n_keys * k * 1024));
+    TRY(grow_dev(hs->k_c, n_keys * k * 1024));
+    HCHECK(hipEventRecord(hs->keys_ready, hs->up));
+    HCHECK(hipStreamWaitEvent(hs->comp, hs->keys_ready, 0));
+    int32_t *s1 = reinterpret_cast<int32_t *>(hs->k_a.dev), *s2 = reinterpret_cast<int32_t *>(hs->k_b.dev),
+            *t0 = reinterpret_cast<int32_t *>(hs->k_c.dev);
+    TRY(mldsa_sk_expand(ctx, set, hs->key_bytes.dev, hs->k_rho.dev, hs->k_capk.dev, hs->k_tr.dev, s1, s2, t0, n_keys, hs->comp));
+    const size_t sub = std::min(n_ops, (size_t)ctx->opt_host_sub_sign);
+    TRY(mldsa_reserve(ctx, set, MLDSA_OP_SIGN, sub));
+    OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
+    const bool pin_rnd = is_pinned(rnd), pin_sigs = is_pinned(sigs);
+    // per-op status always comes back: MLDSA_ERR_AGAIN marks the (practically never) ops that need another pass
+    std::vector<int32_t> st_local;
+    int32_t *st = status;
+    if (!st) { st_local.resize(n_ops); st = st_local.data(); }
+    const bool pin_st = status && is_pinned(status);
+    int rc = MLDSA_OK;
+    size_t i = 0;
+    for (size_t a = 0; a < n_ops && rc == MLDSA_OK; a += sub, i++) {
+        const size_t b = std::min(n_ops, a + sub), n = b - a;
+        Slot &sl = hs->slot[i % N_SLOTS];
+        rc = [&]() -> int {
+            TRY(reclaim(sl));
+            TRY(upload_op_inputs(hs, sl, in, a, b));
+            TRY(upload(sl.rnd, rnd + a * 32, n * 32, pin_rnd, hs->up));
+            TRY(grow_dev(sl.out, n * sgl));
+            TRY(grow_dev(sl.status, n * 4));
+            HCHECK(hipEventRecord(sl.up_done, hs->up));
+            HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
+            const uint8_t *mbase = sl.msgs.dev - msg_off[a];
+            const uint8_t *cbase = ctx_off ? sl.ctxs.dev - ctx_off[a] : nullptr;
+            const size_t kb = key_idx ? 0 : a;
+            TRY(mldsa_sign_async(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_capk.dev + kb * 32, hs->k_tr.dev + kb * 64, s1 + kb * l * 256,
+                                 s2 + kb * k * 256, t0 + kb * k * 256, n_keys - kb,
+                                 key_idx ? reinterpret_cast<const uint32_t *>(sl.key_idx.dev) : nullptr, mbase,
+                                 reinterpret_cast<const uint64_t *>(sl.msg_off.dev), cbase,
+                                 ctx_off ? reinterpret_cast<const uint64_t *>(sl.ctx_off.dev) : nullptr, sl.rnd.dev, sl.out.dev,
+                                 reinterpret_cast<int32_t *>(sl.status.dev), n, hs->comp));
+            HCHECK(hipEventRecord(sl.comp_done, hs->comp));
+            HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
+            TRY(download(sl, sl.out, sigs + a * sgl, n * sgl, pin_sigs, hs->down));
+            TRY(download(sl, sl.status, st + a, n * 4, pin_st, hs->down));
+            HCHECK(hipEventRecord(sl.down_done, hs->down));
+            sl.busy = true;
+            return MLDSA_OK;
+        }();
+    }
+    for (auto &sl : hs->slot) {
+        const int r2 = reclaim(sl);
+        if (rc == MLDSA_OK) rc = r2;
+    }
+    if (rc != MLDSA_OK) { (void)hipDeviceSynchronize(); return rc; }
+    // ops the enqueued rounds left unfinished (probability < 1e-9 per call): sign them again, waiting this time
+    for (size_t op = 0; op < n_ops && rc == MLDSA_OK; op++) {
+        if (st[op] != MLDSA_ERR_AGAIN) continue;
+        Slot &sl = hs->slot[0];
+        const uint32_t ki = key_idx ? key_idx[op] : (uint32_t)op;
+        const uint64_t mo[2] = {0, msg_off[op + 1] - msg_off[op]};
+        const uint64_t co[2] = {0, ctx_off ? ctx_off[op + 1] - ctx_off[op] : 0};
+        rc = [&]() -> int {
+            TRY(upload(sl.msg_off, mo, 16, false, hs->comp));
+            TRY(upload(sl.ctx_off, co, 16, false, hs->comp));
+            TRY(upload(sl.msgs, msgs ? msgs + msg_off[op] : nullptr, msgs ? (size_t)mo[1] : 0, false, hs->comp));
+            TRY(upload(sl.ctxs, ctxs && ctx_off ? ctxs + ctx_off[op] : nullptr, ctxs && ctx_off ? (size_t)co[1] : 0, false, hs->comp));
+            TRY(upload(sl.rnd, rnd + op * 32, 32, false, hs->comp));
+            TRY(mldsa_sign(ctx, set, mode, hs->k_rho.dev + ki * 32, hs->k_capk.dev + ki * 32, hs->k_tr.dev + ki * 64, s1 + ki * l * 256,
+                           s2 + ki * k * 256, t0 + ki * k * 256, 1, nullptr, sl.msgs.dev, reinterpret_cast<const uint64_t *>(sl.msg_off.dev),
+                           sl.ctxs.dev, reinterpret_cast<const uint64_t *>(sl.ctx_off.dev), sl.rnd.dev, sl.out.dev,
+                           reinterpret_cast<int32_t *>(sl.status.dev), 1, hs->comp));
+            HCHECK(hipMemcpyAsync(sigs + op * sgl, sl.out.dev, sgl, hipMemcpyDeviceToHost, hs->comp));
+            HCHECK(hipMemcpyAsync(st + op, sl.status.dev, 4, hipMemcpyDeviceToHost, hs->comp));
+            HCHECK(hipStreamSynchronize(hs->comp));
+            return MLDSA_OK;
+        }();
+    }
+    return rc;
+}
+
+int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys) {
+    REQUIRE(ctx, "mldsa_keygen_host: NULL context");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_keygen_host: unknown parameter set");
+    if (n_keys == 0) return MLDSA_OK;
+    REQUIRE(xi && pk && sk, "mldsa_keygen_host: NULL pointer");
+    DeviceGuard dg(ctx->device);
+    std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
+    HostStage *hs;
+    TRY(stage_get(ctx, &hs));
+    const size_t pkl = (size_t)p->pk_len, skl = (size_t)p->sk_len;
+    const size_t sub = std::min(n_keys, (size_t)ctx->opt_host_sub_verify);
+    TRY(mldsa_reserve(ctx, set, MLDSA_OP_KEYGEN, sub));
+    const bool pin_xi = is_pinned(xi), pin_pk = is_pinned(pk), pin_sk = is_pinned(sk);
+    int rc = MLDSA_OK;
+    size_t i = 0;
+    for (size_t a = 0; a < n_keys && rc == MLDSA_OK; a += sub, i++) {
+        const size_t n = std::min(n_keys, a + sub) - a;
+        Slot &sl = hs->slot[i % N_SLOTS];
+        rc = [&]() -> int {
+            TRY(reclaim(sl));
+            TRY(upload(sl.xi, xi + a * 32, n * 32, pin_xi, hs->up));
+            TRY(grow_dev(sl.pk, n * pkl));
+            TRY(grow_dev(sl.sk, n * skl));
+            HCHECK(hipEventRecord(sl.up_done, hs->up));
+            HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
+            TRY(mldsa_keygen(ctx, set, sl.xi.dev, sl.pk.dev, sl.sk.dev, n, hs->comp));
+            HCHECK(hipEventRecord(sl.comp_done, hs->comp));
+            HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
+            TRY(download(sl, sl.pk, pk + a * pkl, n * pkl, pin_pk, hs->down));
+            TRY(download(sl, sl.sk, sk + a * skl, n * skl, pin_sk, hs->down));
+            HCHECK(hipEventRecord(sl.down_done, hs->down));
+            sl.busy = true;
+            return MLDSA_OK;
+        }();
+    }
+    for (auto &sl : hs->slot) {
+        const int r2 = reclaim(sl);
+        if (rc == MLDSA_OK) rc = r2;
+    }
+    if (rc != MLDSA_OK) (void)hipDeviceSynchronize();
+    return rc;
+}
+
+}  // extern "C"

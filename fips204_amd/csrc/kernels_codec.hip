@@ -122,9 +122,11 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
     const LdsTw ftw{tw_lds, lane};
     const LdsTw itw{tw_lds + FWD_TW * 64, lane};
     const uint32_t wid = blockIdx.x * VW + wave, n_waves = gridDim.x * VW;
+    const unsigned ul = (unsigned)lane;  // unsigned lane offsets: uniform base + zero-extended 32-bit offset addressing
 
     for (size_t op = wid; op < n_ops; op += n_waves) {
-        const size_t key = key_idx ? key_idx[op] : op;
+        // wave-uniform, so row pointers stay scalar (SGPR base + lane offset) instead of per-lane 64-bit addresses
+        const size_t key = key_idx ? (size_t)__builtin_amdgcn_readfirstlane((int)key_idx[op]) : op;
         const size_t aop = a_by_key ? key : op;  // per-key A_hat kept by the caller, or the op's own ExpandA output
         // APACK: A_hat in the pipelines' 24-bit form (768 bytes per polynomial, three dwords per lane)
         using ARow = std::conditional_t<APACK, Packed3, int4>;
@@ -136,8 +138,8 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
         const int4* trow = reinterpret_cast<const int4*>(t1 + (key * K) * (size_t)N);
         ARow av[L];
 #pragma unroll
-        for (int j = 0; j < L; j++) av[j] = arow[j * 64 + lane];
-        int4 tv = trow[lane];
+        for (int j = 0; j < L; j++) av[j] = arow[(unsigned)(j * 64) + ul];
+        int4 tv = trow[ul];
         // ---- forward transforms: z[0..L) from the signature bytes, then c
         const uint8_t* zsrc = sigs + op * sig_len + ctilde_len;
         bool zbad = false;
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
             acc[3] -= mont_mul(cv.w, tv.w);
             if (i + 1 < K) {  // next row: in flight during this row's inverse transform
 #pragma unroll
-                for (int j = 0; j < L; j++) av[j] = arow[((i + 1) * L + j) * 64 + lane];
-                tv = trow[(i + 1) * 64 + lane];
+                for (int j = 0; j < L; j++) av[j] = arow[(unsigned)(((i + 1) * L + j) * 64) + ul];
+                tv = trow[(unsigned)((i + 1) * 64) + ul];
             }
             // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5)
             uint32_t hw[4];
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
                                            const uint32_t* __restrict__ key_idx, int mode,
                                            const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ msg_off,
                                            const uint8_t* __restrict__ ctxs, const uint64_t* __restrict__ ctx_off,
-                                           uint8_t* __restrict__ mu, size_t mu_stride, int32_t* __restrict__ ctx_bad, size_t n_ops) {
+                                           uint8_t* __restrict__ mu, size_t mu_stride, int32_t* __restrict__ ctx_bad,
+                                           const int32_t* __restrict__ key_bad, size_t n_ops) {
     __shared__ uint32_t blk[64 * MU_BLK_STRIDE];
     const int lane = threadIdx.x;
     const size_t op = (size_t)blockIdx.x * 64 + lane;
@@ -241,7 +244,8 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
             cp = ctxs + ctx_off[op];
             clen = (size_t)(ctx_off[op + 1] - ctx_off[op]);
         }
-        if (ctx_bad) ctx_bad[op] = clen > 255 ? 1 : 0;  // lib.rs:274, 368, 589, 605 (every entry point)
+        // 1: ctx too long (lib.rs:274, 368, 589, 605: every entry point); 2: key index out of range
+        if (ctx_bad) ctx_bad[op] = clen > 255 ? 1 : (key_bad ? key_bad[op] : 0);
     }
     const size_t pre = (mode == MLDSA_MODE_INTERNAL) ? 0 : 2 + clen;
     const size_t total = valid ? 64 + pre + mlen : 0;
@@ -301,86 +305,91 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
                                                        const uint32_t* __restrict__ a_idx,
                                                        const uint8_t* __restrict__ b, size_t sb, int lb,
                                                        uint32_t tail, int tail_len,
-                                                       uint8_t* __restrict__ out, size_t so, size_t n_ops) {
+                                                       uint8_t* __restrict__ out, size_t so, size_t n_ops,
+                                                       const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t tiles[CWAVES * 64 * H_STRIDE];
     __shared__ unsigned long long ptr_a[CWAVES * 64], ptr_b[CWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* tile = tiles + wave * 64 * H_STRIDE;
-    const size_t op = (size_t)blockIdx.x * CBLOCK + threadIdx.x;
-    const bool valid = op < n_ops;
-    ptr_a[wave * 64 + lane] = valid ? (unsigned long long)(a + (a_idx ? a_idx[op] : op) * sa) : 0ull;
-    ptr_b[wave * 64 + lane] = (valid && b) ? (unsigned long long)(b + op * sb) : 0ull;
-    wave_lds_sync_c();
+    if (n_dev) n_ops = *n_dev;  // the signer's rounds: the count lives on the device, the grid is sized from its expectation
     const int data = la + lb;              // bytes that come from memory
     const int total = data + tail_len;     // message length
     const int n_blocks = total / SHAKE256_RATE + 1;
-    KeccakState st;
-    keccak_zero(st);
-    // The wave's 64 x 34 dwords of one rate block: element e = 64 i + lane -> (row, word).  All 34
-    // loads of a block are issued back to back, and those of block b+1 are issued before the
-    // permutation of block b, so their latency hides under it (the hash chain of one op is serial
-    // and the kernel often runs a single wave per SIMD).
-    uint32_t pre[34];
-    auto issue = [&](int blk) {
-        const int base = blk * SHAKE256_RATE;
-#pragma unroll
-        for (int i = 0; i < 34; i++) {
-            const int e = 64 * i + lane;
-            const int row = e / 34, wd = e - row * 34;
-            const int off = base + 4 * wd;
-            uint32_t v = 0;
-            if (off + 4 <= data) {
-                const bool in_a = off < la;
-                const unsigned long long pp = in_a ? ptr_a[wave * 64 + row] : ptr_b[wave * 64 + row];
-                if (pp) {
-                    const uint8_t* src = reinterpret_cast<const uint8_t*>(pp) + (in_a ? off : off - la);
-                    v = ALIGNED ? *reinterpret_cast<const uint32_t*>(src) : load_le32(src);
-                }
-            }
-            pre[i] = v;
-        }
-    };
-    issue(0);
-    for (int blk = 0; blk < n_blocks; blk++) {
-        const int base = blk * SHAKE256_RATE;
-#pragma unroll
-        for (int i = 0; i < 34; i++) {
-            const int e = 64 * i + lane;
-            const int row = e / 34, wd = e - row * 34;
-            tile[row * H_STRIDE + wd] = pre[i];
-        }
+    for (size_t base_op = (size_t)blockIdx.x * CBLOCK; base_op < n_ops; base_op += (size_t)gridDim.x * CBLOCK) {
+        const size_t op = base_op + threadIdx.x;
+        const bool valid = op < n_ops;
+        ptr_a[wave * 64 + lane] = valid ? (unsigned long long)(a + (a_idx ? a_idx[op] : op) * sa) : 0ull;
+        ptr_b[wave * 64 + lane] = (valid && b) ? (unsigned long long)(b + op * sb) : 0ull;
         wave_lds_sync_c();
-        static_for_c<0, 17>([&](auto wc) {
-            constexpr int W = decltype(wc)::value;
-            uint32_t lo = tile[lane * H_STRIDE + 2 * W], hi = tile[lane * H_STRIDE + 2 * W + 1];
-            const int off = base + 8 * W;
-            if (off + 8 > data && off <= total) {  // word holds tail bytes and / or the 0x1F pad (lane-uniform)
-                for (int i = 0; i < 8; i++) {
-                    const int pos = off + i;
-                    uint32_t v = 0;
-                    if (pos >= data && pos < total) v = (tail >> (8 * (pos - data))) & 0xFF;
-                    else if (pos == total) v = 0x1F;
-                    if (i < 4) lo |= v << (8 * i); else hi |= v << (8 * (i - 4));
+        KeccakState st;
+        keccak_zero(st);
+        // The wave's 64 x 34 dwords of one rate block: element e = 64 i + lane -> (row, word).  All 34
+        // loads of a block are issued back to back, and those of block b+1 are issued before the
+        // permutation of block b, so their latency hides under it (the hash chain of one op is serial
+        // and the kernel often runs a single wave per SIMD).
+        uint32_t pre[34];
+        auto issue = [&](int blk) {
+            const int base = blk * SHAKE256_RATE;
+#pragma unroll
+            for (int i = 0; i < 34; i++) {
+                const int e = 64 * i + lane;
+                const int row = e / 34, wd = e - row * 34;
+                const int off = base + 4 * wd;
+                uint32_t v = 0;
+                if (off + 4 <= data) {
+                    const bool in_a = off < la;
+                    const unsigned long long pp = in_a ? ptr_a[wave * 64 + row] : ptr_b[wave * 64 + row];
+                    if (pp) {
+                        const uint8_t* src = reinterpret_cast<const uint8_t*>(pp) + (in_a ? off : off - la);
+                        v = ALIGNED ? *reinterpret_cast<const uint32_t*>(src) : load_le32(src);
+                    }
                 }
+                pre[i] = v;
             }
-            st.lo[W] ^= lo;
-            st.hi[W] ^= hi;
-        });
-        if (blk == n_blocks - 1) st.hi[16] ^= 0x80000000u;
-        wave_lds_sync_c();
-        if (blk + 1 < n_blocks) issue(blk + 1);
-        keccak_f1600(st);
+        };
+        issue(0);
+        for (int blk = 0; blk < n_blocks; blk++) {
+            const int base = blk * SHAKE256_RATE;
+#pragma unroll
+            for (int i = 0; i < 34; i++) {
+                const int e = 64 * i + lane;
+                const int row = e / 34, wd = e - row * 34;
+                tile[row * H_STRIDE + wd] = pre[i];
+            }
+            wave_lds_sync_c();
+            static_for_c<0, 17>([&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+                uint32_t lo = tile[lane * H_STRIDE + 2 * W], hi = tile[lane * H_STRIDE + 2 * W + 1];
+                const int off = base + 8 * W;
+                if (off + 8 > data && off <= total) {  // word holds tail bytes and / or the 0x1F pad (lane-uniform)
+                    for (int i = 0; i < 8; i++) {
+                        const int pos = off + i;
+                        uint32_t v = 0;
+                        if (pos >= data && pos < total) v = (tail >> (8 * (pos - data))) & 0xFF;
+                        else if (pos == total) v = 0x1F;
+                        if (i < 4) lo |= v << (8 * i); else hi |= v << (8 * (i - 4));
+                    }
+                }
+                st.lo[W] ^= lo;
+                st.hi[W] ^= hi;
+            });
+            if (blk == n_blocks - 1) st.hi[16] ^= 0x80000000u;
+            wave_lds_sync_c();
+            if (blk + 1 < n_blocks) issue(blk + 1);
+            keccak_f1600(st);
+        }
+        if (valid) {
+            uint8_t* po = out + op * so;
+            static_for_c<0, OUT / 8>([&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    po[8 * W + i] = (uint8_t)(st.lo[W] >> (8 * i));
+                    po[8 * W + 4 + i] = (uint8_t)(st.hi[W] >> (8 * i));
+                }
+            });
+        }
     }
-    if (!valid) return;
-    uint8_t* po = out + op * so;
-    static_for_c<0, OUT / 8>([&](auto wc) {
-        constexpr int W = decltype(wc)::value;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            po[8 * W + i] = (uint8_t)(st.lo[W] >> (8 * i));
-            po[8 * W + 4 + i] = (uint8_t)(st.hi[W] >> (8 * i));
-        }
-    });
 }
 
 // final verdict of verify_internal (ml_dsa.rs:434-436) combined with the decode failures
@@ -436,7 +445,10 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
 #define MLDSA_VM(KK, LL, GB, G2, MW) do { if (a_packed) MLDSA_VM2(KK, LL, GB, G2, MW, true); else MLDSA_VM2(KK, LL, GB, G2, MW, false); } while (0)
     if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false, 5);
     else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true, 4);
-    else MLDSA_VM(8, 7, 19, true, 4);
+    // ML-DSA-87 with the packed A_hat (21 prefetched dwords per lane): compiled for 3 waves per SIMD (137 VGPRs, no
+    // spill); at 4 waves the compiler spills 8 VGPRs of loop-invariant addresses (36 B scratch) for 1.3 % more throughput
+    else if (a_packed) MLDSA_VM2(8, 7, 19, true, 3, true);
+    else MLDSA_VM2(8, 7, 19, true, 4, false);
 #undef MLDSA_VM2
 #undef MLDSA_VM
     MLDSA_HIP_CHECK(hipGetLastError());
@@ -445,23 +457,24 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
 
 int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* key_idx, int mode, const uint8_t* msgs,
               const uint64_t* msg_off, const uint8_t* ctxs, const uint64_t* ctx_off, uint8_t* mu, size_t mu_stride,
-              int32_t* ctx_bad, size_t n_ops, hipStream_t s) {
+              int32_t* ctx_bad, size_t n_ops, hipStream_t s, const int32_t* key_bad) {
     hipLaunchKernelGGL(k_mu, dim3((unsigned)((n_ops + 63) / 64)), dim3(64), 0, s, tr, tr_stride, key_idx, mode, msgs, msg_off,
-                       ctxs, ctx_off, mu, mu_stride, ctx_bad, n_ops);
+                       ctxs, ctx_off, mu, mu_stride, ctx_bad, key_bad, n_ops);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
 
 int launch_shake256_2(mldsa_ctx*, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
-                      size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s) {
-    if (n_ops == 0) return MLDSA_OK;
-    dim3 grid(lane_blocks(n_ops)), block(CBLOCK);
+                      size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
+                      const uint32_t* n_dev) {
+    if (n_ops == 0 && !n_dev) return MLDSA_OK;
+    dim3 grid(lane_blocks(n_ops ? n_ops : 1)), block(CBLOCK);
     if ((la & 3) != 0 || (lb & 3) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: segment lengths must be multiples of 4 bytes");
     const bool al = (((uintptr_t)a | (uintptr_t)sa | (uintptr_t)b | (uintptr_t)sb) & 3) == 0;
 #define MLDSA_SHAKE_CASE(O)                                                                                              \
     case O:                                                                                                              \
-        if (al) hipLaunchKernelGGL((k_shake256_2<O, true>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops); \
-        else hipLaunchKernelGGL((k_shake256_2<O, false>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops);   \
+        if (al) hipLaunchKernelGGL((k_shake256_2<O, true>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev); \
+        else hipLaunchKernelGGL((k_shake256_2<O, false>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev);   \
         break;
     switch (out_len) {
         MLDSA_SHAKE_CASE(32)

@@ -20,8 +20,9 @@ constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
 
 // ------------------------------------------------------------------ NTT (ntt.rs:14-76)
 __global__ __launch_bounds__(BLOCK) void k_ntt(const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                               size_t n_polys, const Twiddle *__restrict__ tab) {
+                                               size_t n_polys, const Twiddle *__restrict__ tab, const uint32_t *__restrict__ n_dev) {
     const int lane = threadIdx.x & 63;
+    if (n_dev) n_polys = *n_dev;  // the signer's rounds: count known only on the device
     const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
     FwdTw tw;
@@ -175,12 +176,15 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
     int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
-    uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op, uint8_t *__restrict__ wrisk, int32_t risk_bound) {
+    uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op, uint8_t *__restrict__ wrisk, int32_t risk_bound,
+    const uint32_t *__restrict__ n_dev) {
     constexpr int NZ = HAS_C ? L + 1 : L;
     __shared__ int4 zh[AW][NZ][64];
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (n_dev) n_ops = *n_dev;  // the signer's rounds: slots of this round, known only on the device
+    if ((size_t)blockIdx.x * AW >= n_ops) return;
     for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * AW) tw_lds[i] = fwd_tab[i];
     for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * AW) tw_lds[FWD_TW * 64 + i] = inv_tab[i];
     __syncthreads();
@@ -276,9 +280,9 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
 }
 
 // ------------------------------------------------------------------------- launchers
-int launch_ntt(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n, hipStream_t s) {
-    if (n == 0) return MLDSA_OK;
-    hipLaunchKernelGGL(k_ntt, dim3(grid_for(ctx, n, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, in, out, n, ctx->d_fwd_tw);
+int launch_ntt(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n, hipStream_t s, const uint32_t *n_dev) {
+    if (n == 0 && !n_dev) return MLDSA_OK;
+    hipLaunchKernelGGL(k_ntt, dim3(grid_for(ctx, n, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, in, out, n, ctx->d_fwd_tw, n_dev);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
@@ -333,20 +337,15 @@ int launch_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t ppo, size_
     return MLDSA_OK;
 }
 
-static unsigned tune_blocks_per_cu(unsigned dflt) {
-    const char *e = getenv("MLDSA_VA_BLOCKS_PER_CU");  // tuning knob for experiments
-    return e ? (unsigned)atoi(e) : dflt;
-}
-
 int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t *z, const int32_t *c, const int32_t *t1,
                         const uint32_t *key_idx, int32_t *w, size_t n_ops, hipStream_t s) {
     if (n_ops == 0) return MLDSA_OK;
     const uint32_t *no_idx = nullptr;
-    dim3 gw(grid_for(ctx, n_ops, AW, tune_blocks_per_cu(16)));
+    dim3 gw(grid_for(ctx, n_ops, AW, (unsigned)ctx->opt_va_blocks));
     uint8_t *nw1 = nullptr;
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0);
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0, no_idx);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0, no_idx);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0, no_idx);
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -355,8 +354,9 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 // w[slot] = inv_ntt(A_hat[a_idx[slot]] * ntt(y[slot]))   (ml_dsa.rs:218-222); with w1 != nullptr also
 // w1Encode(HighBits(w)) (ml_dsa.rs:225-232)
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
-                  size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op, uint8_t *wrisk, bool a_packed) {
-    if (n_ops == 0) return MLDSA_OK;
+                  size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op, uint8_t *wrisk, bool a_packed,
+                  const uint32_t *n_dev) {
+    if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
     const mldsa_params *pp = params_of(set);
@@ -364,7 +364,7 @@ int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_i
     dim3 gw(grid_for(ctx, n_ops, AW, 16));
 #define MLDSA_SW2(KK, LL, W1M, AP)                                                                                               \
     hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M, AP>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
-                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound)
+                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound, n_dev)
 #define MLDSA_SW(KK, LL, W1M) do { if (a_packed) MLDSA_SW2(KK, LL, W1M, true); else MLDSA_SW2(KK, LL, W1M, false); } while (0)
     if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
     else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 2); else MLDSA_SW(6, 5, 0); }

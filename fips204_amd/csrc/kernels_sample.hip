@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
                                                              const uint16_t* __restrict__ kappa, int kappa_by_slot,
                                                              const uint32_t* __restrict__ op_idx,
                                                              int32_t* __restrict__ y, int l, size_t n_ops,
+                                                             const uint32_t* __restrict__ n_dev,
                                                              uint8_t* __restrict__ yrisk, int32_t risk_bound) {
     constexpr int CB = GB + 1;
     constexpr uint32_t MASK = (1u << CB) - 1u;
@@ -123,9 +124,12 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
     uint32_t* my = stage + lane * STAGE_STRIDE;
-    const size_t g = (size_t)blockIdx.x * (64 * SWAVES) + threadIdx.x;
-    const size_t wave_base = g - lane;
+    if (n_dev) n_ops = *n_dev;  // the signer's rounds: slots of this round, known only on the device
     const size_t n_streams = n_ops * (size_t)l;
+    // tiles of 256 streams, grid-stride (the grid is sized from the expected count)
+    for (size_t tile = (size_t)blockIdx.x * (64 * SWAVES); tile < n_streams; tile += (size_t)gridDim.x * (64 * SWAVES)) {
+    const size_t g = tile + threadIdx.x;
+    const size_t wave_base = g - lane;
     const bool valid = g < n_streams;
     const size_t slot = valid ? g / l : 0;          // position in the (compacted) batch
     const uint32_t r = valid ? (uint32_t)(g % l) : 0;
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
         });
     }
     if (yrisk && valid) yrisk[g] = ymax >= risk_bound ? 1 : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -202,56 +207,60 @@ constexpr int SIB_BLK_STRIDE = 35;  // dwords: 136 bytes + pad
 
 template <int CT>  // c_tilde bytes: 32, 48 or 64
 __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict__ c_tilde, size_t ct_stride,
-                                                       int tau, int32_t* __restrict__ c_out, size_t n_ops) {
+                                                       int tau, int32_t* __restrict__ c_out, size_t n_ops,
+                                                       const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t c_lds[64 * SIB_C_STRIDE];
     __shared__ uint32_t b_lds[64 * SIB_BLK_STRIDE];
     const int lane = threadIdx.x;
-    const size_t op = (size_t)blockIdx.x * 64 + lane;
-    const size_t wave_base = (size_t)blockIdx.x * 64;
-    const bool valid = op < n_ops;
+    if (n_dev) n_ops = *n_dev;
     int8_t* c = reinterpret_cast<int8_t*>(c_lds + lane * SIB_C_STRIDE);
     uint32_t* bw = b_lds + lane * SIB_BLK_STRIDE;
     const uint8_t* bb = reinterpret_cast<const uint8_t*>(bw);
+    for (size_t wave_base = (size_t)blockIdx.x * 64; wave_base < n_ops; wave_base += (size_t)gridDim.x * 64) {
+        const size_t op = wave_base + lane;
+        const bool valid = op < n_ops;
 
-    KeccakState st;
-    keccak_zero(st);
-    if (valid) {
-        absorb_words<CT / 8>(st, c_tilde + op * ct_stride);
-    }
-    shake_pad<SHAKE256_RATE, CT>(st);
+        KeccakState st;
+        keccak_zero(st);
+        if (valid) {
+            absorb_words<CT / 8>(st, c_tilde + op * ct_stride);
+        }
+        shake_pad<SHAKE256_RATE, CT>(st);
 #pragma unroll
-    for (int i = 0; i < 64; i++) c_lds[lane * SIB_C_STRIDE + i] = 0;
+        for (int i = 0; i < 64; i++) c_lds[lane * SIB_C_STRIDE + i] = 0;
 
-    keccak_f1600(st);
-    const uint64_t h64 = ((uint64_t)st.hi[0] << 32) | st.lo[0];  // hashing.rs:55-56
-    static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
-    int pos = 8;
-    int i = valid ? 256 - tau : 256;
-    for (;;) {
-        while (i < 256 && pos < SHAKE256_RATE) {
-            const int j = bb[pos++];
-            if (j <= i) {  // hashing.rs:68-83
-                c[i] = c[j];
-                const int index = i + tau - 256;
-                const uint32_t bit = (uint32_t)((h64 >> index) & 1u);
-                c[j] = (int8_t)(1 - 2 * (int)bit);
-                i++;
+        keccak_f1600(st);
+        const uint64_t h64 = ((uint64_t)st.hi[0] << 32) | st.lo[0];  // hashing.rs:55-56
+        static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
+        int pos = 8;
+        int i = valid ? 256 - tau : 256;
+        for (;;) {
+            while (i < 256 && pos < SHAKE256_RATE) {
+                const int j = bb[pos++];
+                if (j <= i) {  // hashing.rs:68-83
+                    c[i] = c[j];
+                    const int index = i + tau - 256;
+                    const uint32_t bit = (uint32_t)((h64 >> index) & 1u);
+                    c[j] = (int8_t)(1 - 2 * (int)bit);
+                    i++;
+                }
+            }
+            if (!__any(i < 256)) break;
+            if (i < 256) {  // this lane used up its block (rare): squeeze the next one
+                keccak_f1600(st);
+                static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
+                pos = 0;
             }
         }
-        if (!__any(i < 256)) break;
-        if (i < 256) {  // this lane used up its block (rare): squeeze the next one
-            keccak_f1600(st);
-            static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
-            pos = 0;
+        wave_lds_sync();
+        for (int row = 0; row < 64; row++) {
+            if (wave_base + row >= n_ops) break;
+            const uint32_t packed = c_lds[row * SIB_C_STRIDE + lane];
+            int4 v = make_int4((int8_t)(packed & 0xFF), (int8_t)((packed >> 8) & 0xFF), (int8_t)((packed >> 16) & 0xFF),
+                               (int8_t)(packed >> 24));
+            reinterpret_cast<int4*>(c_out + (wave_base + row) * N)[lane] = v;
         }
-    }
-    wave_lds_sync();
-    for (int row = 0; row < 64; row++) {
-        if (wave_base + row >= n_ops) break;
-        const uint32_t packed = c_lds[row * SIB_C_STRIDE + lane];
-        int4 v = make_int4((int8_t)(packed & 0xFF), (int8_t)((packed >> 8) & 0xFF), (int8_t)((packed >> 16) & 0xFF),
-                           (int8_t)(packed >> 24));
-        reinterpret_cast<int4*>(c_out + (wave_base + row) * N)[lane] = v;
+        wave_lds_sync();
     }
 }
 
@@ -289,26 +298,28 @@ int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_st
     return MLDSA_OK;
 }
 
+// n_dev != nullptr: the op count is read from the device (the signer's rounds) and n_ops only sizes the grid
 int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_stride, const uint16_t* kappa, int kappa_by_slot,
-                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s, uint8_t* yrisk) {
-    if (n_ops == 0) return MLDSA_OK;
+                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s, uint8_t* yrisk, const uint32_t* n_dev) {
+    if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
-    dim3 grid(stream_blocks(n_ops * (size_t)p->l)), block(64 * SWAVES);
-    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, yrisk, p->gamma1 - 2 * p->beta);
-    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, yrisk, p->gamma1 - 2 * p->beta);
+    dim3 grid(stream_blocks((n_ops ? n_ops : 1) * (size_t)p->l)), block(64 * SWAVES);
+    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta);
+    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
 
-int launch_sample_in_ball(mldsa_ctx*, int set, const uint8_t* c_tilde, size_t ct_stride, int32_t* c, size_t n_ops, hipStream_t s) {
-    if (n_ops == 0) return MLDSA_OK;
+int launch_sample_in_ball(mldsa_ctx*, int set, const uint8_t* c_tilde, size_t ct_stride, int32_t* c, size_t n_ops, hipStream_t s,
+                          const uint32_t* n_dev) {
+    if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sample_in_ball: unknown parameter set");
-    dim3 grid((unsigned)((n_ops + 63) / 64)), block(64);
-    if (p->ctilde_len == 32) hipLaunchKernelGGL((k_sample_in_ball<32>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops);
-    else if (p->ctilde_len == 48) hipLaunchKernelGGL((k_sample_in_ball<48>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops);
-    else hipLaunchKernelGGL((k_sample_in_ball<64>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops);
+    dim3 grid((unsigned)(((n_ops ? n_ops : 1) + 63) / 64)), block(64);
+    if (p->ctilde_len == 32) hipLaunchKernelGGL((k_sample_in_ball<32>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+    else if (p->ctilde_len == 48) hipLaunchKernelGGL((k_sample_in_ball<48>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+    else hipLaunchKernelGGL((k_sample_in_ball<64>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

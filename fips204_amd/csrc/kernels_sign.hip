@@ -81,9 +81,10 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     const int32_t* __restrict__ c_hat, const int32_t* __restrict__ y, const int32_t* __restrict__ w,
     const uint8_t* __restrict__ ctilde, const uint32_t* __restrict__ slot_op, const uint32_t* __restrict__ key_idx,
     const int32_t* __restrict__ s1, const int32_t* __restrict__ s2, const int32_t* __restrict__ t0,
-    uint16_t* __restrict__ kappa, int32_t* __restrict__ done, uint8_t* __restrict__ sigs, int spec,
+    uint16_t* __restrict__ kappa, int32_t* __restrict__ done, uint8_t* __restrict__ sigs,
+    const RoundCtl* __restrict__ ctl,
     uint8_t* __restrict__ stage, size_t stage_stride, int32_t* __restrict__ accept, int gb, int beta, int omega,
-    int ctilde_len, size_t sig_len, size_t n_slots, const Twiddle* __restrict__ inv_tab,
+    int ctilde_len, size_t sig_len, const Twiddle* __restrict__ inv_tab,
     const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk) {
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     __shared__ Twiddle tw_lds[INV_TW * 64];
@@ -91,12 +92,16 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     __shared__ int32_t rr_lds[GWAVES][K][N]; // r_i = w_i - cs2_i, kept for the hint stage
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: slot indices and row pointers stay scalar
+    const int32_t gamma1 = 1 << gb;
+    const int cb = gb + 1;
+    // slots and candidates per op of this round: written by k_make_slots (the host never sees them)
+    const uint32_t n_slots32 = ctl->ns;
+    const int spec = (int)ctl->spec;
+    if (n_slots32 == 0) return;
     for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = inv_tab[i];
     __syncthreads();
     const LdsTw itw{tw_lds, lane};
-    const int32_t gamma1 = 1 << gb;
-    const int cb = gb + 1;
-    const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES, n_slots32 = (uint32_t)n_slots;
+    const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES;
 
     // op / key of the next slot are fetched one slot ahead (two dependent loads off the critical path)
     // ... and so are its risk flags (which polynomials stage 1 has to transform, see below)
@@ -264,60 +269,163 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
 // slots that try kappa, kappa + l, ..., kappa + (spec-1) l in the same round; k_resolve keeps
 // the FIRST accepted candidate, which is exactly the signature the sequential loop of
 // ml_dsa.rs:212-330 would have produced (all earlier candidates were rejected).
-__global__ __launch_bounds__(256) void k_make_slots(const uint32_t* __restrict__ act, size_t m, int spec,
-                                                    const uint16_t* __restrict__ kappa, int l,
+//
+// The loop is driven from the device.  RoundCtl (ctx.h) lives in the workspace: cnt[p] = unfinished ops
+// entering a round of parity p.  k_make_slots opens round r: it reads m = cnt[r & 1], derives the
+// candidates per op from m with the same rule the host used to apply (1 while the active set is wide,
+// then spec_target / m, at most spec_max), publishes {m, spec, ns = m * spec} for the round's other
+// kernels and zeroes cnt[(r + 1) & 1], which k_compact of this round counts the survivors into.  Every
+// round kernel walks its units with a grid-stride loop bounded by those device values, so the host can
+// enqueue any number of rounds ahead of time (or replay them from a hipGraph) with grids sized from the
+// EXPECTED counts: a round that finds more work loops, a round that finds none exits at once.
+__global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, int parity, uint32_t spec_target, uint32_t spec_max,
+                                                    const uint32_t* __restrict__ act, const uint16_t* __restrict__ kappa, int l,
                                                     uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa,
-                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key,
-                                                    uint32_t* __restrict__ counter) {
-    const size_t sidx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (sidx == 0) *counter = 0;  // k_compact of this round counts the survivors from zero
-    if (sidx >= m * (size_t)spec) return;
-    const uint32_t op = act[sidx / spec];
-    slot_op[sidx] = op;
-    if (slot_key) slot_key[sidx] = key_idx ? key_idx[op] : op;  // row of a per-key A_hat table
-    slot_kappa[sidx] = (uint16_t)(kappa[op] + (uint32_t)(sidx % spec) * l);
+                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key) {
+    const uint32_t m = ctl->cnt[parity];
+    uint32_t spec = 1;
+    if (m > 0 && m * 2 <= spec_target) {
+        spec = spec_target / m;
+        if (spec > spec_max) spec = spec_max;
+    }
+    const uint32_t ns = m * spec;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->cnt[parity ^ 1] = 0;
+        ctl->m = m;
+        ctl->spec = spec;
+        ctl->ns = ns;
+        ctl->slots_total += ns;
+        ctl->ops_total += m;
+        ctl->rounds += m ? 1u : 0u;
+    }
+    for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < ns; sidx += gridDim.x * 256) {
+        const uint32_t op = act[sidx / spec];
+        slot_op[sidx] = op;
+        if (slot_key) slot_key[sidx] = key_idx ? key_idx[op] : op;  // row of a per-key A_hat table
+        slot_kappa[sidx] = (uint16_t)(kappa[op] + (sidx % spec) * (uint32_t)l);
+    }
 }
 
-__global__ __launch_bounds__(64) void k_resolve(const uint32_t* __restrict__ act, int spec, const int32_t* __restrict__ accept,
-                                                const uint8_t* __restrict__ stage, size_t stage_stride,
-                                                uint8_t* __restrict__ sigs, size_t sig_len, int32_t* __restrict__ done,
-                                                uint16_t* __restrict__ kappa, int l) {
-    const size_t i = blockIdx.x;
-    const uint32_t op = act[i];
-    const int lane = threadIdx.x;
-    const int mine = lane < spec ? accept[i * spec + lane] : 0;
-    const unsigned long long mask = __ballot(mine != 0);
-    if (mask == 0) {
-        if (lane == 0) kappa[op] = (uint16_t)(kappa[op] + spec * l);
-        return;
+// One 256-thread block per unfinished op: the first wave finds the first accepted candidate, all four copy its staged
+// signature (16-byte aligned rows) to the op's slot of `sigs` (any alignment: SIG_LEN is odd) as dwords assembled from
+// two aligned source words.
+__global__ __launch_bounds__(256) void k_resolve(const RoundCtl* __restrict__ ctl, const uint32_t* __restrict__ act,
+                                                 const int32_t* __restrict__ accept,
+                                                 const uint8_t* __restrict__ stage, size_t stage_stride,
+                                                 uint8_t* __restrict__ sigs, size_t sig_len, int32_t* __restrict__ done,
+                                                 uint16_t* __restrict__ kappa, int l) {
+    __shared__ int winner;
+    const int spec = (int)ctl->spec;
+    if (spec == 1) return;  // sign_tail wrote done[] / kappa[] / the signature itself
+    const uint32_t m = ctl->m;
+    const int tid = threadIdx.x;
+    for (uint32_t i = blockIdx.x; i < m; i += gridDim.x) {
+        const uint32_t op = act[i];
+        if (tid < 64) {
+            const int mine = tid < spec ? accept[(size_t)i * spec + tid] : 0;
+            const unsigned long long mask = __ballot(mine != 0);
+            if (tid == 0) winner = mask ? __ffsll((long long)mask) - 1 : -1;
+        }
+        __syncthreads();
+        const int j = winner;
+        __syncthreads();  // everyone has read `winner` before the next op's first wave overwrites it
+        if (j < 0) {
+            if (tid == 0) kappa[op] = (uint16_t)(kappa[op] + spec * l);
+            continue;
+        }
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + ((size_t)i * spec + j) * stage_stride);
+        uint8_t* dst = sigs + (size_t)op * sig_len;
+        const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);  // bytes until dst is dword aligned
+        const int n_dw = (int)((sig_len - head) / 4);
+        uint32_t* dst4 = reinterpret_cast<uint32_t*>(dst + head);
+        for (int d = tid; d < n_dw; d += 256) {
+            // bytes head + 4 d .. + 3 of the source row: words d and d + 1 funnel-shifted (the row is padded to 16 bytes)
+            const uint32_t lo = src[d], hi = src[d + 1];
+            dst4[d] = head ? __builtin_amdgcn_alignbit(hi, lo, 8 * head) : lo;
+        }
+        const uint8_t* srcb = reinterpret_cast<const uint8_t*>(src);
+        if (tid < head) dst[tid] = srcb[tid];
+        const int tail0 = head + 4 * n_dw;
+        if (tid < (int)sig_len - tail0) dst[tail0 + tid] = srcb[tail0 + tid];
+        if (tid == 0) done[op] = 1;
     }
-    const int j = __ffsll((long long)mask) - 1;
-    const uint8_t* src = stage + (i * spec + j) * stage_stride;
-    uint8_t* dst = sigs + (size_t)op * sig_len;
-    for (size_t bidx = lane; bidx < sig_len; bidx += 64) dst[bidx] = src[bidx];
-    if (lane == 0) done[op] = 1;
 }
 
 // keep the unfinished ops for the next round (order is irrelevant: ops are independent)
-__global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ act_in, size_t n, const int32_t* __restrict__ done,
-                                                 uint32_t* __restrict__ act_out, uint32_t* __restrict__ counter) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t op = act_in[i];
-    if (!done[op]) act_out[atomicAdd(counter, 1u)] = op;
+__global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int parity, const uint32_t* __restrict__ act_in,
+                                                 const int32_t* __restrict__ done, uint32_t* __restrict__ act_out) {
+    const uint32_t m = ctl->m;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        const uint32_t op = act_in[i];
+        if (!done[op]) act_out[atomicAdd(&ctl->cnt[parity ^ 1], 1u)] = op;
+    }
 }
 
-// first active list: every op except those whose ctx is too long (lib.rs:274)
-__global__ __launch_bounds__(256) void k_init_active(size_t n, const int32_t* __restrict__ ctx_bad, int32_t* __restrict__ done,
+// first active list: every op except those whose ctx is too long (lib.rs:274) or whose key index is out of
+// range (bad: 0 = fine, 1 = ctx too long, 2 = bad key index).  ctl must be zeroed beforehand.
+__global__ __launch_bounds__(256) void k_init_active(size_t n, const int32_t* __restrict__ bad_op, int32_t* __restrict__ done,
                                                      uint16_t* __restrict__ kappa, int32_t* __restrict__ status,
-                                                     uint32_t* __restrict__ act_out, uint32_t* __restrict__ counter) {
+                                                     uint32_t* __restrict__ act_out, RoundCtl* __restrict__ ctl) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     kappa[i] = 0;  // ml_dsa.rs:204
-    const int bad = ctx_bad[i];
+    const int bad = bad_op[i];
     done[i] = bad;
-    if (status) status[i] = bad ? MLDSA_ERR_CTX_LEN : MLDSA_OK;
-    if (!bad) act_out[atomicAdd(counter, 1u)] = (uint32_t)i;
+    if (status) status[i] = bad == 0 ? MLDSA_OK : bad == 1 ? MLDSA_ERR_CTX_LEN : MLDSA_ERR_PARAM;
+    if (!bad) act_out[atomicAdd(&ctl->cnt[0], 1u)] = (uint32_t)i;
+}
+
+// mldsa_sign_async: ops that are still unfinished after the enqueued rounds (parity = rounds & 1) get status
+// MLDSA_ERR_AGAIN and an all-zero signature (a rejected attempt may have left bytes there).  One block per op.
+__global__ __launch_bounds__(256) void k_mark_unfinished(const RoundCtl* __restrict__ ctl, int parity, const uint32_t* __restrict__ act,
+                                                         int32_t* __restrict__ status, uint8_t* __restrict__ sigs, size_t sig_len) {
+    const uint32_t m = ctl->cnt[parity];
+    for (uint32_t i = blockIdx.x; i < m; i += gridDim.x) {
+        const uint32_t op = act[i];
+        if (threadIdx.x == 0) status[op] = MLDSA_ERR_AGAIN;
+        for (size_t b = threadIdx.x; b < sig_len; b += 256) sigs[(size_t)op * sig_len + b] = 0;
+    }
+}
+
+// key_idx checked against n_keys (the C ABI's promise: an out-of-range index never reaches memory):
+// safe[op] = key_idx[op] if it is in range, else 0; bad[op] = 2 for the ops that were out of range
+__global__ __launch_bounds__(256) void k_sanitize_keys(const uint32_t* __restrict__ key_idx, uint32_t n_keys, size_t n_ops,
+                                                       uint32_t* __restrict__ safe, int32_t* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ops) return;
+    const uint32_t k = key_idx[i];
+    safe[i] = k < n_keys ? k : 0u;
+    bad[i] = k < n_keys ? 0 : 2;
+}
+
+// memset(dst, 0, bytes) as a kernel (any alignment): the captured pipelines consist of kernel nodes only -- memset and
+// memcpy nodes of a replayed hipGraph were observed to run out of order with the kernels around them (ROCm 7.2).
+__global__ __launch_bounds__(256) void k_zero(uint8_t* __restrict__ dst, size_t bytes) {
+    const size_t head = (size_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15);
+    const size_t h = head < bytes ? head : bytes;
+    const size_t n16 = (bytes - h) / 16;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    int4* mid = reinterpret_cast<int4*>(dst + h);
+    for (size_t i = tid; i < n16; i += stride) mid[i] = make_int4(0, 0, 0, 0);
+    const size_t tail0 = h + n16 * 16;
+    if (tid < h) dst[tid] = 0;
+    if (tid < bytes - tail0) dst[tail0 + tid] = 0;
+}
+
+// dst[i][0 .. row_bytes) = src[i][0 .. row_bytes) for rows of different strides (row_bytes % 4 == 0; kernels
+// instead of hipMemcpy2DAsync so that the pipelines consist of kernel and memset nodes only when captured)
+__global__ __launch_bounds__(256) void k_copy_rows(uint8_t* __restrict__ dst, size_t dst_stride, const uint8_t* __restrict__ src,
+                                                   size_t src_stride, int row_bytes, size_t n_rows) {
+    const int per_row = row_bytes / 4;
+    const size_t total = n_rows * (size_t)per_row;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t r = e / per_row;
+        const int w = (int)(e % per_row);
+        const uint8_t* sp = src + r * src_stride + 4 * w;
+        uint8_t* dp = dst + r * dst_stride + 4 * w;
+        const uint32_t v = load_le32(sp);
+        dp[0] = (uint8_t)v; dp[1] = (uint8_t)(v >> 8); dp[2] = (uint8_t)(v >> 16); dp[3] = (uint8_t)(v >> 24);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -397,6 +505,88 @@ __global__ __launch_bounds__(GBLOCK) void k_keygen_encode(const int32_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The inverse direction of k_unpack_ntt, one wave per polynomial: a key polynomial held as NTT-domain
+// Montgomery values (x_hat * 2^32, src/types.rs:19-41) back to coefficients -- mont_reduce, inv_ntt and the
+// centring of SerDes::into_bytes (src/lib.rs:427-493) and private_to_public_key (src/ml_dsa.rs:510-541) --
+// then either
+//   bits > 0, b >= 0: BitPack field b - centred value       (skEncode: s1 / s2 with b = eta, t0 with b = 2^12)
+//   bits > 0, b <  0: SimpleBitPack field canonical >> 13   (pkEncode of t1 from t1_d2_hat_mont, lib.rs:481-490)
+//   bits == 0:        the centred coefficients as int32[256] (get_public_key's s1 / s2)
+// into dst + key * key_stride + poly_off + j * 32 * bits (bytes) or out32[(key * out_ppk + out_off + j)][256].
+__global__ __launch_bounds__(GBLOCK) void k_key_intt(const int32_t* __restrict__ src, int polys_per_key, size_t n_keys, int bits, int b,
+                                                     uint8_t* __restrict__ dst, size_t key_stride, size_t poly_off,
+                                                     int32_t* __restrict__ out32, int out_ppk, int out_off,
+                                                     const Twiddle* __restrict__ inv_tab) {
+    __shared__ int32_t xp[GWAVES][N];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wid = (size_t)blockIdx.x * GWAVES + wave;
+    const size_t n_waves = (size_t)gridDim.x * GWAVES;
+    const size_t n_polys = n_keys * (size_t)polys_per_key;
+    InvTw tw;
+    load_inv_tw(tw, inv_tab, lane);
+    for (size_t p = wid; p < n_polys; p += n_waves) {
+        const size_t key = p / polys_per_key;
+        const int j = (int)(p % polys_per_key);
+        int32_t r[4];
+        load_packed(r, src + p * N, lane);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = mont_mul(reduce32(r[k]), 1);  // mont_reduce(x_hat_mont) = x_hat
+        ntt_inv_wave(r, tw, lane, F_MONT);                                // canonical [0, q), r[k] = x[64 k + lane]
+#pragma unroll
+        for (int k = 0; k < 4; k++) xp[wave][64 * k + lane] = r[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int4 c4 = reinterpret_cast<const int4*>(&xp[wave][0])[lane];  // coefficients 4 lane .. 4 lane + 3
+        const int32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
+        if (bits == 0) {
+            int32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = cc[k] - ((((Q / 2) - cc[k]) >> 31) & Q);  // > q/2 -> - q (ml_dsa.rs:521-527)
+            store_packed(o, out32 + (key * out_ppk + out_off + j) * (size_t)N, lane);
+        } else {
+            uint32_t f[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int32_t cen = cc[k] - ((((Q / 2) - cc[k]) >> 31) & Q);
+                f[k] = b < 0 ? (uint32_t)(cc[k] >> 13) : (uint32_t)(b - cen);
+                f[k] &= (1u << bits) - 1u;
+            }
+            store_fields(dst + key * key_stride + poly_off + (size_t)j * (32 * bits), f, bits, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// get_public_key tail (ml_dsa.rs:543-556): t = as1 + s2 (full_reduce32), t1 = Power2Round(t).hi,
+// t1_d2_hat_mont = NTT(t1) * 2^13 in Montgomery form.  One wave per polynomial.  as1[key][K] canonical coefficients
+// (k_verify_arith<.., false> output), s1s2[key][L + K] centred coefficients (k_key_intt output).
+__global__ __launch_bounds__(GBLOCK) void k_t1_hat(const int32_t* __restrict__ as1, const int32_t* __restrict__ s1s2, int k, int l,
+                                                   int32_t* __restrict__ t1_out, size_t n_keys, const Twiddle* __restrict__ fwd_tab) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * GWAVES + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * GWAVES;
+    FwdTw tw;
+    load_fwd_tw(tw, fwd_tab, lane);
+    for (size_t p = wave; p < n_keys * (size_t)k; p += n_waves) {
+        const size_t key = p / k;
+        const int i = (int)(p % k);
+        int32_t a[4], s[4], r[4];
+        load_strided(a, as1 + p * N, lane);
+        load_strided(s, s1s2 + (key * (l + k) + l + i) * (size_t)N, lane);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int32_t tt = freeze(a[c] + s[c]);
+            r[c] = (tt + (1 << 12) - 1) >> 13;  // power2round high part, high_low.rs:26-31
+        }
+        ntt_fwd_wave(r, tw, lane);
+#pragma unroll
+        for (int c = 0; c < 4; c++) r[c] = mont_mul(r[c], 6346488 /* 2^13 * 2^64 mod q */);
+        store_packed(r, t1_out + p * N, lane);
+    }
+}
+
 // ------------------------------------------------------------------------- launchers
 int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t* out, int polys_per_key, size_t n_keys, hipStream_t s) {
@@ -409,15 +599,14 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
 
 int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde,
                      const uint32_t* slot_op, const uint32_t* key_idx, const int32_t* s1, const int32_t* s2, const int32_t* t0,
-                     uint16_t* kappa, int32_t* done, uint8_t* sigs, int spec, uint8_t* stage, size_t stage_stride, int32_t* accept,
-                     size_t n_slots, hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk) {
-    if (n_slots == 0) return MLDSA_OK;
+                     uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, uint8_t* stage, size_t stage_stride,
+                     int32_t* accept, size_t slots_hint, hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk) {
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
-    dim3 grid(grid_for(ctx, n_slots, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
+    dim3 grid(grid_for(ctx, slots_hint, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
 #define MLDSA_TAIL(KK, LL, G2)                                                                                              \
     hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
-                       done, sigs, spec, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
-                       n_slots, ctx->d_inv_tw, wrisk, yrisk)
+                       done, sigs, ctl, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
+                       ctx->d_inv_tw, wrisk, yrisk)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_TAIL(6, 5, true);
     else MLDSA_TAIL(8, 7, true);
@@ -426,38 +615,87 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
     return MLDSA_OK;
 }
 
-int launch_make_slots(mldsa_ctx*, const uint32_t* act, size_t m, int spec, const uint16_t* kappa, int l, uint32_t* slot_op,
-                      uint16_t* slot_kappa, hipStream_t s, const uint32_t* key_idx, uint32_t* slot_key, uint32_t* counter) {
-    if (m == 0) return MLDSA_OK;
-    const size_t n = m * (size_t)spec;
-    hipLaunchKernelGGL(k_make_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act, m, spec, kappa, l, slot_op, slot_kappa, key_idx,
-                       slot_key, counter);
+static inline unsigned blocks256(size_t n) { return (unsigned)((n + 255) / 256 ? (n + 255) / 256 : 1); }
+
+int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t* act,
+                      const uint16_t* kappa, int l, uint32_t* slot_op, uint16_t* slot_kappa, const uint32_t* key_idx,
+                      uint32_t* slot_key, size_t slots_hint, hipStream_t s) {
+    hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, spec_target, spec_max, act, kappa, l,
+                       slot_op, slot_kappa, key_idx, slot_key);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
 
-int launch_resolve(mldsa_ctx*, const mldsa_params* p, const uint32_t* act, size_t m, int spec, const int32_t* accept,
-                   const uint8_t* stage, size_t stage_stride, uint8_t* sigs, int32_t* done, uint16_t* kappa, hipStream_t s) {
-    if (m == 0) return MLDSA_OK;
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)m), dim3(64), 0, s, act, spec, accept, stage, stage_stride, sigs,
+int launch_resolve(mldsa_ctx*, const mldsa_params* p, const RoundCtl* ctl, const uint32_t* act, const int32_t* accept,
+                   const uint8_t* stage, size_t stage_stride, uint8_t* sigs, int32_t* done, uint16_t* kappa, size_t ops_hint,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)(ops_hint ? ops_hint : 1)), dim3(256), 0, s, ctl, act, accept, stage, stage_stride, sigs,
                        (size_t)p->sig_len, done, kappa, p->l);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
 
-int launch_compact(mldsa_ctx*, const uint32_t* act_in, size_t n, const int32_t* done, uint32_t* act_out, uint32_t* counter,
-                   hipStream_t s) {
-    if (n == 0) return MLDSA_OK;
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, act_in, n, done, act_out, counter);
+int launch_compact(mldsa_ctx*, RoundCtl* ctl, int parity, const uint32_t* act_in, const int32_t* done, uint32_t* act_out,
+                   size_t ops_hint, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact, dim3(blocks256(ops_hint)), dim3(256), 0, s, ctl, parity, act_in, done, act_out);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
 
-int launch_init_active(mldsa_ctx*, size_t n, const int32_t* ctx_bad, int32_t* done, uint16_t* kappa, int32_t* status,
-                       uint32_t* act_out, uint32_t* counter, hipStream_t s) {
+int launch_init_active(mldsa_ctx*, size_t n, const int32_t* bad_op, int32_t* done, uint16_t* kappa, int32_t* status,
+                       uint32_t* act_out, RoundCtl* ctl, hipStream_t s) {
     if (n == 0) return MLDSA_OK;
-    hipLaunchKernelGGL(k_init_active, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, ctx_bad, done, kappa, status, act_out,
-                       counter);
+    hipLaunchKernelGGL(k_init_active, dim3(blocks256(n)), dim3(256), 0, s, n, bad_op, done, kappa, status, act_out, ctl);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_mark_unfinished(mldsa_ctx*, const RoundCtl* ctl, int parity, const uint32_t* act, int32_t* status, uint8_t* sigs,
+                           size_t sig_len, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_unfinished, dim3(64), dim3(256), 0, s, ctl, parity, act, status, sigs, sig_len);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_sanitize_keys(mldsa_ctx*, const uint32_t* key_idx, size_t n_keys, size_t n_ops, uint32_t* safe, int32_t* bad, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    const uint32_t nk = n_keys > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_keys;
+    hipLaunchKernelGGL(k_sanitize_keys, dim3(blocks256(n_ops)), dim3(256), 0, s, key_idx, nk, n_ops, safe, bad);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_zero(mldsa_ctx* ctx, void* dst, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_zero, dim3(grid_for(ctx, bytes / 16 + 1, 256, 8)), dim3(256), 0, s, static_cast<uint8_t*>(dst), bytes);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_copy_rows(mldsa_ctx* ctx, void* dst, size_t dst_stride, const void* src, size_t src_stride, int row_bytes, size_t n_rows,
+                     hipStream_t s) {
+    if (n_rows == 0 || row_bytes == 0) return MLDSA_OK;
+    if (row_bytes & 3) return set_error(MLDSA_ERR_PARAM, "copy_rows: row length must be a multiple of 4 bytes");
+    hipLaunchKernelGGL(k_copy_rows, dim3(grid_for(ctx, n_rows * (size_t)(row_bytes / 4), 256, 8)), dim3(256), 0, s,
+                       static_cast<uint8_t*>(dst), dst_stride, static_cast<const uint8_t*>(src), src_stride, row_bytes, n_rows);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_key_intt(mldsa_ctx* ctx, const int32_t* src, int polys_per_key, size_t n_keys, int bits, int b, uint8_t* dst,
+                    size_t key_stride, size_t poly_off, int32_t* out32, int out_ppk, int out_off, hipStream_t s) {
+    if (n_keys == 0 || polys_per_key == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_key_intt, dim3(grid_for(ctx, n_keys * (size_t)polys_per_key, GWAVES, 8)), dim3(GBLOCK), 0, s, src, polys_per_key,
+                       n_keys, bits, b, dst, key_stride, poly_off, out32, out_ppk, out_off, ctx->d_inv_tw);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_t1_hat(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* as1, const int32_t* s1s2, int32_t* t1_out, size_t n_keys,
+                  hipStream_t s) {
+    if (n_keys == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_t1_hat, dim3(grid_for(ctx, n_keys * (size_t)p->k, GWAVES, 8)), dim3(GBLOCK), 0, s, as1, s1s2, p->k, p->l, t1_out,
+                       n_keys, ctx->d_fwd_tw);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -1,10 +1,18 @@
 // Op-level sequencing: the batch orchestrator that reproduces the composition of the
 // reference's callers on the device, chunk by chunk.
 //   verify_batch  = verify_internal  (src/ml_dsa.rs:351-437)
-// Intermediates live in one context-owned workspace that grows on demand (sized for HBM:
-// a 65536-op chunk of ML-DSA-87 needs ~4.5 GiB, mostly A_hat; fixed per-kernel latencies are
-// amortised over whole-batch launches).
-#include <cstdlib>
+//   sign_batch    = sign_internal    (src/ml_dsa.rs:153-337)
+//   keygen_batch  = key_gen_internal (src/ml_dsa.rs:57-134) + into_bytes
+// Intermediates live in one context-owned workspace (sized for HBM: a 65536-op chunk of ML-DSA-87 needs
+// ~4.5 GiB, mostly A_hat; fixed per-kernel latencies are amortised over whole-batch launches).
+//
+// Every pipeline is a pure ENQUEUE function: no allocation, no host synchronisation, no host decision that
+// depends on device data.  That makes a call capturable: run_op() replays a repeated call shape as a
+// hipGraph (one graph launch instead of 10 ... 100 kernel launches) and falls back to direct launches for
+// shapes it has not seen twice.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
 
 #include "ctx.h"
 
@@ -14,9 +22,11 @@ constexpr size_t CHUNK_OPS = 65536;
 
 int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return MLDSA_OK;
+    // growing replaces the buffer every captured graph points into
+    drop_graphs(ctx);
     if (ctx->ws) {
         MLDSA_HIP_CHECK(hipDeviceSynchronize());
-        (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // may hold secrets of a previous sign call
+        (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // may hold secrets of a previous sign / keygen call
         MLDSA_HIP_CHECK(hipFree(ctx->ws));
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
@@ -24,6 +34,7 @@ int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     hipError_t e = hipMalloc(&ctx->ws, bytes);
     if (e != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "workspace allocation", e);
     ctx->ws_bytes = bytes;
+    ctx->stats.workspace_growths++;
     return MLDSA_OK;
 }
 
@@ -42,8 +53,8 @@ struct Carver {
 };
 
 struct VerifyWs {
-    int32_t *a_hat, *c, *znorm, *hvalid, *ctx_bad;
-    uint32_t *hmask;
+    int32_t *a_hat, *c, *znorm, *hvalid, *ctx_bad, *key_bad;
+    uint32_t *hmask, *kidx;
     uint8_t *mu_w1, *ctilde_p;
     size_t bytes;
     VerifyWs(void *base, const mldsa_params *p, size_t n, bool own_a_hat) {
@@ -53,6 +64,8 @@ struct VerifyWs {
         znorm = cv.take<int32_t>(n);
         hvalid = cv.take<int32_t>(n);
         ctx_bad = cv.take<int32_t>(n);
+        key_bad = cv.take<int32_t>(n);
+        kidx = cv.take<uint32_t>(n);
         hmask = cv.take<uint32_t>(n * p->k * 8);
         mu_w1 = cv.take<uint8_t>(n * (size_t)(64 + p->w1_len));  // mu || w1_encode(w1') per op
         ctilde_p = cv.take<uint8_t>(n * 64);
@@ -64,8 +77,12 @@ struct VerifyWs {
 #define TRY(expr) do { int _rc = (expr); if (_rc != MLDSA_OK) return _rc; } while (0)
 #define STAGE(name, expr) do { ProfScope _ps(ctx, s, name); TRY(expr); } while (0)
 
+size_t verify_workspace_bytes(const mldsa_params *p, size_t n_ops, bool own_a) {
+    return VerifyWs(nullptr, p, n_ops < CHUNK_OPS ? n_ops : CHUNK_OPS, own_a).bytes;
+}
+
 // verify_internal (ml_dsa.rs:351-437) for n_ops independent (key, message, signature) triples
-int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1,
+int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1, size_t n_keys,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
                  const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t s,
                  const int32_t *a_hat_keys) {
@@ -73,16 +90,25 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
     if (!p) return set_error(MLDSA_ERR_PARAM, "verify: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
     const size_t chunk = n_ops < CHUNK_OPS ? n_ops : CHUNK_OPS;
-    TRY(ensure_workspace(ctx, VerifyWs(nullptr, p, chunk, a_hat_keys == nullptr).bytes));
+    if (ctx->ws_bytes < VerifyWs(nullptr, p, chunk, a_hat_keys == nullptr).bytes)
+        return set_error(MLDSA_ERR_NOMEM, "verify: workspace not reserved");
     const size_t mw = (size_t)(64 + p->w1_len);
     const size_t kl_coeffs = (size_t)(p->k * p->l) * N;
     for (size_t o = 0; o < n_ops; o += chunk) {
         const size_t n = (n_ops - o) < chunk ? (n_ops - o) : chunk;
         VerifyWs w(ctx->ws, p, chunk, a_hat_keys == nullptr);
         const uint8_t *sg = sigs + o * (size_t)p->sig_len;
-        const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
+        // key_idx is checked against n_keys on the device: the kernels below only see in-range indices, ops
+        // with a bad index are flagged (ok = 0).  Identity mapping (key_idx == NULL) was checked by the caller.
+        const uint32_t *kidx = nullptr;
+        const int32_t *key_bad = nullptr;
+        if (key_idx) {
+            TRY(launch_sanitize_keys(ctx, key_idx + o, n_keys, n, w.kidx, w.key_bad, s));
+            kidx = w.kidx;
+            key_bad = w.key_bad;
+        }
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
-        MLDSA_HIP_CHECK(hipMemsetAsync(w.znorm, 0, n * sizeof(int32_t), s));
+        TRY(launch_zero(ctx, w.znorm, n * sizeof(int32_t), s));
         // fork: the small lane-per-op kernels are latency-bound (1-2 Keccak-f per op, <= 1 wave per SIMD) and
         // independent of ExpandA, so they run on the context's second stream underneath it
         hipStream_t aux = ctx->aux_stream;
@@ -97,7 +123,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
             // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
             ProfScope ps(ctx, aux, "mu");
             TRY(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
-                          w.mu_w1, mw, w.ctx_bad, n, aux));
+                          w.mu_w1, mw, w.ctx_bad, n, aux, key_bad));
         }
         {
             // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
@@ -129,7 +155,7 @@ int pk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, ui
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "pk_expand: unknown parameter set");
     if (n == 0) return MLDSA_OK;
-    MLDSA_HIP_CHECK(hipMemcpy2DAsync(rho, 32, pk, (size_t)p->pk_len, 32, n, hipMemcpyDeviceToDevice, s));
+    TRY(launch_copy_rows(ctx, rho, 32, pk, (size_t)p->pk_len, 32, n, s));
     TRY(launch_shake256_2(ctx, 64, pk, (size_t)p->pk_len, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, tr, 64, n, s));  // tr = H(pk)
     // t1_d2_hat_mont = ntt(t1) * 2^13 * 2^32  (ml_dsa.rs:492-495)
     TRY(launch_unpack_ntt(ctx, pk, (size_t)p->pk_len, 32, 10, -1, 6346488 /* 2^13 * 2^64 mod q */, t1, p->k, n, s));
@@ -144,12 +170,39 @@ int sk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, ui
     if (n == 0) return MLDSA_OK;
     const size_t skl = (size_t)p->sk_len;
     const int eb = p->eta == 2 ? 3 : 4;
-    MLDSA_HIP_CHECK(hipMemcpy2DAsync(rho, 32, sk, skl, 32, n, hipMemcpyDeviceToDevice, s));
-    MLDSA_HIP_CHECK(hipMemcpy2DAsync(cap_k, 32, sk + 32, skl, 32, n, hipMemcpyDeviceToDevice, s));
-    MLDSA_HIP_CHECK(hipMemcpy2DAsync(tr, 64, sk + 64, skl, 64, n, hipMemcpyDeviceToDevice, s));
+    TRY(launch_copy_rows(ctx, rho, 32, sk, skl, 32, n, s));
+    TRY(launch_copy_rows(ctx, cap_k, 32, sk + 32, skl, 32, n, s));
+    TRY(launch_copy_rows(ctx, tr, 64, sk + 64, skl, 64, n, s));
     TRY(launch_unpack_ntt(ctx, sk, skl, 128, eb, p->eta, R2_MOD_Q, s1, p->l, n, s));
     TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)p->l * 32 * eb, eb, p->eta, R2_MOD_Q, s2, p->k, n, s));
     TRY(launch_unpack_ntt(ctx, sk, skl, 128 + (size_t)(p->l + p->k) * 32 * eb, 13, 1 << 12, R2_MOD_Q, t0, p->k, n, s));
+    return MLDSA_OK;
+}
+
+// PublicKey::into_bytes (lib.rs:478-493): pk = rho | SimpleBitPack(inv_ntt(mont_reduce(t1_d2_hat_mont)) >> 13, 10 bits)
+int pk_into_bytes_batch(mldsa_ctx *ctx, int set, const uint8_t *rho, const int32_t *t1, uint8_t *pk, size_t n, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "pk_into_bytes: unknown parameter set");
+    if (n == 0) return MLDSA_OK;
+    TRY(launch_copy_rows(ctx, pk, (size_t)p->pk_len, rho, 32, 32, n, s));
+    TRY(launch_key_intt(ctx, t1, p->k, n, 10, -1, pk, (size_t)p->pk_len, 32, nullptr, 0, 0, s));
+    return MLDSA_OK;
+}
+
+// PrivateKey::into_bytes (lib.rs:427-465): sk = rho | K | tr | BitPack(s1, eta) | BitPack(s2, eta) | BitPack(t0, 2^12)
+int sk_into_bytes_batch(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1,
+                        const int32_t *s2, const int32_t *t0, uint8_t *sk, size_t n, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "sk_into_bytes: unknown parameter set");
+    if (n == 0) return MLDSA_OK;
+    const size_t skl = (size_t)p->sk_len;
+    const int eb = p->eta == 2 ? 3 : 4;
+    TRY(launch_copy_rows(ctx, sk, skl, rho, 32, 32, n, s));
+    TRY(launch_copy_rows(ctx, sk + 32, skl, cap_k, 32, 32, n, s));
+    TRY(launch_copy_rows(ctx, sk + 64, skl, tr, 64, 64, n, s));
+    TRY(launch_key_intt(ctx, s1, p->l, n, eb, p->eta, sk, skl, 128, nullptr, 0, 0, s));
+    TRY(launch_key_intt(ctx, s2, p->k, n, eb, p->eta, sk, skl, 128 + (size_t)p->l * 32 * eb, nullptr, 0, 0, s));
+    TRY(launch_key_intt(ctx, t0, p->k, n, 13, 1 << 12, sk, skl, 128 + (size_t)(p->l + p->k) * 32 * eb, nullptr, 0, 0, s));
     return MLDSA_OK;
 }
 
@@ -158,70 +211,112 @@ namespace {
 struct KeygenWs {
     uint8_t *hbuf;
     int32_t *s1s2, *a_hat, *as1;
-    size_t bytes;
+    size_t bytes, secret_bytes;  // secret_bytes: hbuf .. end of as1 (rho' / K, s1, s2, A s1)
     KeygenWs(void *base, const mldsa_params *p, size_t n) {
         Carver cv(base);
+        a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);  // public (ExpandA(rho)): first, outside the zeroised span
         hbuf = cv.take<uint8_t>(n * 128);
+        const size_t secret_off = cv.off - n * 128;
         s1s2 = cv.take<int32_t>(n * (size_t)(p->l + p->k) * N);
-        a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);
         as1 = cv.take<int32_t>(n * (size_t)p->k * N);
+        secret_bytes = cv.off - secret_off;
         bytes = cv.off + 256;
     }
 };
 }  // namespace
+
+size_t keygen_workspace_bytes(const mldsa_params *p, size_t n_keys) {
+    return KeygenWs(nullptr, p, n_keys < CHUNK_OPS ? n_keys : CHUNK_OPS).bytes;
+}
 
 int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t s) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "keygen: unknown parameter set");
     if (n_keys == 0) return MLDSA_OK;
     const size_t chunk = n_keys < CHUNK_OPS ? n_keys : CHUNK_OPS;
-    TRY(ensure_workspace(ctx, KeygenWs(nullptr, p, chunk).bytes));
+    if (ctx->ws_bytes < KeygenWs(nullptr, p, chunk).bytes) return set_error(MLDSA_ERR_NOMEM, "keygen: workspace not reserved");
     const size_t pkl = (size_t)p->pk_len, skl = (size_t)p->sk_len;
-    for (size_t o = 0; o < n_keys; o += chunk) {
+    KeygenWs w(ctx->ws, p, chunk);
+    int rc = MLDSA_OK;
+    for (size_t o = 0; o < n_keys && rc == MLDSA_OK; o += chunk) {
         const size_t n = (n_keys - o) < chunk ? (n_keys - o) : chunk;
-        KeygenWs w(ctx->ws, p, chunk);
         uint8_t *pko = pk + o * pkl, *sko = sk + o * skl;
-        // 1: (rho, rho', K) <- H(xi || k || l, 128)                          ml_dsa.rs:68-74
-        STAGE("seed_hash", launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
-                                             w.hbuf, 128, n, s));
-        STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
-        STAGE("expand_a", launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s, true));          // :85 (24-bit form)
-        // :86-88 inv_ntt(A * ntt(s1)); s1 is read in place from the (s1, s2) rows ExpandS wrote
-        STAGE("sign_w", launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1s2, w.as1, nullptr, 0, n, s, (size_t)(p->l + p->k), nullptr, true));
-        STAGE("keygen_encode", launch_keygen_encode(ctx, p, w.s1s2, w.as1, w.hbuf, pko, sko, n, s));  // :88-92, pk/sk encode incl. rho, K
-        STAGE("tr_hash", launch_shake256_2(ctx, 64, pko, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, sko + 64, skl, n, s));  // tr = H(pk), :99-101
+        rc = [&]() -> int {
+            // 1: (rho, rho', K) <- H(xi || k || l, 128)                          ml_dsa.rs:68-74
+            STAGE("seed_hash", launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
+                                                 w.hbuf, 128, n, s));
+            STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
+            STAGE("expand_a", launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s, true));          // :85 (24-bit form)
+            // :86-88 inv_ntt(A * ntt(s1)); s1 is read in place from the (s1, s2) rows ExpandS wrote
+            STAGE("sign_w", launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1s2, w.as1, nullptr, 0, n, s, (size_t)(p->l + p->k), nullptr, true));
+            STAGE("keygen_encode", launch_keygen_encode(ctx, p, w.s1s2, w.as1, w.hbuf, pko, sko, n, s));  // :88-92, pk/sk encode incl. rho, K
+            STAGE("tr_hash", launch_shake256_2(ctx, 64, pko, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, sko + 64, skl, n, s));  // tr = H(pk), :99-101
+            return MLDSA_OK;
+        }();
     }
-    return MLDSA_OK;
+    // rho' / K, s1, s2 and A s1 are secret: cleared on every path out, like the reference's zeroize-on-drop (types.rs:19)
+    (void)launch_zero(ctx, w.hbuf, w.secret_bytes, s);
+    return rc;
+}
+
+// Signer::get_public_key -> private_to_public_key (ml_dsa.rs:502-559)
+int get_public_key_batch(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint8_t *tr, const int32_t *s1, const int32_t *s2,
+                         uint8_t *pk_rho, uint8_t *pk_tr, int32_t *pk_t1, size_t n_keys, hipStream_t s) {
+    const mldsa_params *p = params_of(set);
+    if (!p) return set_error(MLDSA_ERR_PARAM, "get_public_key: unknown parameter set");
+    if (n_keys == 0) return MLDSA_OK;
+    const size_t chunk = n_keys < CHUNK_OPS ? n_keys : CHUNK_OPS;
+    if (ctx->ws_bytes < KeygenWs(nullptr, p, chunk).bytes) return set_error(MLDSA_ERR_NOMEM, "get_public_key: workspace not reserved");
+    KeygenWs w(ctx->ws, p, chunk);
+    const int k = p->k, l = p->l;
+    int rc = MLDSA_OK;
+    for (size_t o = 0; o < n_keys && rc == MLDSA_OK; o += chunk) {
+        const size_t n = (n_keys - o) < chunk ? (n_keys - o) : chunk;
+        rc = [&]() -> int {
+            // s_1 / s_2 back to centred coefficients (ml_dsa.rs:512-527; the reference keeps s_1 in the NTT domain and
+            // transforms only s_2 -- same values: ntt(inv_ntt(x)) = x)
+            TRY(launch_key_intt(ctx, s1 + o * (size_t)l * N, l, n, 0, 0, nullptr, 0, 0, w.s1s2, l + k, 0, s));
+            TRY(launch_key_intt(ctx, s2 + o * (size_t)k * N, k, n, 0, 0, nullptr, 0, 0, w.s1s2, l + k, l, s));
+            TRY(launch_expand_a(ctx, set, rho + o * 32, 32, nullptr, w.a_hat, n, s, true));                      // :508
+            TRY(launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1s2, w.as1, nullptr, 0, n, s, (size_t)(l + k), nullptr, true));  // :544-545
+            TRY(launch_t1_hat(ctx, p, w.as1, w.s1s2, pk_t1 + o * (size_t)k * N, n, s));                        // :546-556
+            TRY(launch_copy_rows(ctx, pk_rho + o * 32, 32, rho + o * 32, 32, 32, n, s));
+            TRY(launch_copy_rows(ctx, pk_tr + o * 64, 64, tr + o * 64, 64, 64, n, s));
+            return MLDSA_OK;
+        }();
+    }
+    (void)launch_zero(ctx, w.hbuf, w.secret_bytes, s);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------
-// Signer::try_sign_* -> sign_internal (ml_dsa.rs:153-337) with the rejection loop re-batched:
-// every round runs one loop iteration for all unfinished ops of a sub-batch, then compacts its
-// active list.  Sub-batches run on several streams ("lanes") at different phases of the loop,
-// so the short, latency-bound late rounds of one lane fill the machine under the wide early
-// rounds of another; a lane that finishes takes the next sub-batch of the call.
+// Signer::try_sign_* -> sign_internal (ml_dsa.rs:153-337) with the rejection loop re-batched and driven from
+// the device: every round runs one loop iteration for all unfinished ops, then compacts the active list.  The
+// round kernels take their counts from RoundCtl in the workspace (kernels_sign.hip), so the host enqueues a
+// whole call -- prologue + a planned number of rounds -- without reading anything back in between.
 namespace {
-constexpr size_t SIGN_CHUNK_OPS = 65536;     // ops resident per call pass (workspace size), all lanes together
-constexpr size_t SPEC_TARGET_SLOTS = 65536;  // upper bound of candidate slots per speculative round, all lanes together
+constexpr size_t SIGN_CHUNK_OPS = 65536;  // ops resident per call pass (workspace size)
 
 struct SignWs {
-    int32_t *a_hat, *y, *w, *c, *done, *ctx_bad, *accept;
+    int32_t *a_hat, *y, *w, *c, *done, *bad_op, *key_bad, *accept;
     uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage, *wrisk, *yrisk;
     uint16_t *kappa, *slot_kappa;
-    uint32_t *act0, *act1, *slot_op, *slot_key, *counter;
+    uint32_t *act[2], *slot_op, *slot_key, *kidx;
+    RoundCtl *ctl;
     size_t bytes = 0, stage_stride = 0;
     SignWs() = default;
-    // n = ops of the sub-batch, spec_slots = cap of candidate slots in a speculative round
-    SignWs(void *base, const mldsa_params *p, size_t n, size_t spec_slots, bool own_a_hat) {
+    // n = ops of the chunk, ns = most candidate slots of a round
+    SignWs(void *base, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat) {
         Carver cv(base);
-        const size_t ns = n > spec_slots ? n : spec_slots;  // slots per round
         stage_stride = ((size_t)p->sig_len + 15) & ~(size_t)15;
         a_hat = cv.take<int32_t>(own_a_hat ? n * (size_t)(p->k * p->l) * N : 0);
-        y = cv.take<int32_t>(ns * (size_t)p->l * N);
+        key_bad = cv.take<int32_t>(n);
+        kidx = cv.take<uint32_t>(n);
+        y = cv.take<int32_t>(ns * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
         w = cv.take<int32_t>(ns * (size_t)p->k * N);
         c = cv.take<int32_t>(ns * (size_t)N);
         done = cv.take<int32_t>(n);
-        ctx_bad = cv.take<int32_t>(n);
+        bad_op = cv.take<int32_t>(n);
         accept = cv.take<int32_t>(ns);
         rnd_mu = cv.take<uint8_t>(n * 96);  // rnd || mu per op: H(K || rnd || mu) input, ml_dsa.rs:199
         rho_pp = cv.take<uint8_t>(n * 64);
@@ -229,197 +324,325 @@ struct SignWs {
         ctilde = cv.take<uint8_t>(ns * 64);
         wrisk = cv.take<uint8_t>(ns);
         yrisk = cv.take<uint8_t>(ns * (size_t)p->l);
-        stage = cv.take<uint8_t>(spec_slots * stage_stride);
+        stage = cv.take<uint8_t>(ns * stage_stride);
         kappa = cv.take<uint16_t>(n);
         slot_kappa = cv.take<uint16_t>(ns);
-        act0 = cv.take<uint32_t>(n);
-        act1 = cv.take<uint32_t>(n);
+        act[0] = cv.take<uint32_t>(n);
+        act[1] = cv.take<uint32_t>(n);
         slot_op = cv.take<uint32_t>(ns);
         slot_key = cv.take<uint32_t>(ns);
-        counter = cv.take<uint32_t>(64);
+        ctl = cv.take<RoundCtl>(1);
         bytes = (cv.off + 511) & ~(size_t)255;
     }
 };
 
-struct SignLane {
-    hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;
-    volatile uint32_t *h_count = nullptr;
-    SignWs w;
-    size_t o = 0, n = 0, m = 0;
-    uint32_t *act = nullptr, *act_next = nullptr;
-    bool live = false, in_round = false;
+// per-iteration acceptance probability of sign_internal's loop (FIPS 204 table 1: 4.25 / 5.1 / 3.85 expected iterations)
+double accept_prob(int set) { return set == MLDSA_44 ? 1.0 / 4.25 : set == MLDSA_65 ? 1.0 / 5.1 : 1.0 / 3.85; }
+
+// The a-priori round plan of one chunk: the device applies the speculation rule to the ACTUAL number of
+// unfinished ops; the host replays the same rule on the EXPECTED number to size the grids and to know how
+// many rounds to enqueue.  Rounds continue until the expected number of unfinished ops is below a threshold (by
+// Markov's inequality the probability that an op is left is below it too).
+struct SignPlan {
+    uint32_t spec_target = 1, spec_max = 1;
+    size_t ns_max = 0;
+    std::vector<size_t> m_hint, ns_hint;  // per round: ops / slots the grids are sized for
 };
 
-int env_int(const char *name, long lo, long hi, long dflt) {
-    if (const char *e = getenv(name)) {
-        const long v = atol(e);
-        if (v >= lo && v <= hi) return (int)v;
+SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode) {
+    SignPlan pl;
+    pl.spec_max = (uint32_t)ctx->opt_spec_max;
+    // a small batch cannot fill the target however many candidates each op gets: cap it so that the
+    // workspace and the grids follow the batch
+    const size_t tgt = std::min<size_t>((size_t)ctx->opt_spec_target, std::max<size_t>(n * pl.spec_max, 1));
+    pl.spec_target = (uint32_t)tgt;
+    pl.ns_max = std::max(n, tgt);
+    const double q = 1.0 - accept_prob(set);
+    double m = (double)n;
+    // a synchronous call looks at the device once anyway and adds rounds if an op is left (so its plan only has to make
+    // that rare: < 1e-3 of the calls); an asynchronous call cannot, and plans until < 1e-9
+    const double stop = async_mode ? 1e-9 : 1e-3;
+    for (int r = 0; r < 64 && m > stop; r++) {
+        // grids follow mean + 6 sigma of the binomial count (a round that still finds more just loops)
+        const double m_hi = std::min((double)n, m + 6.0 * std::sqrt(m) + 1.0);
+        const size_t mh = (size_t)std::ceil(m_hi);
+        size_t spec = 1;
+        if (mh * 2 <= tgt) spec = std::min<size_t>(tgt / mh, pl.spec_max);
+        double spec_mean = 1;  // the rule applied to the mean (what the device will mostly see)
+        const size_t mm = (size_t)std::max(1.0, std::floor(m));
+        if (mm * 2 <= tgt) spec_mean = (double)std::min<size_t>(tgt / mm, pl.spec_max);
+        pl.m_hint.push_back(mh);
+        pl.ns_hint.push_back(std::min(pl.ns_max, std::max(mh * spec, (size_t)std::ceil(m_hi * spec_mean))));
+        m *= std::pow(q, spec_mean);
     }
-    return (int)dflt;
+    if (ctx->opt_sign_rounds > 0 && (size_t)ctx->opt_sign_rounds < pl.m_hint.size()) {
+        pl.m_hint.resize((size_t)ctx->opt_sign_rounds);
+        pl.ns_hint.resize((size_t)ctx->opt_sign_rounds);
+    }
+    return pl;
+}
+}  // namespace
+
+size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a) {
+    const size_t n = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
+    return SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a).bytes;
+}
+
+// One round of the rejection loop (steps 10-33 of Algorithm 7), counts read from the device
+static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, int round, size_t m_hint,
+                              size_t ns_hint, const uint32_t *kidx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
+                              const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s) {
+    const int set = p->set, par = round & 1;
+    const bool own_a = a_hat_keys == nullptr;
+    const uint32_t *ns_dev = &w.ctl->ns;
+    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.spec_target, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
+                                          w.slot_kappa, kidx, own_a ? nullptr : w.slot_key, ns_hint, s));
+    // 11: y <- ExpandMask(rho'', kappa)                               :215
+    STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns_hint, s, w.yrisk, ns_dev));
+    // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
+    STAGE("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys, own_a ? w.slot_op : w.slot_key, w.y, w.w, w.w1,
+                                  (size_t)p->w1_len, ns_hint, s, 0, w.wrisk, own_a, ns_dev));
+    // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
+    STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
+                                           w.ctilde, 64, ns_hint, s, ns_dev));
+    // 16: c <- SampleInBall(c_tilde)                                  :237
+    STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns_hint, s, ns_dev));
+    // 17: c_hat <- NTT(c), in place                                   :240
+    STAGE("ntt_c", launch_ntt(ctx, w.c, w.c, ns_hint, s, ns_dev));
+    // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
+    STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.stage,
+                                        w.stage_stride, w.accept, ns_hint, s, w.wrisk, w.yrisk));
+    // speculative rounds only (the kernel leaves at once when the device chose one candidate per op)
+    STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa,
+                                    std::min<size_t>(m_hint, 4096), s));
+    STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s));
+    return MLDSA_OK;
+}
+
+namespace {
+struct SignArgs {
+    int set, mode;
+    const uint8_t *rho, *cap_k, *tr;
+    const int32_t *s1, *s2, *t0;
+    size_t n_keys;
+    const uint32_t *key_idx;
+    const uint8_t *msgs;
+    const uint64_t *msg_off;
+    const uint8_t *ctxs;
+    const uint64_t *ctx_off;
+    const uint8_t *rnd;
+    uint8_t *sigs;
+    int32_t *status;
+    const int32_t *a_hat_keys;
+    size_t offset, n;   // this chunk: first op and number of ops
+    size_t chunk;       // ops the workspace / plan is laid out for
+    int async_mode;
+};
+
+struct ChunkKeys {  // per-chunk views of the key tables (identity mapping walks with the chunk)
+    const uint32_t *kidx;
+    const int32_t *s1k, *s2k, *t0k, *ak;
+    uint8_t *sg;
+};
+
+ChunkKeys chunk_keys(const mldsa_params *p, const SignWs &w, const SignArgs &a) {
+    const size_t key_base = a.key_idx ? 0 : a.offset;
+    ChunkKeys c;
+    c.kidx = a.key_idx ? w.kidx : nullptr;
+    c.s1k = a.s1 + key_base * (size_t)p->l * N;
+    c.s2k = a.s2 + key_base * (size_t)p->k * N;
+    c.t0k = a.t0 + key_base * (size_t)p->k * N;
+    c.ak = a.a_hat_keys ? a.a_hat_keys + key_base * (size_t)(p->k * p->l) * N : nullptr;
+    c.sg = a.sigs + a.offset * (size_t)p->sig_len;
+    return c;
+}
+
+void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
+    // y, rho'', cs1 / cs2, staged signatures are secret-dependent (the reference zeroizes on drop, types.rs:19);
+    // A_hat = ExpandA(rho) is public and is the first and largest carve: skipped.
+    uint8_t *secrets = reinterpret_cast<uint8_t *>(w.y);
+    (void)launch_zero(ctx, secrets, (size_t)(static_cast<uint8_t *>(ctx->ws) + w.bytes - secrets), s);
+}
+
+// steps 1-8 of Algorithm 7 and the planned rounds of the loop for one chunk: enqueue only (capturable)
+int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, const SignArgs &a, hipStream_t s) {
+    const bool own_a = a.a_hat_keys == nullptr;
+    const size_t o = a.offset, n = a.n;
+    int32_t *st = a.status ? a.status + o : nullptr;
+    const int32_t *key_bad = nullptr;
+    if (a.key_idx) {
+        TRY(launch_sanitize_keys(ctx, a.key_idx + o, a.n_keys, n, w.kidx, w.key_bad, s));
+        key_bad = w.key_bad;
+    }
+    const ChunkKeys c = chunk_keys(p, w, a);
+    const size_t key_base = a.key_idx ? 0 : o;
+    TRY(launch_zero(ctx, c.sg, n * (size_t)p->sig_len, s));
+    TRY(launch_zero(ctx, w.ctl, sizeof(RoundCtl), s));
+    // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
+    if (own_a) STAGE("expand_a", launch_expand_a(ctx, a.set, a.rho + key_base * 32, 32, c.kidx, w.a_hat, n, s, true));
+    // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
+    STAGE("mu", launch_mu(ctx, a.tr + key_base * 64, 64, c.kidx, a.mode, a.msgs, a.msg_off + o, a.ctxs, a.ctx_off ? a.ctx_off + o : nullptr,
+                          w.rnd_mu + 32, 96, w.bad_op, n, s, key_bad));
+    TRY(launch_copy_rows(ctx, w.rnd_mu, 96, a.rnd + o * 32, 32, 32, n, s));
+    // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
+    STAGE("rho_pp_hash", launch_shake256_2(ctx, 64, a.cap_k + key_base * 32, 32, 32, c.kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
+    // 8: kappa <- 0; active = all ops with a legal ctx and key index
+    TRY(launch_init_active(ctx, n, w.bad_op, w.done, w.kappa, st, w.act[0], w.ctl, s));
+    // 10: while (z, h) = bottom                                            ml_dsa.rs:212
+    const int rounds = (int)pl.m_hint.size();
+    for (int round = 0; round < rounds; round++) {
+        // the plan is for a full chunk; a short last chunk only makes its grids generous
+        TRY(enqueue_sign_round(ctx, p, w, pl, round, std::min(pl.m_hint[round], n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k, c.ak,
+                               c.sg, s));
+    }
+    if (a.async_mode) {
+        // no host wait: what is (with probability < 1e-9) still unfinished is reported per op
+        TRY(launch_mark_unfinished(ctx, w.ctl, rounds & 1, w.act[rounds & 1], st, c.sg, (size_t)p->sig_len, s));
+        zeroise_sign_ws(ctx, w, s);
+    }
+    return MLDSA_OK;
+}
+
+// the one host wait of a synchronous call; stragglers (practically never) get further rounds
+int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, const SignArgs &a, hipStream_t s) {
+    const ChunkKeys c = chunk_keys(p, w, a);
+    int round = (int)pl.m_hint.size();
+    MLDSA_HIP_CHECK(hipMemcpyAsync(ctx->h_ctl, w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
+    for (;;) {
+        MLDSA_HIP_CHECK(hipStreamSynchronize(s));
+        ctx->last_sign_slots += ctx->h_ctl->slots_total;
+        if (ctx->prof_on) {
+            ctx->prof_sign_slots += ctx->h_ctl->slots_total;
+            ctx->prof_sign_op_rounds += ctx->h_ctl->ops_total;
+        }
+        if (ctx->h_ctl->cnt[round & 1] == 0) break;
+        TRY(launch_zero(ctx, &w.ctl->slots_total, 2 * sizeof(unsigned long long), s));
+        for (int e = 0; e < 2; e++, round++) {
+            ctx->stats.sign_extra_rounds++;
+            TRY(enqueue_sign_round(ctx, p, w, pl, round, 64, std::min<size_t>(pl.ns_max, 2048), c.kidx, c.s1k, c.s2k, c.t0k, c.ak, c.sg, s));
+        }
+        MLDSA_HIP_CHECK(hipMemcpyAsync(ctx->h_ctl, w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
+    }
+    return MLDSA_OK;
 }
 }  // namespace
 
 int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
-               const int32_t *s1, const int32_t *s2, const int32_t *t0, const uint32_t *key_idx, const uint8_t *msgs,
-               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-               int32_t *status, size_t n_ops, hipStream_t s, const int32_t *a_hat_keys) {
+               const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx,
+               const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd,
+               uint8_t *sigs, int32_t *status, size_t n_ops, hipStream_t s, const int32_t *a_hat_keys, bool async_mode) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sign: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
-    // lanes: sub-batches of at least MIN_LANE_OPS ops each (a narrower lane only adds launches)
-    constexpr size_t MIN_LANE_OPS = 2048;
-    int n_lanes = env_int("MLDSA_SIGN_LANES", 1, MLDSA_SIGN_MAX_LANES, 1);
-    while (n_lanes > 1 && (n_ops + n_lanes - 1) / n_lanes < MIN_LANE_OPS) n_lanes--;
-    const size_t resident = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
-    const size_t lane_ops = (resident + n_lanes - 1) / n_lanes;
-    // candidate slots per speculative round and candidates per op per round, per lane
-    const size_t spec_target = (size_t)env_int("MLDSA_SPEC_TARGET", 1, SPEC_TARGET_SLOTS, 65536) / n_lanes;
-    const int spec_max = env_int("MLDSA_SPEC_MAX", 1, 64, 32);  // k_resolve scans one wave of candidates
     const bool own_a = a_hat_keys == nullptr;
-    const size_t kl_coeffs = (size_t)(p->k * p->l) * N;
-    const size_t lane_bytes = SignWs(nullptr, p, lane_ops, spec_target, own_a).bytes;
-    TRY(ensure_workspace(ctx, lane_bytes * n_lanes));
-
-    SignLane lanes[MLDSA_SIGN_MAX_LANES];
-    size_t next_op = 0;
+    const size_t chunk = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
+    const SignPlan pl = plan_sign(ctx, set, chunk, async_mode);
+    const SignWs w(ctx->ws, p, chunk, pl.ns_max, own_a);
+    if (ctx->ws_bytes < w.bytes) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
+    ctx->last_sign_slots = 0;
     int rc = MLDSA_OK;
-#define TRYC(expr) do { rc = (expr); if (rc != MLDSA_OK) return rc; } while (0)
-#define STAGEC(name, expr) do { { ProfScope _ps(ctx, st, name); rc = (expr); } if (rc != MLDSA_OK) return rc; } while (0)
-#define HIPC(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, #expr, _e); } while (0)
-
-    // steps 1-8 of Algorithm 7 for the next sub-batch, on the lane's stream
-    auto start_sub_batch = [&](SignLane &L) -> int {
-        hipStream_t st = L.st;
-        L.o = next_op;
-        L.n = (n_ops - next_op) < lane_ops ? (n_ops - next_op) : lane_ops;
-        next_op += L.n;
-        const SignWs &w = L.w;
-        const size_t o = L.o, n = L.n;
-        const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
-        const size_t key_base = key_idx ? 0 : o;
-        HIPC(hipMemsetAsync(sigs + o * (size_t)p->sig_len, 0, n * (size_t)p->sig_len, st));
-        // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
-        if (own_a) STAGEC("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, st, true));
-        // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
-        STAGEC("mu", launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
-                               w.rnd_mu + 32, 96, w.ctx_bad, n, st));
-        HIPC(hipMemcpy2DAsync(w.rnd_mu, 96, rnd + o * 32, 32, 32, n, hipMemcpyDeviceToDevice, st));
-        // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
-        STAGEC("rho_pp_hash", launch_shake256_2(ctx, 64, cap_k + key_base * 32, 32, 32, kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, st));
-        // 8: kappa <- 0; active = all ops with a legal ctx
-        HIPC(hipMemsetAsync(w.counter, 0, sizeof(uint32_t), st));
-        TRYC(launch_init_active(ctx, n, w.ctx_bad, w.done, w.kappa, status ? status + o : nullptr, w.act0, w.counter, st));
-        HIPC(hipMemcpyAsync((void *)L.h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPC(hipEventRecord(L.ev, st));
-        L.act = w.act0;
-        L.act_next = w.act1;
-        L.live = true;
-        L.in_round = false;
-        return MLDSA_OK;
-    };
-
-    // one pass of the rejection loop (steps 10-33) for the lane's L.m unfinished ops
-    auto enqueue_round = [&](SignLane &L) -> int {
-        hipStream_t st = L.st;
-        const SignWs &w = L.w;
-        const size_t o = L.o, m = L.m;
-        const uint32_t *kidx = key_idx ? key_idx + o : nullptr;
-        const size_t key_base = key_idx ? 0 : o;
-        uint8_t *sg = sigs + o * (size_t)p->sig_len;
-        // candidates per op this round (1 while the active set is wide)
-        int spec = 1;
-        if (m * 2 <= spec_target) {
-            const size_t sp = spec_target / m;
-            spec = sp > (size_t)spec_max ? spec_max : (int)sp;
-        }
-        const size_t ns = m * (size_t)spec;
-        if (ctx->prof_on) ctx->prof_sign_slots += ns;
-        STAGEC("make_slots", launch_make_slots(ctx, L.act, m, spec, w.kappa, p->l, w.slot_op, w.slot_kappa, st, kidx,
-                                               own_a ? nullptr : w.slot_key, w.counter));
-        // 11: y <- ExpandMask(rho'', kappa)                               :215
-        STAGEC("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns, st, w.yrisk));
-        // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-        STAGEC("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys + key_base * kl_coeffs, own_a ? w.slot_op : w.slot_key,
-                                       w.y, w.w, w.w1, (size_t)p->w1_len, ns, st, 0, w.wrisk, own_a));
-        // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
-        STAGEC("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len,
-                                                0, 0, w.ctilde, 64, ns, st));
-        // 16: c <- SampleInBall(c_tilde)                                  :237
-        STAGEC("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns, st));
-        // 17: c_hat <- NTT(c), in place                                   :240
-        STAGEC("ntt_c", launch_ntt(ctx, w.c, w.c, ns, st));
-        // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
-        STAGEC("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1 + key_base * (size_t)p->l * N,
-                                             s2 + key_base * (size_t)p->k * N, t0 + key_base * (size_t)p->k * N, w.kappa, w.done, sg,
-                                             spec, w.stage, w.stage_stride, w.accept, ns, st, w.wrisk, w.yrisk));
-        if (spec > 1)
-            STAGEC("resolve", launch_resolve(ctx, p, L.act, m, spec, w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa, st));
-        STAGEC("compact", launch_compact(ctx, L.act, m, w.done, L.act_next, w.counter, st));
-        HIPC(hipMemcpyAsync((void *)L.h_count, w.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPC(hipEventRecord(L.ev, st));
-        L.in_round = true;
-        return MLDSA_OK;
-    };
-
-    auto run = [&]() -> int {
-        // inputs may have been produced on the caller's stream
-        HIPC(hipEventRecord(ctx->fork_ev, s));
-        for (int i = 0; i < n_lanes; i++) {
-            SignLane &L = lanes[i];
-            L.st = ctx->lane_stream[i];
-            L.ev = ctx->lane_ev[i];
-            L.h_count = ctx->h_lane_count + i;
-            L.w = SignWs(static_cast<uint8_t *>(ctx->ws) + lane_bytes * i, p, lane_ops, spec_target, own_a);
-            HIPC(hipStreamWaitEvent(L.st, ctx->fork_ev, 0));
-            if (next_op < n_ops) TRYC(start_sub_batch(L));
-        }
-        int n_live = 0;
-        for (int i = 0; i < n_lanes; i++) n_live += lanes[i].live;
-        while (n_live > 0) {  // 10: while (z, h) = bottom                      ml_dsa.rs:212
-            bool progressed = false;
-            for (int i = 0; i < n_lanes; i++) {
-                SignLane &L = lanes[i];
-                if (!L.live) continue;
-                const hipError_t q = hipEventQuery(L.ev);
-                if (q == hipErrorNotReady) continue;
-                if (q != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "sign: lane event", q);
-                progressed = true;
-                L.m = *L.h_count;
-                if (L.in_round) { uint32_t *t = L.act; L.act = L.act_next; L.act_next = t; }
-                if (L.m > 0) {
-                    TRYC(enqueue_round(L));
-                } else if (next_op < n_ops) {
-                    TRYC(start_sub_batch(L));
-                } else {
-                    L.live = false;
-                    n_live--;
-                }
-            }
-            if (!progressed) {
-                // nothing finished yet: block on the first live lane instead of spinning on the queries
-                for (int i = 0; i < n_lanes; i++)
-                    if (lanes[i].live) { HIPC(hipEventSynchronize(lanes[i].ev)); break; }
-            }
-        }
-        return MLDSA_OK;
-    };
-    rc = run();
-#undef TRYC
-#undef STAGEC
-#undef HIPC
-    // join every lane (also on the error path), then clear y, rho'', cs1/cs2: they are
-    // secret-dependent (the reference zeroizes on drop, types.rs:19)
-    // (A_hat = ExpandA(rho) is public and is the first and largest carve of each lane: skipped.)
-    for (int i = 0; i < n_lanes; i++)
-        if (lanes[i].st) (void)hipStreamSynchronize(lanes[i].st);
-    for (int i = 0; i < n_lanes; i++) {
-        uint8_t *lane_base = static_cast<uint8_t *>(ctx->ws) + lane_bytes * i;
-        uint8_t *secrets = lanes[i].st ? reinterpret_cast<uint8_t *>(lanes[i].w.y) : lane_base;
-        (void)hipMemsetAsync(secrets, 0, (size_t)(lane_base + lane_bytes - secrets), s);
+    for (size_t o = 0; o < n_ops && rc == MLDSA_OK; o += chunk) {
+        SignArgs a;
+        memset(&a, 0, sizeof(a));  // the struct doubles as the graph key: no indeterminate padding
+        a.set = set; a.mode = mode; a.rho = rho; a.cap_k = cap_k; a.tr = tr; a.s1 = s1; a.s2 = s2; a.t0 = t0; a.n_keys = n_keys;
+        a.key_idx = key_idx; a.msgs = msgs; a.msg_off = msg_off; a.ctxs = ctxs; a.ctx_off = ctx_off; a.rnd = rnd; a.sigs = sigs;
+        a.status = status; a.a_hat_keys = a_hat_keys; a.offset = o; a.n = (n_ops - o) < chunk ? (n_ops - o) : chunk; a.chunk = chunk;
+        a.async_mode = async_mode ? 1 : 0;
+        struct { int op; long spec_target, spec_max, rounds; SignArgs a; } key;
+        memset(&key, 0, sizeof(key));
+        key.op = MLDSA_OP_SIGN; key.spec_target = ctx->opt_spec_target; key.spec_max = ctx->opt_spec_max; key.rounds = ctx->opt_sign_rounds;
+        key.a = a;
+        rc = run_op(ctx, s, MLDSA_OP_SIGN, &key, sizeof(key), [&](hipStream_t st) { return sign_chunk_enqueue(ctx, p, w, pl, a, st); });
+        if (rc == MLDSA_OK && !async_mode) rc = sign_chunk_finish(ctx, p, w, pl, a, s);
     }
-    (void)hipStreamSynchronize(s);
+    if (!async_mode || rc != MLDSA_OK) {
+        zeroise_sign_ws(ctx, w, s);  // also on the error path
+        (void)hipStreamSynchronize(s);
+    }
     return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// hipGraph replay.  A call shape = the operation and every argument that ends up in a kernel parameter.
+void drop_graphs(mldsa_ctx *ctx) {
+    for (auto &g : ctx->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    ctx->graphs.clear();
+}
+
+int run_op(mldsa_ctx *ctx, hipStream_t s, int op, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue) {
+    // MLDSA_OPT_GRAPHS: 0 never, 1 signing calls only (the launch-bound ones), 2 every op-level call
+    const bool wanted = ctx->opt_graphs == 2 || (ctx->opt_graphs == 1 && op == MLDSA_OP_SIGN);
+    if (!wanted || ctx->prof_on) {  // per-stage timing needs the individual launches
+        ctx->stats.direct_calls++;
+        return enqueue(s);
+    }
+    // a stream that is itself being captured by the caller: just add our nodes to the caller's graph
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        ctx->stats.direct_calls++;
+        return enqueue(s);
+    }
+    const unsigned char *kb = static_cast<const unsigned char *>(key);
+    GraphEntry *hit = nullptr;
+    for (auto &g : ctx->graphs)
+        if (g.key.size() == key_len && memcmp(g.key.data(), kb, key_len) == 0) { hit = &g; break; }
+    const unsigned long long tick = ++ctx->graph_tick;
+    if (!hit) {
+        // first sighting: remember the shape, launch directly (most shapes of a varied workload never repeat)
+        if ((long)ctx->graphs.size() >= ctx->opt_graph_cache) {
+            auto lru = std::min_element(ctx->graphs.begin(), ctx->graphs.end(),
+                                        [](const GraphEntry &a, const GraphEntry &b) { return a.last_use < b.last_use; });
+            if (lru->exec) (void)hipGraphExecDestroy(lru->exec);
+            if (lru->graph) (void)hipGraphDestroy(lru->graph);
+            ctx->graphs.erase(lru);
+        }
+        GraphEntry e;
+        e.key.assign(kb, kb + key_len);
+        e.last_use = tick;
+        ctx->graphs.push_back(std::move(e));
+        ctx->stats.direct_calls++;
+        return enqueue(s);
+    }
+    hit->last_use = tick;
+    // The legacy default stream (NULL) can neither be captured nor take a graph launch that overlaps properly: graphs
+    // of calls made on it run on a context-owned stream, ordered after and before the default stream by events.
+    hipStream_t gs = s ? s : ctx->graph_stream;
+    if (!s) {
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->graph_fork_ev, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(gs, ctx->graph_fork_ev, 0));
+    }
+    if (!hit->exec) {
+        // second sighting: capture and instantiate
+        MLDSA_HIP_CHECK(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue(gs);
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(gs, &graph);
+        if (rc != MLDSA_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (ee != hipSuccess || !graph) return set_error(MLDSA_ERR_DEVICE, "hipStreamEndCapture", ee);
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ei != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            return set_error(MLDSA_ERR_DEVICE, "hipGraphInstantiate", ei);
+        }
+        hit->graph = graph;
+        hit->exec = exec;
+        ctx->stats.graphs_captured++;
+    } else {
+        ctx->stats.graph_replays++;
+    }
+    MLDSA_HIP_CHECK(hipGraphLaunch(hit->exec, gs));
+    if (!s) {
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->graph_join_ev, gs));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->graph_join_ev, 0));
+    }
+    return MLDSA_OK;
 }
 
 }  // namespace mldsa

@@ -9,7 +9,9 @@
 //     PublicKey::verify                                    (Verifier, src/traits.rs:330-362)
 //     {PublicKey,PrivateKey}::try_from_bytes / into_bytes  (SerDes,   src/traits.rs:372-424)
 //     _internal_sign / _internal_verify                    (src/lib.rs:586-612)
-// plus the batched calls the GPU path exists for: keygen_many / sign_many / verify_many.
+// plus the batched calls the GPU path exists for: keygen_many / sign_many / verify_many (device-resident
+// expanded keys) and keygen_host / sign_host / verify_host (everything in host memory, wire-format keys: the
+// library stages sub-batches itself with upload, kernels and download overlapped).
 // Errors: the reference returns Result<_, &'static str>; here a failed Result is a thrown
 // fips204_hip::Error carrying the same kind of static message.  verify() never throws on a bad
 // signature or an over-long ctx: it returns false (src/lib.rs:368-370).  There is no CPU fallback.
@@ -17,7 +19,9 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -35,11 +39,36 @@ inline void check(int rc, const char* what) {
     if (rc != MLDSA_OK) throw Error(std::string(what) + ": " + mldsa_last_error());
 }
 
-// RAII device buffer
+// one context per device, created on first use and shared by every key object of the process.  The
+// library binds the calling thread to the context's device inside every call, so objects of several
+// devices can be used side by side; Device::use(id) picks the device new key objects are created on.
+class Device {
+  public:
+    static Device& get(int device_id = -1) {
+        static std::mutex mu;
+        static std::map<int, std::unique_ptr<Device>> devices;
+        std::lock_guard<std::mutex> lk(mu);
+        if (device_id < 0) device_id = current();
+        auto& d = devices[device_id];
+        if (!d) d.reset(new Device(device_id));
+        return *d;
+    }
+    static void use(int device_id) { current() = device_id; }
+    mldsa_ctx* ctx() const { return ctx_; }
+    int id() const { return id_; }
+    ~Device() { mldsa_ctx_destroy(ctx_); }
+  private:
+    static int& current() { static thread_local int cur = 0; return cur; }
+    explicit Device(int id) : id_(id) { check(mldsa_ctx_create(id, &ctx_), "mldsa_ctx_create"); }
+    mldsa_ctx* ctx_ = nullptr;
+    int id_ = 0;
+};
+
+// RAII device buffer on the current Device
 class DevBuf {
   public:
     DevBuf() = default;
-    explicit DevBuf(size_t bytes) : n_(bytes) { check(mldsa_malloc(&p_, bytes ? bytes : 1), "mldsa_malloc"); }
+    explicit DevBuf(size_t bytes) : n_(bytes) { check(mldsa_ctx_malloc(Device::get().ctx(), &p_, bytes ? bytes : 1), "mldsa_ctx_malloc"); }
     DevBuf(const void* host, size_t bytes) : DevBuf(bytes) { upload(host, bytes); }
     DevBuf(DevBuf&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
     DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
@@ -60,20 +89,6 @@ class DevBuf {
     void release() { if (p_) { (void)mldsa_memset(p_, 0, n_, nullptr); (void)mldsa_stream_sync(nullptr); (void)mldsa_free(p_); p_ = nullptr; } }
     void* p_ = nullptr;
     size_t n_ = 0;
-};
-
-// one context per device, shared by every key object of the process
-class Device {
-  public:
-    static Device& get(int device_id = 0) {
-        static Device d(device_id);
-        return d;
-    }
-    mldsa_ctx* ctx() const { return ctx_; }
-  private:
-    explicit Device(int id) { check(mldsa_ctx_create(id, &ctx_), "mldsa_ctx_create"); }
-    ~Device() { mldsa_ctx_destroy(ctx_); }
-    mldsa_ctx* ctx_ = nullptr;
 };
 
 // concatenate byte strings + u64 offsets (the msgs / ctxs arguments of the C ABI)
@@ -106,7 +121,6 @@ struct ParamSet {
         static PublicKeys try_from_bytes(const std::vector<PkBytes>& pk) {  // expand_public, ml_dsa.rs:477
             PublicKeys k;
             k.n = pk.size();
-            k.bytes = pk;
             DevBuf raw(pk.data(), pk.size() * PK);
             k.rho = DevBuf(k.n * 32); k.tr = DevBuf(k.n * 64); k.t1 = DevBuf(k.n * (size_t)K * 1024);
             check(mldsa_pk_expand(Device::get().ctx(), SET, raw.as<uint8_t>(), k.rho.as<uint8_t>(), k.tr.as<uint8_t>(),
@@ -114,8 +128,16 @@ struct ParamSet {
             check(mldsa_stream_sync(nullptr), "sync");
             return k;
         }
+        // SerDes::into_bytes (src/lib.rs:478-493): recomputed from the expanded fields on the device
+        std::vector<PkBytes> into_bytes() const {
+            DevBuf out(n * PK);
+            check(mldsa_pk_into_bytes(Device::get().ctx(), SET, rho.template as<uint8_t>(), t1.template as<int32_t>(), out.as<uint8_t>(), n,
+                                      nullptr), "mldsa_pk_into_bytes");
+            std::vector<PkBytes> pk(n);
+            out.download(pk.data(), n * PK);
+            return pk;
+        }
         size_t n = 0;
-        std::vector<PkBytes> bytes;
         DevBuf rho, tr, t1;
     };
     class PrivateKeys {
@@ -123,7 +145,6 @@ struct ParamSet {
         static PrivateKeys try_from_bytes(const std::vector<SkBytes>& sk) {  // expand_private, ml_dsa.rs:445
             PrivateKeys k;
             k.n = sk.size();
-            k.bytes = sk;
             DevBuf raw(sk.data(), sk.size() * SK);
             k.rho = DevBuf(k.n * 32); k.cap_k = DevBuf(k.n * 32); k.tr = DevBuf(k.n * 64);
             k.s1 = DevBuf(k.n * (size_t)L * 1024); k.s2 = DevBuf(k.n * (size_t)K * 1024); k.t0 = DevBuf(k.n * (size_t)K * 1024);
@@ -133,8 +154,28 @@ struct ParamSet {
             check(mldsa_stream_sync(nullptr), "sync");
             return k;
         }
+        // SerDes::into_bytes (src/lib.rs:427-465)
+        std::vector<SkBytes> into_bytes() const {
+            DevBuf out(n * SK);
+            check(mldsa_sk_into_bytes(Device::get().ctx(), SET, rho.template as<uint8_t>(), cap_k.template as<uint8_t>(),
+                                      tr.template as<uint8_t>(), s1.template as<int32_t>(), s2.template as<int32_t>(),
+                                      t0.template as<int32_t>(), out.as<uint8_t>(), n, nullptr), "mldsa_sk_into_bytes");
+            std::vector<SkBytes> sk(n);
+            out.download(sk.data(), n * SK);
+            return sk;
+        }
+        // Signer::get_public_key (src/lib.rs:345-349 -> private_to_public_key, src/ml_dsa.rs:502-559)
+        PublicKeys get_public_key() const {
+            PublicKeys k;
+            k.n = n;
+            k.rho = DevBuf(n * 32); k.tr = DevBuf(n * 64); k.t1 = DevBuf(n * (size_t)K * 1024);
+            check(mldsa_get_public_key(Device::get().ctx(), SET, rho.template as<uint8_t>(), tr.template as<uint8_t>(),
+                                       s1.template as<int32_t>(), s2.template as<int32_t>(), k.rho.template as<uint8_t>(),
+                                       k.tr.template as<uint8_t>(), k.t1.template as<int32_t>(), n, nullptr), "mldsa_get_public_key");
+            check(mldsa_stream_sync(nullptr), "sync");
+            return k;
+        }
         size_t n = 0;
-        std::vector<SkBytes> bytes;
         DevBuf rho, cap_k, tr, s1, s2, t0;
     };
 
@@ -160,13 +201,14 @@ struct ParamSet {
         DevBuf dk(key_idx.data(), n * 4), drnd(rnd.data(), n * 32), dsig(n * SIG), dstat(n * 4);
         check(mldsa_sign(Device::get().ctx(), SET, mode, sks.rho.template as<uint8_t>(), sks.cap_k.template as<uint8_t>(),
                          sks.tr.template as<uint8_t>(), sks.s1.template as<int32_t>(), sks.s2.template as<int32_t>(),
-                         sks.t0.template as<int32_t>(), dk.as<uint32_t>(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(),
+                         sks.t0.template as<int32_t>(), sks.n, dk.as<uint32_t>(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(),
                          c.bytes.as<uint8_t>(), c.offsets.as<uint64_t>(), drnd.as<uint8_t>(), dsig.as<uint8_t>(),
                          dstat.as<int32_t>(), n, nullptr), "mldsa_sign");
         std::vector<int32_t> st(n);
         dstat.download(st.data(), n * 4);
         for (int32_t s : st)
             if (s == MLDSA_ERR_CTX_LEN) throw Error("ML-DSA.Sign: ctx too long");  // src/lib.rs:274
+            else if (s != MLDSA_OK) throw Error("ML-DSA.Sign: key index out of range");
         std::vector<Signature> sig(n);
         dsig.download(sig.data(), n * SIG);
         return sig;
@@ -180,7 +222,7 @@ struct ParamSet {
         Packed m(msgs), c(ctxs);
         DevBuf dk(key_idx.data(), n * 4), dsig(sigs.data(), n * SIG), dok(n);
         check(mldsa_verify(Device::get().ctx(), SET, mode, pks.rho.template as<uint8_t>(), pks.tr.template as<uint8_t>(),
-                           pks.t1.template as<int32_t>(), dk.as<uint32_t>(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(),
+                           pks.t1.template as<int32_t>(), pks.n, dk.as<uint32_t>(), m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(),
                            c.bytes.as<uint8_t>(), c.offsets.as<uint64_t>(), dsig.as<uint8_t>(), dok.as<uint8_t>(), n, nullptr),
               "mldsa_verify");
         std::vector<uint8_t> ok(n);
@@ -188,11 +230,58 @@ struct ParamSet {
         return std::vector<bool>(ok.begin(), ok.end());
     }
 
+    // ---- the same three operations on host memory and wire-format keys (mldsa_*_host) --------------
+    // Contiguous arrays in, contiguous arrays out; the library overlaps upload, kernels and download.
+    struct HostBytes {  // concatenated byte strings + n + 1 offsets
+        std::vector<uint8_t> flat;
+        std::vector<uint64_t> off;
+        explicit HostBytes(const std::vector<std::vector<uint8_t>>& items) : off(items.size() + 1, 0) {
+            for (size_t i = 0; i < items.size(); i++) {
+                flat.insert(flat.end(), items[i].begin(), items[i].end());
+                off[i + 1] = flat.size();
+            }
+            if (flat.empty()) flat.push_back(0);
+        }
+    };
+    static std::pair<std::vector<PkBytes>, std::vector<SkBytes>> keygen_host(const std::vector<std::array<uint8_t, 32>>& xi) {
+        std::vector<PkBytes> pk(xi.size());
+        std::vector<SkBytes> sk(xi.size());
+        check(mldsa_keygen_host(Device::get().ctx(), SET, xi.data()->data(), pk.data()->data(), sk.data()->data(), xi.size()),
+              "mldsa_keygen_host");
+        return {std::move(pk), std::move(sk)};
+    }
+    static std::vector<Signature> sign_host(const std::vector<SkBytes>& sk, const std::vector<uint32_t>& key_idx,
+                                            const std::vector<std::vector<uint8_t>>& msgs, const std::vector<std::vector<uint8_t>>& ctxs,
+                                            const std::vector<std::array<uint8_t, 32>>& rnd, int mode = MLDSA_MODE_PURE) {
+        const size_t n = msgs.size();
+        if (ctxs.size() != n || rnd.size() != n || key_idx.size() != n) throw Error("sign_host: argument lengths differ");
+        HostBytes m(msgs), c(ctxs);
+        std::vector<Signature> sig(n);
+        std::vector<int32_t> st(n, 0);
+        check(mldsa_sign_host(Device::get().ctx(), SET, mode, sk.data()->data(), sk.size(), key_idx.data(), m.flat.data(), m.off.data(),
+                              c.flat.data(), c.off.data(), rnd.data()->data(), sig.data()->data(), st.data(), n), "mldsa_sign_host");
+        for (int32_t s : st)
+            if (s == MLDSA_ERR_CTX_LEN) throw Error("ML-DSA.Sign: ctx too long");
+            else if (s != MLDSA_OK) throw Error("ML-DSA.Sign: key index out of range");
+        return sig;
+    }
+    static std::vector<bool> verify_host(const std::vector<PkBytes>& pk, const std::vector<uint32_t>& key_idx,
+                                         const std::vector<std::vector<uint8_t>>& msgs, const std::vector<Signature>& sigs,
+                                         const std::vector<std::vector<uint8_t>>& ctxs, int mode = MLDSA_MODE_PURE) {
+        const size_t n = msgs.size();
+        if (ctxs.size() != n || sigs.size() != n || key_idx.size() != n) throw Error("verify_host: argument lengths differ");
+        HostBytes m(msgs), c(ctxs);
+        std::vector<uint8_t> ok(n, 0);
+        check(mldsa_verify_host(Device::get().ctx(), SET, mode, pk.data()->data(), pk.size(), key_idx.data(), m.flat.data(), m.off.data(),
+                                c.flat.data(), c.off.data(), sigs.data()->data(), ok.data(), n), "mldsa_verify_host");
+        return std::vector<bool>(ok.begin(), ok.end());
+    }
+
     // ---- single-key objects with the reference's method names -------------------------------------
     class PublicKey {
       public:
         static PublicKey try_from_bytes(const PkBytes& pk) { return PublicKey(PublicKeys::try_from_bytes({pk})); }
-        PkBytes into_bytes() const { return keys_->bytes[0]; }
+        PkBytes into_bytes() const { return keys_->into_bytes()[0]; }
         // Verifier::verify (src/lib.rs:364-380)
         bool verify(const std::vector<uint8_t>& message, const Signature& sig, const std::vector<uint8_t>& ctx) const {
             return verify_many(*keys_, {0u}, {message}, {sig}, {ctx}, MLDSA_MODE_PURE)[0];
@@ -201,15 +290,17 @@ struct ParamSet {
         bool _internal_verify(const std::vector<uint8_t>& message, const Signature& sig, const std::vector<uint8_t>& ctx) const {
             return verify_many(*keys_, {0u}, {message}, {sig}, {ctx}, MLDSA_MODE_INTERNAL)[0];
         }
-      private:
         explicit PublicKey(PublicKeys k) : keys_(std::make_shared<PublicKeys>(std::move(k))) {}
+      private:
         std::shared_ptr<PublicKeys> keys_;
     };
 
     class PrivateKey {
       public:
         static PrivateKey try_from_bytes(const SkBytes& sk) { return PrivateKey(PrivateKeys::try_from_bytes({sk})); }
-        SkBytes into_bytes() const { return keys_->bytes[0]; }
+        SkBytes into_bytes() const { return keys_->into_bytes()[0]; }
+        // Signer::get_public_key (src/lib.rs:345-349)
+        auto get_public_key() const;
         // Signer::try_sign_with_seed (src/traits.rs): rnd supplied by the caller
         Signature try_sign_with_seed(const std::array<uint8_t, 32>& rnd, const std::vector<uint8_t>& message,
                                      const std::vector<uint8_t>& ctx) const {
@@ -248,6 +339,11 @@ struct ParamSet {
         }
     };
 };
+
+template <int SET, int K_, int L_, size_t PK, size_t SK, size_t SIG>
+auto ParamSet<SET, K_, L_, PK, SK, SIG>::PrivateKey::get_public_key() const {
+    return typename ParamSet<SET, K_, L_, PK, SK, SIG>::PublicKey(keys_->get_public_key());
+}
 
 using ml_dsa_44 = ParamSet<MLDSA_44, 4, 4, 1312, 2560, 2420>;
 using ml_dsa_65 = ParamSet<MLDSA_65, 6, 5, 1952, 4032, 3309>;

@@ -63,6 +63,22 @@ class HotPath:
         except Exception:
             pass
 
+    # ---- context knobs -----------------------------------------------------------
+    def set_option(self, option, value):
+        _lib.check(self.lib.mldsa_set_option(self._h, option, value))
+
+    def get_option(self, option):
+        return int(self.lib.mldsa_get_option(self._h, option))
+
+    def stats(self):
+        st = _lib.Stats()
+        _lib.check(self.lib.mldsa_get_stats(self._h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in _lib.Stats._fields_}
+
+    def reserve(self, pset, op, n_ops):
+        """Size the workspace ahead of time (mldsa_reserve): later calls of that size never wait for the device."""
+        _lib.check(self.lib.mldsa_reserve(self._h, pset, op, n_ops))
+
     # ---- per-stage timing (HIP events on the launch stream) -----------------------
     def profile_enable(self, on=True):
         _lib.check(self.lib.mldsa_profile_enable(self._h, 1 if on else 0))

@@ -38,7 +38,8 @@ class PublicKeys:
 
 
 class PrivateKeys:
-    """n expanded private keys (src/types.rs:19-28)."""
+    """n expanded private keys (src/types.rs:19-28).  Like the reference's `Zeroize, ZeroizeOnDrop` struct
+    the secret fields are wiped when the object goes away (before their memory returns to the allocator)."""
 
     def __init__(self, pset, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont):
         self.pset, self.rho, self.cap_k, self.tr = pset, rho, cap_k, tr
@@ -46,6 +47,31 @@ class PrivateKeys:
 
     def __len__(self):
         return self.rho.shape[0]
+
+    def zeroize(self):
+        for t in (self.cap_k, self.s_1_hat_mont, self.s_2_hat_mont, self.t_0_hat_mont):
+            if t is not None:
+                t.zero_()
+
+    def __del__(self):
+        try:
+            self.zeroize()
+        except Exception:
+            pass
+
+
+def _check_key_idx(key_idx, n_keys, n_ops):
+    """Host-side courtesy check (the library itself also refuses out-of-range indices per op)."""
+    if key_idx is None:
+        if n_keys < n_ops:
+            raise ValueError(f"{n_ops} operations but only {n_keys} keys and no key_idx")
+        return None
+    a = np.asarray(key_idx, dtype=np.int64)
+    if a.shape != (n_ops,):
+        raise ValueError("key_idx: one entry per operation expected")
+    if n_ops and (a.min() < 0 or a.max() >= n_keys):
+        raise IndexError(f"key_idx out of range (n_keys = {n_keys})")
+    return a.astype(np.uint32)
 
 
 class MlDsa:
@@ -79,9 +105,10 @@ class MlDsa:
             ctx_buf, ctx_off = _cat_with_offsets(ctxs, self.device)
         if key_idx is None and len(pks) != n_ops:
             key_idx = np.arange(n_ops, dtype=np.uint32) % len(pks)
+        key_idx = _check_key_idx(key_idx, len(pks), n_ops)
         kidx = None
         if key_idx is not None:
-            kidx = torch.as_tensor(np.asarray(key_idx, dtype=np.uint32).view(np.int32)).to(self.device)
+            kidx = torch.as_tensor(key_idx.view(np.int32)).to(self.device)
         ok = torch.zeros(max(n_ops, 1), dtype=torch.uint8, device=self.device)
         self.verify_device(pks, msg_buf, msg_off, sigs, ok, n_ops, ctx_buf, ctx_off, kidx, mode)
         torch.cuda.synchronize()
@@ -102,7 +129,7 @@ class MlDsa:
         null = C.c_void_p(0)
         fn, first = (self.lib.mldsa_verify, pks.rho) if a_hat is None else (self.lib.mldsa_verify_cached_a, a_hat)
         _lib.check(fn(
-            self.hp._h, self.pset, mode, _ptr(first), _ptr(pks.tr), _ptr(pks.t1_d2_hat_mont),
+            self.hp._h, self.pset, mode, _ptr(first), _ptr(pks.tr), _ptr(pks.t1_d2_hat_mont), len(pks),
             _ptr(key_idx) if key_idx is not None else null, _ptr(msg_buf), _ptr(msg_off),
             _ptr(ctx_buf) if ctx_buf is not None else null, _ptr(ctx_off) if ctx_off is not None else null,
             _ptr(sigs), _ptr(ok), n_ops, _stream()))
@@ -119,39 +146,135 @@ class MlDsa:
                 raise ValueError(f"{what}: wrong length {len(b)} (expected {length})")
         return torch.frombuffer(bytearray(b"".join(bytes(b) for b in keys)), dtype=torch.uint8).to(self.device).view(-1, length)
 
-    def public_keys_from_bytes(self, pk_bytes):
-        """PublicKey::try_from_bytes for a batch -> PublicKeys (expand_public, src/ml_dsa.rs:477)"""
+    def empty_public_keys(self, n):
+        k = self.params.k
+        return PublicKeys(self.pset, torch.empty((n, 32), dtype=torch.uint8, device=self.device),
+                          torch.empty((n, 64), dtype=torch.uint8, device=self.device),
+                          torch.empty((n, k, N), dtype=torch.int32, device=self.device))
+
+    def empty_private_keys(self, n):
+        k, l, dev = self.params.k, self.params.l, self.device
+        return PrivateKeys(self.pset, torch.empty((n, 32), dtype=torch.uint8, device=dev), torch.empty((n, 32), dtype=torch.uint8, device=dev),
+                           torch.empty((n, 64), dtype=torch.uint8, device=dev), torch.empty((n, l, N), dtype=torch.int32, device=dev),
+                           torch.empty((n, k, N), dtype=torch.int32, device=dev), torch.empty((n, k, N), dtype=torch.int32, device=dev))
+
+    def public_keys_from_bytes(self, pk_bytes, out=None):
+        """PublicKey::try_from_bytes for a batch -> PublicKeys (expand_public, src/ml_dsa.rs:477).
+        out: a PublicKeys from empty_public_keys() to fill (same buffers every call: a repeated call shape)."""
         pk = self._key_bytes(pk_bytes, self.PK_LEN, "pk")
-        n, k = pk.shape[0], self.params.k
+        n = pk.shape[0]
+        o = out or self.empty_public_keys(n)
+        _lib.check(self.lib.mldsa_pk_expand(self.hp._h, self.pset, _ptr(pk), _ptr(o.rho), _ptr(o.tr), _ptr(o.t1_d2_hat_mont), n, _stream()))
+        return o
+
+    def private_keys_from_bytes(self, sk_bytes, out=None):
+        """PrivateKey::try_from_bytes for a batch -> PrivateKeys (expand_private, src/ml_dsa.rs:445)"""
+        sk = self._key_bytes(sk_bytes, self.SK_LEN, "sk")
+        n = sk.shape[0]
+        o = out or self.empty_private_keys(n)
+        _lib.check(self.lib.mldsa_sk_expand(self.hp._h, self.pset, _ptr(sk), _ptr(o.rho), _ptr(o.cap_k), _ptr(o.tr), _ptr(o.s_1_hat_mont),
+                                            _ptr(o.s_2_hat_mont), _ptr(o.t_0_hat_mont), n, _stream()))
+        return o
+
+    def public_keys_into_bytes(self, pks):
+        """PublicKey::into_bytes for a batch (src/lib.rs:478-493): uint8 tensor [n, PK_LEN]"""
+        n = len(pks)
+        pk = torch.empty((n, self.PK_LEN), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.mldsa_pk_into_bytes(self.hp._h, self.pset, _ptr(pks.rho), _ptr(pks.t1_d2_hat_mont), _ptr(pk), n, _stream()))
+        return pk
+
+    def private_keys_into_bytes(self, sks):
+        """PrivateKey::into_bytes for a batch (src/lib.rs:427-465): uint8 tensor [n, SK_LEN]"""
+        n = len(sks)
+        sk = torch.empty((n, self.SK_LEN), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.mldsa_sk_into_bytes(self.hp._h, self.pset, _ptr(sks.rho), _ptr(sks.cap_k), _ptr(sks.tr),
+                                                _ptr(sks.s_1_hat_mont), _ptr(sks.s_2_hat_mont), _ptr(sks.t_0_hat_mont), _ptr(sk), n,
+                                                _stream()))
+        return sk
+
+    def get_public_key(self, sks):
+        """PrivateKey::get_public_key for a batch (src/lib.rs:345-349 -> private_to_public_key, ml_dsa.rs:502-559)"""
+        n, k = len(sks), self.params.k
         rho = torch.empty((n, 32), dtype=torch.uint8, device=self.device)
         tr = torch.empty((n, 64), dtype=torch.uint8, device=self.device)
         t1 = torch.empty((n, k, N), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.mldsa_pk_expand(self.hp._h, self.pset, _ptr(pk), _ptr(rho), _ptr(tr), _ptr(t1), n, _stream()))
+        _lib.check(self.lib.mldsa_get_public_key(self.hp._h, self.pset, _ptr(sks.rho), _ptr(sks.tr), _ptr(sks.s_1_hat_mont),
+                                                 _ptr(sks.s_2_hat_mont), _ptr(rho), _ptr(tr), _ptr(t1), n, _stream()))
         return PublicKeys(self.pset, rho, tr, t1)
 
-    def private_keys_from_bytes(self, sk_bytes):
-        """PrivateKey::try_from_bytes for a batch -> PrivateKeys (expand_private, src/ml_dsa.rs:445)"""
-        sk = self._key_bytes(sk_bytes, self.SK_LEN, "sk")
-        n, k, l = sk.shape[0], self.params.k, self.params.l
-        dev = self.device
-        rho = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-        cap_k = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-        tr = torch.empty((n, 64), dtype=torch.uint8, device=dev)
-        s1 = torch.empty((n, l, N), dtype=torch.int32, device=dev)
-        s2 = torch.empty((n, k, N), dtype=torch.int32, device=dev)
-        t0 = torch.empty((n, k, N), dtype=torch.int32, device=dev)
-        _lib.check(self.lib.mldsa_sk_expand(self.hp._h, self.pset, _ptr(sk), _ptr(rho), _ptr(cap_k), _ptr(tr), _ptr(s1),
-                                            _ptr(s2), _ptr(t0), n, _stream()))
-        return PrivateKeys(self.pset, rho, cap_k, tr, s1, s2, t0)
+    # ---- host-memory entry points (numpy arrays in, numpy arrays out; staging inside the library) --------
+    @staticmethod
+    def _np_u8(a, row, what):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        if row and a.size % row:
+            raise ValueError(f"{what}: length is not a multiple of {row}")
+        return a
+
+    @staticmethod
+    def _cat_host(items):
+        lens = np.fromiter((len(b) for b in items), dtype=np.uint64, count=len(items))
+        off = np.zeros(len(items) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        flat = np.frombuffer(b"".join(bytes(b) for b in items) or b"\0", dtype=np.uint8)
+        return flat, off
+
+    def verify_host(self, pk_bytes, messages, sigs, ctxs=None, key_idx=None, mode=MODE_PURE, out=None):
+        """mldsa_verify_host: wire-format public keys [n_keys, PK_LEN], signatures [n_ops, SIG_LEN] and messages
+        in HOST memory (numpy); returns a bool array.  `messages` / `ctxs`: list of byte strings, or a
+        (flat uint8 array, uint64 offsets[n + 1]) pair."""
+        pk = self._np_u8(pk_bytes, self.PK_LEN, "pk")
+        sg = self._np_u8(sigs, self.SIG_LEN, "sigs")
+        n_keys, n_ops = pk.size // self.PK_LEN, sg.size // self.SIG_LEN
+        mflat, moff = messages if isinstance(messages, tuple) else self._cat_host(messages)
+        cflat = coff = None
+        if ctxs is not None:
+            cflat, coff = ctxs if isinstance(ctxs, tuple) else self._cat_host(ctxs)
+        kidx = _check_key_idx(key_idx, n_keys, n_ops)
+        ok = out if out is not None else np.zeros(max(n_ops, 1), dtype=np.uint8)  # out: caller's (page-locked) uint8[n_ops]
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+        _lib.check(self.lib.mldsa_verify_host(self.hp._h, self.pset, mode, vp(pk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
+                                              vp(coff), vp(sg), vp(ok), n_ops))
+        return ok[:n_ops].astype(bool)
+
+    def sign_host(self, sk_bytes, messages, rnd, ctxs=None, key_idx=None, mode=MODE_PURE, out=None):
+        """mldsa_sign_host: wire-format private keys, messages and rnd in HOST memory; returns uint8 [n_ops, SIG_LEN].
+        out: (sig uint8[n_ops, SIG_LEN], status int32[n_ops]) buffers of the caller (page-locked ones are filled by DMA)."""
+        sk = self._np_u8(sk_bytes, self.SK_LEN, "sk")
+        rn = self._np_u8(rnd, 32, "rnd")
+        n_keys, n_ops = sk.size // self.SK_LEN, rn.size // 32
+        mflat, moff = messages if isinstance(messages, tuple) else self._cat_host(messages)
+        cflat = coff = None
+        if ctxs is not None:
+            cflat, coff = ctxs if isinstance(ctxs, tuple) else self._cat_host(ctxs)
+        kidx = _check_key_idx(key_idx, n_keys, n_ops)
+        sig, status = out if out is not None else (np.zeros((max(n_ops, 1), self.SIG_LEN), dtype=np.uint8),
+                                                     np.zeros(max(n_ops, 1), dtype=np.int32))
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+        _lib.check(self.lib.mldsa_sign_host(self.hp._h, self.pset, mode, vp(sk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
+                                            vp(coff), vp(rn), vp(sig), vp(status), n_ops))
+        if n_ops and int(status[:n_ops].min()) < 0:
+            raise ValueError("ML-DSA.Sign: ctx too long")
+        return sig[:n_ops]
+
+    def keygen_host(self, xi):
+        """mldsa_keygen_host: seeds [n, 32] in host memory -> (pk [n, PK_LEN], sk [n, SK_LEN]) numpy arrays."""
+        x = self._np_u8(xi, 32, "xi")
+        n = x.size // 32
+        pk = np.zeros((max(n, 1), self.PK_LEN), dtype=np.uint8)
+        sk = np.zeros((max(n, 1), self.SK_LEN), dtype=np.uint8)
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        _lib.check(self.lib.mldsa_keygen_host(self.hp._h, self.pset, vp(x), vp(pk), vp(sk), n))
+        return pk[:n], sk[:n]
 
     # ---- KeyGen (src/traits.rs:8-114; src/lib.rs:247-250) ------------------------------
-    def keygen_from_seed(self, xi):
+    def keygen_from_seed(self, xi, out=None):
         """KG::keygen_from_seed for a batch of 32-byte seeds -> (pk bytes, sk bytes) tensors
-        [n, PK_LEN] / [n, SK_LEN] in FIPS 204 wire format (= the reference's into_bytes())."""
+        [n, PK_LEN] / [n, SK_LEN] in FIPS 204 wire format (= the reference's into_bytes()).
+        out: (pk, sk) tensors to fill."""
         xi = self._key_bytes(xi, 32, "xi")
         n = xi.shape[0]
-        pk = torch.empty((n, self.PK_LEN), dtype=torch.uint8, device=self.device)
-        sk = torch.empty((n, self.SK_LEN), dtype=torch.uint8, device=self.device)
+        pk, sk = out or (torch.empty((n, self.PK_LEN), dtype=torch.uint8, device=self.device),
+                         torch.empty((n, self.SK_LEN), dtype=torch.uint8, device=self.device))
         _lib.check(self.lib.mldsa_keygen(self.hp._h, self.pset, _ptr(xi), _ptr(pk), _ptr(sk), n, _stream()))
         return pk, sk
 
@@ -172,9 +295,10 @@ class MlDsa:
             ctx_buf, ctx_off = _cat_with_offsets(ctxs, self.device)
         if key_idx is None and len(sks) != n_ops:
             key_idx = np.arange(n_ops, dtype=np.uint32) % len(sks)
+        key_idx = _check_key_idx(key_idx, len(sks), n_ops)
         kidx = None
         if key_idx is not None:
-            kidx = torch.as_tensor(np.asarray(key_idx, dtype=np.uint32).view(np.int32)).to(self.device)
+            kidx = torch.as_tensor(key_idx.view(np.int32)).to(self.device)
         rnd = self._key_bytes(rnd, 32, "rnd") if n_ops else torch.zeros((1, 32), dtype=torch.uint8, device=self.device)
         sigs = torch.empty((max(n_ops, 1), self.SIG_LEN), dtype=torch.uint8, device=self.device)
         status = torch.zeros(max(n_ops, 1), dtype=torch.int32, device=self.device)
@@ -185,12 +309,18 @@ class MlDsa:
         return sigs[:n_ops]
 
     def sign_device(self, sks, msg_buf, msg_off, rnd, sigs, n_ops, ctx_buf=None, ctx_off=None, key_idx=None,
-                    mode=MODE_PURE, status=None, a_hat=None):
+                    mode=MODE_PURE, status=None, a_hat=None, wait=True):
+        """Everything already resident in HBM (what bench.py times).  wait=False -> mldsa_sign_async: the call
+        only enqueues; an op the enqueued rounds leave unfinished (p < 1e-9 per call) has status
+        MLDSA_ERR_AGAIN and must be signed again."""
         null = C.c_void_p(0)
-        fn, first = (self.lib.mldsa_sign, sks.rho) if a_hat is None else (self.lib.mldsa_sign_cached_a, a_hat)
+        if a_hat is not None:
+            fn, first = self.lib.mldsa_sign_cached_a, a_hat
+        else:
+            fn, first = (self.lib.mldsa_sign if wait else self.lib.mldsa_sign_async), sks.rho
         _lib.check(fn(
             self.hp._h, self.pset, mode, _ptr(first), _ptr(sks.cap_k), _ptr(sks.tr), _ptr(sks.s_1_hat_mont),
-            _ptr(sks.s_2_hat_mont), _ptr(sks.t_0_hat_mont), _ptr(key_idx) if key_idx is not None else null,
+            _ptr(sks.s_2_hat_mont), _ptr(sks.t_0_hat_mont), len(sks), _ptr(key_idx) if key_idx is not None else null,
             _ptr(msg_buf), _ptr(msg_off), _ptr(ctx_buf) if ctx_buf is not None else null,
             _ptr(ctx_off) if ctx_off is not None else null, _ptr(rnd), _ptr(sigs),
             _ptr(status) if status is not None else null, n_ops, _stream()))

@@ -9,8 +9,14 @@
  * Conventions
  *  - Plain pointers and sizes only.  All data pointers are DEVICE pointers (hipMalloc'd
  *    by anyone: this library's mldsa_malloc, PyTorch, a Rust hip-sys binding ...) unless
- *    the name ends in _host.  `stream` is a hipStream_t passed as void* (NULL = the
- *    default stream); calls are asynchronous on it.
+ *    the name ends in _host (those take HOST pointers and do their own staging, see the end
+ *    of this file).  `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    calls are asynchronous on it.
+ *  - Devices.  A context belongs to the device it was created for.  Every call that takes a
+ *    context binds the calling thread to that device for the duration of the call and restores
+ *    the thread's previous device before it returns, so contexts of several GPUs can be driven
+ *    from one process and from any thread.  The context-free memory helpers (mldsa_malloc ...)
+ *    act on the calling thread's current device; mldsa_ctx_malloc allocates on the context's.
  *  - Polynomials are the reference's `R` / `T` (src/types.rs:45-55): 256 contiguous
  *    int32_t, arrays of polynomials contiguous and row-major ([[T; L]; K] = K*L*256).
  *    Inputs may be any signed representative inside the contract the reference's
@@ -26,8 +32,16 @@
  *    workspace: they may also be called from any thread on any stream, and the context serialises
  *    them (a mutex on the host side, a device-side event wait when consecutive calls use different
  *    streams -- never a host synchronisation).  For op-level calls that should overlap on the device,
- *    use one context per stream.  mldsa_sign returns after its last rejection round completed;
- *    everything else is asynchronous on `stream`.
+ *    use one context per stream.  mldsa_sign returns after its last rejection round completed
+ *    (mldsa_sign_async does not wait); everything else is asynchronous on `stream`.
+ *  - Workspaces.  The op-level calls use a context-owned device workspace.  mldsa_reserve sizes it
+ *    ahead of time; a call that finds it too small grows it, which waits for the device once.
+ *  - hipGraphs.  An op-level call whose shape -- operation, parameter set, mode, n_ops and the pointer
+ *    arguments -- repeats is captured into a hipGraph the second time it is seen and replayed from then
+ *    on (one graph launch instead of ~100 kernel launches for a signing call).  MLDSA_OPT_GRAPHS selects
+ *    which operations do this: by default only signing, whose ~10 kernels per round times ~12 rounds are
+ *    launch-bound at small batches; verify and keygen are 6 ... 8 kernels and gain nothing (measured).
+ *    Results are identical either way.
  */
 #ifndef MLDSA_HIP_H
 #define MLDSA_HIP_H
@@ -44,6 +58,7 @@ extern "C" {
 #define MLDSA_ERR_CTX_LEN (-2)  /* ctx longer than 255 bytes (src/lib.rs:274)           */
 #define MLDSA_ERR_DEVICE (-3)   /* HIP runtime error; see mldsa_last_error()            */
 #define MLDSA_ERR_NOMEM (-4)    /* device workspace allocation failed                   */
+#define MLDSA_ERR_AGAIN (-5)    /* mldsa_sign_async only: op still unfinished, sign it again */
 
 /* parameter sets: src/lib.rs:639-656, 681-698, 723-740 */
 #define MLDSA_44 44
@@ -69,6 +84,30 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx);
 const char *mldsa_last_error(void);
 int mldsa_get_params(int set, mldsa_params *out);
 int mldsa_device_count(void);
+int mldsa_ctx_device(const mldsa_ctx *ctx); /* device id the context is bound to (negative: NULL ctx) */
+
+/* Size the context's workspace for op-level calls of up to n_ops operations of `op` on `set`, so that
+ * no later call of that size has to grow it (growing waits for the device).  op: MLDSA_OP_*. */
+#define MLDSA_OP_KEYGEN 1
+#define MLDSA_OP_SIGN 2
+#define MLDSA_OP_VERIFY 3
+int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
+
+/* Tuning knobs (per context).  Defaults are the measured best; none changes any result. */
+#define MLDSA_OPT_GRAPHS 1          /* hipGraph replay of repeated call shapes: 0 never, 1 (default) signing calls, 2 every op-level call */
+#define MLDSA_OPT_SPEC_TARGET 2     /* sign: candidate slots per speculative round (1 ... 65536, default 65536)        */
+#define MLDSA_OPT_SPEC_MAX 3        /* sign: most speculative candidates per op and round (1 ... 64, default 32)        */
+#define MLDSA_OPT_VA_BLOCKS_PER_CU 4 /* mldsa_verify_arith: workgroups per CU of the persistent grid (default 16)      */
+#define MLDSA_OPT_GRAPH_CACHE 5     /* graphs kept per context before the least recently used one is dropped (default 24) */
+#define MLDSA_OPT_SIGN_ROUNDS 6     /* sign: rounds enqueued before the host looks at the device; 0 (default) = as many as the
+                                       plan says finish the batch (see mldsa_sign); a small value exercises the extra-round path */
+int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
+long mldsa_get_option(const mldsa_ctx *ctx, int option);
+/* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths */
+typedef struct {
+    unsigned long long graphs_captured, graph_replays, direct_calls, workspace_growths, sign_extra_rounds;
+} mldsa_stats;
+int mldsa_get_stats(mldsa_ctx *ctx, mldsa_stats *out);
 
 /* Per-stage timing of the op-level calls (bench.py's roofline figure): while enabled, every
  * kernel launch of mldsa_verify / mldsa_sign is bracketed by a HIP event pair on the launch
@@ -79,7 +118,12 @@ int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len);
 
 /* ---- device memory helpers for hosts without their own HIP binding ------------------ */
 int mldsa_malloc(void **dev_ptr, size_t bytes);
+int mldsa_ctx_malloc(mldsa_ctx *ctx, void **dev_ptr, size_t bytes); /* on the context's device */
 int mldsa_free(void *dev_ptr);
+/* page-locked host memory: buffers handed to the *_host entry points stream at the PCIe rate when
+ * they come from here (pageable memory works too, through a bounce copy) */
+int mldsa_host_alloc(void **host_ptr, size_t bytes);
+int mldsa_host_free(void *host_ptr);
 int mldsa_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int mldsa_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int mldsa_memset(void *dst_dev, int value, size_t bytes, void *stream);
@@ -155,14 +199,16 @@ int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_
  * verify_internal (src/ml_dsa.rs:351-437) for n_ops independent operations.
  *   Public keys are passed EXPANDED, field by field, as the reference's PublicKey holds them
  *   (src/types.rs:35-41): rho[n_keys][32], tr[n_keys][64], t1_d2_hat_mont[n_keys][K][256]
- *   (produce them with mldsa_pk_expand).  key_idx[op] selects the key of op (NULL: op i uses
- *   key i).  A_hat is re-derived from rho for every op, as the reference does (ml_dsa.rs:406).
+ *   (produce them with mldsa_pk_expand).  key_idx[op] < n_keys selects the key of op (NULL: op i
+ *   uses key i, n_keys >= n_ops).  An op whose key_idx is out of range gets ok = 0 and never touches
+ *   memory outside the n_keys rows.  A_hat is re-derived from rho for every op, as the reference does
+ *   (ml_dsa.rs:406).
  *   msgs/msg_off: concatenated messages and n_ops + 1 byte offsets; ctxs/ctx_off likewise
  *   (ctx_off NULL = every ctx empty).  mode: MLDSA_MODE_*.  sigs: n_ops * SIG_LEN bytes.
  *   ok[op] = 1 iff the reference returns true; malformed hints, |ctx| > 255, z too large and
  *   c_tilde mismatch all give 0 (ml_dsa.rs:368-376, 434-436; lib.rs:368-370). */
 int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr,
-                 const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                 const int32_t *t1_d2_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                  const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                  const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream);
 
@@ -180,6 +226,25 @@ int mldsa_sk_expand(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, ui
                     uint8_t *tr, int32_t *s_1_hat_mont, int32_t *s_2_hat_mont,
                     int32_t *t_0_hat_mont, size_t n_keys, void *stream);
 
+/* SerDes::into_bytes for PublicKey (src/lib.rs:478-493): the expanded fields back to pk[n][PK_LEN]:
+ * t1 = inv_ntt(mont_reduce(t1_d2_hat_mont)) >> 13, pk = pkEncode(rho, t1).  tr is not needed. */
+int mldsa_pk_into_bytes(mldsa_ctx *ctx, int set, const uint8_t *rho, const int32_t *t1_d2_hat_mont,
+                        uint8_t *pk, size_t n_keys, void *stream);
+
+/* SerDes::into_bytes for PrivateKey (src/lib.rs:427-465): s1, s2, t0 = centred inv_ntt of the Montgomery
+ * fields, sk[n][SK_LEN] = skEncode(rho, K, tr, s1, s2, t0). */
+int mldsa_sk_into_bytes(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
+                        const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont, const int32_t *t_0_hat_mont,
+                        uint8_t *sk, size_t n_keys, void *stream);
+
+/* Signer::get_public_key (src/lib.rs:345-349) -> private_to_public_key (src/ml_dsa.rs:502-559):
+ * expanded private keys -> expanded public keys.  t = inv_ntt(A_hat o s_1_hat) + s_2 with A_hat = ExpandA(rho),
+ * t1 = Power2Round(t), t1_d2_hat_mont = NTT(t1) * 2^13 (Montgomery form); rho and tr are copied.
+ * (cap_k and t_0_hat_mont are not inputs: the reference only uses t_0 in a debug assertion.) */
+int mldsa_get_public_key(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint8_t *tr,
+                         const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont, uint8_t *pk_rho, uint8_t *pk_tr,
+                         int32_t *pk_t1_d2_hat_mont, size_t n_keys, void *stream);
+
 /* KeyGen::keygen_from_seed (src/lib.rs:247-250) -> key_gen_internal (src/ml_dsa.rs:57-134)
  * followed by SerDes::into_bytes: xi[n][32] -> pk[n][PK_LEN], sk[n][SK_LEN] (FIPS 204 wire
  * format; expand with mldsa_pk_expand / mldsa_sk_expand to use them). */
@@ -189,17 +254,28 @@ int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
 /* Signer::try_sign_with_seed / _internal_sign / try_hash_sign_with_seed (src/lib.rs:268-342,
  * 586-600) -> sign_internal (src/ml_dsa.rs:153-337) for n_ops independent operations.
  *   Private keys EXPANDED, field by field (src/types.rs:19-28), from mldsa_sk_expand;
- *   key_idx / msgs / ctxs / mode as in mldsa_verify.  rnd[n_ops][32]: the caller's per-
+ *   n_keys / key_idx / msgs / ctxs / mode as in mldsa_verify.  rnd[n_ops][32]: the caller's per-
  *   signature randomness (all zero = deterministic variant), src/lib.rs:282-283.
- *   sigs[n_ops][SIG_LEN].  status (may be NULL): per-op MLDSA_OK or MLDSA_ERR_CTX_LEN
- *   (|ctx| > 255, src/lib.rs:274; that op's signature is all zero).
- *   The rejection loop (ml_dsa.rs:212-330) runs in rounds over the unfinished ops; the call
- *   synchronises `stream` between rounds and before returning. */
+ *   sigs[n_ops][SIG_LEN].  status (may be NULL): per-op MLDSA_OK, MLDSA_ERR_CTX_LEN (|ctx| > 255,
+ *   src/lib.rs:274) or MLDSA_ERR_PARAM (key_idx out of range); the signature of a failed op is all zero.
+ *   The rejection loop (ml_dsa.rs:212-330) runs in rounds over the unfinished ops and is driven from the
+ *   device: the round kernels read the number of unfinished ops and the candidates per op from device
+ *   memory, so a whole call is enqueued without the host looking at the device.
+ *   mldsa_sign enqueues as many rounds as finish the batch in more than 999 of 1000 calls, waits for
+ *   `stream` once, and enqueues further rounds in the rare case that an op is left: when it returns every
+ *   op is signed, exactly like the reference's loop.
+ *   mldsa_sign_async does not wait: it enqueues rounds until the probability that any op is left is below
+ *   1e-9; such an op gets status MLDSA_ERR_AGAIN and an all-zero signature (status must not be NULL). */
 int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k,
                const uint8_t *tr, const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont,
-               const int32_t *t_0_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+               const int32_t *t_0_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream);
+int mldsa_sign_async(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k,
+                     const uint8_t *tr, const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont,
+                     const int32_t *t_0_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
+                     const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                     const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream);
 
 /* ---- A_hat kept with the keys --------------------------------------------------------
  * The reference re-derives A_hat = ExpandA(rho) inside every sign and verify (src/ml_dsa.rs:181,
@@ -208,17 +284,36 @@ int mldsa_sign(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
  * optimisation: identical to mldsa_verify / mldsa_sign (same arguments, same results, bit for
  * bit) except that ExpandA is skipped and row key_idx[op] (or row op when key_idx is NULL) of
  * `a_hat` is used instead.  a_hat[n_keys][K][L][256] = mldsa_expand_a(set, rho of the keys), any
- * representative mldsa_expand_a produces; `rho` may then be NULL.  bench.py reports them as
- * separate workloads (verify65_cached_a, sign65_cached_a), never as the headline. */
+ * representative mldsa_expand_a produces.  bench.py reports them as separate workloads
+ * (verify65_cached_a, sign65_cached_a), never as the headline. */
 int mldsa_verify_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *tr,
-                          const int32_t *t1_d2_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                          const int32_t *t1_d2_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                           const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                           const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream);
 int mldsa_sign_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *cap_k,
                         const uint8_t *tr, const int32_t *s_1_hat_mont, const int32_t *s_2_hat_mont,
-                        const int32_t *t_0_hat_mont, const uint32_t *key_idx, const uint8_t *msgs,
+                        const int32_t *t_0_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                         const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                         const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *stream);
+
+/* ---- host-memory entry points ----------------------------------------------------------
+ * The reference's API works on host slices (src/traits.rs:118-308 Signer, 330-362 Verifier:
+ * `verify(&self, message: &[u8], sig: &Signature, ctx: &[u8])`).  These variants take HOST pointers, keys
+ * in FIPS 204 wire format, and do the staging themselves: the keys are uploaded and expanded once
+ * (try_from_bytes), then the batch streams through the device in sub-batches with the upload of
+ * sub-batch i + 1 and the download of sub-batch i - 1 running beside the kernels of sub-batch i (three
+ * HIP streams, context-owned device and page-locked staging buffers, so the kernel sequence of a
+ * sub-batch replays as a hipGraph).  Buffers obtained from mldsa_host_alloc (or otherwise page-locked)
+ * are copied by DMA directly; pageable buffers go through a page-locked bounce buffer first.
+ * Arguments are those of mldsa_verify / mldsa_sign / mldsa_keygen with every pointer on the host;
+ * the calls return when the results are in the caller's buffers. */
+int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size_t n_keys, const uint32_t *key_idx,
+                      const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                      const uint8_t *sigs, uint8_t *ok, size_t n_ops);
+int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t n_keys, const uint32_t *key_idx,
+                    const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                    const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops);
+int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys);
 
 #ifdef __cplusplus
 }

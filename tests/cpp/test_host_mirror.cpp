@@ -58,6 +58,11 @@ static void smoke_test(int expect_pk0) {  // src/lib.rs:497-552
     try { (void)sk.try_sign_with_seed(seed12, message1, std::vector<uint8_t>(257, 0)); } catch (const Error&) { threw = true; }
     ASSERT(threw);                                                                 // lib.rs:528
     ASSERT(pk.into_bytes()[0] == expect_pk0);                                      // lib.rs:543-545
+    // Signer::get_public_key (lib.rs:345-349): the public key derived from the private key is the one keygen gave
+    ASSERT(sk.get_public_key().into_bytes() == pk.into_bytes());
+    ASSERT(sk.get_public_key().verify(message1, sig, {}));
+    // SerDes round trip of the private key through its expanded form (lib.rs:421-465)
+    ASSERT(P::PrivateKey::try_from_bytes(sk.into_bytes()).into_bytes() == sk.into_bytes());
     FailingRng bad;
     threw = false;
     try { (void)P::KG::try_keygen_with_rng(bad); } catch (const Error&) { threw = true; }
@@ -125,6 +130,26 @@ int main(int argc, char** argv) {
         sigs[5][100] ^= 1;
         auto ok = P::verify_many(pks, kidx, msgs, sigs, ctxs);
         for (int i = 0; i < 12; i++) ASSERT(ok[i] == (i != 5));
+    }
+    // the same batch through the host-memory entry points (wire-format keys, staging inside the library)
+    {
+        using P = ml_dsa_87;
+        const size_t n = 40;
+        std::vector<std::array<uint8_t, 32>> xi(4), rnd(n);
+        for (int i = 0; i < 4; i++) xi[i].fill((uint8_t)(90 + i));
+        for (size_t i = 0; i < n; i++) rnd[i].fill((uint8_t)(3 * i));
+        auto ks = P::keygen_host(xi);
+        auto ks_dev = P::keygen_many(xi);
+        ASSERT(ks.first == ks_dev.first && ks.second == ks_dev.second);
+        std::vector<uint32_t> kidx(n);
+        std::vector<std::vector<uint8_t>> msgs(n), ctxs(n);
+        for (size_t i = 0; i < n; i++) { kidx[i] = (uint32_t)(i % 4); msgs[i].assign(i * 11, (uint8_t)i); ctxs[i].assign(i % 3, 5); }
+        auto sigs = P::sign_host(ks.second, kidx, msgs, ctxs, rnd);
+        auto sigs_dev = P::sign_many(P::PrivateKeys::try_from_bytes(ks.second), kidx, msgs, ctxs, rnd);
+        ASSERT(sigs == sigs_dev);
+        sigs[7][2000] ^= 4;
+        auto ok = P::verify_host(ks.first, kidx, msgs, sigs, ctxs);
+        for (size_t i = 0; i < n; i++) ASSERT(ok[i] == (i != 7));
     }
     std::printf("OK\n");
     return 0;

@@ -50,3 +50,29 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
                 assert "liboracle" not in text and "mldsa_oracle" not in text, f
+
+
+def test_no_kernel_spills_registers():
+    """k_verify_main<8,7,...,APACK> spilled 8 VGPRs.  The Makefile keeps hipcc's
+    -Rpass-analysis=kernel-resource-usage remarks next to every object (*.res): no instantiated kernel may
+    spill vector registers or use scratch memory."""
+    import glob
+    import os
+    import re
+    from fips204_amd import build
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "csrc")
+    if not glob.glob(os.path.join(csrc, "kernels_*.res")):
+        build.build(force=True)
+    n_kernels = 0
+    for path in sorted(glob.glob(os.path.join(csrc, "*.res"))):
+        text = open(path).read()
+        names = re.findall(r"Function Name: (\S+)", text)
+        spills = re.findall(r"VGPRs Spill: (\d+)", text)
+        sgpr_spills = re.findall(r"SGPRs Spill: (\d+)", text)
+        scratch = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)
+        assert len(names) == len(spills) == len(scratch) == len(sgpr_spills)
+        for n, v, sg, sc in zip(names, spills, sgpr_spills, scratch):
+            # (SGPR "spills" are allowed: the compiler parks scalar values in lanes of a VGPR, no memory is involved)
+            assert int(v) == 0 and int(sc) == 0, f"{os.path.basename(path)}: {n} spills {v} VGPRs, {sc} B scratch"
+        n_kernels += len(names)
+    assert n_kernels >= 60

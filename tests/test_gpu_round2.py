@@ -1,0 +1,406 @@
+"""GPU parity for what round 2 added behind the C ABI: get_public_key / into_bytes (ACVP keyGen KATs),
+key_idx bounds, the device-driven signing loop (planned rounds, extra-round path, mldsa_sign_async),
+hipGraph replay, the host-memory entry points, contexts used from other threads, and the BASELINE shapes at
+full size (ML-DSA-65 sign at 65 536, ML-DSA-87 verify at 131 072 = config 4's per-GPU slice)."""
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PSET
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from fips204_amd.hotpath import HotPath
+    h = HotPath(0)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def sets(hp):
+    from fips204_amd.ml_dsa import MlDsa
+    return {s: MlDsa(s, hotpath=hp) for s in (44, 65, 87)}
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def shake(tag, i, n=32):
+    return hashlib.shake_256(tag + i.to_bytes(8, "little")).digest(n)
+
+
+def make_batch(m, n_ops, n_keys, tag):
+    """n_keys key pairs, n_ops 32-byte messages + rnd, keys dealt round-robin: device-resident inputs"""
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    xi = [shake(tag + b"key", i) for i in range(n_keys)]
+    pk, sk = m.keygen_from_seed(xi)
+    msgs = [shake(tag + b"msg", i) for i in range(n_ops)]
+    rnd = [shake(tag + b"rnd", i) for i in range(n_ops)]
+    mb, mo = _cat_with_offsets(msgs, m.device)
+    rn = torch.frombuffer(bytearray(b"".join(rnd)), dtype=torch.uint8).cuda().view(n_ops, 32)
+    kidx_host = (np.arange(n_ops) % n_keys).astype(np.uint32)
+    kidx = torch.from_numpy(kidx_host.view(np.int32)).cuda()
+    return dict(xi=xi, pk=pk, sk=sk, pks=m.public_keys_from_bytes(pk), sks=m.private_keys_from_bytes(sk), msgs=msgs, rnd=rnd,
+                mb=mb, mo=mo, rn=rn, kidx=kidx, kidx_host=kidx_host, n=n_ops)
+
+
+def oracle_sigs(pset, b, idx):
+    skb = host(b["sk"])
+    sks = {}
+    out = []
+    for i in idx:
+        ki = int(b["kidx_host"][i])
+        if ki not in sks:
+            sks[ki] = orc.sk_try_from_bytes(pset, skb[ki].tobytes())
+        out.append(orc.sign_internal(pset, sks[ki], b["msgs"][i], b["rnd"][i], mode=0))
+    return out
+
+
+# ------------------------------------------------------------------------------ SerDes / get_public_key
+def test_get_public_key_and_into_bytes_on_every_acvp_keygen_case(sets, acvp_keygen):
+    """Signer::get_public_key (lib.rs:345-349 -> ml_dsa.rs:502-559) and SerDes::into_bytes (lib.rs:427-493) from the
+    EXPANDED fields: for every ACVP keyGen case the public key derived from sk, re-encoded, is the KAT's pk, and
+    both keys survive try_from_bytes -> into_bytes."""
+    n_cases = 0
+    for g in acvp_keygen["testGroups"]:
+        pset = PSET[g["parameterSet"]]
+        m = sets[pset]
+        sk_b = [bytes.fromhex(t["sk"]) for t in g["tests"]]
+        pk_b = [bytes.fromhex(t["pk"]) for t in g["tests"]]
+        sks = m.private_keys_from_bytes(sk_b)
+        pks_from_sk = m.get_public_key(sks)
+        got_pk = host(m.public_keys_into_bytes(pks_from_sk))
+        got_sk = host(m.private_keys_into_bytes(sks))
+        pks = m.public_keys_from_bytes(pk_b)
+        again_pk = host(m.public_keys_into_bytes(pks))
+        for i in range(len(sk_b)):
+            assert got_pk[i].tobytes() == pk_b[i], (pset, i, "pk from sk")
+            assert got_sk[i].tobytes() == sk_b[i], (pset, i, "sk round trip")
+            assert again_pk[i].tobytes() == pk_b[i], (pset, i, "pk round trip")
+        # the expanded fields themselves: rho / tr copied from sk (ml_dsa.rs:558), t1_d2_hat_mont equal mod q
+        assert torch.equal(pks_from_sk.rho, pks.rho) and torch.equal(pks_from_sk.tr, sks.tr)
+        q = orc.Q
+        assert torch.equal(pks_from_sk.t1_d2_hat_mont % q, pks.t1_d2_hat_mont % q)
+        # and against the oracle's restatement of private_to_public_key for one case per group
+        sk_o = orc.sk_try_from_bytes(pset, sk_b[0])
+        assert orc.pk_into_bytes(pset, orc.get_public_key(pset, sk_o)) == pk_b[0]
+        n_cases += len(sk_b)
+    assert n_cases == 75
+
+
+def test_malformed_secret_key_bytes_round_trip_like_the_reference(sets):
+    """expand_private never rejects (conversion.rs:259-260 is vacuous): out-of-range eta fields (a 4-bit field 15 is
+    s = -11 for eta = 4) are used as they are, and into_bytes re-encodes eta - s: random bytes must come back the
+    way the oracle's restatement of lib.rs:427-465 returns them."""
+    m = sets[65]
+    rng = np.random.default_rng(5)
+    sk = rng.integers(0, 256, (3, m.SK_LEN), dtype=np.uint8)
+    sks = m.private_keys_from_bytes(torch.from_numpy(sk).cuda())
+    got = host(m.private_keys_into_bytes(sks))
+    for i in range(3):
+        want = orc.sk_into_bytes(65, orc.sk_try_from_bytes(65, sk[i].tobytes()))
+        assert got[i].tobytes() == want
+
+
+# ------------------------------------------------------------------------------ key_idx bounds
+@pytest.mark.parametrize("pset", [44, 87])
+def test_out_of_range_key_index_is_refused_per_op(sets, pset):
+    m = sets[pset]
+    b = make_batch(m, 40, 3, b"bounds%d" % pset)
+    sig = torch.empty((b["n"], m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(b["n"], dtype=torch.int32, device="cuda")
+    bad = b["kidx"].clone()
+    bad[5], bad[17] = 3, 0x7FFFFFF0  # n_keys = 3: both out of range (the second far outside any allocation)
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, b["n"], key_idx=bad, status=st)
+    st_h, sig_h = host(st), host(sig)
+    assert st_h[5] == -1 and st_h[17] == -1 and (np.delete(st_h, [5, 17]) == 0).all()  # MLDSA_ERR_PARAM for those two only
+    assert not sig_h[5].any() and not sig_h[17].any()
+    good = [i for i in range(b["n"]) if i not in (5, 17)]
+    for i, want in zip(good[:6], oracle_sigs(pset, b, good[:6])):
+        assert sig_h[i].tobytes() == want
+    # verify: valid signatures everywhere, same two bad indices -> exactly those two are rejected
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, b["n"], key_idx=b["kidx"], status=st)
+    ok = torch.zeros(b["n"], dtype=torch.uint8, device="cuda")
+    m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, b["n"], key_idx=bad)
+    ok_h = host(ok)
+    assert not ok_h[5] and not ok_h[17] and np.delete(ok_h, [5, 17]).all()
+    # the Python wrapper also refuses up front
+    with pytest.raises(IndexError):
+        m.verify(b["pks"], b["msgs"], sig, key_idx=[3] * b["n"])
+    # identity mapping needs a key per op
+    from fips204_amd import _lib
+    with pytest.raises(_lib.MldsaError):
+        m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, b["n"], key_idx=None)
+
+
+# ------------------------------------------------------------------------------ device-driven loop, graphs
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_sign_graph_replay_async_and_extra_rounds_are_bit_identical(hp, sets, pset):
+    """One batch signed (a) with direct launches, (b) three times through the same buffers so that the call is captured
+    and replayed as a hipGraph, (c) with mldsa_sign_async, (d) with only 2 rounds enqueued before the host looks (the
+    extra-round path): all byte-identical and equal to the oracle."""
+    m = sets[pset]
+    n = 700
+    b = make_batch(m, n, 5, b"loop%d" % pset)
+    want = oracle_sigs(pset, b, range(0, n, 7))
+    sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(n, dtype=torch.int32, device="cuda")
+
+    def run(wait=True):
+        sig.zero_()
+        m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st, wait=wait)
+        s = host(sig).copy()
+        assert int(host(st).min()) == 0 and int(host(st).max()) == 0
+        return s
+
+    hp.set_option(1, 0)  # MLDSA_OPT_GRAPHS off
+    s0 = hp.stats()
+    direct = run()
+    assert hp.stats()["graph_replays"] == s0["graph_replays"]
+    for got, w in zip(direct[::7], want):
+        assert got.tobytes() == w
+    hp.set_option(1, 1)
+    s0 = hp.stats()
+    for _ in range(3):
+        assert np.array_equal(run(), direct)
+    s1 = hp.stats()
+    assert s1["graphs_captured"] - s0["graphs_captured"] == 1 and s1["graph_replays"] - s0["graph_replays"] == 1
+    assert s1["sign_extra_rounds"] == s0["sign_extra_rounds"]  # the planned rounds finished the batch
+    for _ in range(3):
+        assert np.array_equal(run(wait=False), direct)  # mldsa_sign_async: its own call shape, captured + replayed too
+    assert hp.stats()["graph_replays"] - s1["graph_replays"] == 1
+    # (d) two planned rounds of one candidate per op cannot finish 700 ops: the synchronous call adds rounds until every
+    # op is signed ...
+    hp.set_option(6, 2)  # MLDSA_OPT_SIGN_ROUNDS
+    hp.set_option(3, 1)  # MLDSA_OPT_SPEC_MAX: no speculation
+    try:
+        s0 = hp.stats()
+        assert np.array_equal(run(), direct)
+        assert hp.stats()["sign_extra_rounds"] > s0["sign_extra_rounds"]
+        # ... and the asynchronous call reports the unfinished ops instead (status MLDSA_ERR_AGAIN, zero signature)
+        sig.zero_()
+        m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st, wait=False)
+        s, stat = host(sig), host(st)
+        again = stat == -5
+        assert 0 < again.sum() < n and (stat[~again] == 0).all()
+        assert not s[again].any()
+        assert np.array_equal(s[~again], direct[~again])
+    finally:
+        hp.set_option(6, 0)
+        hp.set_option(3, 32)
+
+
+def test_verify_and_keygen_replay_as_graphs(hp, sets):
+    m = sets[65]
+    b = make_batch(m, 300, 4, b"vgraph")
+    sig = m.try_sign_with_seed(b["sks"], b["msgs"], b["rnd"], key_idx=b["kidx_host"])
+    sig[11, 40] ^= 1
+    ok = torch.zeros(b["n"], dtype=torch.uint8, device="cuda")
+    hp.set_option(1, 2)  # MLDSA_OPT_GRAPHS = every op-level call (the default, 1, replays signing calls only)
+    s0 = hp.stats()
+    outs = []
+    for _ in range(4):
+        ok.zero_()
+        m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, b["n"], key_idx=b["kidx"])
+        outs.append(host(ok).copy())
+    s1 = hp.stats()
+    assert s1["graphs_captured"] - s0["graphs_captured"] == 1 and s1["graph_replays"] - s0["graph_replays"] == 2
+    want = np.ones(b["n"], dtype=np.uint8)
+    want[11] = 0
+    assert all(np.array_equal(o, want) for o in outs)
+    xi = torch.frombuffer(bytearray(b"".join(b["xi"])), dtype=torch.uint8).cuda().view(-1, 32)
+    pk = torch.empty((4, m.PK_LEN), dtype=torch.uint8, device="cuda")
+    sk = torch.empty((4, m.SK_LEN), dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        pk.zero_()
+        m.keygen_from_seed(xi, out=(pk, sk))
+        assert torch.equal(pk, b["pk"]) and torch.equal(sk, b["sk"])
+    assert hp.stats()["graphs_captured"] - s1["graphs_captured"] == 1
+    hp.set_option(1, 1)
+    s2 = hp.stats()
+    for _ in range(3):
+        m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, b["n"], key_idx=b["kidx"])
+    assert hp.stats()["graph_replays"] == s2["graph_replays"]  # default policy: verify is launched directly
+
+
+def test_reserve_makes_later_calls_allocation_free(sets):
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    h = HotPath(0)
+    try:
+        m = MlDsa(44, hotpath=h)
+        h.reserve(44, 2, 3000)  # MLDSA_OP_SIGN
+        g0 = h.stats()["workspace_growths"]
+        assert g0 == 1
+        b = make_batch(m, 3000, 2, b"reserve")
+        sig = m.try_sign_with_seed(b["sks"], b["msgs"], b["rnd"], key_idx=b["kidx_host"])
+        assert m.verify(b["pks"], b["msgs"], sig, key_idx=b["kidx_host"]).all()
+        assert h.stats()["workspace_growths"] == g0  # keygen, sign and verify of that size all fit
+    finally:
+        h.close()
+
+
+# ------------------------------------------------------------------------------ contexts, threads, devices
+def test_contexts_keep_their_device_and_work_from_a_fresh_thread(sets):
+    """the device was bound only in mldsa_ctx_create.  Two contexts created back to back keep their
+    own device id, and an op-level call issued from a brand-new host thread (whose current device the runtime
+    initialises to 0, not to the context's) gives the right answer."""
+    from fips204_amd import _lib
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    n_dev = torch.cuda.device_count()
+    a, c = HotPath(0), HotPath(n_dev - 1)
+    try:
+        lib = _lib.load()
+        assert lib.mldsa_ctx_device(a._h) == 0 and lib.mldsa_ctx_device(c._h) == n_dev - 1
+        m = MlDsa(44, hotpath=c)
+        res = {}
+
+        def work():
+            try:
+                xi = [bytes([7]) * 32]
+                pk, sk = m.keygen_from_seed(xi)
+                sig = m.try_sign_with_seed(m.private_keys_from_bytes(sk), [b"thread"], [bytes(32)])
+                res["ok"] = bool(m.verify(m.public_keys_from_bytes(pk), [b"thread"], sig)[0])
+                pk_o, sk_o = orc.keygen_from_seed(44, xi[0])
+                res["same"] = sig[0].cpu().numpy().tobytes() == orc.sign_internal(44, sk_o, b"thread", bytes(32), mode=0)
+            except Exception as e:  # noqa: BLE001
+                res["err"] = repr(e)
+
+        t = threading.Thread(target=work)
+        t.start()
+        t.join(300)
+        assert res == {"ok": True, "same": True}, res
+        import ctypes as C
+        h = C.c_void_p()
+        assert lib.mldsa_ctx_create(n_dev + 3, C.byref(h)) < 0 and not h.value  # no such device: an error, not a crash
+    finally:
+        a.close()
+        c.close()
+
+
+# ------------------------------------------------------------------------------ host-memory entry points
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_entry_points_match_the_device_resident_path(sets, pinned):
+    """mldsa_keygen_host / mldsa_sign_host / mldsa_verify_host (wire-format keys, host buffers, three sub-batches of which
+    the last is ragged) against the device-pointer API: identical keys, signatures and verdicts."""
+    m = sets[65]
+    n, nk = 2 * 16384 + 77, 6
+    b = make_batch(m, n, nk, b"host")
+    keep = []
+
+    def mk(a):
+        a = np.ascontiguousarray(a)
+        if not pinned:
+            return a.copy()
+        t = torch.empty(max(a.nbytes, 1), dtype=torch.uint8, pin_memory=True)  # page-locked: the DMA path of the library
+        keep.append(t)
+        v = t.numpy()[:a.nbytes].view(a.dtype).reshape(a.shape)
+        v[...] = a
+        return v
+    xi = mk(np.frombuffer(b"".join(b["xi"]), dtype=np.uint8).reshape(nk, 32))
+    pk_h, sk_h = m.keygen_host(xi)
+    assert np.array_equal(pk_h, host(b["pk"])) and np.array_equal(sk_h, host(b["sk"]))
+    # variable-length messages and ctxs so that the per-sub-batch offsets matter
+    rng = np.random.default_rng(11)
+    msgs = [rng.integers(0, 256, int(l), dtype=np.uint8).tobytes() for l in rng.integers(0, 200, n)]
+    ctxs = [rng.integers(0, 256, int(l), dtype=np.uint8).tobytes() for l in rng.integers(0, 9, n)]
+    rnd = mk(np.frombuffer(b"".join(b["rnd"]), dtype=np.uint8).reshape(n, 32))
+    kidx = mk(b["kidx_host"])
+    mflat, moff = m._cat_host(msgs)
+    cflat, coff = m._cat_host(ctxs)
+    mflat, moff, cflat, coff = mk(mflat), mk(moff), mk(cflat), mk(coff)
+    sig_h = m.sign_host(mk(sk_h), (mflat, moff), rnd, ctxs=(cflat, coff), key_idx=kidx)
+    sig_d = host(m.try_sign_with_seed(b["sks"], msgs, b["rnd"], ctxs=ctxs, key_idx=b["kidx_host"]))
+    assert np.array_equal(sig_h, sig_d)
+    sk_o = orc.sk_try_from_bytes(65, sk_h[int(b["kidx_host"][n - 1])].tobytes())
+    assert sig_h[n - 1].tobytes() == orc.sign_internal(65, sk_o, msgs[n - 1], b["rnd"][n - 1], ctx=ctxs[n - 1], mode=0)
+    bad = [3, 16383, 16384, n - 1]
+    sig_c = mk(sig_h)
+    for i in bad:
+        sig_c[i, 100 + i % 50] ^= 0x20
+    ok = m.verify_host(mk(pk_h), (mflat, moff), sig_c, ctxs=(cflat, coff), key_idx=kidx)
+    want = np.ones(n, dtype=bool)
+    want[bad] = False
+    assert np.array_equal(ok, want)
+    # ctx too long is an error for sign, a plain False for verify (lib.rs:274, 368)
+    long_ctx = [b"\x01" * 256] + [b""] * 9
+    with pytest.raises(ValueError):
+        m.sign_host(sk_h, msgs[:10], rnd[:10], ctxs=long_ctx, key_idx=kidx[:10])
+    assert not m.verify_host(pk_h, msgs[:10], sig_h[:10], ctxs=long_ctx, key_idx=kidx[:10])[0]
+
+
+# ------------------------------------------------------------------------------ BASELINE shapes at full size
+def test_config3_ml_dsa_65_sign_at_65536(sets):
+    """BASELINE config 3 / SURVEY row C3: ML-DSA-65, B = 65 536 (sk, 32-byte msg, hedged rnd) triples: signatures
+    byte-exact against the oracle on the first 1024 ops, every signature accepted by the verifier."""
+    m = sets[65]
+    n = 65536
+    b = make_batch(m, n, 1024, b"c3")
+    sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st)
+    assert int(host(st).max()) == 0 and int(host(st).min()) == 0
+    skb = host(b["sk"])
+    sk_o = [orc.sk_try_from_bytes(65, skb[i].tobytes()) for i in range(1024)]
+    want = orc.sign_batch_mt(65, sk_o, b["kidx_host"][:1024], b["msgs"][:1024], b["rnd"][:1024], 8, 1)
+    got = host(sig[:1024])
+    for i in range(1024):
+        assert got[i].tobytes() == want[i], i
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, n, key_idx=b["kidx"])
+    assert bool(host(ok).all())
+
+
+def test_config4_slice_ml_dsa_87_verify_at_131072(sets):
+    """BASELINE config 4's per-GPU slice: 131 072 ML-DSA-87 verifies = two pipeline chunks, 1 % of the signatures
+    corrupted in a known pattern; the oracle agrees on a sample from both chunks."""
+    m = sets[87]
+    n = 131072
+    b = make_batch(m, n, 1024, b"c4")
+    sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"])
+    bad = np.arange(37, n, 100)
+    cols = (bad * 7919) % m.SIG_LEN
+    sig[torch.from_numpy(bad).cuda(), torch.from_numpy(cols).cuda()] ^= 0x10
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, n, key_idx=b["kidx"])
+    ok_h = host(ok)
+    want = np.ones(n, dtype=np.uint8)
+    want[bad] = 0
+    # a flipped bit in the hint section can leave a signature valid only if it hits padding that must be zero -> it
+    # cannot: every corrupted signature must be rejected, every other accepted
+    assert np.array_equal(ok_h, want)
+    pkb = host(b["pk"])
+    sig_h = host(sig[[5, 37, 65535, 65536, 65637, n - 1]])
+    for row, i in enumerate([5, 37, 65535, 65536, 65637, n - 1]):
+        pk_o = orc.pk_try_from_bytes(87, pkb[int(b["kidx_host"][i])].tobytes())
+        assert orc.verify_internal(87, pk_o, b["msgs"][i], sig_h[row].tobytes(), mode=0) == bool(want[i])
+
+
+@pytest.mark.parametrize("pset", [65, 87])
+def test_multichunk_sign(sets, pset):
+    """a signing batch larger than one pipeline chunk (65 536 ops): second-chunk signatures byte-exact, all verify"""
+    m = sets[pset]
+    n = 65536 + 1500
+    b = make_batch(m, n, 64, b"mc%d" % pset)
+    sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st)
+    assert int(host(st).max()) == 0
+    idx = [0, 65535, 65536, 65537, n - 1]
+    got = host(sig[idx])
+    for row, w in enumerate(oracle_sigs(pset, b, idx)):
+        assert got[row].tobytes() == w
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, n, key_idx=b["kidx"])
+    assert bool(host(ok).all())

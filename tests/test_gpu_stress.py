@@ -95,24 +95,29 @@ def test_sign_speculation_regimes_match_oracle(sets, n_ops):
     assert m.verify(pks, msgs, sig).all()
 
 
-@pytest.mark.parametrize("lanes,target,spec_max", [(1, 65536, 32), (3, 65536, 32), (4, 4096, 7), (8, 1, 1), (2, 65536, 64)])
-def test_sign_schedule_knobs_do_not_change_signatures(sets, monkeypatch, lanes, target, spec_max):
-    """The rejection loop's scheduling (stream lanes, candidate slots per round, candidates per op)
-    is invisible in the output: the first accepted kappa wins, exactly as in ml_dsa.rs:212-336."""
+@pytest.mark.parametrize("target,spec_max,rounds", [(65536, 32, 0), (4096, 7, 0), (1, 1, 0), (65536, 64, 0), (65536, 32, 1), (512, 3, 4)])
+def test_sign_schedule_knobs_do_not_change_signatures(sets, target, spec_max, rounds):
+    """The rejection loop's scheduling (candidate slots per round, candidates per op, rounds enqueued before the
+    host looks) is invisible in the output: the first accepted kappa wins, exactly as in ml_dsa.rs:212-336."""
     m = sets[44]
+    hp = m.hp
     n_ops = 9001
     rng = np.random.default_rng(5)
     pk_o, sk_o = orc.keygen_from_seed(44, bytes([3] * 32))
     sks = m.private_keys_from_bytes([orc.sk_into_bytes(44, sk_o)])
     msgs = [rng.integers(0, 256, 20, dtype=np.uint8).tobytes() for _ in range(n_ops)]
     rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_ops)]
-    for k in ("MLDSA_SIGN_LANES", "MLDSA_SPEC_TARGET", "MLDSA_SPEC_MAX"):
-        monkeypatch.delenv(k, raising=False)
-    base = host(m.try_sign_with_seed(sks, msgs, rnd)).copy()
-    monkeypatch.setenv("MLDSA_SIGN_LANES", str(lanes))
-    monkeypatch.setenv("MLDSA_SPEC_TARGET", str(target))
-    monkeypatch.setenv("MLDSA_SPEC_MAX", str(spec_max))
-    got = host(m.try_sign_with_seed(sks, msgs, rnd))
+    defaults = {o: hp.get_option(o) for o in (2, 3, 6)}  # MLDSA_OPT_SPEC_TARGET, _SPEC_MAX, _SIGN_ROUNDS
+    assert defaults == {2: 65536, 3: 32, 6: 0}
+    base = host(m.try_sign_with_seed(sks, msgs, rnd, key_idx=[0] * n_ops)).copy()
+    try:
+        hp.set_option(2, target)
+        hp.set_option(3, spec_max)
+        hp.set_option(6, rounds)
+        got = host(m.try_sign_with_seed(sks, msgs, rnd, key_idx=[0] * n_ops))
+    finally:
+        for o, v in defaults.items():
+            hp.set_option(o, v)
     assert np.array_equal(got, base)
     for i in (0, 4500, 9000):
         assert base[i].tobytes() == orc.sign_internal(44, sk_o, msgs[i], rnd[i], mode=0), i

@@ -1,75 +1,111 @@
-"""Multi-rank path on CPU (gloo, world_size 2): the batch split of SURVEY.md 8e has no data-path
-collective -- each rank derives its own slice of the synthetic workload from the global op
-index -- so what must hold is: slices are disjoint and cover the job, and the timing reduction
-bench.py performs (barrier + MAX over ranks) works across processes."""
+"""Multi-rank path on CPU (gloo, world_size 2 and 3): the batch split of SURVEY.md 8e has no data-path
+collective, so what must hold is that the PRODUCT code bench.py and the host layers use --
+fips204_amd.multi_gpu.shard / launch_ranks / init_process_group / gather_verdicts / max_over_ranks --
+partitions a batch into disjoint contiguous slices that cover it (ragged B % N != 0 included), starts one
+fresh process per rank before any GPU call, and reassembles the per-rank verdict bytes in batch order."""
+import json
 import os
-import socket
 import subprocess
 import sys
 import textwrap
 
+import pytest
+
+from fips204_amd import multi_gpu
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("n,world", [(0, 1), (1, 1), (10, 3), (65536, 8), (1 << 20, 8), (7, 8), (1000003, 7), (5, 2)])
+def test_shard_partitions_the_batch(n, world):
+    pieces = [multi_gpu.shard(n, r, world) for r in range(world)]
+    pos = 0
+    for start, count in pieces:
+        assert start == pos and count >= 0  # contiguous, in rank order
+        pos += count
+    assert pos == n
+    per = -(-n // world) if world else 0
+    assert all(c <= per for _, c in pieces)  # ceil(B / N) per GPU
+    assert all(c == per for _, c in pieces[:n // per if per else 0])
+    with pytest.raises(ValueError):
+        multi_gpu.shard(n, world, world)
+
+
+def test_config4_slice():
+    """BASELINE config 4: 2^20 ML-DSA-87 verifies over 8 GPUs = 131072 per GPU."""
+    assert [multi_gpu.shard(1 << 20, r, 8) for r in (0, 7)] == [(0, 131072), (7 * 131072, 131072)]
+
 
 WORKER = textwrap.dedent("""
     import os, sys, json, hashlib
     sys.path.insert(0, %r)
-    import torch, torch.distributed as dist
+    import torch
+    from fips204_amd import multi_gpu
     import bench
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    batch = 64
-    base = rank * batch
-    # the same derivation bench.WholeOp uses for this rank's slice
-    msgs = [bench._shake(b"mldsa-bench-msg", base + i, 8) for i in range(batch)]
-    keys = [bench._shake(b"mldsa-bench-key" + bytes([65]), base + i, 4) for i in range(8)]
-    digest = hashlib.sha256(b"".join(msgs + keys)).digest()
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (rank, base, digest.hex(), msgs[0].hex(), msgs[-1].hex()))
-    # bench.py's timing reduction: MAX over ranks
-    t = torch.tensor([1.0 + rank], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.barrier()
+    rank, local_rank, world = multi_gpu.init_process_group("gloo")
+    n_total = int(sys.argv[1])
+    start, count = multi_gpu.shard(n_total, rank, world)
+    # this rank's slice of the synthetic job, derived from the GLOBAL op index like bench.WholeOp does
+    msgs = [bench._shake(b"mldsa-bench-msg", start + i, 8) for i in range(count)]
+    # a verdict pattern that depends on the global index only: op i fails iff i %% 7 == 3
+    ok = torch.tensor([0 if (start + i) %% 7 == 3 else 1 for i in range(count)], dtype=torch.uint8)
+    allok = multi_gpu.gather_verdicts(ok, n_total)
+    tmax = multi_gpu.max_over_ranks(1.0 + rank)
+    multi_gpu.barrier()
     if rank == 0:
-        print(json.dumps({"gathered": gathered, "tmax": float(t.item())}))
-    dist.destroy_process_group()
+        print(json.dumps({"world": world, "verdicts": allok.tolist(), "tmax": tmax,
+                          "first_msg": msgs[0].hex() if msgs else None}), flush=True)
+    multi_gpu.finish()
 """ % ROOT)
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def test_batch_split_world_size_2(tmp_path):
+@pytest.mark.parametrize("world,n_total", [(2, 64), (2, 65), (3, 10)])
+def test_launch_shard_gather(tmp_path, world, n_total, capfd):
+    """launch_ranks starts `world` fresh processes (RANK / WORLD_SIZE / MASTER_* set), they shard the job,
+    and the gathered verdict array is the whole batch in order -- also when B %% N != 0."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                      text=True))
-    outs = [p.communicate(timeout=180) for p in procs]
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e[-2000:]
-    import json
-    res = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
-    g = sorted(res["gathered"])
-    assert [x[0] for x in g] == [0, 1] and [x[1] for x in g] == [0, 64]  # contiguous, disjoint slices
-    assert g[0][2] != g[1][2]                                              # distinct data per rank
+    rc = multi_gpu.launch_ranks(world, [str(script), str(n_total)], timeout=240)
+    out = capfd.readouterr().out
+    assert rc == 0, out[-2000:]
+    res = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert res["world"] == world
+    assert res["verdicts"] == [0 if i % 7 == 3 else 1 for i in range(n_total)]
+    assert res["tmax"] == float(world)  # MAX over ranks of 1 + rank
     import bench
-    assert g[1][3] == bench._shake(b"mldsa-bench-msg", 64, 8).hex()      # rank 1 starts where rank 0 ends
-    assert g[0][4] == bench._shake(b"mldsa-bench-msg", 63, 8).hex()
-    assert res["tmax"] == 2.0                                              # MAX over ranks
+    assert res["first_msg"] == bench._shake(b"mldsa-bench-msg", 0, 8).hex()
 
 
-def test_bench_reads_torchrun_environment(monkeypatch):
+def test_launch_ranks_reports_failure(tmp_path):
+    script = tmp_path / "bad.py"
+    script.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    assert multi_gpu.launch_ranks(2, [str(script)], timeout=60) == 3
+
+
+def test_bench_gpus_flag_launches_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no torchrun environment must start N ranks itself (the flag was
+    parsed and ignored).  The launcher is intercepted here: no GPU in this container."""
+    import bench
+    seen = {}
+
+    def fake_launch(n, argv, **kw):
+        seen["n"], seen["argv"] = n, list(argv)
+        return 0
+
+    monkeypatch.setattr(multi_gpu, "launch_ranks", fake_launch)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--workload", "verify87", "--batch", "131072"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen["n"] == 4
+    assert seen["argv"][0].endswith("bench.py") and seen["argv"][1:] == ["--gpus", "4", "--workload", "verify87", "--batch", "131072"]
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus(monkeypatch):
     import bench
     monkeypatch.setenv("RANK", "0")
     monkeypatch.setenv("LOCAL_RANK", "0")
-    monkeypatch.setenv("WORLD_SIZE", "1")
-    assert bench.max_over_ranks(3.5, 1) == 3.5
-    args_default = bench.parse.__wrapped__() if hasattr(bench.parse, "__wrapped__") else None
-    assert args_default is None or args_default.gpus == 1
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit):
+        bench.dist_setup(bench.parse(["--gpus", "8"]))

@@ -1,5 +1,5 @@
 """Quick A/B harness for the config-2 kernel: interleaved rounds in one process per variant
-(env knobs are read at launch time)."""
+(the knob is a per-context option)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ variants = [v for v in os.environ.get("VARIANTS", "6,3,4,8,12,16").split(",")]
 res = {v: [] for v in variants}
 for rnd in range(5):
     for v in variants:
-        os.environ["MLDSA_VA_BLOCKS_PER_CU"] = v
+        hp.set_option(4, int(v))  # MLDSA_OPT_VA_BLOCKS_PER_CU
         for i in range(3): wl.step(i)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
