@@ -83,7 +83,7 @@ def dist_setup(args):
                          "--backend gloo shares GPUs for a functional check)")
     dev = local_rank % max(n_dev, 1)
     torch.cuda.set_device(dev)
-    rank, _, world = multi_gpu.init_process_group(args.backend if world > 1 else None, device_index=dev)
+    rank, _, world = multi_gpu.init_process_group(args.backend, device_index=dev)
     return rank, dev, world
 
 

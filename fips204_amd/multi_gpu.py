@@ -72,7 +72,8 @@ def init_process_group(backend=None, device_index=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # MLDSA_BENCH_FORCE_DIST=1: join a process group even with one rank (exercises the RCCL path on a 1-GPU box)
+    if world > 1 or (os.environ.get("MLDSA_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,22 +1,41 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   bench JSON lines, rocprofv3 kernel stats, and HBM-traffic PMC passes (separate --pmc runs, no other trace domains).
-# Everything lands in gpurun_out/final/; copy what is to be judged into profiles/.
+#   bench JSON lines, rocprofv3 kernel stats, HBM-traffic and SQ PMC passes (separate --pmc runs with --kernel-trace only,
+#   the program itself directly after `--`).  Everything lands in gpurun_out/final_$R/ and, summarised, in profiles/.
 set -u
-OUT=$PWD/gpurun_out/final
+R=${1:-r02}
+OUT=$PWD/gpurun_out/final_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python bench.py --workload sign65 > "$OUT/bench_sign65.json" 2>> "$OUT/bench_default.err"
-python bench.py --workload verify_arith44 --steps 200 --warmup 10 > "$OUT/bench_verify_arith44.json" 2>> "$OUT/bench_default.err"
+ERR="$OUT/bench.err"
+python bench.py > "$OUT/bench_default.json" 2> "$ERR"
+python bench.py --workload sign65 --no-extras > "$OUT/bench_sign65.json" 2>> "$ERR"
+python bench.py --workload verify_arith44 --steps 200 --warmup 10 > "$OUT/bench_verify_arith44.json" 2>> "$ERR"
+: > "$OUT/bench_other_workloads.jsonl"
 for w in verify44 verify87 sign44 sign87 keygen44 keygen65 keygen87 ntt inv_ntt mat_vec_mul65 expand_a65 expand_mask65 verify44_cached_a verify65_cached_a verify87_cached_a sign44_cached_a sign65_cached_a sign87_cached_a mixed; do
-  python bench.py --workload $w --no-cpu-baseline 2>> "$OUT/bench_default.err" | tail -1 > "$OUT/bench_$w.json"
+  python bench.py --workload $w --no-cpu-baseline 2>> "$ERR" | grep "^{" | tail -1 >> "$OUT/bench_other_workloads.jsonl"
 done
+# BASELINE config 4's per-GPU slice (131072 ML-DSA-87 verifies = two pipeline chunks) and config 5 at a larger step
+python bench.py --workload verify87 --batch 131072 --no-cpu-baseline --steps 10 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_config4_slice.json"
+python bench.py --workload mixed --batch 65536 --no-cpu-baseline --steps 5 --warmup 2 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_mixed_65536.json"
+# the multi-rank launch path on this 1-GPU box: two ranks started by bench.py itself, sharing GPU 0, gloo rendezvous
+python bench.py --gpus 2 --backend gloo --workload verify87 --batch 32768 --no-cpu-baseline --steps 5 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_gpus2_gloo_shared_gpu.json"
+# and the RCCL code path with a world of one (torchrun-style environment)
+MLDSA_BENCH_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --gpus 1 --workload verify87 --batch 32768 --no-cpu-baseline --steps 5 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_rccl_world1.json"
+./tools/ubench_graph 90 > "$OUT/ubench_graph.txt" 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_default" -o r -- python3 "$OLDPWD/bench.py" --no-cpu-baseline > "$OUT/prof_default.log" 2>&1 )
-for wl in verify65:v65 verify_arith44:c2 sign65:s65; do
-  w=${wl%%:*}; tag=${wl##*:}
+cp "$OUT"/prof_default/*/*kernel_stats.csv "$OUT/rocprofv3_kernel_stats_default.csv" 2>/dev/null || find "$OUT/prof_default" -name "*kernel_stats.csv" -exec cp {} "$OUT/rocprofv3_kernel_stats_default.csv" \;
+for w in verify65 verify_arith44 sign65; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- python3 "$OLDPWD/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/pmc_${tag}_$c.log" 2>&1 )
+    ( cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${w}_$c" -o p -- python3 "$OLDPWD/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/pmc_${w}_$c.log" 2>&1 )
   done
+  python tools/pmc_summary.py hbm $w "$OUT/pmc_${w}_FETCH_SIZE" "$OUT/pmc_${w}_WRITE_SIZE" $R
 done
+# is ExpandA VALU-issue-bound?  SQ counters of the kernel on its own (one pass: 5 of the 8 SQ slots)
+( cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/sq_expand_a65" -o p -- python3 "$OLDPWD/bench.py" --workload expand_a65 --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/sq_expand_a65.log" 2>&1 )
+python tools/pmc_summary.py sq expand_a65 "$OUT/sq_expand_a65" $R
+( cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d "$OUT/sq_sign65" -o p -- python3 "$OLDPWD/bench.py" --workload sign65 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/sq_sign65.log" 2>&1 )
+python tools/pmc_summary.py sq sign65 "$OUT/sq_sign65" $R
+cp profiles/${R}_pmc_*.json profiles/${R}_sq_*.json "$OUT"/ 2>/dev/null
+rm -rf "$OUT"/pmc_*_FETCH_SIZE "$OUT"/pmc_*_WRITE_SIZE "$OUT"/sq_expand_a65 "$OUT"/sq_sign65 "$OUT"/prof_default  # raw traces: large
 ls -la "$OUT"
