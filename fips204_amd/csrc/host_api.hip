@@ -28,7 +28,11 @@ struct Buf {  // a device buffer with an optional page-locked bounce twin, grown
 };
 
 struct Slot {
-    Buf sigs, msgs, msg_off, ctxs, ctx_off, key_idx, rnd, out, status, xi, pk, sk;
+    Buf sigs, msgs, msg_off, ctxs, ctx_off, key_idx, rnd, out, status, xi, pk, sk, pack;
+    // device views of the sub-batch's small inputs (inside `pack`, or the separate buffers above)
+    const uint32_t *d_kidx = nullptr;
+    const uint64_t *d_moff = nullptr, *d_coff = nullptr;
+    const uint8_t *d_msgs = nullptr, *d_ctxs = nullptr;
     hipEvent_t up_done = nullptr, comp_done = nullptr, down_done = nullptr;
     bool busy = false;
     // pending bounce copies back to the caller's pageable memory, done when the slot is reclaimed
@@ -151,7 +155,7 @@ void host_stage_destroy(mldsa_ctx *ctx) {
     HostStage *hs = ctx->host_stage;
     if (!hs) return;
     for (auto &sl : hs->slot) {
-        for (Buf *b : {&sl.sigs, &sl.msgs, &sl.msg_off, &sl.ctxs, &sl.ctx_off, &sl.key_idx, &sl.rnd, &sl.out, &sl.status, &sl.xi, &sl.pk, &sl.sk})
+        for (Buf *b : {&sl.sigs, &sl.msgs, &sl.msg_off, &sl.ctxs, &sl.ctx_off, &sl.key_idx, &sl.rnd, &sl.out, &sl.status, &sl.xi, &sl.pk, &sl.sk, &sl.pack})
             free_buf(*b);
         if (sl.up_done) (void)hipEventDestroy(sl.up_done);
         if (sl.comp_done) (void)hipEventDestroy(sl.comp_done);
@@ -176,15 +180,48 @@ struct OpInputs {
     bool pin_kidx, pin_msgs, pin_moff, pin_ctxs, pin_coff;
 };
 
+// The per-op side inputs (key indices, offsets, messages, ctxs) are a few hundred KB per sub-batch in 3-5 arrays; every
+// separate DMA costs ~15-20 us of link time whatever its size.  They are gathered into ONE page-locked buffer on the
+// host (a sub-100-us memcpy that overlaps the previous sub-batch's DMA) and go up in one copy; only the bulk array
+// (signatures / rnd) is copied straight from the caller's memory.
+constexpr size_t PACK_LIMIT = 8u << 20;
+
 static int upload_op_inputs(HostStage *hs, Slot &sl, const OpInputs &in, size_t a, size_t b) {
     const size_t n = b - a;
-    if (in.key_idx) TRY(upload(sl.key_idx, in.key_idx + a, n * 4, in.pin_kidx, hs->up));
-    TRY(upload(sl.msg_off, in.msg_off + a, (n + 1) * 8, in.pin_moff, hs->up));
-    TRY(upload(sl.msgs, in.msgs ? in.msgs + in.msg_off[a] : nullptr, in.msgs ? span(in.msg_off, a, b) : 0, in.pin_msgs, hs->up));
-    if (in.ctx_off) {
-        TRY(upload(sl.ctx_off, in.ctx_off + a, (n + 1) * 8, in.pin_coff, hs->up));
-        TRY(upload(sl.ctxs, in.ctxs ? in.ctxs + in.ctx_off[a] : nullptr, in.ctxs ? span(in.ctx_off, a, b) : 0, in.pin_ctxs, hs->up));
+    const size_t kb = in.key_idx ? n * 4 : 0, mob = (n + 1) * 8, mb = in.msgs ? span(in.msg_off, a, b) : 0;
+    const size_t cob = in.ctx_off ? (n + 1) * 8 : 0, cb = (in.ctx_off && in.ctxs) ? span(in.ctx_off, a, b) : 0;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_k = 0, o_mo = al(kb), o_m = o_mo + al(mob), o_co = o_m + al(mb + 8), o_c = o_co + al(cob), total = o_c + al(cb + 8);
+    if (total <= PACK_LIMIT) {
+        TRY(grow_dev(sl.pack, total));
+        TRY(grow_pin(sl.pack, total));
+        uint8_t *h = sl.pack.pin;
+        if (kb) memcpy(h + o_k, in.key_idx + a, kb);
+        memcpy(h + o_mo, in.msg_off + a, mob);
+        if (mb) memcpy(h + o_m, in.msgs + in.msg_off[a], mb);
+        if (cob) memcpy(h + o_co, in.ctx_off + a, cob);
+        if (cb) memcpy(h + o_c, in.ctxs + in.ctx_off[a], cb);
+        HCHECK(hipMemcpyAsync(sl.pack.dev, h, total, hipMemcpyHostToDevice, hs->up));
+        uint8_t *d = sl.pack.dev;
+        sl.d_kidx = kb ? reinterpret_cast<const uint32_t *>(d + o_k) : nullptr;
+        sl.d_moff = reinterpret_cast<const uint64_t *>(d + o_mo);
+        sl.d_msgs = d + o_m;
+        sl.d_coff = cob ? reinterpret_cast<const uint64_t *>(d + o_co) : nullptr;
+        sl.d_ctxs = d + o_c;
+        return MLDSA_OK;
     }
+    if (in.key_idx) TRY(upload(sl.key_idx, in.key_idx + a, kb, in.pin_kidx, hs->up));
+    TRY(upload(sl.msg_off, in.msg_off + a, mob, in.pin_moff, hs->up));
+    TRY(upload(sl.msgs, in.msgs ? in.msgs + in.msg_off[a] : nullptr, mb, in.pin_msgs, hs->up));
+    if (in.ctx_off) {
+        TRY(upload(sl.ctx_off, in.ctx_off + a, cob, in.pin_coff, hs->up));
+        TRY(upload(sl.ctxs, in.ctxs ? in.ctxs + in.ctx_off[a] : nullptr, cb, in.pin_ctxs, hs->up));
+    }
+    sl.d_kidx = in.key_idx ? reinterpret_cast<const uint32_t *>(sl.key_idx.dev) : nullptr;
+    sl.d_moff = reinterpret_cast<const uint64_t *>(sl.msg_off.dev);
+    sl.d_msgs = sl.msgs.dev;
+    sl.d_coff = in.ctx_off ? reinterpret_cast<const uint64_t *>(sl.ctx_off.dev) : nullptr;
+    sl.d_ctxs = in.ctx_off ? sl.ctxs.dev : nullptr;
     return MLDSA_OK;
 }
 
@@ -239,14 +276,12 @@ int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size
             HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
             // the slice's byte strings start at offset msg_off[a] of the caller's array: hand the kernels a base
             // pointer that makes the caller's own offsets land in the staging buffer
-            const uint8_t *mbase = sl.msgs.dev - msg_off[a];
-            const uint8_t *cbase = ctx_off ? sl.ctxs.dev - ctx_off[a] : nullptr;
+            const uint8_t *mbase = sl.d_msgs - msg_off[a];
+            const uint8_t *cbase = ctx_off ? sl.d_ctxs - ctx_off[a] : nullptr;
             const size_t kb = key_idx ? 0 : a;  // identity mapping walks the key table with the batch
             TRY(mldsa_verify(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_tr.dev + kb * 64,
-                             reinterpret_cast<const int32_t *>(hs->k_a.dev) + kb * k * 256, n_keys - kb,
-                             key_idx ? reinterpret_cast<const uint32_t *>(sl.key_idx.dev) : nullptr, mbase,
-                             reinterpret_cast<const uint64_t *>(sl.msg_off.dev), cbase,
-                             ctx_off ? reinterpret_cast<const uint64_t *>(sl.ctx_off.dev) : nullptr, sl.sigs.dev, sl.out.dev, n, hs->comp));
+                             reinterpret_cast<const int32_t *>(hs->k_a.dev) + kb * k * 256, n_keys - kb, sl.d_kidx, mbase, sl.d_moff, cbase,
+                             sl.d_coff, sl.sigs.dev, sl.out.dev, n, hs->comp));
             HCHECK(hipEventRecord(sl.comp_done, hs->comp));
             HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
             TRY(download(sl, sl.out, ok + a, n, pin_ok, hs->down));
@@ -313,15 +348,12 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
             TRY(grow_dev(sl.status, n * 4));
             HCHECK(hipEventRecord(sl.up_done, hs->up));
             HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
-            const uint8_t *mbase = sl.msgs.dev - msg_off[a];
-            const uint8_t *cbase = ctx_off ? sl.ctxs.dev - ctx_off[a] : nullptr;
+            const uint8_t *mbase = sl.d_msgs - msg_off[a];
+            const uint8_t *cbase = ctx_off ? sl.d_ctxs - ctx_off[a] : nullptr;
             const size_t kb = key_idx ? 0 : a;
             TRY(mldsa_sign_async(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_capk.dev + kb * 32, hs->k_tr.dev + kb * 64, s1 + kb * l * 256,
-                                 s2 + kb * k * 256, t0 + kb * k * 256, n_keys - kb,
-                                 key_idx ? reinterpret_cast<const uint32_t *>(sl.key_idx.dev) : nullptr, mbase,
-                                 reinterpret_cast<const uint64_t *>(sl.msg_off.dev), cbase,
-                                 ctx_off ? reinterpret_cast<const uint64_t *>(sl.ctx_off.dev) : nullptr, sl.rnd.dev, sl.out.dev,
-                                 reinterpret_cast<int32_t *>(sl.status.dev), n, hs->comp));
+                                 s2 + kb * k * 256, t0 + kb * k * 256, n_keys - kb, sl.d_kidx, mbase, sl.d_moff, cbase, sl.d_coff,
+                                 sl.rnd.dev, sl.out.dev, reinterpret_cast<int32_t *>(sl.status.dev), n, hs->comp));
             HCHECK(hipEventRecord(sl.comp_done, hs->comp));
             HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
             TRY(download(sl, sl.out, sigs + a * sgl, n * sgl, pin_sigs, hs->down));

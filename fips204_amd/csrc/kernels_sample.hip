@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
 // y[r][i] = gamma1 - (c-bit field i of v), c = 1 + bitlen(gamma1 - 1) (bit_unpack,
 // conversion.rs:227-262).  No rejection: all lanes advance in lock step.
 template <int GB>  // gamma1 = 2^GB, GB = 17 or 19
-__global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __restrict__ rho_pp, size_t rho_stride,
+__global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_expand_mask(const uint8_t* __restrict__ rho_pp, size_t rho_stride,
                                                              const uint16_t* __restrict__ kappa, int kappa_by_slot,
                                                              const uint32_t* __restrict__ op_idx,
                                                              int32_t* __restrict__ y, int l, size_t n_ops,
@@ -177,7 +177,9 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask(const uint8_t* __re
             if (fc > 0) {
                 wave_lds_sync();
                 const int grp = lane >> 3, j4 = (lane & 7) * 4;
-#pragma unroll
+                // rolled on purpose: unrolled, the eight row addresses stay live across the permutations and cost the
+                // kernel its fourth wave per SIMD (142 -> 118 VGPRs)
+#pragma unroll 1
                 for (int i = 0; i < 8; i++) {
                     const int row = 8 * i + grp;
                     if (j4 < fc && wave_base + row < n_streams) {

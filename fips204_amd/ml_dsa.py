@@ -61,17 +61,23 @@ class PrivateKeys:
 
 
 def _check_key_idx(key_idx, n_keys, n_ops):
-    """Host-side courtesy check (the library itself also refuses out-of-range indices per op)."""
+    """Host-side courtesy check (the library itself also refuses out-of-range indices per op).
+    A uint32 array is passed through without a copy."""
     if key_idx is None:
         if n_keys < n_ops:
             raise ValueError(f"{n_ops} operations but only {n_keys} keys and no key_idx")
         return None
-    a = np.asarray(key_idx, dtype=np.int64)
+    a = np.asarray(key_idx)
+    if a.dtype != np.uint32:
+        a64 = a.astype(np.int64)
+        if n_ops and a64.size and a64.min() < 0:
+            raise IndexError(f"key_idx out of range (n_keys = {n_keys})")
+        a = a64.astype(np.uint32) if (not a64.size or a64.max() < 2 ** 32) else np.full(a64.shape, 0xFFFFFFFF, np.uint32)
     if a.shape != (n_ops,):
         raise ValueError("key_idx: one entry per operation expected")
-    if n_ops and (a.min() < 0 or a.max() >= n_keys):
+    if n_ops and int(a.max()) >= n_keys:
         raise IndexError(f"key_idx out of range (n_keys = {n_keys})")
-    return a.astype(np.uint32)
+    return np.ascontiguousarray(a)
 
 
 class MlDsa:
