@@ -122,9 +122,14 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
     const LdsTw ftw{tw_lds, lane};
     const LdsTw itw{tw_lds + FWD_TW * 64, lane};
     const uint32_t wid = blockIdx.x * VW + wave, n_waves = gridDim.x * VW;
-    const unsigned ul = (unsigned)lane;  // unsigned lane offsets: uniform base + zero-extended 32-bit offset addressing
 
     for (size_t op = wid; op < n_ops; op += n_waves) {
+        // the lane index made opaque per operation: address arithmetic on it is then redone where it is used instead of being
+        // hoisted out of the op loop and kept (or, at the register budget of 4 waves per SIMD, spilled) across it: 18-24 VGPRs
+        // less (ML-DSA-87: 120, no spill at 4 waves per SIMD), -6 % / -3 % run time for ML-DSA-65 / 87 in a same-box A/B.
+        // (The same trick made k_verify_arith ~4 % slower and left k_sign_tail unchanged: not applied there.)
+        unsigned ul = (unsigned)lane;
+        asm volatile("" : "+v"(ul));
         // wave-uniform, so row pointers stay scalar (SGPR base + lane offset) instead of per-lane 64-bit addresses
         const size_t key = key_idx ? (size_t)__builtin_amdgcn_readfirstlane((int)key_idx[op]) : op;
         const size_t aop = a_by_key ? key : op;  // per-key A_hat kept by the caller, or the op's own ExpandA output
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
                 int32_t mx = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t v = load_field_aligned(src, (64 * k + lane) * CB, CB);  // hints follow z: over-read is in-buffer
+                    const uint32_t v = load_field_aligned(src, (int)(64 * k + ul) * CB, CB);  // hints follow z: over-read is in-buffer
                     r[k] = (1 << GB) - (int32_t)v;
                     const int32_t a = r[k] < 0 ? -r[k] : r[k];
                     mx = a > mx ? a : mx;
@@ -194,10 +199,9 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
                 for (int j = 0; j < L; j++) av[j] = arow[(unsigned)(((i + 1) * L + j) * 64) + ul];
                 tv = trow[(unsigned)((i + 1) * 64) + ul];
             }
-            // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5)
-            uint32_t hw[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) hw[k] = hmask[(op * K + i) * 8 + 2 * k + (lane >> 5)];
+            // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5).  One dword per lane (lane l holds word l & 7),
+            // handed out with v_readlane after the inverse transform: one live register instead of four
+            const uint32_t hword = hmask[(op * K + i) * 8 + (ul & 7)];
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
             ntt_inv_wave(acc, itw, lane, F_MONT2);
@@ -206,7 +210,9 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
             uint32_t v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t h = (hw[k] >> (lane & 31)) & 1u;
+                const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)hword, 2 * k), whi = (uint32_t)__builtin_amdgcn_readlane((int)hword, 2 * k + 1);
+                const uint32_t hwk = lane < 32 ? wlo : whi;
+                const uint32_t h = (hwk >> (lane & 31)) & 1u;
                 v[k] = (uint32_t)use_hint<G2HI>((int32_t)h, acc[k]);
             }
             pack_w1_strided<G2HI>(v, dst, lane);
@@ -447,7 +453,7 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
     else if (p->set == MLDSA_65) MLDSA_VM(6, 5, 19, true, 4);
     // ML-DSA-87 with the packed A_hat (21 prefetched dwords per lane): compiled for 3 waves per SIMD (137 VGPRs, no
     // spill); at 4 waves the compiler spills 8 VGPRs of loop-invariant addresses (36 B scratch) for 1.3 % more throughput
-    else if (a_packed) MLDSA_VM2(8, 7, 19, true, 3, true);
+    else if (a_packed) MLDSA_VM2(8, 7, 19, true, 4, true);
     else MLDSA_VM2(8, 7, 19, true, 4, false);
 #undef MLDSA_VM2
 #undef MLDSA_VM
