@@ -56,8 +56,8 @@ REFERENCE_PUBLISHED = {
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("MLDSA_BENCH_WORKLOAD", "verify65"))
     ap.add_argument("--batch", type=int, default=0, help="ops per GPU (0 = the workload's BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -619,6 +619,7 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
         from fips204_amd import multi_gpu
         import torch.distributed as dist
         on_cpu = multi_gpu.is_distributed() and dist.get_backend() != "nccl"
+        multi_gpu.gather_verdicts(wl.ok.cpu() if on_cpu else wl.ok, wl.batch * world).sum().item()  # first use: communicator set-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         allok = multi_gpu.gather_verdicts(wl.ok.cpu() if on_cpu else wl.ok, wl.batch * world)
@@ -744,7 +745,7 @@ def main():
     # (same JSON line): config[1] = the HBM-roofline kernel, config[2] = whole sign
     if default_run:
         also = {}
-        for name, st, wu, cb in (("verify_arith44", 50, 5, False), ("sign65", 10, 2, not args.no_cpu_baseline)):
+        for name, st, wu, cb in (("verify_arith44", 200, 10, False), ("sign65", 30, 3, not args.no_cpu_baseline)):
             sub = run_one(args, hp, rank, world, name, st, wu, cb, with_host_fed=(name == "sign65"))
             also[name] = {k: sub[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline") if k in sub}
             for k in ("stage_ms_per_step", "launch_gap_ms_per_step", "sign_iterations_per_signature", "launch_mode", "profiled_pass", "cpu_baseline",

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 ERR="$OUT/bench.err"
 python bench.py > "$OUT/bench_default.json" 2> "$ERR"
 python bench.py --workload sign65 --no-extras > "$OUT/bench_sign65.json" 2>> "$ERR"
-python bench.py --workload verify_arith44 --steps 200 --warmup 10 > "$OUT/bench_verify_arith44.json" 2>> "$ERR"
+python bench.py --workload verify_arith44 --steps 500 --warmup 20 > "$OUT/bench_verify_arith44.json" 2>> "$ERR"
 : > "$OUT/bench_other_workloads.jsonl"
 for w in verify44 verify87 sign44 sign87 keygen44 keygen65 keygen87 ntt inv_ntt mat_vec_mul65 expand_a65 expand_mask65 verify44_cached_a verify65_cached_a verify87_cached_a sign44_cached_a sign65_cached_a sign87_cached_a mixed; do
   python bench.py --workload $w --no-cpu-baseline 2>> "$ERR" | grep "^{" | tail -1 >> "$OUT/bench_other_workloads.jsonl"
@@ -23,8 +23,15 @@ python bench.py --gpus 2 --backend gloo --workload verify87 --batch 32768 --no-c
 # and the RCCL code path with a world of one (torchrun-style environment)
 MLDSA_BENCH_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --gpus 1 --workload verify87 --batch 32768 --no-cpu-baseline --steps 5 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_rccl_world1.json"
 ./tools/ubench_graph 90 > "$OUT/ubench_graph.txt" 2>&1
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_default" -o r -- python3 "$OLDPWD/bench.py" --no-cpu-baseline > "$OUT/prof_default.log" 2>&1 )
-cp "$OUT"/prof_default/*/*kernel_stats.csv "$OUT/rocprofv3_kernel_stats_default.csv" 2>/dev/null || find "$OUT/prof_default" -name "*kernel_stats.csv" -exec cp {} "$OUT/rocprofv3_kernel_stats_default.csv" \;
+# rocprofv3 per-kernel summaries of the commands whose kernel times bench.py reports: the headline workload on its own (every
+# k_expand_a / k_verify_main launch is a 65536-op launch: the averages must agree with roofline.kernel_ms), sign65 on its
+# own, and the whole default run (which also contains the smaller launches of the host-fed passes)
+for spec in "verify65:--no-extras" "sign65:--workload sign65 --no-extras --steps 30 --warmup 3" "default:"; do
+  tag=${spec%%:*}; flags=${spec#*:}
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$tag" -o r -- python3 "$OLDPWD/bench.py" --no-cpu-baseline $flags > "$OUT/prof_$tag.log" 2>&1 )
+  find "$OUT/prof_$tag" -name "*kernel_stats.csv" -exec cp {} "$OUT/rocprofv3_kernel_stats_$tag.csv" \;
+  rm -rf "$OUT/prof_$tag"
+done
 for w in verify65 verify_arith44 sign65; do
   for c in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${w}_$c" -o p -- python3 "$OLDPWD/bench.py" --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/pmc_${w}_$c.log" 2>&1 )
@@ -37,5 +44,5 @@ python tools/pmc_summary.py sq expand_a65 "$OUT/sq_expand_a65" $R
 ( cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d "$OUT/sq_sign65" -o p -- python3 "$OLDPWD/bench.py" --workload sign65 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/sq_sign65.log" 2>&1 )
 python tools/pmc_summary.py sq sign65 "$OUT/sq_sign65" $R
 cp profiles/${R}_pmc_*.json profiles/${R}_sq_*.json "$OUT"/ 2>/dev/null
-rm -rf "$OUT"/pmc_*_FETCH_SIZE "$OUT"/pmc_*_WRITE_SIZE "$OUT"/sq_expand_a65 "$OUT"/sq_sign65 "$OUT"/prof_default  # raw traces: large
+rm -rf "$OUT"/pmc_*_FETCH_SIZE "$OUT"/pmc_*_WRITE_SIZE "$OUT"/sq_expand_a65 "$OUT"/sq_sign65  # raw traces: large
 ls -la "$OUT"
