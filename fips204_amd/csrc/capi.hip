@@ -88,6 +88,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_graphs = env_long("MLDSA_GRAPHS", 0, 2, ctx->opt_graphs);
     ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 65536, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
+    ctx->opt_sign_lanes = env_long("MLDSA_SIGN_LANES", 1, 2, ctx->opt_sign_lanes);
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
     ctx->opt_host_sub_verify = env_long("MLDSA_HOST_SUB_VERIFY", 64, 65536, ctx->opt_host_sub_verify);
     ctx->opt_host_sub_sign = env_long("MLDSA_HOST_SUB_SIGN", 64, 65536, ctx->opt_host_sub_sign);
@@ -114,12 +115,12 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctl, sizeof(RoundCtl));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctl, 2 * sizeof(RoundCtl));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
     }
-    memset(ctx->h_ctl, 0, sizeof(RoundCtl));
+    memset(ctx->h_ctl, 0, 2 * sizeof(RoundCtl));
     *out = ctx;
     return MLDSA_OK;
 }
@@ -177,6 +178,10 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             REQUIRE(value >= 0 && value <= 64, "mldsa_set_option: MLDSA_OPT_SIGN_ROUNDS out of range");
             ctx->opt_sign_rounds = value;
             return MLDSA_OK;
+        case MLDSA_OPT_SIGN_LANES:
+            REQUIRE(value == 1 || value == 2, "mldsa_set_option: MLDSA_OPT_SIGN_LANES is 1 or 2");
+            ctx->opt_sign_lanes = value;
+            return MLDSA_OK;
         default: return set_error(MLDSA_ERR_PARAM, "mldsa_set_option: unknown option");
     }
 }
@@ -190,6 +195,7 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option) {
         case MLDSA_OPT_VA_BLOCKS_PER_CU: return ctx->opt_va_blocks;
         case MLDSA_OPT_GRAPH_CACHE: return ctx->opt_graph_cache;
         case MLDSA_OPT_SIGN_ROUNDS: return ctx->opt_sign_rounds;
+        case MLDSA_OPT_SIGN_LANES: return ctx->opt_sign_lanes;
         default: return MLDSA_ERR_PARAM;
     }
 }
@@ -426,7 +432,7 @@ static int verify_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, co
     key.op = MLDSA_OP_VERIFY; key.set = set; key.mode = mode; key.rho = rho; key.a_hat = a_hat; key.tr = tr; key.t1 = t1; key.n_keys = n_keys;
     key.key_idx = key_idx; key.msgs = msgs; key.msg_off = msg_off; key.ctxs = ctxs; key.ctx_off = ctx_off; key.sigs = sigs; key.ok = ok;
     key.n_ops = n_ops;
-    return run_op(ctx, s, MLDSA_OP_VERIFY, &key, sizeof(key), [&](hipStream_t st) {
+    return run_op(ctx, s, MLDSA_OP_VERIFY, n_ops, &key, sizeof(key), [&](hipStream_t st) {
         return verify_batch(ctx, set, mode, rho, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, st, a_hat);
     });
 }
@@ -518,7 +524,7 @@ int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     struct { int op, set; const void *xi, *pk, *sk; size_t n; } key;
     memset(&key, 0, sizeof(key));
     key.op = MLDSA_OP_KEYGEN; key.set = set; key.xi = xi; key.pk = pk; key.sk = sk; key.n = n_keys;
-    return run_op(ctx, s, MLDSA_OP_KEYGEN, &key, sizeof(key), [&](hipStream_t st) { return keygen_batch(ctx, set, xi, pk, sk, n_keys, st); });
+    return run_op(ctx, s, MLDSA_OP_KEYGEN, n_keys, &key, sizeof(key), [&](hipStream_t st) { return keygen_batch(ctx, set, xi, pk, sk, n_keys, st); });
 }
 
 static int sign_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,

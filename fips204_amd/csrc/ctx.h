@@ -37,7 +37,7 @@ struct mldsa_ctx {
     int n_cu = 256;
     // tuning knobs (mldsa_set_option)
     long opt_graphs = 1, opt_spec_target = 65536, opt_spec_max = 32, opt_va_blocks = 16, opt_graph_cache = 24;
-    long opt_sign_rounds = 0;
+    long opt_sign_rounds = 0, opt_sign_lanes = 1;
     long opt_host_sub_verify = 8192, opt_host_sub_sign = 32768;  // ops per sub-batch of the *_host entry points
     mldsa_stats stats = {};
     // hipGraph replay of repeated op-level call shapes
@@ -256,7 +256,7 @@ size_t verify_workspace_bytes(const mldsa_params *, size_t n_ops, bool own_a);
 size_t sign_workspace_bytes(const mldsa_ctx *, const mldsa_params *, size_t n_ops, bool own_a);
 size_t keygen_workspace_bytes(const mldsa_params *, size_t n_keys);
 // hipGraph replay of repeated call shapes: `key` = every value that ends up in a kernel parameter
-int run_op(mldsa_ctx *, hipStream_t, int op, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue);
+int run_op(mldsa_ctx *, hipStream_t, int op, size_t n_ops, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue);
 void drop_graphs(mldsa_ctx *);
 void host_stage_destroy(mldsa_ctx *);  // host_api.hip
 

@@ -141,6 +141,12 @@ int stage_get(mldsa_ctx *ctx, HostStage **out) {
     return MLDSA_OK;
 }
 
+// secrets must not outlive the call in the staging buffers (the reference zeroizes on drop, types.rs:19)
+void wipe_buf(Buf &b, hipStream_t st) {
+    if (b.dev) (void)hipMemsetAsync(b.dev, 0, b.cap, st);
+    if (b.pin) memset(b.pin, 0, b.pin_cap);
+}
+
 void free_buf(Buf &b) {
     if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); }
     if (b.pin) { memset(b.pin, 0, b.pin_cap); (void)hipHostFree(b.pin); }
@@ -367,7 +373,13 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
         const int r2 = reclaim(sl);
         if (rc == MLDSA_OK) rc = r2;
     }
-    if (rc != MLDSA_OK) { (void)hipDeviceSynchronize(); return rc; }
+    if (rc != MLDSA_OK) {
+        (void)hipDeviceSynchronize();
+        for (Buf *b : {&hs->key_bytes, &hs->k_capk, &hs->k_a, &hs->k_b, &hs->k_c}) wipe_buf(*b, hs->comp);
+        for (auto &sl : hs->slot) wipe_buf(sl.rnd, hs->comp);
+        (void)hipStreamSynchronize(hs->comp);
+        return rc;
+    }
     // ops the enqueued rounds left unfinished (probability < 1e-9 per call): sign them again, waiting this time
     for (size_t op = 0; op < n_ops && rc == MLDSA_OK; op++) {
         if (st[op] != MLDSA_ERR_AGAIN) continue;
@@ -391,6 +403,10 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
             return MLDSA_OK;
         }();
     }
+    // the private keys (wire bytes and expanded fields) and the per-signature randomness leave the staging buffers
+    for (Buf *b : {&hs->key_bytes, &hs->k_capk, &hs->k_a, &hs->k_b, &hs->k_c}) wipe_buf(*b, hs->comp);
+    for (auto &sl : hs->slot) wipe_buf(sl.rnd, hs->comp);
+    (void)hipStreamSynchronize(hs->comp);
     return rc;
 }
 
@@ -435,6 +451,8 @@ int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, u
         if (rc == MLDSA_OK) rc = r2;
     }
     if (rc != MLDSA_OK) (void)hipDeviceSynchronize();
+    for (auto &sl : hs->slot) { wipe_buf(sl.xi, hs->comp); wipe_buf(sl.sk, hs->comp); }  // seeds and private keys
+    (void)hipStreamSynchronize(hs->comp);
     return rc;
 }
 

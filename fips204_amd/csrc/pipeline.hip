@@ -22,10 +22,10 @@ constexpr size_t CHUNK_OPS = 65536;
 
 int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return MLDSA_OK;
-    // growing replaces the buffer every captured graph points into
+    // growing replaces the buffer every captured graph points into: wait for whatever still runs, then drop them
+    MLDSA_HIP_CHECK(hipDeviceSynchronize());
     drop_graphs(ctx);
     if (ctx->ws) {
-        MLDSA_HIP_CHECK(hipDeviceSynchronize());
         (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // may hold secrets of a previous sign / keygen call
         MLDSA_HIP_CHECK(hipFree(ctx->ws));
         ctx->ws = nullptr;
@@ -304,10 +304,11 @@ struct SignWs {
     uint32_t *act[2], *slot_op, *slot_key, *kidx;
     RoundCtl *ctl;
     size_t bytes = 0, stage_stride = 0;
+    uint8_t *base = nullptr;
     SignWs() = default;
     // n = ops of the chunk, ns = most candidate slots of a round
-    SignWs(void *base, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat) {
-        Carver cv(base);
+    SignWs(void *base_, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat) : base(static_cast<uint8_t *>(base_)) {
+        Carver cv(base_);
         stage_stride = ((size_t)p->sig_len + 15) & ~(size_t)15;
         a_hat = cv.take<int32_t>(own_a_hat ? n * (size_t)(p->k * p->l) * N : 0);
         key_bad = cv.take<int32_t>(n);
@@ -383,9 +384,15 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode) {
 }
 }  // namespace
 
+// lanes of a chunk of `chunk` ops: two when the option asks for it and each would still be a sizeable batch
+static int sign_lanes_for(const mldsa_ctx *ctx, size_t chunk) { return (ctx->opt_sign_lanes >= 2 && chunk >= 8192) ? 2 : 1; }
+static size_t lane_ops(size_t chunk, int n_lanes) { return n_lanes == 1 ? chunk : ((chunk + 1) / 2 + 255) & ~(size_t)255; }
+
 size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a) {
-    const size_t n = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
-    return SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a).bytes;
+    const size_t chunk = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
+    const int n_lanes = sign_lanes_for(ctx, chunk);
+    const size_t n = lane_ops(chunk, n_lanes);
+    return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a).bytes;
 }
 
 // One round of the rejection loop (steps 10-33 of Algorithm 7), counts read from the device
@@ -461,11 +468,11 @@ void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
     // y, rho'', cs1 / cs2, staged signatures are secret-dependent (the reference zeroizes on drop, types.rs:19);
     // A_hat = ExpandA(rho) is public and is the first and largest carve: skipped.
     uint8_t *secrets = reinterpret_cast<uint8_t *>(w.y);
-    (void)launch_zero(ctx, secrets, (size_t)(static_cast<uint8_t *>(ctx->ws) + w.bytes - secrets), s);
+    (void)launch_zero(ctx, secrets, (size_t)(w.base + w.bytes - secrets), s);
 }
 
-// steps 1-8 of Algorithm 7 and the planned rounds of the loop for one chunk: enqueue only (capturable)
-int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, const SignArgs &a, hipStream_t s) {
+// steps 1-8 of Algorithm 7 for one lane's slice of a chunk: enqueue only (capturable)
+int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignArgs &a, hipStream_t s) {
     const bool own_a = a.a_hat_keys == nullptr;
     const size_t o = a.offset, n = a.n;
     int32_t *st = a.status ? a.status + o : nullptr;
@@ -488,43 +495,88 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, c
     STAGE("rho_pp_hash", launch_shake256_2(ctx, 64, a.cap_k + key_base * 32, 32, 32, c.kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
     // 8: kappa <- 0; active = all ops with a legal ctx and key index
     TRY(launch_init_active(ctx, n, w.bad_op, w.done, w.kappa, st, w.act[0], w.ctl, s));
+    return MLDSA_OK;
+}
+
+// One chunk = up to MLDSA_SIGN_MAX_LANES slices ("lanes"), each with its own workspace carve, control block and stream:
+// lane 0 runs on the call's stream, lane 1 on the context's second stream, forked and joined with events.  The two
+// kernel chains are independent, so the latency-bound kernels of one (the 7-block c~ hash, SampleInBall, the tiny
+// bookkeeping kernels) run beside the throughput-bound kernels of the other.  Enqueue only (capturable).
+struct SignLane {
+    SignWs w;
+    SignArgs a;
+    hipStream_t st = nullptr;
+};
+
+int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl, SignLane *lanes, int n_lanes, hipStream_t s) {
+    lanes[0].st = s;
+    if (n_lanes > 1) {
+        lanes[1].st = ctx->aux_stream;
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->fork_ev, 0));
+    }
+    for (int i = 0; i < n_lanes; i++) TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st));
     // 10: while (z, h) = bottom                                            ml_dsa.rs:212
     const int rounds = (int)pl.m_hint.size();
     for (int round = 0; round < rounds; round++) {
-        // the plan is for a full chunk; a short last chunk only makes its grids generous
-        TRY(enqueue_sign_round(ctx, p, w, pl, round, std::min(pl.m_hint[round], n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k, c.ak,
-                               c.sg, s));
+        for (int i = 0; i < n_lanes; i++) {
+            const SignLane &L = lanes[i];
+            const ChunkKeys c = chunk_keys(p, L.w, L.a);
+            // the plan is for a full slice; a short last one only makes its grids generous
+            TRY(enqueue_sign_round(ctx, p, L.w, pl, round, std::min(pl.m_hint[round], L.a.n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k,
+                                   c.ak, c.sg, L.st));
+        }
     }
-    if (a.async_mode) {
-        // no host wait: what is (with probability < 1e-9) still unfinished is reported per op
-        TRY(launch_mark_unfinished(ctx, w.ctl, rounds & 1, w.act[rounds & 1], st, c.sg, (size_t)p->sig_len, s));
-        zeroise_sign_ws(ctx, w, s);
+    for (int i = 0; i < n_lanes; i++) {
+        const SignLane &L = lanes[i];
+        if (L.a.async_mode) {
+            // no host wait: what is (with probability < 1e-9) still unfinished is reported per op
+            const ChunkKeys c = chunk_keys(p, L.w, L.a);
+            TRY(launch_mark_unfinished(ctx, L.w.ctl, rounds & 1, L.w.act[rounds & 1], L.a.status ? L.a.status + L.a.offset : nullptr, c.sg,
+                                       (size_t)p->sig_len, L.st));
+            zeroise_sign_ws(ctx, L.w, L.st);
+        }
+    }
+    if (n_lanes > 1) {
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, ctx->aux_stream));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));
     }
     return MLDSA_OK;
 }
 
 // the one host wait of a synchronous call; stragglers (practically never) get further rounds
-int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, const SignArgs &a, hipStream_t s) {
-    const ChunkKeys c = chunk_keys(p, w, a);
+int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl, SignLane *lanes, int n_lanes, hipStream_t s) {
     int round = (int)pl.m_hint.size();
-    MLDSA_HIP_CHECK(hipMemcpyAsync(ctx->h_ctl, w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
+    for (int i = 0; i < n_lanes; i++)
+        MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], lanes[i].w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
     for (;;) {
         MLDSA_HIP_CHECK(hipStreamSynchronize(s));
-        ctx->last_sign_slots += ctx->h_ctl->slots_total;
-        if (ctx->prof_on) {
-            ctx->prof_sign_slots += ctx->h_ctl->slots_total;
-            ctx->prof_sign_op_rounds += ctx->h_ctl->ops_total;
+        bool left = false;
+        for (int i = 0; i < n_lanes; i++) {
+            ctx->last_sign_slots += ctx->h_ctl[i].slots_total;
+            if (ctx->prof_on) {
+                ctx->prof_sign_slots += ctx->h_ctl[i].slots_total;
+                ctx->prof_sign_op_rounds += ctx->h_ctl[i].ops_total;
+            }
+            left |= ctx->h_ctl[i].cnt[round & 1] != 0;
         }
-        if (ctx->h_ctl->cnt[round & 1] == 0) break;
-        TRY(launch_zero(ctx, &w.ctl->slots_total, 2 * sizeof(unsigned long long), s));
-        for (int e = 0; e < 2; e++, round++) {
-            ctx->stats.sign_extra_rounds++;
-            TRY(enqueue_sign_round(ctx, p, w, pl, round, 64, std::min<size_t>(pl.ns_max, 2048), c.kidx, c.s1k, c.s2k, c.t0k, c.ak, c.sg, s));
+        if (!left) break;
+        for (int i = 0; i < n_lanes; i++) {
+            const SignLane &L = lanes[i];
+            const ChunkKeys c = chunk_keys(p, L.w, L.a);
+            TRY(launch_zero(ctx, &L.w.ctl->slots_total, 2 * sizeof(unsigned long long), s));
+            for (int e = 0; e < 2; e++) {
+                ctx->stats.sign_extra_rounds++;
+                TRY(enqueue_sign_round(ctx, p, L.w, pl, round + e, 64, std::min<size_t>(pl.ns_max, 2048), c.kidx, c.s1k, c.s2k, c.t0k, c.ak,
+                                       c.sg, s));
+            }
+            MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], L.w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
         }
-        MLDSA_HIP_CHECK(hipMemcpyAsync(ctx->h_ctl, w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
+        round += 2;
     }
     return MLDSA_OK;
 }
+
 }  // namespace
 
 int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
@@ -536,27 +588,41 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     if (n_ops == 0) return MLDSA_OK;
     const bool own_a = a_hat_keys == nullptr;
     const size_t chunk = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
-    const SignPlan pl = plan_sign(ctx, set, chunk, async_mode);
-    const SignWs w(ctx->ws, p, chunk, pl.ns_max, own_a);
-    if (ctx->ws_bytes < w.bytes) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
+    const int n_lanes = sign_lanes_for(ctx, chunk);
+    const size_t per_lane = lane_ops(chunk, n_lanes);
+    const SignPlan pl = plan_sign(ctx, set, per_lane, async_mode);
+    SignLane lanes[2];
+    size_t ws_off = 0;
+    for (int i = 0; i < n_lanes; i++) {
+        lanes[i].w = SignWs(static_cast<uint8_t *>(ctx->ws) + ws_off, p, per_lane, pl.ns_max, own_a);
+        ws_off += lanes[i].w.bytes;
+    }
+    if (ctx->ws_bytes < ws_off) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
     ctx->last_sign_slots = 0;
     int rc = MLDSA_OK;
     for (size_t o = 0; o < n_ops && rc == MLDSA_OK; o += chunk) {
-        SignArgs a;
-        memset(&a, 0, sizeof(a));  // the struct doubles as the graph key: no indeterminate padding
-        a.set = set; a.mode = mode; a.rho = rho; a.cap_k = cap_k; a.tr = tr; a.s1 = s1; a.s2 = s2; a.t0 = t0; a.n_keys = n_keys;
-        a.key_idx = key_idx; a.msgs = msgs; a.msg_off = msg_off; a.ctxs = ctxs; a.ctx_off = ctx_off; a.rnd = rnd; a.sigs = sigs;
-        a.status = status; a.a_hat_keys = a_hat_keys; a.offset = o; a.n = (n_ops - o) < chunk ? (n_ops - o) : chunk; a.chunk = chunk;
-        a.async_mode = async_mode ? 1 : 0;
-        struct { int op; long spec_target, spec_max, rounds; SignArgs a; } key;
-        memset(&key, 0, sizeof(key));
-        key.op = MLDSA_OP_SIGN; key.spec_target = ctx->opt_spec_target; key.spec_max = ctx->opt_spec_max; key.rounds = ctx->opt_sign_rounds;
-        key.a = a;
-        rc = run_op(ctx, s, MLDSA_OP_SIGN, &key, sizeof(key), [&](hipStream_t st) { return sign_chunk_enqueue(ctx, p, w, pl, a, st); });
-        if (rc == MLDSA_OK && !async_mode) rc = sign_chunk_finish(ctx, p, w, pl, a, s);
+        const size_t n_chunk = (n_ops - o) < chunk ? (n_ops - o) : chunk;
+        struct { int op, n_lanes; long spec_target, spec_max, rounds; SignArgs a[2]; } key;
+        memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
+        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_max = ctx->opt_spec_max;
+        key.rounds = ctx->opt_sign_rounds;
+        int live = 0;
+        for (int i = 0; i < n_lanes; i++) {
+            const size_t lo = std::min(n_chunk, (size_t)i * per_lane), hi = std::min(n_chunk, lo + per_lane);
+            if (hi == lo) continue;
+            SignArgs &a = key.a[live];
+            a.set = set; a.mode = mode; a.rho = rho; a.cap_k = cap_k; a.tr = tr; a.s1 = s1; a.s2 = s2; a.t0 = t0; a.n_keys = n_keys;
+            a.key_idx = key_idx; a.msgs = msgs; a.msg_off = msg_off; a.ctxs = ctxs; a.ctx_off = ctx_off; a.rnd = rnd; a.sigs = sigs;
+            a.status = status; a.a_hat_keys = a_hat_keys; a.offset = o + lo; a.n = hi - lo; a.chunk = per_lane;
+            a.async_mode = async_mode ? 1 : 0;
+            lanes[live].a = a;
+            live++;
+        }
+        rc = run_op(ctx, s, MLDSA_OP_SIGN, n_chunk, &key, sizeof(key), [&](hipStream_t st) { return sign_chunk_enqueue(ctx, p, pl, lanes, live, st); });
+        if (rc == MLDSA_OK && !async_mode) rc = sign_chunk_finish(ctx, p, pl, lanes, live, s);
     }
     if (!async_mode || rc != MLDSA_OK) {
-        zeroise_sign_ws(ctx, w, s);  // also on the error path
+        for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, s);  // also on the error path
         (void)hipStreamSynchronize(s);
     }
     return rc;
@@ -572,9 +638,14 @@ void drop_graphs(mldsa_ctx *ctx) {
     ctx->graphs.clear();
 }
 
-int run_op(mldsa_ctx *ctx, hipStream_t s, int op, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue) {
-    // MLDSA_OPT_GRAPHS: 0 never, 1 signing calls only (the launch-bound ones), 2 every op-level call
-    const bool wanted = ctx->opt_graphs == 2 || (ctx->opt_graphs == 1 && op == MLDSA_OP_SIGN);
+int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key, size_t key_len,
+           const std::function<int(hipStream_t)> &enqueue) {
+    // MLDSA_OPT_GRAPHS: 0 never; 1 signing calls of up to GRAPH_AUTO_MAX_OPS ops -- ~100 launches for a few ms of device
+    // work, where the 0.15-0.4 ms of host time a directly launched call costs is a sizeable share of the call; 2 every
+    // op-level call.  A replayed graph is NOT faster on the device (the device-driven loop never waits for the host):
+    // it costs the call 20-50 us of launch latency and saves the host thread 5-25x of its time per call.
+    constexpr size_t GRAPH_AUTO_MAX_OPS = 16384;
+    const bool wanted = ctx->opt_graphs == 2 || (ctx->opt_graphs == 1 && op == MLDSA_OP_SIGN && n_ops <= GRAPH_AUTO_MAX_OPS);
     if (!wanted || ctx->prof_on) {  // per-stage timing needs the individual launches
         ctx->stats.direct_calls++;
         return enqueue(s);

@@ -37,11 +37,13 @@
  *  - Workspaces.  The op-level calls use a context-owned device workspace.  mldsa_reserve sizes it
  *    ahead of time; a call that finds it too small grows it, which waits for the device once.
  *  - hipGraphs.  An op-level call whose shape -- operation, parameter set, mode, n_ops and the pointer
- *    arguments -- repeats is captured into a hipGraph the second time it is seen and replayed from then
- *    on (one graph launch instead of ~100 kernel launches for a signing call).  MLDSA_OPT_GRAPHS selects
- *    which operations do this: by default only signing, whose ~10 kernels per round times ~12 rounds are
- *    launch-bound at small batches; verify and keygen are 6 ... 8 kernels and gain nothing (measured).
- *    Results are identical either way.
+ *    arguments -- repeats can be captured into a hipGraph the second time it is seen and replayed from then
+ *    on: one graph launch instead of ~100 kernel launches for a signing call, 5 ... 25 times less host time
+ *    per call (27 us instead of 150 us for a 4096-op ML-DSA-65 signing call).  The device is not faster for
+ *    it -- the signing loop is driven from device memory and never waits for the host either way, and a graph
+ *    launch adds 20 ... 50 us of latency -- so MLDSA_OPT_GRAPHS defaults to replaying signing calls of up to
+ *    16384 ops, where the host time is a sizeable share of the call; verify and keygen are 6 ... 8 kernels and
+ *    are launched directly unless the option says otherwise.  Results are identical either way.
  */
 #ifndef MLDSA_HIP_H
 #define MLDSA_HIP_H
@@ -94,13 +96,14 @@ int mldsa_ctx_device(const mldsa_ctx *ctx); /* device id the context is bound to
 int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
 
 /* Tuning knobs (per context).  Defaults are the measured best; none changes any result. */
-#define MLDSA_OPT_GRAPHS 1          /* hipGraph replay of repeated call shapes: 0 never, 1 (default) signing calls, 2 every op-level call */
+#define MLDSA_OPT_GRAPHS 1          /* hipGraph replay of repeated call shapes: 0 never, 1 (default) signing calls of <= 16384 ops, 2 every call */
 #define MLDSA_OPT_SPEC_TARGET 2     /* sign: candidate slots per speculative round (1 ... 65536, default 65536)        */
 #define MLDSA_OPT_SPEC_MAX 3        /* sign: most speculative candidates per op and round (1 ... 64, default 32)        */
 #define MLDSA_OPT_VA_BLOCKS_PER_CU 4 /* mldsa_verify_arith: workgroups per CU of the persistent grid (default 16)      */
 #define MLDSA_OPT_GRAPH_CACHE 5     /* graphs kept per context before the least recently used one is dropped (default 24) */
 #define MLDSA_OPT_SIGN_ROUNDS 6     /* sign: rounds enqueued before the host looks at the device; 0 (default) = as many as the
                                        plan says finish the batch (see mldsa_sign); a small value exercises the extra-round path */
+#define MLDSA_OPT_SIGN_LANES 7      /* sign: 1 (default) or 2 slices of a batch running their round chains side by side on two streams */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths */
