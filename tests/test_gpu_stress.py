@@ -95,10 +95,12 @@ def test_sign_speculation_regimes_match_oracle(sets, n_ops):
     assert m.verify(pks, msgs, sig).all()
 
 
-@pytest.mark.parametrize("target,spec_max,rounds", [(65536, 32, 0), (4096, 7, 0), (1, 1, 0), (65536, 64, 0), (65536, 32, 1), (512, 3, 4)])
-def test_sign_schedule_knobs_do_not_change_signatures(sets, target, spec_max, rounds):
+@pytest.mark.parametrize("target,spec_max,rounds,lanes", [(65536, 32, 0, 1), (4096, 7, 0, 1), (1, 1, 0, 1), (65536, 64, 0, 1), (65536, 32, 1, 1),
+                                                           (512, 3, 4, 1), (65536, 32, 0, 2), (2048, 5, 2, 2)])
+def test_sign_schedule_knobs_do_not_change_signatures(sets, target, spec_max, rounds, lanes):
     """The rejection loop's scheduling (candidate slots per round, candidates per op, rounds enqueued before the
-    host looks) is invisible in the output: the first accepted kappa wins, exactly as in ml_dsa.rs:212-336."""
+    host looks, one or two slices on two streams) is invisible in the output: the first accepted kappa wins,
+    exactly as in ml_dsa.rs:212-336."""
     m = sets[44]
     hp = m.hp
     n_ops = 9001
@@ -107,13 +109,14 @@ def test_sign_schedule_knobs_do_not_change_signatures(sets, target, spec_max, ro
     sks = m.private_keys_from_bytes([orc.sk_into_bytes(44, sk_o)])
     msgs = [rng.integers(0, 256, 20, dtype=np.uint8).tobytes() for _ in range(n_ops)]
     rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_ops)]
-    defaults = {o: hp.get_option(o) for o in (2, 3, 6)}  # MLDSA_OPT_SPEC_TARGET, _SPEC_MAX, _SIGN_ROUNDS
-    assert defaults == {2: 65536, 3: 32, 6: 0}
+    defaults = {o: hp.get_option(o) for o in (2, 3, 6, 7)}  # MLDSA_OPT_SPEC_TARGET, _SPEC_MAX, _SIGN_ROUNDS, _SIGN_LANES
+    assert defaults == {2: 65536, 3: 32, 6: 0, 7: 1}
     base = host(m.try_sign_with_seed(sks, msgs, rnd, key_idx=[0] * n_ops)).copy()
     try:
         hp.set_option(2, target)
         hp.set_option(3, spec_max)
         hp.set_option(6, rounds)
+        hp.set_option(7, lanes)
         got = host(m.try_sign_with_seed(sks, msgs, rnd, key_idx=[0] * n_ops))
     finally:
         for o, v in defaults.items():
