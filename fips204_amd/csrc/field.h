@@ -27,6 +27,14 @@ __device__ __forceinline__ int32_t mont_mul(int32_t a, int32_t b) {
     return (int32_t)(((int64_t)t * (-Q) + p) >> 32);
 }
 
+// mont_reduce (helpers.rs:156-165) of a 64-bit sum of products: p * 2^-32 mod q in (-q, q) for |p| < 2^31 * q.  The fused
+// arithmetic kernels accumulate a row's K * L products in 64 bits (one v_mad_i64_i32 per term) and reduce ONCE per
+// coefficient instead of once per term: sum_j mont(a_j z_j) and mont(sum_j a_j z_j) agree mod q.
+__device__ __forceinline__ int32_t mont_reduce64(int64_t p) {
+    const int32_t t = (int32_t)((uint32_t)p * QINV);
+    return (int32_t)(((int64_t)t * (-Q) + p) >> 32);
+}
+
 // helpers.rs:61-67: |a| < 2^31 - 2^22  ->  (-q, q)
 __device__ __forceinline__ int32_t reduce32(int32_t a) {
     int32_t x = (a + (1 << 22)) >> 23;

@@ -179,21 +179,24 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             asm volatile("" ::: "memory");
-            int32_t acc[4] = {0, 0, 0, 0};
+            // 64-bit accumulation, one Montgomery reduction per coefficient and row (field.h): |a| < 2^24 (what ExpandA
+            // produces), |z_hat| < 9 q, at most L + 1 <= 8 terms: |sum| < 2^54 = the reduction's input bound
+            int64_t acc64[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < L; j++) {
                 const int4 zv = zh[wave][j][lane];
                 const int4 a4 = coeffs(av[j]);
-                acc[0] += mont_mul(a4.x, zv.x);
-                acc[1] += mont_mul(a4.y, zv.y);
-                acc[2] += mont_mul(a4.z, zv.z);
-                acc[3] += mont_mul(a4.w, zv.w);
+                acc64[0] += (int64_t)a4.x * zv.x;
+                acc64[1] += (int64_t)a4.y * zv.y;
+                acc64[2] += (int64_t)a4.z * zv.z;
+                acc64[3] += (int64_t)a4.w * zv.w;
             }
-            const int4 cv = zh[wave][L][lane];
-            acc[0] -= mont_mul(cv.x, tv.x);
-            acc[1] -= mont_mul(cv.y, tv.y);
-            acc[2] -= mont_mul(cv.z, tv.z);
-            acc[3] -= mont_mul(cv.w, tv.w);
+            const int4 cv = zh[wave][L][lane];  // c_hat * 2^-32 in (-q, q); t1 from mldsa_pk_expand is in (-q, q)
+            acc64[0] -= (int64_t)cv.x * tv.x;
+            acc64[1] -= (int64_t)cv.y * tv.y;
+            acc64[2] -= (int64_t)cv.z * tv.z;
+            acc64[3] -= (int64_t)cv.w * tv.w;
+            int32_t acc[4];
             if (i + 1 < K) {  // next row: in flight during this row's inverse transform
 #pragma unroll
                 for (int j = 0; j < L; j++) av[j] = arow[(unsigned)(((i + 1) * L + j) * 64) + ul];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
             // handed out with v_readlane after the inverse transform: one live register instead of four
             const uint32_t hword = hmask[(op * K + i) * 8 + (ul & 7)];
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
+            for (int k = 0; k < 4; k++) acc[k] = mont_reduce64(acc64[k]);  // (-q, q): the inverse transform's input range
             ntt_inv_wave(acc, itw, lane, F_MONT2);
             // acc[k] = w'[64 k + lane], canonical.  UseHint, then pack BITS-bit fields.
             uint8_t* dst = w1 + op * w1_stride + (size_t)i * (32 * BITS);

@@ -229,30 +229,33 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
             asm volatile("" ::: "memory");
-            int32_t acc[4] = {0, 0, 0, 0};
+            // 64-bit accumulation, one Montgomery reduction per coefficient and row (field.h): |a| < 2^24 (what ExpandA
+            // produces), |z_hat| < 9 q, at most L + 1 <= 8 terms: |sum| < 2^54 = the reduction's input bound
+            int64_t acc64[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < L; j++) {
                 const int4 zv = zh[wave][j][lane];
                 const int4 a4 = coeffs(av[j]);
-                acc[0] += mont_mul(a4.x, zv.x);
-                acc[1] += mont_mul(a4.y, zv.y);
-                acc[2] += mont_mul(a4.z, zv.z);
-                acc[3] += mont_mul(a4.w, zv.w);
+                acc64[0] += (int64_t)a4.x * zv.x;
+                acc64[1] += (int64_t)a4.y * zv.y;
+                acc64[2] += (int64_t)a4.z * zv.z;
+                acc64[3] += (int64_t)a4.w * zv.w;
             }
             if constexpr (HAS_C) {
-                const int4 cv = zh[wave][L][lane];
-                acc[0] -= mont_mul(cv.x, tv.x);
-                acc[1] -= mont_mul(cv.y, tv.y);
-                acc[2] -= mont_mul(cv.z, tv.z);
-                acc[3] -= mont_mul(cv.w, tv.w);
+                const int4 cv = zh[wave][L][lane];  // c_hat * 2^-32 in (-q, q); t1 in Montgomery form: |product| < 2^46 ...
+                acc64[0] -= (int64_t)cv.x * reduce32(tv.x);  // ... for any t1 representative the seam contract allows
+                acc64[1] -= (int64_t)cv.y * reduce32(tv.y);
+                acc64[2] -= (int64_t)cv.z * reduce32(tv.z);
+                acc64[3] -= (int64_t)cv.w * reduce32(tv.w);
             }
+            int32_t acc[4];
             if (i + 1 < K) {  // next row: in flight during this row's inverse transform
 #pragma unroll
                 for (int j = 0; j < L; j++) av[j] = arow[((i + 1) * L + j) * 64 + lane];
                 if constexpr (HAS_C) tv = reinterpret_cast<const int4 *>(t1 + (key * K + i + 1) * (size_t)N)[lane];
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] = reduce32(acc[k]);
+            for (int k = 0; k < 4; k++) acc[k] = mont_reduce64(acc64[k]);  // (-q, q): the inverse transform's input range
             ntt_inv_wave(acc, itw, lane, F_MONT2);
             store_strided(acc, w_out + (op * K + i) * (size_t)N, lane);
             if constexpr (W1 != 0) {

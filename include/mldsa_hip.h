@@ -168,8 +168,9 @@ int mldsa_infinity_norm(mldsa_ctx *ctx, const int32_t *polys, size_t polys_per_o
 
 /* The verify-arithmetic unit (BASELINE config 2), src/ml_dsa.rs:407-416 fused in one
  * kernel: w'[op] = inv_ntt(a_hat[op] * ntt(z[op]) - ntt(c[op]) o t1_d2_hat_mont[op]).
- * a_hat: n_ops*K*L, z: n_ops*L, c: n_ops, t1_d2_hat_mont: n_ops*K (Montgomery form as in
- * PublicKey, src/types.rs:40), w_out: n_ops*K polys, canonical [0, q). */
+ * a_hat: n_ops*K*L (|a| < 2^24: what mldsa_expand_a produces; the K*L products of a row are accumulated in 64 bits
+ * and reduced once), z: n_ops*L, c: n_ops, t1_d2_hat_mont: n_ops*K (Montgomery form as in PublicKey,
+ * src/types.rs:40; z, c, t1 any representative of the general contract), w_out: n_ops*K polys, canonical [0, q). */
 int mldsa_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *z,
                        const int32_t *c, const int32_t *t1_d2_hat_mont, int32_t *w_out,
                        size_t n_ops, void *stream);
