@@ -625,7 +625,8 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
         allok = multi_gpu.gather_verdicts(wl.ok.cpu() if on_cpu else wl.ok, wl.batch * world)
         n_ok = int(allok.sum().item())
         gather = {"ms": (time.perf_counter() - t0) * 1e3, "verdicts": wl.batch * world, "ok": n_ok,
-                  "collective": "all_gather_into_tensor (RCCL)" if not on_cpu else "all_gather_into_tensor (gloo)"}
+                  "collective": ("none (single rank: a copy)" if not multi_gpu.is_distributed() else
+                                 "all_gather_into_tensor (gloo)" if on_cpu else "all_gather_into_tensor (RCCL)")}
         assert n_ok == wl.batch * world, "a rank reported a failed verification of a valid signature"
     if rank != 0:
         return None
