@@ -50,9 +50,10 @@ __device__ __forceinline__ void rotl64(uint32_t lo, uint32_t hi, uint32_t& olo, 
     }
 }
 
-// a ^ (~b & c): hipcc lowers this to one v_bitop3_b32 on gfx950
+// a ^ (~b & c) as one v_bitop3_b32 (truth table 0xF0 ^ (~0xCC & 0xAA) = 0xD2).  Spelled with the builtin: left to
+// pattern matching, the kernels under register pressure (k_shake256_2) got and / not / xor sequences for a fifth of them.
 __device__ __forceinline__ uint32_t chi(uint32_t a, uint32_t b, uint32_t c) {
-    return a ^ (~b & c);
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xD2);
 }
 
 // a ^ b ^ c as one v_bitop3_b32 (truth table 0x96); gfx950 has no v_xor3_b32

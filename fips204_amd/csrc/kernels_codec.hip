@@ -327,33 +327,31 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
     for (size_t base_op = (size_t)blockIdx.x * CBLOCK; base_op < n_ops; base_op += (size_t)gridDim.x * CBLOCK) {
         const size_t op = base_op + threadIdx.x;
         const bool valid = op < n_ops;
-        ptr_a[wave * 64 + lane] = valid ? (unsigned long long)(a + (a_idx ? a_idx[op] : op) * sa) : 0ull;
-        ptr_b[wave * 64 + lane] = (valid && b) ? (unsigned long long)(b + op * sb) : 0ull;
+        // rows of ops past the end of the batch point at the tile's first op: their loads stay legal, their results unused
+        const size_t opc = valid ? op : base_op;
+        const unsigned long long pa = (unsigned long long)(a + (a_idx ? a_idx[opc] : opc) * sa);
+        ptr_a[wave * 64 + lane] = pa;
+        ptr_b[wave * 64 + lane] = b ? (unsigned long long)(b + opc * sb) : pa;
         wave_lds_sync_c();
         KeccakState st;
         keccak_zero(st);
-        // The wave's 64 x 34 dwords of one rate block: element e = 64 i + lane -> (row, word).  All 34
-        // loads of a block are issued back to back, and those of block b+1 are issued before the
-        // permutation of block b, so their latency hides under it (the hash chain of one op is serial
-        // and the kernel often runs a single wave per SIMD).
+        // The wave's 64 rows x 34 dwords of one rate block.  Passes 0..31: lanes 0-31 fetch dwords 0..31 of row 2 i, lanes
+        // 32-63 those of row 2 i + 1 (coalesced 128-byte runs); passes 32, 33: lane r fetches dword 32 / 33 of row r.
+        // Branch-free: a dword past the end of the data is fetched from the row start and zeroed.  All 34 loads of a
+        // block are issued back to back, and those of block b + 1 before the permutation of block b, so their latency
+        // hides under it (the hash chain of one op is serial and the kernel runs a single wave per SIMD).
         uint32_t pre[34];
         auto issue = [&](int blk) {
             const int base = blk * SHAKE256_RATE;
 #pragma unroll
             for (int i = 0; i < 34; i++) {
-                const int e = 64 * i + lane;
-                const int row = e / 34, wd = e - row * 34;
-                const int off = base + 4 * wd;
-                uint32_t v = 0;
-                if (off + 4 <= data) {
-                    const bool in_a = off < la;
-                    const unsigned long long pp = in_a ? ptr_a[wave * 64 + row] : ptr_b[wave * 64 + row];
-                    if (pp) {
-                        const uint8_t* src = reinterpret_cast<const uint8_t*>(pp) + (in_a ? off : off - la);
-                        v = ALIGNED ? *reinterpret_cast<const uint32_t*>(src) : load_le32(src);
-                    }
-                }
-                pre[i] = v;
+                const int row = i < 32 ? 2 * i + (lane >> 5) : lane;
+                const int off = base + 4 * (i < 32 ? (lane & 31) : i);
+                const bool have = off + 4 <= data, in_a = off < la;
+                const unsigned long long pp = in_a ? ptr_a[wave * 64 + row] : ptr_b[wave * 64 + row];
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(pp) + (have ? (in_a ? off : off - la) : 0);
+                const uint32_t v = ALIGNED ? *reinterpret_cast<const uint32_t*>(src) : load_le32(src);
+                pre[i] = have ? v : 0u;
             }
         };
         issue(0);
@@ -361,8 +359,8 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
             const int base = blk * SHAKE256_RATE;
 #pragma unroll
             for (int i = 0; i < 34; i++) {
-                const int e = 64 * i + lane;
-                const int row = e / 34, wd = e - row * 34;
+                const int row = i < 32 ? 2 * i + (lane >> 5) : lane;
+                const int wd = i < 32 ? (lane & 31) : i;
                 tile[row * H_STRIDE + wd] = pre[i];
             }
             wave_lds_sync_c();
