@@ -86,7 +86,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->device = device_id;
     // experiment knobs: the environment only sets the initial value of the per-context options
     ctx->opt_graphs = env_long("MLDSA_GRAPHS", 0, 2, ctx->opt_graphs);
-    ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 65536, ctx->opt_spec_target);
+    ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 524288, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
     ctx->opt_sign_lanes = env_long("MLDSA_SIGN_LANES", 1, 2, ctx->opt_sign_lanes);
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
@@ -158,7 +158,7 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             ctx->opt_graphs = value;
             return MLDSA_OK;
         case MLDSA_OPT_SPEC_TARGET:
-            REQUIRE(value >= 1 && value <= 65536, "mldsa_set_option: MLDSA_OPT_SPEC_TARGET out of range");
+            REQUIRE(value >= 1 && value <= 524288, "mldsa_set_option: MLDSA_OPT_SPEC_TARGET out of range");
             ctx->opt_spec_target = value;
             return MLDSA_OK;
         case MLDSA_OPT_SPEC_MAX:

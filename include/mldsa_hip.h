@@ -97,7 +97,7 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
 
 /* Tuning knobs (per context).  Defaults are the measured best; none changes any result. */
 #define MLDSA_OPT_GRAPHS 1          /* hipGraph replay of repeated call shapes: 0 never, 1 (default) signing calls of <= 16384 ops, 2 every call */
-#define MLDSA_OPT_SPEC_TARGET 2     /* sign: candidate slots per speculative round (1 ... 65536, default 65536)        */
+#define MLDSA_OPT_SPEC_TARGET 2     /* sign: candidate slots per speculative round (1 ... 524288, default 65536)       */
 #define MLDSA_OPT_SPEC_MAX 3        /* sign: most speculative candidates per op and round (1 ... 64, default 32)        */
 #define MLDSA_OPT_VA_BLOCKS_PER_CU 4 /* mldsa_verify_arith: workgroups per CU of the persistent grid (default 16)      */
 #define MLDSA_OPT_GRAPH_CACHE 5     /* graphs kept per context before the least recently used one is dropped (default 24) */
