@@ -193,8 +193,8 @@ int launch_mu(mldsa_ctx *, const uint8_t *tr, size_t tr_stride, const uint32_t *
 int launch_shake256_2(mldsa_ctx *, int out_len, const uint8_t *a, size_t sa, int la, const uint32_t *a_idx, const uint8_t *b, size_t sb,
                       int lb, uint32_t tail, int tail_len, uint8_t *out, size_t so, size_t n_ops, hipStream_t,
                       const uint32_t *n_dev = nullptr);
-int launch_verify_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, const uint8_t *ctilde_p, size_t cp_stride,
-                          const int32_t *znorm, const int32_t *hvalid, const int32_t *ctx_bad, uint8_t *ok, size_t n_ops, hipStream_t);
+int launch_ctilde_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *mu_w1, size_t mw, const uint8_t *sigs, const int32_t *znorm,
+                          const int32_t *hvalid, const int32_t *ctx_bad, uint8_t *ok, size_t n_ops, hipStream_t);
 
 // ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
 // y_polys_per_op: distance between consecutive ops' y vectors in polynomials (0 = L, contiguous)

@@ -309,13 +309,26 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
 // multiples of 4; ALIGNED = all pointers / strides are multiples of 4 (dword loads).
 constexpr int H_STRIDE = 35;  // dwords per tile row (136 bytes + pad, odd stride)
 
+// With vd.ok != nullptr the kernel is the tail of verify_internal (ml_dsa.rs:429-436): instead of storing the digest it
+// compares it with the signature's c_tilde and writes the verdict, combined with the decode failures that make the
+// reference return false early (ml_dsa.rs:368-376, lib.rs:368-370).
+struct VerdictArgs {
+    const uint8_t* sigs;
+    size_t sig_len;
+    const int32_t* znorm;
+    int32_t zbound;
+    const int32_t* hvalid;
+    const int32_t* ctx_bad;
+    uint8_t* ok;
+};
+
 template <int OUT, bool ALIGNED>
 __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict__ a, size_t sa, int la,
                                                        const uint32_t* __restrict__ a_idx,
                                                        const uint8_t* __restrict__ b, size_t sb, int lb,
                                                        uint32_t tail, int tail_len,
                                                        uint8_t* __restrict__ out, size_t so, size_t n_ops,
-                                                       const uint32_t* __restrict__ n_dev) {
+                                                       const uint32_t* __restrict__ n_dev, VerdictArgs vd) {
     __shared__ uint32_t tiles[CWAVES * 64 * H_STRIDE];
     __shared__ unsigned long long ptr_a[CWAVES * 64], ptr_b[CWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -385,7 +398,15 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
             if (blk + 1 < n_blocks) issue(blk + 1);
             keccak_f1600(st);
         }
-        if (valid) {
+        if (valid && vd.ok) {
+            const uint8_t* c0 = vd.sigs + op * vd.sig_len;  // c_tilde opens the signature (encodings.rs:251)
+            uint32_t diff = 0;
+            static_for_c<0, OUT / 8>([&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+                diff |= (st.lo[W] ^ load_le32(c0 + 8 * W)) | (st.hi[W] ^ load_le32(c0 + 8 * W + 4));
+            });
+            vd.ok[op] = (uint8_t)(diff == 0 && vd.znorm[op] < vd.zbound && vd.hvalid[op] && !vd.ctx_bad[op]);
+        } else if (valid) {
             uint8_t* po = out + op * so;
             static_for_c<0, OUT / 8>([&](auto wc) {
                 constexpr int W = decltype(wc)::value;
@@ -397,23 +418,6 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
             });
         }
     }
-}
-
-// final verdict of verify_internal (ml_dsa.rs:434-436) combined with the decode failures
-// that make the reference return false early (ml_dsa.rs:368-376, lib.rs:368-370)
-__global__ __launch_bounds__(CBLOCK) void k_verify_verdict(const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
-                                                           const uint8_t* __restrict__ ctilde_p, size_t cp_stride,
-                                                           const int32_t* __restrict__ znorm, int32_t zbound,
-                                                           const int32_t* __restrict__ hvalid,
-                                                           const int32_t* __restrict__ ctx_bad,
-                                                           uint8_t* __restrict__ ok, size_t n_ops) {
-    const size_t op = (size_t)blockIdx.x * CBLOCK + threadIdx.x;
-    if (op >= n_ops) return;
-    const uint8_t* c0 = sigs + op * sig_len;
-    const uint8_t* c1 = ctilde_p + op * cp_stride;
-    int same = 1;
-    for (int i = 0; i < ctilde_len; i++) same &= (c0[i] == c1[i]);
-    ok[op] = (uint8_t)(same && znorm[op] < zbound && hvalid[op] && !ctx_bad[op]);
 }
 
 // ------------------------------------------------------------------------- launchers
@@ -471,17 +475,35 @@ int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* k
     return MLDSA_OK;
 }
 
+static int launch_shake256_2v(int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
+                              size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
+                              const uint32_t* n_dev, const VerdictArgs& vd);
+
 int launch_shake256_2(mldsa_ctx*, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                       size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
                       const uint32_t* n_dev) {
+    VerdictArgs none{};
+    return launch_shake256_2v(out_len, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, s, n_dev, none);
+}
+
+// c_tilde' = H(mu | w1Encode(w1')) and the final verdict of verify_internal in one kernel (ml_dsa.rs:429-436)
+int launch_ctilde_verdict(mldsa_ctx*, const mldsa_params* p, const uint8_t* mu_w1, size_t mw, const uint8_t* sigs, const int32_t* znorm,
+                          const int32_t* hvalid, const int32_t* ctx_bad, uint8_t* ok, size_t n_ops, hipStream_t s) {
+    VerdictArgs vd{sigs, (size_t)p->sig_len, znorm, p->gamma1 - p->beta, hvalid, ctx_bad, ok};
+    return launch_shake256_2v(p->ctilde_len, mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, n_ops, s, nullptr, vd);
+}
+
+static int launch_shake256_2v(int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
+                              size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
+                              const uint32_t* n_dev, const VerdictArgs& vd) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     dim3 grid(lane_blocks(n_ops ? n_ops : 1)), block(CBLOCK);
     if ((la & 3) != 0 || (lb & 3) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: segment lengths must be multiples of 4 bytes");
     const bool al = (((uintptr_t)a | (uintptr_t)sa | (uintptr_t)b | (uintptr_t)sb) & 3) == 0;
 #define MLDSA_SHAKE_CASE(O)                                                                                              \
     case O:                                                                                                              \
-        if (al) hipLaunchKernelGGL((k_shake256_2<O, true>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev); \
-        else hipLaunchKernelGGL((k_shake256_2<O, false>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev);   \
+        if (al) hipLaunchKernelGGL((k_shake256_2<O, true>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd); \
+        else hipLaunchKernelGGL((k_shake256_2<O, false>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd);   \
         break;
     switch (out_len) {
         MLDSA_SHAKE_CASE(32)
@@ -491,15 +513,6 @@ int launch_shake256_2(mldsa_ctx*, int out_len, const uint8_t* a, size_t sa, int 
         default: return set_error(MLDSA_ERR_PARAM, "shake256_2: unsupported output length");
     }
 #undef MLDSA_SHAKE_CASE
-    MLDSA_HIP_CHECK(hipGetLastError());
-    return MLDSA_OK;
-}
-
-int launch_verify_verdict(mldsa_ctx*, const mldsa_params* p, const uint8_t* sigs, const uint8_t* ctilde_p, size_t cp_stride,
-                          const int32_t* znorm, const int32_t* hvalid, const int32_t* ctx_bad, uint8_t* ok, size_t n_ops,
-                          hipStream_t s) {
-    hipLaunchKernelGGL(k_verify_verdict, dim3(lane_blocks(n_ops)), dim3(CBLOCK), 0, s, sigs, (size_t)p->sig_len, p->ctilde_len,
-                       ctilde_p, cp_stride, znorm, p->gamma1 - p->beta, hvalid, ctx_bad, ok, n_ops);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

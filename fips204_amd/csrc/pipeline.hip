@@ -55,7 +55,7 @@ struct Carver {
 struct VerifyWs {
     int32_t *a_hat, *c, *znorm, *hvalid, *ctx_bad, *key_bad;
     uint32_t *hmask, *kidx;
-    uint8_t *mu_w1, *ctilde_p;
+    uint8_t *mu_w1;
     size_t bytes;
     VerifyWs(void *base, const mldsa_params *p, size_t n, bool own_a_hat) {
         Carver cv(base);
@@ -68,7 +68,6 @@ struct VerifyWs {
         kidx = cv.take<uint32_t>(n);
         hmask = cv.take<uint32_t>(n * p->k * 8);
         mu_w1 = cv.take<uint8_t>(n * (size_t)(64 + p->w1_len));  // mu || w1_encode(w1') per op
-        ctilde_p = cv.take<uint8_t>(n * 64);
         bytes = cv.off + 256;
     }
 };
@@ -140,10 +139,8 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         STAGE("verify_main", launch_verify_main(ctx, p, a_hat_keys ? a_hat_keys + key_base * kl_coeffs : w.a_hat, sg, w.c,
                                                 t1 + key_base * (size_t)p->k * N, kidx, w.hmask, w.mu_w1 + 64, mw, w.znorm, n, s,
                                                 a_hat_keys != nullptr, a_hat_keys == nullptr));
-        // 12: c_tilde' <- H(mu || w1Encode(w1'), lambda/4)                 ml_dsa.rs:429-431
-        STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, w.ctilde_p, 64, n, s));
-        // 13: [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]      ml_dsa.rs:434-436
-        STAGE("verdict", launch_verify_verdict(ctx, p, sg, w.ctilde_p, 64, w.znorm, w.hvalid, w.ctx_bad, ok + o, n, s));
+        // 12-13: c_tilde' <- H(mu || w1Encode(w1'), lambda/4); [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]   ml_dsa.rs:429-436
+        STAGE("ctilde_hash", launch_ctilde_verdict(ctx, p, w.mu_w1, mw, sg, w.znorm, w.hvalid, w.ctx_bad, ok + o, n, s));
     }
     return MLDSA_OK;
 }
