@@ -182,10 +182,8 @@ int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t c
 
 
 // ---- launchers (kernels_codec.hip) ----
-int launch_hint_unpack(mldsa_ctx *, const mldsa_params *, const uint8_t *sigs, uint32_t *hmask, int32_t *hvalid, size_t n_ops, hipStream_t);
-int launch_use_hint_w1(mldsa_ctx *, const mldsa_params *, const int32_t *w, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, size_t n_ops, hipStream_t);
 int launch_verify_main(mldsa_ctx *, const mldsa_params *, const int32_t *a_hat, const uint8_t *sigs, const int32_t *c, const int32_t *t1,
-                       const uint32_t *key_idx, const uint32_t *hmask, uint8_t *w1, size_t w1_stride, int32_t *znorm, size_t n_ops,
+                       const uint32_t *key_idx, int32_t *hvalid, uint8_t *w1, size_t w1_stride, int32_t *znorm, size_t n_ops,
                        hipStream_t, bool a_by_key = false, bool a_packed = false);
 int launch_mu(mldsa_ctx *, const uint8_t *tr, size_t tr_stride, const uint32_t *key_idx, int mode, const uint8_t *msgs,
               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, uint8_t *mu, size_t mu_stride, int32_t *ctx_bad,

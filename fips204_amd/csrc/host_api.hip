@@ -44,6 +44,7 @@ struct Slot {
 struct HostStage {
     hipStream_t up = nullptr, comp = nullptr, down = nullptr;
     Slot slot[N_SLOTS];
+    Slot call;                              // verify: the side inputs of a whole call when they fit one pack (only .pack and the views)
     Buf key_bytes;                          // wire-format keys of the call
     Buf k_rho, k_capk, k_tr, k_a, k_b, k_c;  // expanded key fields (pk: rho, tr, t1; sk: rho, K, tr, s1, s2, t0)
     hipEvent_t keys_ready = nullptr;
@@ -160,6 +161,7 @@ inline size_t span(const uint64_t *off, size_t a, size_t b) { return (size_t)(of
 void host_stage_destroy(mldsa_ctx *ctx) {
     HostStage *hs = ctx->host_stage;
     if (!hs) return;
+    free_buf(hs->call.pack);
     for (auto &sl : hs->slot) {
         for (Buf *b : {&sl.sigs, &sl.msgs, &sl.msg_off, &sl.ctxs, &sl.ctx_off, &sl.key_idx, &sl.rnd, &sl.out, &sl.status, &sl.xi, &sl.pk, &sl.sk, &sl.pack})
             free_buf(*b);
@@ -192,7 +194,7 @@ struct OpInputs {
 // (signatures / rnd) is copied straight from the caller's memory.
 constexpr size_t PACK_LIMIT = 8u << 20;
 
-static int upload_op_inputs(HostStage *hs, Slot &sl, const OpInputs &in, size_t a, size_t b) {
+static int upload_op_inputs(hipStream_t up, Slot &sl, const OpInputs &in, size_t a, size_t b) {
     const size_t n = b - a;
     const size_t kb = in.key_idx ? n * 4 : 0, mob = (n + 1) * 8, mb = in.msgs ? span(in.msg_off, a, b) : 0;
     const size_t cob = in.ctx_off ? (n + 1) * 8 : 0, cb = (in.ctx_off && in.ctxs) ? span(in.ctx_off, a, b) : 0;
@@ -207,7 +209,7 @@ static int upload_op_inputs(HostStage *hs, Slot &sl, const OpInputs &in, size_t 
         if (mb) memcpy(h + o_m, in.msgs + in.msg_off[a], mb);
         if (cob) memcpy(h + o_co, in.ctx_off + a, cob);
         if (cb) memcpy(h + o_c, in.ctxs + in.ctx_off[a], cb);
-        HCHECK(hipMemcpyAsync(sl.pack.dev, h, total, hipMemcpyHostToDevice, hs->up));
+        HCHECK(hipMemcpyAsync(sl.pack.dev, h, total, hipMemcpyHostToDevice, up));
         uint8_t *d = sl.pack.dev;
         sl.d_kidx = kb ? reinterpret_cast<const uint32_t *>(d + o_k) : nullptr;
         sl.d_moff = reinterpret_cast<const uint64_t *>(d + o_mo);
@@ -216,12 +218,12 @@ static int upload_op_inputs(HostStage *hs, Slot &sl, const OpInputs &in, size_t 
         sl.d_ctxs = d + o_c;
         return MLDSA_OK;
     }
-    if (in.key_idx) TRY(upload(sl.key_idx, in.key_idx + a, kb, in.pin_kidx, hs->up));
-    TRY(upload(sl.msg_off, in.msg_off + a, mob, in.pin_moff, hs->up));
-    TRY(upload(sl.msgs, in.msgs ? in.msgs + in.msg_off[a] : nullptr, mb, in.pin_msgs, hs->up));
+    if (in.key_idx) TRY(upload(sl.key_idx, in.key_idx + a, kb, in.pin_kidx, up));
+    TRY(upload(sl.msg_off, in.msg_off + a, mob, in.pin_moff, up));
+    TRY(upload(sl.msgs, in.msgs ? in.msgs + in.msg_off[a] : nullptr, mb, in.pin_msgs, up));
     if (in.ctx_off) {
-        TRY(upload(sl.ctx_off, in.ctx_off + a, cob, in.pin_coff, hs->up));
-        TRY(upload(sl.ctxs, in.ctxs ? in.ctxs + in.ctx_off[a] : nullptr, cb, in.pin_ctxs, hs->up));
+        TRY(upload(sl.ctx_off, in.ctx_off + a, cob, in.pin_coff, up));
+        TRY(upload(sl.ctxs, in.ctxs ? in.ctxs + in.ctx_off[a] : nullptr, cb, in.pin_ctxs, up));
     }
     sl.d_kidx = in.key_idx ? reinterpret_cast<const uint32_t *>(sl.key_idx.dev) : nullptr;
     sl.d_moff = reinterpret_cast<const uint64_t *>(sl.msg_off.dev);
@@ -269,25 +271,35 @@ int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size
     OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
     const bool pin_sigs = is_pinned(sigs), pin_ok = is_pinned(ok);
     int rc = MLDSA_OK;
+    // Side inputs (key indices, offsets, messages, ctxs): when the whole call's fit one pack they go up ONCE, right after
+    // the first sub-batch's signatures (the host-side gather then overlaps that DMA); a separate small DMA per
+    // sub-batch idles the link for ~30 us out of every ~520.
+    const size_t side_bytes = n_ops * 12 + 8 + span(msg_off, 0, n_ops) + (ctx_off ? n_ops * 8 + 8 + span(ctx_off, 0, n_ops) : 0);
+    const bool whole = side_bytes + 2048 <= PACK_LIMIT;
     size_t i = 0;
     for (size_t a = 0; a < n_ops && rc == MLDSA_OK; a += sub, i++) {
         const size_t b = std::min(n_ops, a + sub), n = b - a;
         Slot &sl = hs->slot[i % N_SLOTS];
         rc = [&]() -> int {
             TRY(reclaim(sl));
-            TRY(upload_op_inputs(hs, sl, in, a, b));
+            if (!whole) TRY(upload_op_inputs(hs->up, sl, in, a, b));
             TRY(upload(sl.sigs, sigs + a * sgl, n * sgl, pin_sigs, hs->up));
+            if (whole && a == 0) TRY(upload_op_inputs(hs->up, hs->call, in, 0, n_ops));
             TRY(grow_dev(sl.out, n));
             HCHECK(hipEventRecord(sl.up_done, hs->up));
             HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
-            // the slice's byte strings start at offset msg_off[a] of the caller's array: hand the kernels a base
+            // the slice's byte strings start at offset msg_off[v0] of the caller's array: hand the kernels a base
             // pointer that makes the caller's own offsets land in the staging buffer
-            const uint8_t *mbase = sl.d_msgs - msg_off[a];
-            const uint8_t *cbase = ctx_off ? sl.d_ctxs - ctx_off[a] : nullptr;
+            const Slot &v = whole ? hs->call : sl;
+            const size_t v0 = whole ? 0 : a, vo = a - v0;  // first op of the view, this sub-batch's position in it
+            const uint32_t *d_kidx = v.d_kidx ? v.d_kidx + vo : nullptr;
+            const uint64_t *d_moff = v.d_moff + vo, *d_coff = v.d_coff ? v.d_coff + vo : nullptr;
+            const uint8_t *mbase = v.d_msgs - msg_off[v0];
+            const uint8_t *cbase = ctx_off ? v.d_ctxs - ctx_off[v0] : nullptr;
             const size_t kb = key_idx ? 0 : a;  // identity mapping walks the key table with the batch
             TRY(mldsa_verify(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_tr.dev + kb * 64,
-                             reinterpret_cast<const int32_t *>(hs->k_a.dev) + kb * k * 256, n_keys - kb, sl.d_kidx, mbase, sl.d_moff, cbase,
-                             sl.d_coff, sl.sigs.dev, sl.out.dev, n, hs->comp));
+                             reinterpret_cast<const int32_t *>(hs->k_a.dev) + kb * k * 256, n_keys - kb, d_kidx, mbase, d_moff, cbase,
+                             d_coff, sl.sigs.dev, sl.out.dev, n, hs->comp));
             HCHECK(hipEventRecord(sl.comp_done, hs->comp));
             HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
             TRY(download(sl, sl.out, ok + a, n, pin_ok, hs->down));
@@ -348,7 +360,7 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
         Slot &sl = hs->slot[i % N_SLOTS];
         rc = [&]() -> int {
             TRY(reclaim(sl));
-            TRY(upload_op_inputs(hs, sl, in, a, b));
+            TRY(upload_op_inputs(hs->up, sl, in, a, b));
             TRY(upload(sl.rnd, rnd + a * 32, n * 32, pin_rnd, hs->up));
             TRY(grow_dev(sl.out, n * sgl));
             TRY(grow_dev(sl.status, n * 4));

@@ -33,71 +33,65 @@ __device__ __forceinline__ void wave_lds_sync_c() {
 }
 
 // ------------------------------------------------------------------------------------
-// sig_decode part 2: hint_bit_unpack (conversion.rs:340-414), one op per lane.  Output: a
-// 256-bit mask per hint polynomial and a validity flag (0 = the reference returns Err).
-__global__ __launch_bounds__(CBLOCK) void k_hint_unpack(const uint8_t* __restrict__ sigs, size_t sig_len, int hint_off,
-                                                        int k, int omega, uint32_t* __restrict__ hmask,
-                                                        int32_t* __restrict__ hvalid, size_t n_ops) {
-    const size_t op = (size_t)blockIdx.x * CBLOCK + threadIdx.x;
-    if (op >= n_ops) return;
-    const uint8_t* y = sigs + op * sig_len + hint_off;
-    uint32_t* hm = hmask + op * (size_t)k * 8;
-    for (int i = 0; i < k * 8; i++) hm[i] = 0;
-    int valid = 1, index = 0;
-    for (int i = 0; i < k && valid; i++) {
-        const int yi = y[omega + i];
-        if (yi < index || yi > omega) { valid = 0; break; }
-        const int first = index;
-        while (index < yi) {
-            if (index > first && y[index - 1] >= y[index]) { valid = 0; break; }
-            const int pos = y[index];
-            hm[i * 8 + (pos >> 5)] |= 1u << (pos & 31);
-            index++;
-        }
-    }
-    if (valid)
-        for (int i = index; i < omega; i++)
-            if (y[i] != 0) { valid = 0; break; }
-    hvalid[op] = valid;
+// sig_decode part 2: hint_bit_unpack (conversion.rs:340-414) by one wave, inside k_verify_main.  Output: a 256-bit
+// mask per hint polynomial in the wave's LDS words mw[k * 8] and the validity flag (false = the reference returns Err).
+// The reference walks the omega + k bytes serially; here every lane owns one position byte (two when omega > 64) and
+// tests the reference's conditions for it independently:
+//   limits y[omega + i] non-decreasing and <= omega; positions strictly increasing inside a polynomial; bytes past
+//   the last limit zero.
+// (As a lane-per-op kernel of its own the walk was ~60 dependent byte loads, ~190 us whatever the batch: the longest
+// link of a small batch's chain.)
+constexpr int HINT_LDS_DWORDS = 24 + 64;  // 96 hint bytes (omega + k <= 84) | k * 8 <= 64 mask words
+struct HintBytes { uint32_t b0, b1; };       // bytes lane and 64 + lane of the hint section
+// the loads are issued early (with the op's first A_hat row) and consumed after the forward transforms
+__device__ __forceinline__ HintBytes hint_load(const uint8_t* __restrict__ y, int omega, int k, int lane) {
+    HintBytes h;
+    h.b0 = lane < omega + k ? y[lane] : 0u;  // ML-DSA-65: 61 bytes, the signature ends there
+    h.b1 = lane + 64 < omega + k ? y[lane + 64] : 0u;
+    return h;
 }
-
-// ------------------------------------------------------------------------------------
-// w1' = use_hint(h, w') (ml_dsa.rs:420-422) followed by w1_encode (encodings.rs:338-360 ->
-// simple_bit_pack): 6 bits per coefficient for gamma2 = (q-1)/88, 4 bits otherwise.
-// One wave per polynomial, 4 consecutive coefficients per lane.  With hmask == nullptr this
-// is high_bits + w1_encode of the signer (ml_dsa.rs:225-232).
-template <bool G2HI>
-__global__ __launch_bounds__(CBLOCK) void k_use_hint_w1(const int32_t* __restrict__ w, const uint32_t* __restrict__ hmask,
-                                                        uint8_t* __restrict__ w1, int k, size_t w1_stride, size_t n_ops) {
-    constexpr int BITS = G2HI ? 4 : 6;
-    const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6);
-    const size_t n_waves = (size_t)gridDim.x * CWAVES;
-    const size_t n_polys = n_ops * (size_t)k;
-    for (size_t p = wave; p < n_polys; p += n_waves) {
-        const size_t op = p / k;
-        const int i = (int)(p % k);
-        const int4 v = reinterpret_cast<const int4*>(w + p * N)[lane];
-        uint32_t hb = 0;
-        if (hmask) hb = (hmask[p * 8 + (lane >> 3)] >> ((lane & 7) * 4)) & 0xFu;
-        const uint32_t a0 = (uint32_t)use_hint<G2HI>(hb & 1, v.x), a1 = (uint32_t)use_hint<G2HI>((hb >> 1) & 1, v.y);
-        const uint32_t a2 = (uint32_t)use_hint<G2HI>((hb >> 2) & 1, v.z), a3 = (uint32_t)use_hint<G2HI>((hb >> 3) & 1, v.w);
-        const uint32_t packed = a0 | (a1 << BITS) | (a2 << (2 * BITS)) | (a3 << (3 * BITS));
-        uint8_t* dst = w1 + op * w1_stride + (size_t)i * (32 * BITS);
-        if constexpr (G2HI) {
-            reinterpret_cast<uint16_t*>(dst)[lane] = (uint16_t)packed;  // 2 bytes per lane
-        } else {
-            dst[3 * lane] = (uint8_t)packed;
-            dst[3 * lane + 1] = (uint8_t)(packed >> 8);
-            dst[3 * lane + 2] = (uint8_t)(packed >> 16);
+template <int K>
+__device__ __forceinline__ bool hint_unpack_wave(HintBytes h, int omega, uint32_t* __restrict__ hl, int lane) {
+    uint8_t* yb = reinterpret_cast<uint8_t*>(hl);
+    uint32_t* mw = hl + 24;
+    yb[lane] = (uint8_t)h.b0;
+    if (lane < 32) yb[lane + 64] = (uint8_t)h.b1;
+    mw[lane] = 0;
+    wave_lds_sync_c();
+    // lane i < K keeps limit i; they are handed round with v_readlane
+    const int lim = lane < K ? yb[omega + lane] : 0;
+    int bad = 0;
+    if (lane < K) {
+        const int prev = lane ? yb[omega + lane - 1] : 0;
+        bad = (lim < prev) | (lim > omega);
+    }
+    const int last = __builtin_amdgcn_readlane(lim, K - 1);
+    for (int j = lane; j < omega; j += 64) {
+        const int pos = yb[j];
+        if (j < last) {
+            int i = 0, first = 0;  // the polynomial position j belongs to = limits at or below j (at most K - 1: `last` is above)
+#pragma unroll
+            for (int t = 0; t < K - 1; t++) {
+                const int lt = __builtin_amdgcn_readlane(lim, t);
+                const bool le = lt <= j;
+                i += le ? 1 : 0;
+                first = le ? lt : first;
+            }
+            if (j > first && yb[j - 1] >= pos) bad = 1;
+            atomicOr(&mw[i * 8 + (pos >> 5)], 1u << (pos & 31));
+        } else if (pos != 0) {
+            bad = 1;
         }
     }
+    wave_lds_sync_c();
+    return __ballot(bad) == 0ull;
 }
 
 // ------------------------------------------------------------------------------------
 // Whole-verify arithmetic in one kernel (ml_dsa.rs:368-372, 407-428), ONE WAVE PER OPERATION (the
 // structure of k_verify_arith: no barriers, lane-private LDS rows, next A_hat row requested under the
 // current row's inverse NTT):
+//   decode:  the hint section of the signature -> bit masks in LDS (hint_unpack_wave above)
 //   forward: z[j] is unpacked straight from the signature bytes into NTT registers (bit_unpack,
 //            conversion.rs:227-262; with the ||z||inf test of ml_dsa.rs:434), then c; results to LDS
 //   rows:    A_hat[i] o z_hat - c_hat o t1_hat[i] -> inverse NTT -> UseHint (high_low.rs:155-192)
@@ -108,11 +102,12 @@ template <int K, int L, int GB, bool G2HI, int MINW, bool APACK>
 __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW))) void k_verify_main(
     const int32_t* __restrict__ a_hat, const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len,
     const int32_t* __restrict__ c, const int32_t* __restrict__ t1, const uint32_t* __restrict__ key_idx,
-    const uint32_t* __restrict__ hmask, uint8_t* __restrict__ w1, size_t w1_stride, int32_t* __restrict__ znorm,
+    int32_t* __restrict__ hvalid, int omega, uint8_t* __restrict__ w1, size_t w1_stride, int32_t* __restrict__ znorm,
     int32_t zbound, size_t n_ops, const Twiddle* __restrict__ fwd_tab, const Twiddle* __restrict__ inv_tab, int a_by_key) {
     constexpr int CB = GB + 1;
     constexpr int BITS = G2HI ? 4 : 6;
     __shared__ int4 zh[VW][L + 1][64];
+    __shared__ uint32_t hint_lds[VW][HINT_LDS_DWORDS];
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -130,7 +125,6 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
         // (The same trick made k_verify_arith ~4 % slower and left k_sign_tail unchanged: not applied there.)
         unsigned ul = (unsigned)lane;
         asm volatile("" : "+v"(ul));
-        // wave-uniform, so row pointers stay scalar (SGPR base + lane offset) instead of per-lane 64-bit addresses
         const size_t key = key_idx ? (size_t)__builtin_amdgcn_readfirstlane((int)key_idx[op]) : op;
         const size_t aop = a_by_key ? key : op;  // per-key A_hat kept by the caller, or the op's own ExpandA output
         // APACK: A_hat in the pipelines' 24-bit form (768 bytes per polynomial, three dwords per lane)
@@ -145,8 +139,9 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
 #pragma unroll
         for (int j = 0; j < L; j++) av[j] = arow[(unsigned)(j * 64) + ul];
         int4 tv = trow[ul];
-        // ---- forward transforms: z[0..L) from the signature bytes, then c
+        // ---- (c_tilde, z, h) <- sigDecode: z in the forward loop, the hint bytes requested here and decoded after it
         const uint8_t* zsrc = sigs + op * sig_len + ctilde_len;
+        const HintBytes hbytes = hint_load(zsrc + L * (32 * CB), omega, K, (int)ul);
         bool zbad = false;
 #pragma unroll 1
         for (int j = 0; j <= L; j++) {
@@ -173,8 +168,12 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
             }
             zh[wave][j][lane] = make_int4(r[0], r[1], r[2], r[3]);
         }
-        // ||z||inf >= gamma1 - beta (ml_dsa.rs:434) as a flag; znorm[] is zeroed by the pipeline
-        if (__ballot(zbad) != 0ull && lane == 0) znorm[op] = 0x7fffffff;
+        const bool hint_ok = hint_unpack_wave<K>(hbytes, omega, hint_lds[wave], (int)ul);  // the masks stay in LDS for the rows below
+        // ||z||inf >= gamma1 - beta (ml_dsa.rs:434) and a malformed hint section as per-op flags for the verdict
+        if (lane == 0) {
+            znorm[op] = __ballot(zbad) != 0ull ? 0x7fffffff : 0;
+            hvalid[op] = hint_ok ? 1 : 0;
+        }
         // ---- rows
 #pragma unroll 1
         for (int i = 0; i < K; i++) {
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
             }
             // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5).  One dword per lane (lane l holds word l & 7),
             // handed out with v_readlane after the inverse transform: one live register instead of four
-            const uint32_t hword = hmask[(op * K + i) * 8 + (ul & 7)];
+            const uint32_t hword = hint_lds[wave][24 + i * 8 + (ul & 7)];
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = mont_reduce64(acc64[k]);  // (-q, q): the inverse transform's input range
             ntt_inv_wave(acc, itw, lane, F_MONT2);
@@ -423,35 +422,14 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
 // ------------------------------------------------------------------------- launchers
 static inline unsigned lane_blocks(size_t n) { return (unsigned)((n + CBLOCK - 1) / CBLOCK); }
 
-int launch_hint_unpack(mldsa_ctx*, const mldsa_params* p, const uint8_t* sigs, uint32_t* hmask, int32_t* hvalid, size_t n_ops,
-                       hipStream_t s) {
-    const int c = (p->gamma1 == (1 << 17)) ? 18 : 20;
-    const int hint_off = p->ctilde_len + p->l * 32 * c;
-    hipLaunchKernelGGL(k_hint_unpack, dim3(lane_blocks(n_ops)), dim3(CBLOCK), 0, s, sigs, (size_t)p->sig_len, hint_off, p->k,
-                       p->omega, hmask, hvalid, n_ops);
-    MLDSA_HIP_CHECK(hipGetLastError());
-    return MLDSA_OK;
-}
-
-int launch_use_hint_w1(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* w, const uint32_t* hmask, uint8_t* w1,
-                       size_t w1_stride, size_t n_ops, hipStream_t s) {
-    dim3 grid(grid_for(ctx, n_ops * (size_t)p->k, CWAVES, 8)), block(CBLOCK);
-    if (p->gamma2 == (Q - 1) / 32)
-        hipLaunchKernelGGL((k_use_hint_w1<true>), grid, block, 0, s, w, hmask, w1, p->k, w1_stride, n_ops);
-    else
-        hipLaunchKernelGGL((k_use_hint_w1<false>), grid, block, 0, s, w, hmask, w1, p->k, w1_stride, n_ops);
-    MLDSA_HIP_CHECK(hipGetLastError());
-    return MLDSA_OK;
-}
-
 int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_hat, const uint8_t* sigs, const int32_t* c,
-                       const int32_t* t1, const uint32_t* key_idx, const uint32_t* hmask, uint8_t* w1, size_t w1_stride,
+                       const int32_t* t1, const uint32_t* key_idx, int32_t* hvalid, uint8_t* w1, size_t w1_stride,
                        int32_t* znorm, size_t n_ops, hipStream_t s, bool a_by_key, bool a_packed) {
     if (n_ops == 0) return MLDSA_OK;
     dim3 grid(grid_for(ctx, n_ops, VW, 16));
 #define MLDSA_VM2(KK, LL, GB, G2, MW, AP)                                                                                    \
     hipLaunchKernelGGL((k_verify_main<KK, LL, GB, G2, MW, AP>), grid, dim3(64 * VW), 0, s, a_hat, sigs,                       \
-                       (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hmask, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, \
+                       (size_t)p->sig_len, p->ctilde_len, c, t1, key_idx, hvalid, p->omega, w1, w1_stride, znorm, p->gamma1 - p->beta, n_ops, \
                        ctx->d_fwd_tw, ctx->d_inv_tw, a_by_key ? 1 : 0)
 #define MLDSA_VM(KK, LL, GB, G2, MW) do { if (a_packed) MLDSA_VM2(KK, LL, GB, G2, MW, true); else MLDSA_VM2(KK, LL, GB, G2, MW, false); } while (0)
     if (p->set == MLDSA_44) MLDSA_VM(4, 4, 17, false, 5);

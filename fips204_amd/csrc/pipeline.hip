@@ -54,7 +54,7 @@ struct Carver {
 
 struct VerifyWs {
     int32_t *a_hat, *c, *znorm, *hvalid, *ctx_bad, *key_bad;
-    uint32_t *hmask, *kidx;
+    uint32_t *kidx;
     uint8_t *mu_w1;
     size_t bytes;
     VerifyWs(void *base, const mldsa_params *p, size_t n, bool own_a_hat) {
@@ -66,7 +66,6 @@ struct VerifyWs {
         ctx_bad = cv.take<int32_t>(n);
         key_bad = cv.take<int32_t>(n);
         kidx = cv.take<uint32_t>(n);
-        hmask = cv.take<uint32_t>(n * p->k * 8);
         mu_w1 = cv.take<uint8_t>(n * (size_t)(64 + p->w1_len));  // mu || w1_encode(w1') per op
         bytes = cv.off + 256;
     }
@@ -107,17 +106,11 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
             key_bad = w.key_bad;
         }
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
-        TRY(launch_zero(ctx, w.znorm, n * sizeof(int32_t), s));
         // fork: the small lane-per-op kernels are latency-bound (1-2 Keccak-f per op, <= 1 wave per SIMD) and
         // independent of ExpandA, so they run on the context's second stream underneath it
         hipStream_t aux = ctx->aux_stream;
         MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(aux, ctx->fork_ev, 0));
-        {
-            // 2: (c_tilde, z, h) <- sigDecode(sigma): hints here, z inside k_verify_main      ml_dsa.rs:368-376
-            ProfScope ps(ctx, aux, "hint_unpack");
-            TRY(launch_hint_unpack(ctx, p, sg, w.hmask, w.hvalid, n, aux));
-        }
         {
             // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
             ProfScope ps(ctx, aux, "mu");
@@ -135,9 +128,10 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         //  names as missing; the rows are then looked up by key instead of by op)
         if (!a_hat_keys) STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s, true));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
+        // 2: (c_tilde, z, h) <- sigDecode(sigma), inside k_verify_main                      ml_dsa.rs:368-376
         // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
         STAGE("verify_main", launch_verify_main(ctx, p, a_hat_keys ? a_hat_keys + key_base * kl_coeffs : w.a_hat, sg, w.c,
-                                                t1 + key_base * (size_t)p->k * N, kidx, w.hmask, w.mu_w1 + 64, mw, w.znorm, n, s,
+                                                t1 + key_base * (size_t)p->k * N, kidx, w.hvalid, w.mu_w1 + 64, mw, w.znorm, n, s,
                                                 a_hat_keys != nullptr, a_hat_keys == nullptr));
         // 12-13: c_tilde' <- H(mu || w1Encode(w1'), lambda/4); [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]   ml_dsa.rs:429-436
         STAGE("ctilde_hash", launch_ctilde_verdict(ctx, p, w.mu_w1, mw, sg, w.znorm, w.hvalid, w.ctx_bad, ok + o, n, s));
