@@ -419,3 +419,81 @@ def test_multichunk_sign(sets, pset):
     ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
     m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, n, key_idx=b["kidx"])
     assert bool(host(ok).all())
+
+
+# ------------------------------------------------------------------------------ non-canonical hint encodings
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_non_canonical_hint_encodings_are_rejected_like_the_reference(sets, pset):
+    """hint_bit_unpack (conversion.rs:340-414) refuses encodings that describe the SAME hint set differently: positions
+    out of order inside a polynomial, a non-zero byte behind the last position, limits that run backwards or past
+    omega.  The hint masks (and therefore c_tilde') are unchanged by the first two, so only the decoder's own checks
+    stand between such a signature and `true` -- the wave-cooperative decoder in k_verify_main tests every position
+    independently instead of walking the bytes, and must refuse exactly what the reference refuses."""
+    m = sets[pset]
+    n = 512
+    b = make_batch(m, n, 8, b"hint%d" % pset)
+    sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"])
+    base = host(sig).copy()
+    p = m.params
+    k, omega = p.k, p.omega
+    hoff = m.SIG_LEN - omega - k
+    rng = np.random.default_rng(pset)
+    variants, kinds = [], []
+    for i in range(n):
+        h = base[i, hoff:].copy()
+        lim = [0] + [int(x) for x in h[omega:]]
+        total = lim[-1]
+        made = []
+        # (a) two positions of one polynomial swapped (same set, no longer strictly increasing)
+        polys = [j for j in range(k) if lim[j + 1] - lim[j] >= 2]
+        if polys:
+            j = polys[int(rng.integers(len(polys)))]
+            a = lim[j] + int(rng.integers(lim[j + 1] - lim[j] - 1))
+            v = h.copy(); v[a], v[a + 1] = v[a + 1], v[a]
+            made.append(("swap", v))
+            v = h.copy(); v[a + 1] = v[a]  # equal neighbours: >= must refuse, not only >
+            made.append(("dup", v))
+        # (b) non-zero padding behind the last position
+        if total < omega:
+            v = h.copy(); v[total + int(rng.integers(omega - total))] = 1 + int(rng.integers(255))
+            made.append(("pad", v))
+        # (c) limits: one runs backwards / one exceeds omega
+        v = h.copy(); jj = int(rng.integers(k)); v[omega + jj] = omega + 1 + int(rng.integers(255 - omega))
+        made.append(("limit>omega", v))
+        if k >= 2 and total >= 1:
+            cand = [j for j in range(1, k) if lim[j] >= 1]
+            if cand:
+                j = cand[int(rng.integers(len(cand)))]
+                v = h.copy(); v[omega + j] = lim[j] - 1  # polynomial j's limit below polynomial j-1's
+                made.append(("limit backwards", v))
+        for kind, v in made:
+            s = base[i].copy(); s[hoff:] = v
+            variants.append((i, s)); kinds.append(kind)
+    assert {"swap", "dup", "pad", "limit>omega", "limit backwards"} <= set(kinds)
+    nv = len(variants)
+    sig_v = torch.from_numpy(np.stack([s for _, s in variants])).cuda()
+    src = np.array([i for i, _ in variants])
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    mb, mo = _cat_with_offsets([b["msgs"][i] for i in src], m.device)
+    kidx = torch.from_numpy(b["kidx_host"][src].view(np.int32)).cuda()
+    ok = torch.ones(nv, dtype=torch.uint8, device="cuda")
+    m.verify_device(b["pks"], mb, mo, sig_v, ok, nv, key_idx=kidx)
+    got = host(ok)
+    # the untouched signatures verify
+    ok0 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok0, n, key_idx=b["kidx"])
+    assert bool(host(ok0).all())
+    # the oracle (serial walk of the reference) on a sample of every kind, the product on all of them
+    pkb = host(b["pk"])
+    seen = {}
+    for row, kind in enumerate(kinds):
+        if seen.get(kind, 0) >= 12:
+            continue
+        seen[kind] = seen.get(kind, 0) + 1
+        i = int(src[row])
+        pk_o = orc.pk_try_from_bytes(pset, pkb[int(b["kidx_host"][i])].tobytes())
+        want = orc.verify_internal(pset, pk_o, b["msgs"][i], variants[row][1].tobytes(), mode=0)
+        assert bool(got[row]) == want, (kind, row)
+    # 'limit backwards' may by chance still be a well-formed (different) hint -> c_tilde mismatch; every kind is refused
+    assert not got.any(), [kinds[r] for r in np.nonzero(got)[0][:5]]
