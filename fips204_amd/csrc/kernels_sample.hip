@@ -130,6 +130,8 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
     for (size_t tile = (size_t)blockIdx.x * (64 * SWAVES); tile < n_streams; tile += (size_t)gridDim.x * (64 * SWAVES)) {
     const size_t g = tile + threadIdx.x;
     const size_t wave_base = g - lane;
+    const size_t wave_base_u = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_base >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);  // the same value, in SGPRs
     const bool valid = g < n_streams;
     const size_t slot = valid ? g / l : 0;          // position in the (compacted) batch
     const uint32_t r = valid ? (uint32_t)(g % l) : 0;
@@ -177,6 +179,9 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
             if (fc > 0) {
                 wave_lds_sync();
                 const int grp = lane >> 3, j4 = (lane & 7) * 4;
+                // wave-uniform base + 32-bit byte offsets (see flush_rows4)
+                char* base = reinterpret_cast<char*>(y) + wave_base_u * (size_t)(N * 4);
+                const uint32_t lane_b = (uint32_t)(grp * N + n + j4) * 4u;
                 // rolled on purpose: unrolled, the eight row addresses stay live across the permutations and cost the
                 // kernel its fourth wave per SIMD (142 -> 118 VGPRs)
 #pragma unroll 1
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
                     const int row = 8 * i + grp;
                     if (j4 < fc && wave_base + row < n_streams) {
                         const uint32_t* src = stage + row * STAGE_STRIDE + j4;
-                        *reinterpret_cast<int4*>(y + (wave_base + row) * N + n + j4) =
+                        *reinterpret_cast<int4*>(base + (lane_b + (uint32_t)i * (8u * N * 4u))) =
                             make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
                     }
                 }

@@ -41,34 +41,6 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Flush: lane row `r` holds take[r] dwords that continue stream r's polynomial at
-// coefficient n[r].  Two streams per iteration (half-wave each, <= 32 dwords per row).  The
-// per-row (n, take) pairs go through a 64-word LDS table so that every LDS read of a batch of
-// 8 iterations is independent and can be in flight together (one wait per batch).
-__device__ __forceinline__ void flush_rows(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
-                                           int take, int n, int lane) {
-    meta[lane] = ((uint32_t)n << 8) | (uint32_t)take;
-    wave_lds_sync();
-    const int half = lane >> 5, l5 = lane & 31;
-#pragma unroll 1
-    for (int i0 = 0; i0 < 32; i0 += 8) {
-        uint32_t m[8], v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int row = 2 * (i0 + u) + half;
-            m[u] = meta[row];
-            v[u] = stage[row * STAGE_STRIDE + l5];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int row = 2 * (i0 + u) + half;
-            if (l5 < (int)(m[u] & 0xFFu)) out[(wave_base + row) * N + (m[u] >> 8) + l5] = (int32_t)v[u];
-        }
-    }
-    wave_lds_sync();
-}
-
-
 // Flush in 16-byte pieces: lane row `r` holds fc[r] dwords (a multiple of 4) that continue stream
 // r's polynomial at coefficient n[r] (a multiple of 4).  Eight lanes serve one row, so one
 // iteration stores 8 rows x 32 coefficients with one dwordx4 store per lane: 8 iterations per
@@ -84,25 +56,34 @@ constexpr int PACKED_POLY_DWORDS = 192;  // 256 * 24 bits
 template <bool PACK24 = false>
 __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
                                             int fc, int n, int lane) {
-    meta[lane] = ((uint32_t)n << 8) | (uint32_t)fc;
+    constexpr uint32_t POLY_BYTES = PACK24 ? PACKED_POLY_DWORDS * 4 : N * 4;
+    // per row: fc << 16 | byte offset of coefficient n inside the stream's polynomial
+    meta[lane] = ((uint32_t)fc << 16) | (uint32_t)(PACK24 ? (n >> 2) * 12 : n * 4);
     wave_lds_sync();
     const int grp = lane >> 3, j4 = (lane & 7) * 4;
+    // The wave's 64 polynomials are contiguous and start at a wave-uniform address: scalar base + 32-bit byte offset per
+    // store (global_store ... v_off, s[base]) instead of a 64-bit address per row kept in registers or rebuilt each time.
+    const size_t wb = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_base >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
+    char* base = reinterpret_cast<char*>(out) + wb * POLY_BYTES;
+    const uint32_t lane_b = (uint32_t)grp * POLY_BYTES + (uint32_t)(lane & 7) * (PACK24 ? 12u : 16u);
     uint32_t m[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) m[i] = meta[8 * i + grp];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int row = 8 * i + grp;
-        if (j4 < (int)(m[i] & 0xFFu)) {
+        if (j4 < (int)(m[i] >> 16)) {
             const uint32_t* src = stage + row * STAGE_STRIDE + j4;
+            const uint32_t off = lane_b + (uint32_t)i * (8u * POLY_BYTES) + (m[i] & 0xFFFFu);
             if constexpr (PACK24) {
-                const uint32_t c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
-                Packed3 v{c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8)};
-                uint32_t* o = reinterpret_cast<uint32_t*>(out) + (wave_base + row) * PACKED_POLY_DWORDS + (((m[i] >> 8) + j4) >> 2) * 3;
-                *reinterpret_cast<Packed3*>(o) = v;
+                const uint32_t c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];  // < 2^23: the top bytes are zero
+                // c0 | c1 << 24,  c1 >> 8 | c2 << 16,  c2 >> 16 | c3 << 8  as byte selections
+                Packed3 v{__builtin_amdgcn_perm(c1, c0, 0x04020100u), __builtin_amdgcn_perm(c2, c1, 0x05040201u),
+                          __builtin_amdgcn_perm(c3, c2, 0x06050402u)};
+                *reinterpret_cast<Packed3*>(base + off) = v;
             } else {
-                const int4 v = make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
-                *reinterpret_cast<int4*>(out + (wave_base + row) * N + (m[i] >> 8) + j4) = v;
+                *reinterpret_cast<int4*>(base + off) = make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
             }
         }
     }
