@@ -7,6 +7,8 @@
 //     PrivateKey::try_sign_with_rng / try_sign_with_seed   (Signer,   src/traits.rs:118-308)
 //     PrivateKey::get_public_key
 //     PublicKey::verify                                    (Verifier, src/traits.rs:330-362)
+//     PrivateKey::try_hash_sign_with_rng / _with_seed, PublicKey::hash_verify with Ph::{SHA256,SHA512,SHAKE128}
+//                                                          (HashML-DSA, src/lib.rs:310-342, 391-411; prehash.hpp)
 //     {PublicKey,PrivateKey}::try_from_bytes / into_bytes  (SerDes,   src/traits.rs:372-424)
 //     _internal_sign / _internal_verify                    (src/lib.rs:586-612)
 // plus the batched calls the GPU path exists for: keygen_many / sign_many / verify_many (device-resident
@@ -28,6 +30,7 @@
 #include <vector>
 
 #include "../../include/mldsa_hip.h"
+#include "prehash.hpp"
 
 namespace fips204_hip {
 
@@ -290,6 +293,10 @@ struct ParamSet {
         bool _internal_verify(const std::vector<uint8_t>& message, const Signature& sig, const std::vector<uint8_t>& ctx) const {
             return verify_many(*keys_, {0u}, {message}, {sig}, {ctx}, MLDSA_MODE_INTERNAL)[0];
         }
+        // Verifier::hash_verify (src/traits.rs:361, src/lib.rs:391-411): HashML-DSA.Verify, PH(M) computed on the host
+        bool hash_verify(const std::vector<uint8_t>& message, const Signature& sig, const std::vector<uint8_t>& ctx, Ph ph) const {
+            return verify_many(*keys_, {0u}, {hash_message(message, ph)}, {sig}, {ctx}, MLDSA_MODE_PREHASH)[0];
+        }
         explicit PublicKey(PublicKeys k) : keys_(std::make_shared<PublicKeys>(std::move(k))) {}
       private:
         std::shared_ptr<PublicKeys> keys_;
@@ -313,6 +320,18 @@ struct ParamSet {
             std::array<uint8_t, 32> rnd{};
             if (!rng.try_fill_bytes(rnd.data(), 32)) throw Error("ML-DSA.Sign: random number generator failed");
             return try_sign_with_seed(rnd, message, ctx);
+        }
+        // Signer::try_hash_sign_with_seed / try_hash_sign_with_rng (src/traits.rs:265-284, src/lib.rs:310-342): HashML-DSA.Sign
+        Signature try_hash_sign_with_seed(const std::array<uint8_t, 32>& rnd, const std::vector<uint8_t>& message,
+                                          const std::vector<uint8_t>& ctx, Ph ph) const {
+            return sign_many(*keys_, {0u}, {hash_message(message, ph)}, {ctx}, {rnd}, MLDSA_MODE_PREHASH)[0];
+        }
+        template <class Rng>
+        Signature try_hash_sign_with_rng(Rng& rng, const std::vector<uint8_t>& message, const std::vector<uint8_t>& ctx, Ph ph) const {
+            if (ctx.size() > 255) throw Error("HashML-DSA.Sign: ctx too long");  // before the rng is touched, lib.rs:316
+            std::array<uint8_t, 32> rnd{};
+            if (!rng.try_fill_bytes(rnd.data(), 32)) throw Error("HashML-DSA.Sign: random number generator failed");
+            return try_hash_sign_with_seed(rnd, message, ctx, ph);
         }
         // _internal_sign (src/lib.rs:586-600)
         Signature _internal_sign(const std::vector<uint8_t>& message, const std::vector<uint8_t>& ctx,

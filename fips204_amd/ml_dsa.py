@@ -16,6 +16,24 @@ from .hotpath import HotPath, N, _ptr, _stream
 
 MODE_PURE, MODE_INTERNAL, MODE_PREHASH = 0, 1, 2
 
+# Ph (src/types.rs:5-12) and hash_message (src/hashing.rs:316-354): the pre-hash of HashML-DSA is message-length-bound
+# host work; the device sees OID || PH(M) as the message of a MODE_PREHASH call.
+PH_SHA256, PH_SHA512, PH_SHAKE128 = "SHA256", "SHA512", "SHAKE128"
+_PH_OID = bytes([0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02])
+
+
+def hash_message(message, ph):
+    """OID || PH(M): DER object identifier of the hash (11 bytes) followed by its digest (32 / 64 / 32 bytes)."""
+    import hashlib
+    message = bytes(message)
+    if ph == PH_SHA256:
+        return _PH_OID + b"\x01" + hashlib.sha256(message).digest()
+    if ph == PH_SHA512:
+        return _PH_OID + b"\x03" + hashlib.sha512(message).digest()
+    if ph == PH_SHAKE128:
+        return _PH_OID + b"\x0b" + hashlib.shake_128(message).digest(32)
+    raise ValueError("Ph: SHA256, SHA512 or SHAKE128")
+
 
 def _cat_with_offsets(items, device):
     """list of bytes -> (uint8 device buffer, uint64 offsets[n + 1] on device)"""
@@ -122,6 +140,11 @@ class MlDsa:
         if wrong_len is not None:
             res &= ~wrong_len
         return res
+
+    def hash_verify(self, pks, messages, sigs, ctxs=None, ph=PH_SHA512, key_idx=None):
+        """PublicKey::hash_verify (src/traits.rs:361, src/lib.rs:391-411) for a batch: HashML-DSA.Verify with the
+        pre-hash `ph` computed on the host."""
+        return self.verify(pks, [hash_message(m, ph) for m in messages], sigs, ctxs=ctxs, key_idx=key_idx, mode=MODE_PREHASH)
 
     def expand_a_for_keys(self, keys):
         """A_hat = ExpandA(rho) of every key of a PublicKeys / PrivateKeys batch: the `cap_a_hat`
@@ -313,6 +336,12 @@ class MlDsa:
         if n_ops and int(status[:n_ops].min()) < 0:
             raise ValueError("ML-DSA.Sign: ctx too long")
         return sigs[:n_ops]
+
+    def try_hash_sign_with_seed(self, sks, messages, rnd, ctxs=None, ph=PH_SHA512, key_idx=None):
+        """PrivateKey::try_hash_sign_with_seed (src/traits.rs:280-284, src/lib.rs:310-342) for a batch: HashML-DSA.Sign
+        with the pre-hash `ph` computed on the host."""
+        return self.try_sign_with_seed(sks, [hash_message(m, ph) for m in messages], rnd, ctxs=ctxs, key_idx=key_idx,
+                                       mode=MODE_PREHASH)
 
     def sign_device(self, sks, msg_buf, msg_off, rnd, sigs, n_ops, ctx_buf=None, ctx_off=None, key_idx=None,
                     mode=MODE_PURE, status=None, a_hat=None, wait=True):

@@ -291,6 +291,32 @@ def get_public_key(pset, sk):
 MODE_PURE, MODE_INTERNAL, MODE_PREHASH = 0, 1, 2
 
 
+def hash_message(message, ph):
+    """hash_message (src/hashing.rs:316-354): (oid, PH(M)) of HashML-DSA; `ph` in "SHA256" / "SHA512" / "SHAKE128".
+    The three hashes are third-party crates in the reference (sha2, sha3); hashlib supplies them here."""
+    import hashlib
+    oid = bytes([0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02])
+    if ph == "SHA256":  # :318-329
+        return oid + b"\x01", hashlib.sha256(message).digest()
+    if ph == "SHA512":  # :330-340
+        return oid + b"\x03", hashlib.sha512(message).digest()
+    if ph == "SHAKE128":  # :341-352
+        return oid + b"\x0b", hashlib.shake_128(message).digest(32)
+    raise ValueError(ph)
+
+
+def hash_sign(pset, sk, message, rnd, ctx, ph):
+    """try_hash_sign_with_rng (src/lib.rs:310-342): M' = 0x01 | len(ctx) | ctx | OID | PH(M) under sign_internal."""
+    oid, phm = hash_message(message, ph)
+    return sign_internal(pset, sk, oid + phm, rnd, ctx=ctx, mode=MODE_PREHASH)
+
+
+def hash_verify(pset, pk, message, sig, ctx, ph):
+    """hash_verify (src/lib.rs:391-411)"""
+    oid, phm = hash_message(message, ph)
+    return verify_internal(pset, pk, oid + phm, sig, ctx=ctx, mode=MODE_PREHASH)
+
+
 def sign_internal(pset, sk, msg, rnd, ctx=b"", mode=MODE_INTERNAL, want_iters=False):
     sig = (C.c_uint8 * params(pset).sig_len)()
     iters = C.c_int(0)

@@ -57,6 +57,21 @@ static void smoke_test(int expect_pk0) {  // src/lib.rs:497-552
     bool threw = false;
     try { (void)sk.try_sign_with_seed(seed12, message1, std::vector<uint8_t>(257, 0)); } catch (const Error&) { threw = true; }
     ASSERT(threw);                                                                 // lib.rs:528
+    // HashML-DSA with every pre-hash function (lib.rs:510-541)
+    for (Ph ph : {Ph::SHA256, Ph::SHA512, Ph::SHAKE128}) {
+        auto hsig = sk.try_hash_sign_with_rng(rng, message1, {}, ph);
+        ASSERT(pk.hash_verify(message1, hsig, {}, ph));
+        ASSERT(!pk.hash_verify(message2, hsig, {}, ph));
+        ASSERT(!pk.verify(message1, hsig, {}));                                    // domain separation: not a pure signature
+        ASSERT(!pk.hash_verify(message1, hsig, {}, ph == Ph::SHA256 ? Ph::SHAKE128 : Ph::SHA256));  // same length, other OID
+    }
+    std::array<uint8_t, 32> seed34; seed34.fill(34);
+    auto hsig = sk.try_hash_sign_with_seed(seed34, message1, {}, Ph::SHA256);     // lib.rs:539-540
+    ASSERT(pk.hash_verify(message1, hsig, {}, Ph::SHA256));
+    threw = false;
+    try { (void)sk.try_hash_sign_with_seed(seed34, message1, std::vector<uint8_t>(256, 0), Ph::SHA512); } catch (const Error&) { threw = true; }
+    ASSERT(threw);                                                                 // lib.rs:316
+    ASSERT(!pk.hash_verify(message1, hsig, std::vector<uint8_t>(256, 0), Ph::SHA256));  // lib.rs:395-397
     ASSERT(pk.into_bytes()[0] == expect_pk0);                                      // lib.rs:543-545
     // Signer::get_public_key (lib.rs:345-349): the public key derived from the private key is the one keygen gave
     ASSERT(sk.get_public_key().into_bytes() == pk.into_bytes());
@@ -113,6 +128,15 @@ int main(int argc, char** argv) {
         auto skb = sk.into_bytes(); auto pkb = pk.into_bytes();
         std::printf("sk %s\nsig %s\npk %s\n", to_hex(skb.data(), skb.size()).c_str(), to_hex(sig.data(), sig.size()).c_str(),
                     to_hex(pkb.data(), pkb.size()).c_str());
+        // HashML-DSA under the same key and seed, one line per pre-hash function: the driver compares them with the oracle
+        const std::vector<uint8_t> ctx = {'c', 't', 'x'};
+        const char* names[] = {"SHA256", "SHA512", "SHAKE128"};
+        int pi = 0;
+        for (Ph ph : {Ph::SHA256, Ph::SHA512, Ph::SHAKE128}) {
+            auto hs = sk.try_hash_sign_with_seed(rnd, {'a', 's', 'd', 'f'}, ctx, ph);
+            ASSERT(pk.hash_verify({'a', 's', 'd', 'f'}, hs, ctx, ph));
+            std::printf("hsig_%s %s\n", names[pi++], to_hex(hs.data(), hs.size()).c_str());
+        }
     }
     // a small batch through the *_many calls: 3 keys, 12 ops, one corrupted signature
     {

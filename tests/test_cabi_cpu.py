@@ -5,6 +5,7 @@ import ctypes as C
 
 import pytest
 
+from conftest import ROOT
 from fips204_amd import _lib
 from oracle import oracle as orc
 
@@ -76,3 +77,42 @@ def test_no_kernel_spills_registers():
             assert int(v) == 0 and int(sc) == 0, f"{os.path.basename(path)}: {n} spills {v} VGPRs, {sc} B scratch"
         n_kernels += len(names)
     assert n_kernels >= 60
+
+
+def test_host_prehash_matches_hashlib(tmp_path):
+    """fips204_amd/host/prehash.hpp (the C++ mirror's hash_message, src/hashing.rs:316-354) carries its own SHA-256 /
+    SHA-512 / SHAKE128: OID || PH(M) must equal what hashlib gives, across the padding boundaries of all three."""
+    import hashlib
+    import subprocess
+    src = tmp_path / "ph.cpp"
+    src.write_text(r'''
+#include "fips204_amd/host/prehash.hpp"
+#include <cstdio>
+using namespace fips204_hip;
+int main() {
+    const size_t lens[] = {0, 1, 3, 55, 56, 63, 64, 65, 111, 112, 119, 120, 127, 128, 129, 135, 136, 167, 168, 169, 335, 336, 337, 1000, 7727};
+    for (size_t n : lens) {
+        std::vector<uint8_t> m(n);
+        for (size_t i = 0; i < n; i++) m[i] = (uint8_t)(i * 131 + 7 + n);
+        for (Ph ph : {Ph::SHA256, Ph::SHA512, Ph::SHAKE128}) {
+            const auto v = hash_message(m, ph);
+            for (uint8_t b : v) std::printf("%02x", b);
+            std::printf("\n");
+        }
+    }
+}
+''')
+    exe = tmp_path / "ph"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, str(src), "-o", str(exe)])
+    got = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    from fips204_amd.ml_dsa import hash_message
+    oid = bytes([0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02])
+    i = 0
+    for n in (0, 1, 3, 55, 56, 63, 64, 65, 111, 112, 119, 120, 127, 128, 129, 135, 136, 167, 168, 169, 335, 336, 337, 1000, 7727):
+        m = bytes((j * 131 + 7 + n) & 255 for j in range(n))
+        want = {"SHA256": oid + b"\x01" + hashlib.sha256(m).digest(), "SHA512": oid + b"\x03" + hashlib.sha512(m).digest(),
+                "SHAKE128": oid + b"\x0b" + hashlib.shake_128(m).digest(32)}
+        for ph in ("SHA256", "SHA512", "SHAKE128"):
+            assert got[i] == want[ph].hex(), (n, ph)
+            assert hash_message(m, ph) == want[ph]  # the Python mirror's front-end
+            i += 1

@@ -24,3 +24,9 @@ def test_cpp_host_mirror(tmp_path, ref_hex):
     v = ref_hex["messages_rs"]
     assert lines["sk"] == v["sk"] and lines["sig"] == v["sig"] and lines["pk"] == v["pk"]
     assert out.stdout.strip().endswith("OK")
+    # HashML-DSA lines: the mirror's own SHA-256 / SHA-512 / SHAKE128 + MLDSA_MODE_PREHASH against the oracle's
+    # restatement of try_hash_sign (src/lib.rs:310-342) with hashlib's hashes
+    from oracle import oracle as orc
+    sk_o = orc.sk_try_from_bytes(44, bytes.fromhex(lines["sk"]))
+    for ph in ("SHA256", "SHA512", "SHAKE128"):
+        assert lines["hsig_" + ph] == orc.hash_sign(44, sk_o, b"asdf", rnd, b"ctx", ph).hex(), ph

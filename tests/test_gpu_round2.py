@@ -497,3 +497,31 @@ def test_non_canonical_hint_encodings_are_rejected_like_the_reference(sets, pset
         assert bool(got[row]) == want, (kind, row)
     # 'limit backwards' may by chance still be a well-formed (different) hint -> c_tilde mismatch; every kind is refused
     assert not got.any(), [kinds[r] for r in np.nonzero(got)[0][:5]]
+
+
+# ------------------------------------------------------------------------------ HashML-DSA (pre-hash) front-end
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_hash_sign_and_hash_verify_match_the_oracle(sets, pset):
+    """try_hash_sign_with_seed / hash_verify (src/lib.rs:310-342, 391-411) with Ph = SHA256 / SHA512 / SHAKE128: the
+    pre-hash on the host, M' = 0x01 | len(ctx) | ctx | OID | PH(M) on the device; byte-exact against the oracle."""
+    m = sets[pset]
+    rng = np.random.default_rng(50 + pset)
+    pk_o, sk_o = orc.keygen_from_seed(pset, bytes(range(7, 39)))
+    pks = m.public_keys_from_bytes([orc.pk_into_bytes(pset, pk_o)])
+    sks = m.private_keys_from_bytes([orc.sk_into_bytes(pset, sk_o)])
+    msgs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 1, 64, 200, 5000)]
+    ctxs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 255, 3, 17, 1)]
+    rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in msgs]
+    for ph in ("SHA256", "SHA512", "SHAKE128"):
+        sig = host(m.try_hash_sign_with_seed(sks, msgs, rnd, ctxs=ctxs, ph=ph))
+        for i in range(len(msgs)):
+            assert sig[i].tobytes() == orc.hash_sign(pset, sk_o, msgs[i], rnd[i], ctxs[i], ph), (ph, i)
+            assert orc.hash_verify(pset, pk_o, msgs[i], sig[i].tobytes(), ctxs[i], ph)
+        sig_t = torch.from_numpy(sig).cuda()
+        assert m.hash_verify(pks, msgs, sig_t, ctxs=ctxs, ph=ph).all()
+        other = "SHAKE128" if ph == "SHA256" else "SHA256"
+        assert not m.hash_verify(pks, msgs, sig_t, ctxs=ctxs, ph=other).any()  # the OID is part of M'
+        assert not m.verify(pks, msgs, sig_t, ctxs=ctxs).any()                 # and 0x01 != 0x00
+    with pytest.raises(ValueError):
+        m.try_hash_sign_with_seed(sks, msgs[:1], rnd[:1], ctxs=[bytes(256)], ph="SHA512")  # lib.rs:316
+    assert not m.hash_verify(pks, msgs[:1], torch.from_numpy(sig[:1]).cuda(), ctxs=[bytes(256)], ph="SHAKE128").any()  # lib.rs:395
