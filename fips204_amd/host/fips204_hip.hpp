@@ -3,8 +3,8 @@
 //
 // Same names, argument meaning and error behaviour as the reference crate:
 //   fips204_hip::ml_dsa_44 / ml_dsa_65 / ml_dsa_87        (src/lib.rs:639-740)
-//     KG::try_keygen_with_rng / KG::keygen_from_seed       (KeyGen,   src/traits.rs:8-114)
-//     PrivateKey::try_sign_with_rng / try_sign_with_seed   (Signer,   src/traits.rs:118-308)
+//     KG::try_keygen / try_keygen_with_rng / keygen_from_seed        (KeyGen, src/traits.rs:8-114)
+//     PrivateKey::try_sign / try_sign_with_rng / try_sign_with_seed  (Signer, src/traits.rs:118-308)
 //     PrivateKey::get_public_key
 //     PublicKey::verify                                    (Verifier, src/traits.rs:330-362)
 //     PrivateKey::try_hash_sign_with_rng / _with_seed, PublicKey::hash_verify with Ph::{SHA256,SHA512,SHAKE128}
@@ -20,6 +20,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -33,6 +34,18 @@
 #include "prehash.hpp"
 
 namespace fips204_hip {
+
+// rand_core::OsRng, the generator behind the reference's try_keygen / try_sign / try_hash_sign (src/traits.rs:45, 157, 250):
+// the kernel's CSPRNG through /dev/urandom
+struct OsRng {
+    bool try_fill_bytes(uint8_t* out, size_t n) {
+        std::FILE* f = std::fopen("/dev/urandom", "rb");
+        if (!f) return false;
+        const size_t got = std::fread(out, 1, n, f);
+        std::fclose(f);
+        return got == n;
+    }
+};
 
 struct Error : std::runtime_error {
     using std::runtime_error::runtime_error;
@@ -321,6 +334,15 @@ struct ParamSet {
             if (!rng.try_fill_bytes(rnd.data(), 32)) throw Error("ML-DSA.Sign: random number generator failed");
             return try_sign_with_seed(rnd, message, ctx);
         }
+        // Signer::try_sign (src/traits.rs:156-158) / try_hash_sign (247-251): rnd from OsRng
+        Signature try_sign(const std::vector<uint8_t>& message, const std::vector<uint8_t>& ctx) const {
+            OsRng rng;
+            return try_sign_with_rng(rng, message, ctx);
+        }
+        Signature try_hash_sign(const std::vector<uint8_t>& message, const std::vector<uint8_t>& ctx, Ph ph) const {
+            OsRng rng;
+            return try_hash_sign_with_rng(rng, message, ctx, ph);
+        }
         // Signer::try_hash_sign_with_seed / try_hash_sign_with_rng (src/traits.rs:265-284, src/lib.rs:310-342): HashML-DSA.Sign
         Signature try_hash_sign_with_seed(const std::array<uint8_t, 32>& rnd, const std::vector<uint8_t>& message,
                                           const std::vector<uint8_t>& ctx, Ph ph) const {
@@ -348,6 +370,11 @@ struct ParamSet {
         static std::pair<PublicKey, PrivateKey> keygen_from_seed(const std::array<uint8_t, 32>& xi) {
             auto ks = keygen_many({xi});
             return {PublicKey::try_from_bytes(ks.first[0]), PrivateKey::try_from_bytes(ks.second[0])};
+        }
+        // KeyGen::try_keygen (src/traits.rs:44-46): xi <- OsRng
+        static std::pair<PublicKey, PrivateKey> try_keygen() {
+            OsRng rng;
+            return try_keygen_with_rng(rng);
         }
         // KeyGen::try_keygen_with_rng (src/lib.rs:241-245): xi <- rng (32 bytes)
         template <class Rng>

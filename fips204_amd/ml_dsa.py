@@ -22,6 +22,14 @@ PH_SHA256, PH_SHA512, PH_SHAKE128 = "SHA256", "SHA512", "SHAKE128"
 _PH_OID = bytes([0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02])
 
 
+class OsRng:
+    """rand_core::OsRng as the reference's default generator (src/traits.rs:45, 157, 250): the kernel's CSPRNG"""
+
+    def fill_bytes(self, n):
+        import os
+        return os.urandom(n)
+
+
 def hash_message(message, ph):
     """OID || PH(M): DER object identifier of the hash (11 bytes) followed by its digest (32 / 64 / 32 bytes)."""
     import hashlib
@@ -312,7 +320,32 @@ class MlDsa:
         xi = [rng.fill_bytes(32) for _ in range(n)]
         return self.keygen_from_seed(xi)
 
+    def try_keygen(self, n=1):
+        """KG::try_keygen (src/traits.rs:44-46): xi from the operating system's generator (OsRng)"""
+        return self.try_keygen_with_rng(OsRng(), n)
+
     # ---- Signer (src/traits.rs:118-308; src/lib.rs:268-342, 586-600) -------------------
+    def try_sign_with_rng(self, rng, sks, messages, ctxs=None, key_idx=None):
+        """PrivateKey::try_sign_with_rng (src/lib.rs:268-296): one rnd = rng.fill_bytes(32) per op, drawn only after
+        every ctx passed the length check (lib.rs:274 comes before lib.rs:282)"""
+        if ctxs is not None and any(len(c) > 255 for c in ctxs):
+            raise ValueError("ML-DSA.Sign: ctx too long")
+        return self.try_sign_with_seed(sks, messages, [rng.fill_bytes(32) for _ in messages], ctxs=ctxs, key_idx=key_idx)
+
+    def try_sign(self, sks, messages, ctxs=None, key_idx=None):
+        """PrivateKey::try_sign (src/traits.rs:156-158): hedged signing with rnd from OsRng"""
+        return self.try_sign_with_rng(OsRng(), sks, messages, ctxs=ctxs, key_idx=key_idx)
+
+    def try_hash_sign_with_rng(self, rng, sks, messages, ctxs=None, ph=PH_SHA512, key_idx=None):
+        """PrivateKey::try_hash_sign_with_rng (src/lib.rs:310-342)"""
+        if ctxs is not None and any(len(c) > 255 for c in ctxs):
+            raise ValueError("HashML-DSA.Sign: ctx too long")
+        return self.try_hash_sign_with_seed(sks, messages, [rng.fill_bytes(32) for _ in messages], ctxs=ctxs, ph=ph, key_idx=key_idx)
+
+    def try_hash_sign(self, sks, messages, ctxs=None, ph=PH_SHA512, key_idx=None):
+        """PrivateKey::try_hash_sign (src/traits.rs:247-251)"""
+        return self.try_hash_sign_with_rng(OsRng(), sks, messages, ctxs=ctxs, ph=ph, key_idx=key_idx)
+
     def try_sign_with_seed(self, sks, messages, rnd, ctxs=None, key_idx=None, mode=MODE_PURE):
         """PrivateKey::try_sign_with_seed for a batch: rnd = one 32-byte seed per op (zeros =
         deterministic signing).  Raises ValueError if any ctx is longer than 255 bytes

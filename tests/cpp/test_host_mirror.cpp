@@ -78,6 +78,13 @@ static void smoke_test(int expect_pk0) {  // src/lib.rs:497-552
     ASSERT(sk.get_public_key().verify(message1, sig, {}));
     // SerDes round trip of the private key through its expanded form (lib.rs:421-465)
     ASSERT(P::PrivateKey::try_from_bytes(sk.into_bytes()).into_bytes() == sk.into_bytes());
+    {   // the OsRng entry points (traits.rs:44-46, 156-158, 247-251): hedged, so two signatures of one message differ
+        auto [pk2, sk2] = P::KG::try_keygen();
+        auto s1 = sk2.try_sign(message1, {}), s2 = sk2.try_sign(message1, {});
+        ASSERT(pk2.verify(message1, s1, {}) && pk2.verify(message1, s2, {}) && s1 != s2);
+        ASSERT(pk2.hash_verify(message1, sk2.try_hash_sign(message1, {}, Ph::SHA512), {}, Ph::SHA512));
+        ASSERT(pk2.into_bytes() != pk.into_bytes());
+    }
     FailingRng bad;
     threw = false;
     try { (void)P::KG::try_keygen_with_rng(bad); } catch (const Error&) { threw = true; }

@@ -525,3 +525,33 @@ def test_hash_sign_and_hash_verify_match_the_oracle(sets, pset):
     with pytest.raises(ValueError):
         m.try_hash_sign_with_seed(sks, msgs[:1], rnd[:1], ctxs=[bytes(256)], ph="SHA512")  # lib.rs:316
     assert not m.hash_verify(pks, msgs[:1], torch.from_numpy(sig[:1]).cuda(), ctxs=[bytes(256)], ph="SHAKE128").any()  # lib.rs:395
+
+
+def test_os_rng_entry_points(sets):
+    """try_keygen / try_sign / try_hash_sign (src/traits.rs:44-46, 156-158, 247-251): xi and rnd from the operating
+    system; hedged signatures of one message differ and both verify; an over-long ctx is refused before the
+    generator is touched (src/lib.rs:274 precedes 282)."""
+    m = sets[44]
+    pk, sk = m.try_keygen(2)
+    assert not torch.equal(pk[0], pk[1])
+    pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+    msgs = [b"one", b"one"]
+    kidx = np.zeros(2, dtype=np.uint32)
+    sig = m.try_sign(sks, msgs, key_idx=kidx)
+    assert not torch.equal(sig[0], sig[1]) and m.verify(pks, msgs, sig, key_idx=kidx).all()
+    hsig = m.try_hash_sign(sks, msgs, ph="SHAKE128", key_idx=kidx)
+    assert m.hash_verify(pks, msgs, hsig, ph="SHAKE128", key_idx=kidx).all()
+
+    class Counting:
+        calls = 0
+
+        def fill_bytes(self, n):
+            self.calls += 1
+            return bytes(n)
+
+    rng = Counting()
+    with pytest.raises(ValueError):
+        m.try_sign_with_rng(rng, sks, msgs, ctxs=[b"", bytes(256)], key_idx=kidx)
+    with pytest.raises(ValueError):
+        m.try_hash_sign_with_rng(rng, sks, msgs, ctxs=[bytes(256), b""], key_idx=kidx)
+    assert rng.calls == 0
