@@ -43,6 +43,12 @@ done
 python tools/pmc_summary.py sq expand_a65 "$OUT/sq_expand_a65" $R
 ( cd /tmp && rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d "$OUT/sq_sign65" -o p -- python3 "$OLDPWD/bench.py" --workload sign65 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/sq_sign65.log" 2>&1 )
 python tools/pmc_summary.py sq sign65 "$OUT/sq_sign65" $R
+# the verify65 kernels (k_verify_main: how much of it is VALU issue?), two passes: issue counters, instruction classes
+( cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d "$OUT/sq_verify65" -o p -- python3 "$OLDPWD/bench.py" --workload verify65 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/sq_verify65.log" 2>&1 )
+python tools/pmc_summary.py sq verify65 "$OUT/sq_verify65" $R
+( cd /tmp && rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d "$OUT/sq2_verify65" -o p -- python3 "$OLDPWD/bench.py" --workload verify65 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/sq2_verify65.log" 2>&1 )
+python tools/pmc_summary.py sq verify65b "$OUT/sq2_verify65" $R
+rm -rf "$OUT"/sq_verify65 "$OUT"/sq2_verify65
 cp profiles/${R}_pmc_*.json profiles/${R}_sq_*.json "$OUT"/ 2>/dev/null
 rm -rf "$OUT"/pmc_*_FETCH_SIZE "$OUT"/pmc_*_WRITE_SIZE "$OUT"/sq_expand_a65 "$OUT"/sq_sign65  # raw traces: large
 ls -la "$OUT"
