@@ -68,6 +68,9 @@ __device__ __forceinline__ Coef4 ld4(const int32_t* p, int u) {
 //   -- only if both hold (about 1 slot in 5):
 //   ct0_i = inv_ntt(c_hat o t0_hat_i)                 ||ct0|| < gamma2 ?
 //   h_i  = MakeHint(-ct0_i, r_i + ct0_i)              weight(h) <= omega ?
+//   (ML-DSA-65 / 87: tau * 2^12 < gamma2, the ct0 test cannot fail, and h_i comes from ONE transform per row:
+//    r_i + ct0_i = w_i + inv_ntt(c_hat o (t0_hat_i - s2_hat_i)) against HighBits(w_i) -- 13 / 17 instead of 17 / 23
+//    inverse transforms per accepted attempt, and no r_i kept in LDS)
 // (c_hat = ntt(c) comes from k_ntt.)  sigEncode (encodings.rs:238-276) is written EAGERLY while the
 // polynomials stream through: z bytes in stage 1, hint bytes in stage 2.  If the attempt is then
 // rejected the bytes are garbage, but the op's next attempt rewrites every byte, and only an
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
-    __shared__ int32_t rr_lds[GWAVES][K][N]; // r_i = w_i - cs2_i, kept for the hint stage
+    // r_i = w_i - cs2_i, kept for the hint stage -- only where ||ct0||inf < gamma2 can fail (ML-DSA-44), see stage 2
+    constexpr bool CT0_CAN_FAIL = !G2HI;
+    __shared__ int32_t rr_lds[GWAVES][CT0_CAN_FAIL ? K : 1][N];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: slot indices and row pointers stay scalar
     const int32_t gamma1 = 1 << gb;
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
         };
 #pragma unroll 1
         for (int pass = 0; pass < 2 && ok; pass++) {
-            uint32_t work = pass == 0 ? (risky & todo) : todo;
+            // pass 1 of the sets whose stage 2 works from w itself needs only the z_j (signature bytes)
+            uint32_t work = pass == 0 ? (risky & todo) : (CT0_CAN_FAIL ? todo : (todo & ~((1u << K) - 1u)));
             todo &= ~work;
             int cur = work ? __ffs((int)work) - 1 : -1;
             int32_t nv[4] = {0, 0, 0, 0}, nx[4] = {0, 0, 0, 0};
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int32_t rr = caddq(x[k] - r[k]);     // w - cs2, canonical (both operands are in [0, q))
-                        rr_lds[wave][cur][64 * k + lane] = rr;      // kept for the hint stage
+                        if constexpr (CT0_CAN_FAIL) rr_lds[wave][cur][64 * k + lane] = rr;  // kept for the hint stage
                         int32_t r1, r0;
                         decompose<G2HI>(rr, r1, r0);
                         bad |= (r0 < 0 ? -r0 : r0) >= GAMMA2 - beta;
@@ -221,21 +227,35 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
             int index = 0;  // running count of hints, wave-uniform
 #pragma unroll 1
             for (int i = 0; i < K; i++) {
-                int32_t v[4], r[4];
+                int32_t v[4], r[4], base[4];
                 load_packed(v, t0 + (key * K + i) * (size_t)N, lane);
+                if constexpr (!CT0_CAN_FAIL) {
+                    // gamma2 = (q-1)/32: |c t0| <= tau * 2^12 = 200 704 (65) / 245 760 (87) < gamma2, so the ||ct0||inf test of
+                    // ml_dsa.rs:312 cannot fail and ct0 is never needed on its own.  The attempt passed the LowBits test, hence
+                    // HighBits(w - cs2) = HighBits(w) (what makes verification recover w1), and
+                    //   h = [HighBits(w - cs2 + ct0) != HighBits(w)],  w - cs2 + ct0 = w + invNTT(c_hat o (t0_hat - s2_hat)):
+                    // ONE inverse transform per row instead of two (cs2 in pass 1 and ct0 here).
+                    int32_t v2[4];
+                    load_packed(v2, s2 + (key * K + i) * (size_t)N, lane);
+                    load_strided(base, w + (slot * K + i) * (size_t)N, lane);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] -= v2[k];
+                }
                 r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
                 ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);  // center_mod of a canonical value
-                    tc = tc < 0 ? -tc : tc;
-                    tmax = tc > tmax ? tc : tmax;
+                    if constexpr (CT0_CAN_FAIL) {
+                        int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);  // center_mod of a canonical value
+                        tc = tc < 0 ? -tc : tc;
+                        tmax = tc > tmax ? tc : tmax;
+                        base[k] = rr_lds[wave][i][64 * k + lane];  // w - cs2
+                    }
                     // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
-                    const int32_t rr = rr_lds[wave][i][64 * k + lane];
                     int32_t a1, a0, b1, b0;
-                    const int32_t sum = rr + r[k] - Q;  // both in [0, q)
+                    const int32_t sum = base[k] + r[k] - Q;  // both in [0, q)
                     decompose<G2HI>(caddq(sum), a1, a0);
-                    decompose<G2HI>(rr, b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q)
+                    decompose<G2HI>(base[k], b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q); same high part as w
                     const bool h = a1 != b1;
                     const unsigned long long mask = __ballot(h);
                     if (h) {
