@@ -351,9 +351,10 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode) {
     pl.ns_max = std::max(n, tgt);
     const double q = 1.0 - accept_prob(set);
     double m = (double)n;
-    // a synchronous call looks at the device once anyway and adds rounds if an op is left (so its plan only has to make
-    // that rare: < 1e-3 of the calls); an asynchronous call cannot, and plans until < 1e-9
-    const double stop = async_mode ? 1e-9 : 1e-3;
+    // a synchronous call looks at the device once anyway and adds rounds if an op is left, so its plan stops when that is
+    // unlikely (< 5 % of the calls: a planned round for 0.002 expected ops costs every call the ~0.2 ms latency chain of an
+    // empty round, two extra rounds cost the rare call ~0.5 ms); an asynchronous call cannot look, and plans until < 1e-9
+    const double stop = async_mode ? 1e-9 : 0.05;
     for (int r = 0; r < 64 && m > stop; r++) {
         // grids follow mean + 6 sigma of the binomial count (a round that still finds more just loops)
         const double m_hi = std::min((double)n, m + 6.0 * std::sqrt(m) + 1.0);
