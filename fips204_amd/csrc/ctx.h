@@ -205,7 +205,9 @@ int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,
                      const uint32_t *slot_op, const uint32_t *key_idx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
                      uint16_t *kappa, int32_t *done, uint8_t *sigs, const RoundCtl *ctl, uint8_t *stage, size_t stage_stride,
-                     int32_t *accept, size_t slots_hint, hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr);
+                     int32_t *accept, size_t slots_hint, hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr,
+                     const uint8_t *key_oor = nullptr, int oor_by_op = 0);
+int launch_key_range(mldsa_ctx *, const mldsa_params *, const int32_t *s2, const uint32_t *kidx, size_t n_units, uint8_t *oor, hipStream_t);
 int launch_make_slots(mldsa_ctx *, RoundCtl *ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t *act,
                       const uint16_t *kappa, int l, uint32_t *slot_op, uint16_t *slot_kappa, const uint32_t *key_idx,
                       uint32_t *slot_key, size_t slots_hint, hipStream_t);

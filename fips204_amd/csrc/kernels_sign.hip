@@ -80,7 +80,7 @@ __device__ __forceinline__ Coef4 ld4(const int32_t* p, int u) {
 // below), the more selective LowBits test first, and leaves at the first rejection: a rejected
 // ML-DSA-65 attempt costs about 1.5 of the 11 inverse NTTs of stage 1.
 template <int K, int L, bool G2HI>
-__global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
+__global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_sign_tail(
     const int32_t* __restrict__ c_hat, const int32_t* __restrict__ y, const int32_t* __restrict__ w,
     const uint8_t* __restrict__ ctilde, const uint32_t* __restrict__ slot_op, const uint32_t* __restrict__ key_idx,
     const int32_t* __restrict__ s1, const int32_t* __restrict__ s2, const int32_t* __restrict__ t0,
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
     const RoundCtl* __restrict__ ctl,
     uint8_t* __restrict__ stage, size_t stage_stride, int32_t* __restrict__ accept, int gb, int beta, int omega,
     int ctilde_len, size_t sig_len, const Twiddle* __restrict__ inv_tab,
-    const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk) {
+    const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk, const uint8_t* __restrict__ key_oor, int oor_by_op) {
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
@@ -119,19 +119,24 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
             for (int j = 0; j < L; j++) zr |= (yrisk[(size_t)sl * L + j] ? 1u : 0u) << j;
         }
     };
-    uint32_t op_next = 0, key_next = 0, rrisk_next = 0, zrisk_next = 0;
+    uint32_t op_next = 0, key_next = 0, rrisk_next = 0, zrisk_next = 0, oor_next = 0;
     if (wid < n_slots32) {
         op_next = slot_op[wid];
         key_next = key_idx ? key_idx[op_next] : op_next;
         risk_flags(wid, rrisk_next, zrisk_next);
+        oor_next = key_oor ? key_oor[oor_by_op ? op_next : key_next] : 0u;
     }
     for (uint32_t slot32 = wid; slot32 < n_slots32; slot32 += n_waves) {
         const size_t slot = slot32, op = op_next, key = key_next;
-        const uint32_t r_risky = rrisk_next, z_risky = zrisk_next;
+        // a key whose s2 leaves [-eta, eta] (k_key_range) voids ||c s2||inf <= beta: every polynomial can reject and the
+        // hint stage takes the reference's two-transform form
+        const bool s2_oor = oor_next != 0;  // wave-uniform
+        const uint32_t r_risky = s2_oor ? (1u << K) - 1u : rrisk_next, z_risky = zrisk_next;
         if (slot32 + n_waves < n_slots32) {
             op_next = slot_op[slot32 + n_waves];
             key_next = key_idx ? key_idx[op_next] : op_next;
             risk_flags(slot32 + n_waves, rrisk_next, zrisk_next);
+            oor_next = key_oor ? key_oor[oor_by_op ? op_next : key_next] : 0u;
         }
         uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
         const int4 cv = reinterpret_cast<const int4*>(c_hat + slot * N)[lane];
@@ -238,8 +243,17 @@ __global__ __launch_bounds__(64 * GWAVES) void k_sign_tail(
                     int32_t v2[4];
                     load_packed(v2, s2 + (key * K + i) * (size_t)N, lane);
                     load_strided(base, w + (slot * K + i) * (size_t)N, lane);
+                    if (s2_oor) {
+                        // out-of-range s2: the identity above is not guaranteed; r_i = w_i - c s2_i explicitly (it passed the
+                        // LowBits test in stage 1, where every polynomial counted as risky), then r_i + c t0_i as the reference does
+                        r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
+                        ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) v[k] -= v2[k];
+                        for (int k = 0; k < 4; k++) base[k] = caddq(base[k] - r[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[k] -= v2[k];
+                    }
                 }
                 r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
                 ntt_inv_wave(r, itw, lane, F_MONT);
@@ -579,6 +593,34 @@ __global__ __launch_bounds__(GBLOCK) void k_key_intt(const int32_t* __restrict__
     }
 }
 
+// Does a key's s2 lie in [-eta, eta]?  expand_private accepts every bit pattern (conversion.rs:259-260), so s2 may hold
+// -5 (eta = 2) or -11 (eta = 4), and then ||c s2||inf can exceed beta = tau * eta -- the bound k_sign_tail's one-transform hint
+// stage rests on.  One wave per (unit, polynomial): unit = key of the table, or op of the chunk when the table is larger than
+// the chunk (then the key comes from kidx).  oor[unit] = 1 if any coefficient is out of range (zeroed by the caller).
+__global__ __launch_bounds__(GBLOCK) void k_key_range(const int32_t* __restrict__ s2, int k, int eta, const uint32_t* __restrict__ kidx,
+                                                      size_t n_units, uint8_t* __restrict__ oor, const Twiddle* __restrict__ inv_tab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wid = (size_t)blockIdx.x * GWAVES + wave, n_waves = (size_t)gridDim.x * GWAVES;
+    InvTw tw;
+    load_inv_tw(tw, inv_tab, lane);
+    for (size_t u = wid; u < n_units * (size_t)k; u += n_waves) {
+        const size_t unit = u / k;
+        const size_t key = kidx ? kidx[unit] : unit;
+        int32_t r[4];
+        load_packed(r, s2 + (key * k + u % k) * (size_t)N, lane);
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = mont_mul(reduce32(r[i]), 1);  // mont_reduce(x_hat_mont) = x_hat
+        ntt_inv_wave(r, tw, lane, F_MONT);                                // canonical [0, q)
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int32_t cen = r[i] - ((((Q / 2) - r[i]) >> 31) & Q);
+            bad |= (cen < 0 ? -cen : cen) > eta;
+        }
+        if (__ballot(bad) != 0ull && lane == 0) oor[unit] = 1;
+    }
+}
+
 // get_public_key tail (ml_dsa.rs:543-556): t = as1 + s2 (full_reduce32), t1 = Power2Round(t).hi,
 // t1_d2_hat_mont = NTT(t1) * 2^13 in Montgomery form.  One wave per polynomial.  as1[key][K] canonical coefficients
 // (k_verify_arith<.., false> output), s1s2[key][L + K] centred coefficients (k_key_intt output).
@@ -620,13 +662,14 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
 int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde,
                      const uint32_t* slot_op, const uint32_t* key_idx, const int32_t* s1, const int32_t* s2, const int32_t* t0,
                      uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, uint8_t* stage, size_t stage_stride,
-                     int32_t* accept, size_t slots_hint, hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk) {
+                     int32_t* accept, size_t slots_hint, hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk,
+                     const uint8_t* key_oor, int oor_by_op) {
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
     dim3 grid(grid_for(ctx, slots_hint, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
 #define MLDSA_TAIL(KK, LL, G2)                                                                                              \
     hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
                        done, sigs, ctl, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
-                       ctx->d_inv_tw, wrisk, yrisk)
+                       ctx->d_inv_tw, wrisk, yrisk, key_oor, oor_by_op)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_TAIL(6, 5, true);
     else MLDSA_TAIL(8, 7, true);
@@ -636,6 +679,15 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
 }
 
 static inline unsigned blocks256(size_t n) { return (unsigned)((n + 255) / 256 ? (n + 255) / 256 : 1); }
+
+int launch_key_range(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s2, const uint32_t* kidx, size_t n_units, uint8_t* oor,
+                     hipStream_t s) {
+    if (n_units == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_key_range, dim3(grid_for(ctx, n_units * (size_t)p->k, GWAVES, 8)), dim3(GBLOCK), 0, s, s2, p->k, p->eta, kidx, n_units,
+                       oor, ctx->d_inv_tw);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
 
 int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t* act,
                       const uint16_t* kappa, int l, uint32_t* slot_op, uint16_t* slot_kappa, const uint32_t* key_idx,

@@ -290,7 +290,7 @@ constexpr size_t SIGN_CHUNK_OPS = 65536;  // ops resident per call pass (workspa
 
 struct SignWs {
     int32_t *a_hat, *y, *w, *c, *done, *bad_op, *key_bad, *accept;
-    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage, *wrisk, *yrisk;
+    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage, *wrisk, *yrisk, *key_oor;
     uint16_t *kappa, *slot_kappa;
     uint32_t *act[2], *slot_op, *slot_key, *kidx;
     RoundCtl *ctl;
@@ -316,6 +316,7 @@ struct SignWs {
         ctilde = cv.take<uint8_t>(ns * 64);
         wrisk = cv.take<uint8_t>(ns);
         yrisk = cv.take<uint8_t>(ns * (size_t)p->l);
+        key_oor = cv.take<uint8_t>(n);  // per key of the table, or per op when the table is larger than the chunk
         stage = cv.take<uint8_t>(ns * stage_stride);
         kappa = cv.take<uint16_t>(n);
         slot_kappa = cv.take<uint16_t>(ns);
@@ -390,7 +391,7 @@ size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t 
 // One round of the rejection loop (steps 10-33 of Algorithm 7), counts read from the device
 static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, int round, size_t m_hint,
                               size_t ns_hint, const uint32_t *kidx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
-                              const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s) {
+                              const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s, bool oor_by_op) {
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
     const uint32_t *ns_dev = &w.ctl->ns;
@@ -410,7 +411,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     STAGE("ntt_c", launch_ntt(ctx, w.c, w.c, ns_hint, s, ns_dev));
     // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
     STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.stage,
-                                        w.stage_stride, w.accept, ns_hint, s, w.wrisk, w.yrisk));
+                                        w.stage_stride, w.accept, ns_hint, s, w.wrisk, w.yrisk, w.key_oor, oor_by_op ? 1 : 0));
     // speculative rounds only (the kernel leaves at once when the device chose one candidate per op)
     STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa,
                                     std::min<size_t>(m_hint, 4096), s));
@@ -456,6 +457,9 @@ ChunkKeys chunk_keys(const mldsa_params *p, const SignWs &w, const SignArgs &a) 
     return c;
 }
 
+// the key-range flags of a slice are per op when the key table is larger than the slice (see sign_prologue)
+bool oor_by_op(const SignArgs &a) { return a.key_idx && a.n_keys > a.n; }
+
 void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
     // y, rho'', cs1 / cs2, staged signatures are secret-dependent (the reference zeroizes on drop, types.rs:19);
     // A_hat = ExpandA(rho) is public and is the first and largest carve: skipped.
@@ -485,6 +489,15 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     TRY(launch_copy_rows(ctx, w.rnd_mu, 96, a.rnd + o * 32, 32, 32, n, s));
     // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
     STAGE("rho_pp_hash", launch_shake256_2(ctx, 64, a.cap_k + key_base * 32, 32, 32, c.kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
+    // is every key's s2 within [-eta, eta]?  (k_sign_tail's one-transform hint stage needs ||c s2||inf <= beta; a key that
+    // expand_private decoded out of range takes the reference's two-transform form.)  Per key of the table when it fits the
+    // chunk-sized flag array, else per op.
+    {
+        const bool by_op = oor_by_op(a);
+        const size_t units = a.key_idx ? (by_op ? n : a.n_keys) : n;
+        TRY(launch_zero(ctx, w.key_oor, n, s));
+        TRY(launch_key_range(ctx, p, c.s2k, by_op ? c.kidx : nullptr, units, w.key_oor, s));
+    }
     // 8: kappa <- 0; active = all ops with a legal ctx and key index
     TRY(launch_init_active(ctx, n, w.bad_op, w.done, w.kappa, st, w.act[0], w.ctl, s));
     return MLDSA_OK;
@@ -516,7 +529,7 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
             const ChunkKeys c = chunk_keys(p, L.w, L.a);
             // the plan is for a full slice; a short last one only makes its grids generous
             TRY(enqueue_sign_round(ctx, p, L.w, pl, round, std::min(pl.m_hint[round], L.a.n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k,
-                                   c.ak, c.sg, L.st));
+                                   c.ak, c.sg, L.st, oor_by_op(L.a)));
         }
     }
     for (int i = 0; i < n_lanes; i++) {
@@ -560,7 +573,7 @@ int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl,
             for (int e = 0; e < 2; e++) {
                 ctx->stats.sign_extra_rounds++;
                 TRY(enqueue_sign_round(ctx, p, L.w, pl, round + e, 64, std::min<size_t>(pl.ns_max, 2048), c.kidx, c.s1k, c.s2k, c.t0k, c.ak,
-                                       c.sg, s));
+                                       c.sg, s, oor_by_op(L.a)));
             }
             MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], L.w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
         }

@@ -555,3 +555,54 @@ def test_os_rng_entry_points(sets):
     with pytest.raises(ValueError):
         m.try_hash_sign_with_rng(rng, sks, msgs, ctxs=[bytes(256), b""], key_idx=kidx)
     assert rng.calls == 0
+
+
+# ------------------------------------------------------------------------------ signing with out-of-range secret keys
+@pytest.mark.parametrize("pset", [44, 65, 87])
+@pytest.mark.parametrize("kind", ["random_bytes", "extreme_fields", "few_flips"])
+def test_signing_with_out_of_range_secret_keys_matches_the_reference(sets, pset, kind):
+    """expand_private accepts every bit pattern (conversion.rs:259-260): an eta field may decode to s = -5 (eta = 2) or
+    -11 (eta = 4), and then ||c s||inf can exceed beta = tau * eta -- the bound the signer's short cuts (which
+    polynomials can reject at all, HighBits(w - c s2) = HighBits(w) in the hint stage) rest on.  The reference just
+    computes with what it decoded; the signatures must still be byte-identical."""
+    m = sets[pset]
+    rng = np.random.default_rng(100 * pset + len(kind))
+    pk_o, sk_o = orc.keygen_from_seed(pset, bytes(range(3, 35)))
+    good = np.frombuffer(orc.sk_into_bytes(pset, sk_o), dtype=np.uint8)
+    p = m.params
+    eta_bits = 3 if p.eta == 2 else 4
+    s_off, s_len = 128, (p.k + p.l) * 32 * eta_bits
+    n_keys = 4
+    sk = np.tile(good, (n_keys, 1)).copy()
+    for i in range(n_keys):
+        if kind == "random_bytes":
+            sk[i, s_off:] = rng.integers(0, 256, m.SK_LEN - s_off, dtype=np.uint8)
+        elif kind == "extreme_fields":  # every s1 / s2 field all-ones: s = eta - (2^bits - 1)
+            sk[i, s_off:s_off + s_len] = 0xFF
+            sk[i, 0] ^= i  # distinct rho per key
+        else:
+            for pos in rng.integers(s_off, s_off + s_len, 6):
+                sk[i, pos] ^= 1 << int(rng.integers(8))
+    # coherent extreme keys make ||c s2||inf > beta common enough to matter in about 1 signature in 500 (ML-DSA-65):
+    # enough of them that a short cut resting on the bound shows
+    n = 3000 if kind == "extreme_fields" else 64
+    msgs = [shake(b"oor-msg", i, 40) for i in range(n)]
+    rnd = [shake(b"oor-rnd", i) for i in range(n)]
+    kidx = (np.arange(n) % n_keys).astype(np.uint32)
+    sks = m.private_keys_from_bytes(torch.from_numpy(sk).cuda())
+    sig = host(m.try_sign_with_seed(sks, msgs, rnd, key_idx=kidx, mode=1))
+    sk_or = [orc.sk_try_from_bytes(pset, sk[i].tobytes()) for i in range(n_keys)]
+    want = orc.sign_batch_mt(pset, sk_or, kidx, msgs, rnd, 8, 1, mode=1)
+    bad = [i for i in range(n) if sig[i].tobytes() != want[i]]
+    assert not bad, (kind, len(bad), bad[:5])
+    # the same keys as a table larger than the batch (flags per op instead of per key) and one key per op (identity mapping)
+    if kind == "extreme_fields":
+        big = np.tile(sk, (40, 1))  # 160 keys
+        sks_big = m.private_keys_from_bytes(torch.from_numpy(big).cuda())
+        k2 = ((np.arange(100) * 7) % 160).astype(np.uint32)
+        sig2 = host(m.try_sign_with_seed(sks_big, msgs[:100], rnd[:100], key_idx=k2, mode=1))
+        want2 = orc.sign_batch_mt(pset, sk_or, (k2 % n_keys).astype(np.uint32), msgs[:100], rnd[:100], 8, 1, mode=1)
+        assert all(sig2[i].tobytes() == want2[i] for i in range(100))
+        sig3 = host(m.try_sign_with_seed(sks_big, msgs[:160], rnd[:160], mode=1))  # key_idx None: op i uses key i
+        want3 = orc.sign_batch_mt(pset, sk_or, (np.arange(160) % n_keys).astype(np.uint32), msgs[:160], rnd[:160], 8, 1, mode=1)
+        assert all(sig3[i].tobytes() == want3[i] for i in range(160))
