@@ -182,6 +182,11 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             REQUIRE(value == 1 || value == 2, "mldsa_set_option: MLDSA_OPT_SIGN_LANES is 1 or 2");
             ctx->opt_sign_lanes = value;
             return MLDSA_OK;
+        case MLDSA_OPT_SIGN_CT0_EXACT:
+            REQUIRE(value == 0 || value == 1, "mldsa_set_option: MLDSA_OPT_SIGN_CT0_EXACT is 0 or 1");
+            if (ctx->opt_ct0_exact != value) drop_graphs(ctx);  // the flag is a kernel argument of captured launches
+            ctx->opt_ct0_exact = value;
+            return MLDSA_OK;
         default: return set_error(MLDSA_ERR_PARAM, "mldsa_set_option: unknown option");
     }
 }
@@ -196,6 +201,7 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option) {
         case MLDSA_OPT_GRAPH_CACHE: return ctx->opt_graph_cache;
         case MLDSA_OPT_SIGN_ROUNDS: return ctx->opt_sign_rounds;
         case MLDSA_OPT_SIGN_LANES: return ctx->opt_sign_lanes;
+        case MLDSA_OPT_SIGN_CT0_EXACT: return ctx->opt_ct0_exact;
         default: return MLDSA_ERR_PARAM;
     }
 }

@@ -37,7 +37,7 @@ struct mldsa_ctx {
     int n_cu = 256;
     // tuning knobs (mldsa_set_option)
     long opt_graphs = 1, opt_spec_target = 65536, opt_spec_max = 32, opt_va_blocks = 16, opt_graph_cache = 24;
-    long opt_sign_rounds = 0, opt_sign_lanes = 1;
+    long opt_sign_rounds = 0, opt_sign_lanes = 1, opt_ct0_exact = 0;
     long opt_host_sub_verify = 8192, opt_host_sub_sign = 32768;  // ops per sub-batch of the *_host entry points
     mldsa_stats stats = {};
     // hipGraph replay of repeated op-level call shapes

@@ -88,13 +88,13 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
     const RoundCtl* __restrict__ ctl,
     uint8_t* __restrict__ stage, size_t stage_stride, int32_t* __restrict__ accept, int gb, int beta, int omega,
     int ctilde_len, size_t sig_len, const Twiddle* __restrict__ inv_tab,
-    const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk, const uint8_t* __restrict__ key_oor, int oor_by_op) {
+    const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk, const uint8_t* __restrict__ key_oor, int oor_by_op,
+    int ct0_exact) {
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
-    // r_i = w_i - cs2_i, kept for the hint stage -- only where ||ct0||inf < gamma2 can fail (ML-DSA-44), see stage 2
+    // ||c t0||inf <= tau * 2^12: below gamma2 = (q-1)/32 for ML-DSA-65 / 87 (200 704, 245 760 < 261 888), not for ML-DSA-44
     constexpr bool CT0_CAN_FAIL = !G2HI;
-    __shared__ int32_t rr_lds[GWAVES][CT0_CAN_FAIL ? K : 1][N];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: slot indices and row pointers stay scalar
     const int32_t gamma1 = 1 << gb;
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
         };
 #pragma unroll 1
         for (int pass = 0; pass < 2 && ok; pass++) {
-            // pass 1 of the sets whose stage 2 works from w itself needs only the z_j (signature bytes)
-            uint32_t work = pass == 0 ? (risky & todo) : (CT0_CAN_FAIL ? todo : (todo & ~((1u << K) - 1u)));
+            // pass 1 needs only the remaining z_j (signature bytes): stage 2 works from w itself
+            uint32_t work = pass == 0 ? (risky & todo) : (todo & ~((1u << K) - 1u));
             todo &= ~work;
             int cur = work ? __ffs((int)work) - 1 : -1;
             int32_t nv[4] = {0, 0, 0, 0}, nx[4] = {0, 0, 0, 0};
@@ -183,7 +183,6 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int32_t rr = caddq(x[k] - r[k]);     // w - cs2, canonical (both operands are in [0, q))
-                        if constexpr (CT0_CAN_FAIL) rr_lds[wave][cur][64 * k + lane] = rr;  // kept for the hint stage
                         int32_t r1, r0;
                         decompose<G2HI>(rr, r1, r0);
                         bad |= (r0 < 0 ? -r0 : r0) >= GAMMA2 - beta;
@@ -228,42 +227,36 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
         if (ok) {
             uint8_t* hy = sig + ctilde_len + (size_t)L * (32 * cb);
             for (int i = lane; i < omega + K; i += 64) hy[i] = 0;
-            int32_t tmax = 0;
-            int index = 0;  // running count of hints, wave-uniform
+            int32_t dmax = 0;  // ML-DSA-44: largest |centred coefficient| of the rows' transform outputs
+            int index = 0;     // running count of hints, wave-uniform
 #pragma unroll 1
             for (int i = 0; i < K; i++) {
-                int32_t v[4], r[4], base[4];
+                // The attempt passed the LowBits test, hence HighBits(w - cs2) = HighBits(w) (what makes verification recover
+                // w1), and  h = [HighBits(w - cs2 + ct0) != HighBits(w)],  w - cs2 + ct0 = w + invNTT(c_hat o (t0_hat - s2_hat)):
+                // ONE inverse transform per row instead of the reference's two (cs2 and ct0).
+                int32_t v[4], v2[4], r[4], base[4];
                 load_packed(v, t0 + (key * K + i) * (size_t)N, lane);
-                if constexpr (!CT0_CAN_FAIL) {
-                    // gamma2 = (q-1)/32: |c t0| <= tau * 2^12 = 200 704 (65) / 245 760 (87) < gamma2, so the ||ct0||inf test of
-                    // ml_dsa.rs:312 cannot fail and ct0 is never needed on its own.  The attempt passed the LowBits test, hence
-                    // HighBits(w - cs2) = HighBits(w) (what makes verification recover w1), and
-                    //   h = [HighBits(w - cs2 + ct0) != HighBits(w)],  w - cs2 + ct0 = w + invNTT(c_hat o (t0_hat - s2_hat)):
-                    // ONE inverse transform per row instead of two (cs2 in pass 1 and ct0 here).
-                    int32_t v2[4];
-                    load_packed(v2, s2 + (key * K + i) * (size_t)N, lane);
-                    load_strided(base, w + (slot * K + i) * (size_t)N, lane);
-                    if (s2_oor) {
-                        // out-of-range s2: the identity above is not guaranteed; r_i = w_i - c s2_i explicitly (it passed the
-                        // LowBits test in stage 1, where every polynomial counted as risky), then r_i + c t0_i as the reference does
-                        r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
-                        ntt_inv_wave(r, itw, lane, F_MONT);
+                load_packed(v2, s2 + (key * K + i) * (size_t)N, lane);
+                load_strided(base, w + (slot * K + i) * (size_t)N, lane);
+                if (s2_oor) {
+                    // out-of-range s2: the identity is not guaranteed; r_i = w_i - c s2_i explicitly (it passed the LowBits
+                    // test in stage 1, where every polynomial counted as risky), then r_i + c t0_i as the reference does
+                    r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
+                    ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
-                        for (int k = 0; k < 4; k++) base[k] = caddq(base[k] - r[k]);
-                    } else {
+                    for (int k = 0; k < 4; k++) base[k] = caddq(base[k] - r[k]);
+                } else {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) v[k] -= v2[k];
-                    }
+                    for (int k = 0; k < 4; k++) v[k] -= v2[k];
                 }
                 r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-                ntt_inv_wave(r, itw, lane, F_MONT);
+                ntt_inv_wave(r, itw, lane, F_MONT);  // ct0 - cs2 (ct0 for an out-of-range key), canonical
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if constexpr (CT0_CAN_FAIL) {
                         int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);  // center_mod of a canonical value
                         tc = tc < 0 ? -tc : tc;
-                        tmax = tc > tmax ? tc : tmax;
-                        base[k] = rr_lds[wave][i][64 * k + lane];  // w - cs2
+                        dmax = tc > dmax ? tc : dmax;
                     }
                     // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
                     int32_t a1, a0, b1, b0;
@@ -280,12 +273,40 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
                 }
                 if (lane == 0) hy[omega + i] = (uint8_t)(index < 255 ? index : 255);
             }
+            ok = index <= omega;  // ml_dsa.rs:313-315
+            if constexpr (CT0_CAN_FAIL) {
+                // ||ct0||inf < gamma2 (ml_dsa.rs:312).  The rows gave d = ct0 - cs2 with ||cs2||inf <= beta, so max|d| + beta bounds
+                // it; an out-of-range key gave ct0 itself.  Only if that bound cannot decide (|d| within beta of gamma2: ~1e-7
+                // of the attempts) are the K transforms of ct0 proper spent.
+                auto wave_max = [](int32_t x) {
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const int32_t o = __shfl_xor(tmax, m);
-                tmax = o > tmax ? o : tmax;
+                    for (int m = 32; m >= 1; m >>= 1) {
+                        const int32_t o = __shfl_xor(x, m);
+                        x = o > x ? o : x;
+                    }
+                    return x;
+                };
+                dmax = wave_max(dmax);
+                bool ct0_ok = dmax + (s2_oor ? 0 : beta) < GAMMA2;
+                if (!s2_oor && (!ct0_ok || ct0_exact)) {
+                    int32_t tmax = 0;
+#pragma unroll 1
+                    for (int i = 0; i < K; i++) {
+                        int32_t v[4], r[4];
+                        load_packed(v, t0 + (key * K + i) * (size_t)N, lane);
+                        r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+                        ntt_inv_wave(r, itw, lane, F_MONT);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);
+                            tc = tc < 0 ? -tc : tc;
+                            tmax = tc > tmax ? tc : tmax;
+                        }
+                    }
+                    ct0_ok = wave_max(tmax) < GAMMA2;
+                }
+                ok = ok && ct0_ok;
             }
-            ok = (tmax < GAMMA2) && (index <= omega);  // ml_dsa.rs:312-315
         }
         if (lane == 0) {
             if (spec == 1) {
@@ -669,7 +690,7 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
 #define MLDSA_TAIL(KK, LL, G2)                                                                                              \
     hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
                        done, sigs, ctl, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
-                       ctx->d_inv_tw, wrisk, yrisk, key_oor, oor_by_op)
+                       ctx->d_inv_tw, wrisk, yrisk, key_oor, oor_by_op, (int)ctx->opt_ct0_exact)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_TAIL(6, 5, true);
     else MLDSA_TAIL(8, 7, true);

@@ -104,6 +104,8 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
 #define MLDSA_OPT_SIGN_ROUNDS 6     /* sign: rounds enqueued before the host looks at the device; 0 (default) = as many as the
                                        plan says finish the batch (see mldsa_sign); a small value exercises the extra-round path */
 #define MLDSA_OPT_SIGN_LANES 7      /* sign: 1 (default) or 2 slices of a batch running their round chains side by side on two streams */
+#define MLDSA_OPT_SIGN_CT0_EXACT 8  /* sign, ML-DSA-44 (test knob): 1 = always compute ||c t0||inf for the test of ml_dsa.rs:312, 0 (default) = only
+                                       when the bound the hint stage gets for free cannot decide; signatures are identical */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths */

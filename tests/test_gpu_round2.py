@@ -606,3 +606,25 @@ def test_signing_with_out_of_range_secret_keys_matches_the_reference(sets, pset,
         sig3 = host(m.try_sign_with_seed(sks_big, msgs[:160], rnd[:160], mode=1))  # key_idx None: op i uses key i
         want3 = orc.sign_batch_mt(pset, sk_or, (np.arange(160) % n_keys).astype(np.uint32), msgs[:160], rnd[:160], 8, 1, mode=1)
         assert all(sig3[i].tobytes() == want3[i] for i in range(160))
+
+
+def test_ml_dsa_44_ct0_bound_and_exact_test_agree(hp, sets):
+    """ML-DSA-44: ||c t0||inf < gamma2 (ml_dsa.rs:312) CAN fail (tau * 2^12 > gamma2).  The hint stage's single transform per
+    row gives ct0 - cs2, whose maximum + beta bounds ||ct0||inf; only if that bound cannot decide is ct0 transformed on its
+    own.  MLDSA_OPT_SIGN_CT0_EXACT = 1 takes the exact test for every surviving attempt: same signatures, same oracle."""
+    m = sets[44]
+    n = 4096
+    b = make_batch(m, n, 16, b"ct0")
+    sig0 = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    sig1 = torch.empty_like(sig0)
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig0, n, key_idx=b["kidx"])
+    assert hp.get_option(8) == 0
+    hp.set_option(8, 1)
+    try:
+        m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig1, n, key_idx=b["kidx"])
+    finally:
+        hp.set_option(8, 0)
+    assert torch.equal(sig0, sig1)
+    got = host(sig0)
+    for row, want in zip(range(0, n, 97), oracle_sigs(44, b, range(0, n, 97))):
+        assert got[row].tobytes() == want
