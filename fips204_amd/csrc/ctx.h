@@ -38,7 +38,10 @@ struct mldsa_ctx {
     // tuning knobs (mldsa_set_option)
     long opt_graphs = 1, opt_spec_target = 65536, opt_spec_max = 32, opt_va_blocks = 16, opt_graph_cache = 24;
     long opt_sign_rounds = 0, opt_sign_lanes = 1, opt_ct0_exact = 0;
-    long opt_host_sub_verify = 8192, opt_host_sub_sign = 32768;  // ops per sub-batch of the *_host entry points
+    // expected number of unfinished ops at which an ASYNCHRONOUS sign call stops planning rounds (1e-9: practically never an
+    // MLDSA_ERR_AGAIN); mldsa_sign_host, which re-signs such ops anyway, raises it to the synchronous plan's 0.05 for its calls
+    double async_stop = 1e-9;
+    long opt_host_sub_verify = 8192, opt_host_sub_sign = 65536;  // ops per sub-batch of the *_host entry points
     mldsa_stats stats = {};
     // hipGraph replay of repeated op-level call shapes
     std::vector<mldsa::GraphEntry> graphs;

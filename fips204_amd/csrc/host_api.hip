@@ -19,8 +19,12 @@ namespace mldsa {
 
 namespace {
 constexpr int N_SLOTS = 3;
-// ops per sub-batch (ctx->opt_host_sub_*): verify is PCIe-bound -- small sub-batches keep the pipeline fill and drain
-// short; sign is compute-bound and its rounds are launch-bound on small batches -- large sub-batches
+// ops per sub-batch (ctx->opt_host_sub_*): verify is PCIe-bound on the way IN (SDMA uploads overlap the kernels) -- small
+// sub-batches keep the pipeline fill and drain short.  Sign is compute-bound with its traffic on the way OUT, and on this
+// platform a large device -> host transfer is a blit kernel whose PCIe writes hold back every other kernel's stores
+// (traced: a 108 MB download running beside the next sub-batch made its first memset 50x and its ExpandA 1.2x slower; a
+// copy kernel of our own with 1 ... 128 workgroups changed nothing): downloads do not hide behind signing, so sign runs
+// one pipeline chunk per sub-batch and saves the per-call costs instead
 
 struct Buf {  // a device buffer with an optional page-locked bounce twin, grown on demand
     uint8_t *dev = nullptr, *pin = nullptr;
@@ -355,6 +359,13 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     const bool pin_st = status && is_pinned(status);
     int rc = MLDSA_OK;
     size_t i = 0;
+    // the calls below cannot wait for the device, but an op they leave unfinished is signed again further down: plan the
+    // rounds like a synchronous call (three or four empty ~0.2 ms rounds less per sub-batch than the 1e-9 plan)
+    struct StopGuard {
+        mldsa_ctx *c; double old;
+        explicit StopGuard(mldsa_ctx *cc) : c(cc), old(cc->async_stop) { c->async_stop = 0.05; }
+        ~StopGuard() { c->async_stop = old; }
+    } stop_guard(ctx);
     for (size_t a = 0; a < n_ops && rc == MLDSA_OK; a += sub, i++) {
         const size_t b = std::min(n_ops, a + sub), n = b - a;
         Slot &sl = hs->slot[i % N_SLOTS];

@@ -355,7 +355,7 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode) {
     // a synchronous call looks at the device once anyway and adds rounds if an op is left, so its plan stops when that is
     // unlikely (< 5 % of the calls: a planned round for 0.002 expected ops costs every call the ~0.2 ms latency chain of an
     // empty round, two extra rounds cost the rare call ~0.5 ms); an asynchronous call cannot look, and plans until < 1e-9
-    const double stop = async_mode ? 1e-9 : 0.05;
+    const double stop = async_mode ? ctx->async_stop : 0.05;
     for (int r = 0; r < 64 && m > stop; r++) {
         // grids follow mean + 6 sigma of the binomial count (a round that still finds more just loops)
         const double m_hi = std::min((double)n, m + 6.0 * std::sqrt(m) + 1.0);
@@ -610,7 +610,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         struct { int op, n_lanes; long spec_target, spec_max, rounds; SignArgs a[2]; } key;
         memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
         key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_max = ctx->opt_spec_max;
-        key.rounds = ctx->opt_sign_rounds;
+        key.rounds = (long)pl.m_hint.size();  // the planned rounds (options, the asynchronous stop threshold) shape the launch sequence
         int live = 0;
         for (int i = 0; i < n_lanes; i++) {
             const size_t lo = std::min(n_chunk, (size_t)i * per_lane), hi = std::min(n_chunk, lo + per_lane);

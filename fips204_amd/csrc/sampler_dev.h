@@ -1,5 +1,5 @@
-// Device-side building blocks shared by the sampler kernels (kernels_sample.hip) and the fused
-// verify kernel (kernels_fused.hip): compile-time loops, static access to the squeezed block,
+// Device-side building blocks of the sampler kernels (kernels_sample.hip; static_for and the block accessors are also used
+// by the hash kernels of kernels_codec.hip): compile-time loops, static access to the squeezed block,
 // lane-private LDS staging rows and their cooperative, coalesced flush.
 #pragma once
 #include <type_traits>
