@@ -316,3 +316,25 @@ def test_hint_weight_and_z_bound_rejections(sets, acvp_sigver):
     sigs = [bytes.fromhex(t["signature"]) for t in tests]
     got = m.verify(pks, msgs, sigs, mode=1)
     assert got.tolist() == [t["testPassed"] for t in tests]
+
+
+def test_very_long_and_empty_messages_in_one_batch(sets):
+    """mu = H(tr || M') absorbs messages of any length (ml_dsa.rs:185-196): a 300 000-byte message, an empty one and a
+    135 / 136 / 137-byte boundary group share one batch with ragged offsets; signatures byte-identical to the oracle, in all
+    three message modes, and the verifier accepts them only under the mode they were made in."""
+    m = sets[65]
+    rng = np.random.default_rng(77)
+    pk_o, sk_o = orc.keygen_from_seed(65, bytes(range(9, 41)))
+    pks = m.public_keys_from_bytes([orc.pk_into_bytes(65, pk_o)])
+    sks = m.private_keys_from_bytes([orc.sk_into_bytes(65, sk_o)])
+    lens = [300000, 0, 135, 136, 137, 1, 70001]
+    msgs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+    ctxs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 255, 1, 0, 17, 3, 200)]
+    rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in lens]
+    for mode in (0, 1, 2):
+        sig = host(m.try_sign_with_seed(sks, msgs, rnd, ctxs=ctxs, mode=mode))
+        for i in range(len(lens)):
+            assert sig[i].tobytes() == orc.sign_internal(65, sk_o, msgs[i], rnd[i], ctx=ctxs[i], mode=mode), (mode, lens[i])
+        st = torch.from_numpy(sig).cuda()
+        assert m.verify(pks, msgs, st, ctxs=ctxs, mode=mode).all()
+        assert not m.verify(pks, msgs, st, ctxs=ctxs, mode=(mode + 1) % 3).any()
