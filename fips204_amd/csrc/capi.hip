@@ -1,6 +1,7 @@
 // extern "C" entry points of include/mldsa_hip.h: argument validation, context and
 // device-memory helpers.  Kernels live in kernels_*.hip, op-level sequencing in pipeline.hip.
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -182,6 +183,10 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             REQUIRE(value == 1 || value == 2, "mldsa_set_option: MLDSA_OPT_SIGN_LANES is 1 or 2");
             ctx->opt_sign_lanes = value;
             return MLDSA_OK;
+        case MLDSA_OPT_SIGN_ASYNC_EXP:
+            REQUIRE(value >= 1 && value <= 12, "mldsa_set_option: MLDSA_OPT_SIGN_ASYNC_EXP is 1 .. 12");
+            ctx->async_stop = std::pow(10.0, -(double)value);
+            return MLDSA_OK;
         case MLDSA_OPT_SIGN_CT0_EXACT:
             REQUIRE(value == 0 || value == 1, "mldsa_set_option: MLDSA_OPT_SIGN_CT0_EXACT is 0 or 1");
             if (ctx->opt_ct0_exact != value) drop_graphs(ctx);  // the flag is a kernel argument of captured launches
@@ -202,6 +207,7 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option) {
         case MLDSA_OPT_SIGN_ROUNDS: return ctx->opt_sign_rounds;
         case MLDSA_OPT_SIGN_LANES: return ctx->opt_sign_lanes;
         case MLDSA_OPT_SIGN_CT0_EXACT: return ctx->opt_ct0_exact;
+        case MLDSA_OPT_SIGN_ASYNC_EXP: return std::lround(-std::log10(ctx->async_stop));
         default: return MLDSA_ERR_PARAM;
     }
 }

@@ -106,6 +106,10 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
 #define MLDSA_OPT_SIGN_LANES 7      /* sign: 1 (default) or 2 slices of a batch running their round chains side by side on two streams */
 #define MLDSA_OPT_SIGN_CT0_EXACT 8  /* sign, ML-DSA-44 (test knob): 1 = always compute ||c t0||inf for the test of ml_dsa.rs:312, 0 (default) = only
                                        when the bound the hint stage gets for free cannot decide; signatures are identical */
+#define MLDSA_OPT_SIGN_ASYNC_EXP 9   /* mldsa_sign_async: rounds are planned until the expected number of unfinished ops of the call is below
+                                       10^-value (1..12, default 9: practically never an MLDSA_ERR_AGAIN).  A caller that re-signs such
+                                       ops anyway can lower it: 2 plans like the synchronous call (three ~0.2 ms rounds less, an op
+                                       left over in about 1 call in 500) */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths */

@@ -628,3 +628,33 @@ def test_ml_dsa_44_ct0_bound_and_exact_test_agree(hp, sets):
     got = host(sig0)
     for row, want in zip(range(0, n, 97), oracle_sigs(44, b, range(0, n, 97))):
         assert got[row].tobytes() == want
+
+
+def test_async_plan_exponent_option(hp, sets):
+    """MLDSA_OPT_SIGN_ASYNC_EXP: an asynchronous call plans until the expected number of unfinished ops is below 10^-value.
+    With 1 (plan stops early) some ops of a large batch may come back MLDSA_ERR_AGAIN with an all-zero signature; every other
+    signature is the one the synchronous call produces."""
+    m = sets[44]
+    n = 20000
+    b = make_batch(m, n, 8, b"aexp")
+    ref = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], ref, n, key_idx=b["kidx"])
+    assert hp.get_option(9) == 9
+    for exp in (1, 2, 12):
+        hp.set_option(9, exp)
+        try:
+            assert hp.get_option(9) == exp
+            sig = torch.full((n, m.SIG_LEN), 7, dtype=torch.uint8, device="cuda")
+            st = torch.zeros(n, dtype=torch.int32, device="cuda")
+            m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st, wait=False)
+            st_h = host(st)
+            assert set(np.unique(st_h)) <= {0, -5}
+            done = torch.from_numpy(st_h == 0).cuda()
+            assert torch.equal(sig[done], ref[done])
+            assert not sig[~done].any()
+            if exp == 12:
+                assert (st_h == 0).all()
+        finally:
+            hp.set_option(9, 9)
+    with pytest.raises(Exception):
+        hp.set_option(9, 0)
