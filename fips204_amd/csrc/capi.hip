@@ -139,6 +139,8 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    for (size_t i = 1; i < ctx->helper_streams.size(); i++) (void)hipStreamDestroy(ctx->helper_streams[i]);  // [0] is aux_stream
+    if (ctx->d_probe) (void)hipFree(ctx->d_probe);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->graph_fork_ev) (void)hipEventDestroy(ctx->graph_fork_ev);
     if (ctx->graph_join_ev) (void)hipEventDestroy(ctx->graph_join_ev);

@@ -41,7 +41,7 @@ struct mldsa_ctx {
     // expected number of unfinished ops at which an ASYNCHRONOUS sign call stops planning rounds (1e-9: practically never an
     // MLDSA_ERR_AGAIN); mldsa_sign_host, which re-signs such ops anyway, raises it to the synchronous plan's 0.05 for its calls
     double async_stop = 1e-9;
-    long opt_host_sub_verify = 8192, opt_host_sub_sign = 65536;  // ops per sub-batch of the *_host entry points
+    long opt_host_sub_verify = 8192, opt_host_sub_sign = 16384;  // *_host entry points: ops per sub-batch (verify), ops of the LAST sub-batch (sign)
     mldsa_stats stats = {};
     // hipGraph replay of repeated op-level call shapes
     std::vector<mldsa::GraphEntry> graphs;
@@ -58,6 +58,13 @@ struct mldsa_ctx {
     // SampleInBall) run here, concurrently with the VALU-bound ExpandA on the caller's stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // HIP maps streams onto a handful of hardware queues (four here, handed out 0 1 2 3 3 2 1 0 ...: tools/ubench_queues.hip);
+    // two streams on one queue run their kernels strictly one after the other.  parallel_stream() therefore PROBES which of
+    // the context's helper streams really runs beside a given stream (a spin kernel on one, an empty kernel on the other)
+    // and remembers the answer per stream handle.
+    std::vector<hipStream_t> helper_streams;             // aux_stream first, more created on demand
+    std::vector<std::pair<hipStream_t, hipStream_t>> parallel_of;  // (stream, helper that does not share its queue)
+    unsigned *d_probe = nullptr;
     // graphs of calls made on the legacy default stream run here (that stream cannot be captured)
     hipStream_t graph_stream = nullptr;
     hipEvent_t graph_fork_ev = nullptr, graph_join_ev = nullptr;
@@ -225,6 +232,11 @@ int launch_mark_unfinished(mldsa_ctx *, const RoundCtl *ctl, int parity, const u
                            size_t sig_len, hipStream_t);
 int launch_sanitize_keys(mldsa_ctx *, const uint32_t *key_idx, size_t n_keys, size_t n_ops, uint32_t *safe, int32_t *bad, hipStream_t);
 int launch_zero(mldsa_ctx *, void *dst, size_t bytes, hipStream_t);
+// true if a kernel on `b` only starts once a kernel on `a` has finished (same hardware queue); ~0.3 ms, waits for both streams
+bool streams_serialise(mldsa_ctx *, hipStream_t a, hipStream_t b);
+// a context-owned stream whose kernels run beside those of `s` (probed once per stream handle; `avoid`: a second stream it
+// must not share a queue with either, or nullptr).  Falls back to aux_stream while `s` is being captured.
+hipStream_t parallel_stream(mldsa_ctx *, hipStream_t s, hipStream_t avoid = nullptr);
 int launch_copy_rows(mldsa_ctx *, void *dst, size_t dst_stride, const void *src, size_t src_stride, int row_bytes, size_t n_rows,
                      hipStream_t);
 int launch_key_intt(mldsa_ctx *, const int32_t *src, int polys_per_key, size_t n_keys, int bits, int b, uint8_t *dst, size_t key_stride,

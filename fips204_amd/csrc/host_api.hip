@@ -12,6 +12,7 @@
 // repeated call shape and replays as a hipGraph (pipeline.hip run_op).
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "ctx.h"
 
@@ -19,12 +20,14 @@ namespace mldsa {
 
 namespace {
 constexpr int N_SLOTS = 3;
-// ops per sub-batch (ctx->opt_host_sub_*): verify is PCIe-bound on the way IN (SDMA uploads overlap the kernels) -- small
-// sub-batches keep the pipeline fill and drain short.  Sign is compute-bound with its traffic on the way OUT, and on this
-// platform a large device -> host transfer is a blit kernel whose PCIe writes hold back every other kernel's stores
-// (traced: a 108 MB download running beside the next sub-batch made its first memset 50x and its ExpandA 1.2x slower; a
-// copy kernel of our own with 1 ... 128 workgroups changed nothing): downloads do not hide behind signing, so sign runs
-// one pipeline chunk per sub-batch and saves the per-call costs instead
+// ops per sub-batch (ctx->opt_host_sub_*): verify is PCIe-bound on the way IN -- small sub-batches keep the pipeline fill
+// and drain short.  Sign is compute-bound with its traffic on the way OUT: large sub-batches (its rounds are latency-bound on
+// small batches) and a small LAST one, the only download nothing hides.
+// Two properties of the platform shape the loops (tools/ubench_queues.hip):
+//  * copies are served in the order they were SUBMITTED, across streams: an H2D copy submitted after a D2H copy that still
+//    waits for its kernels waits with it -- so the uploads of sub-batch i + 1 are submitted before the download of sub-batch i;
+//  * HIP streams share a few hardware queues (handed out 0 1 2 3 3 2 1 0 ...), and two streams on one queue take turns -- so
+//    the three streams are probed against each other when the stage is created (streams_serialise).
 
 struct Buf {  // a device buffer with an optional page-locked bounce twin, grown on demand
     uint8_t *dev = nullptr, *pin = nullptr;
@@ -130,9 +133,28 @@ int stage_get(mldsa_ctx *ctx, HostStage **out) {
     if (!ctx->host_stage) {
         HostStage *hs = new (std::nothrow) HostStage();
         if (!hs) return set_error(MLDSA_ERR_NOMEM, "host path: allocation failed");
-        hipError_t e = hipStreamCreateWithFlags(&hs->up, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&hs->comp, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&hs->down, hipStreamNonBlocking);
+        // Three streams that really run side by side: HIP hands its few hardware queues out in the order 0 1 2 3 3 2 1 0 ...,
+        // so two streams created one after the other can land on ONE queue and then take turns (measured: with `comp` and
+        // `down` on one queue the download of sub-batch i ran to the end before sub-batch i + 1 started signing).  Candidates
+        // are probed against each other (ctx.h streams_serialise); the ones not chosen are released again.
+        hipError_t e = hipStreamCreateWithFlags(&hs->comp, hipStreamNonBlocking);
+        std::vector<hipStream_t> spare;
+        for (int tries = 0; e == hipSuccess && tries < 10 && !(hs->up && hs->down); tries++) {
+            hipStream_t c = nullptr;
+            e = hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
+            if (e != hipSuccess) break;
+            const bool beside_comp = !streams_serialise(ctx, hs->comp, c);
+            if (beside_comp && !hs->up) hs->up = c;
+            else if (beside_comp && !hs->down && !streams_serialise(ctx, hs->up, c)) hs->down = c;
+            else spare.push_back(c);
+        }
+        // fewer queues than hoped for: correctness does not depend on the choice
+        for (hipStream_t *want : {&hs->up, &hs->down})
+            if (e == hipSuccess && !*want) {
+                if (!spare.empty()) { *want = spare.back(); spare.pop_back(); }
+                else e = hipStreamCreateWithFlags(want, hipStreamNonBlocking);
+            }
+        for (hipStream_t c : spare) (void)hipStreamDestroy(c);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&hs->keys_ready, hipEventDisableTiming);
         for (auto &sl : hs->slot) {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.up_done, hipEventDisableTiming);
@@ -280,37 +302,48 @@ int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size
     // sub-batch idles the link for ~30 us out of every ~520.
     const size_t side_bytes = n_ops * 12 + 8 + span(msg_off, 0, n_ops) + (ctx_off ? n_ops * 8 + 8 + span(ctx_off, 0, n_ops) : 0);
     const bool whole = side_bytes + 2048 <= PACK_LIMIT;
-    size_t i = 0;
-    for (size_t a = 0; a < n_ops && rc == MLDSA_OK; a += sub, i++) {
-        const size_t b = std::min(n_ops, a + sub), n = b - a;
+    // Copies are served in the order they were SUBMITTED, across streams (tools/ubench_queues.hip: an H2D copy submitted
+    // after a D2H copy that still waits for its kernels waits with it).  So the uploads of sub-batch i + 1 are submitted
+    // BEFORE the download of sub-batch i.
+    const size_t n_sub = (n_ops + sub - 1) / sub;
+    auto stage_up = [&](size_t i) -> int {
+        const size_t a = i * sub, b = std::min(n_ops, a + sub), n = b - a;
         Slot &sl = hs->slot[i % N_SLOTS];
-        rc = [&]() -> int {
-            TRY(reclaim(sl));
-            if (!whole) TRY(upload_op_inputs(hs->up, sl, in, a, b));
-            TRY(upload(sl.sigs, sigs + a * sgl, n * sgl, pin_sigs, hs->up));
-            if (whole && a == 0) TRY(upload_op_inputs(hs->up, hs->call, in, 0, n_ops));
-            TRY(grow_dev(sl.out, n));
-            HCHECK(hipEventRecord(sl.up_done, hs->up));
-            HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
-            // the slice's byte strings start at offset msg_off[v0] of the caller's array: hand the kernels a base
-            // pointer that makes the caller's own offsets land in the staging buffer
-            const Slot &v = whole ? hs->call : sl;
-            const size_t v0 = whole ? 0 : a, vo = a - v0;  // first op of the view, this sub-batch's position in it
-            const uint32_t *d_kidx = v.d_kidx ? v.d_kidx + vo : nullptr;
-            const uint64_t *d_moff = v.d_moff + vo, *d_coff = v.d_coff ? v.d_coff + vo : nullptr;
-            const uint8_t *mbase = v.d_msgs - msg_off[v0];
-            const uint8_t *cbase = ctx_off ? v.d_ctxs - ctx_off[v0] : nullptr;
-            const size_t kb = key_idx ? 0 : a;  // identity mapping walks the key table with the batch
-            TRY(mldsa_verify(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_tr.dev + kb * 64,
-                             reinterpret_cast<const int32_t *>(hs->k_a.dev) + kb * k * 256, n_keys - kb, d_kidx, mbase, d_moff, cbase,
-                             d_coff, sl.sigs.dev, sl.out.dev, n, hs->comp));
-            HCHECK(hipEventRecord(sl.comp_done, hs->comp));
-            HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
-            TRY(download(sl, sl.out, ok + a, n, pin_ok, hs->down));
-            HCHECK(hipEventRecord(sl.down_done, hs->down));
-            sl.busy = true;
-            return MLDSA_OK;
-        }();
+        TRY(reclaim(sl));
+        if (!whole) TRY(upload_op_inputs(hs->up, sl, in, a, b));
+        TRY(upload(sl.sigs, sigs + a * sgl, n * sgl, pin_sigs, hs->up));
+        if (whole && i == 0) TRY(upload_op_inputs(hs->up, hs->call, in, 0, n_ops));
+        TRY(grow_dev(sl.out, n));
+        HCHECK(hipEventRecord(sl.up_done, hs->up));
+        return MLDSA_OK;
+    };
+    auto run = [&](size_t i) -> int {
+        const size_t a = i * sub, b = std::min(n_ops, a + sub), n = b - a;
+        Slot &sl = hs->slot[i % N_SLOTS];
+        HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
+        // the slice's byte strings start at offset msg_off[v0] of the caller's array: hand the kernels a base
+        // pointer that makes the caller's own offsets land in the staging buffer
+        const Slot &v = whole ? hs->call : sl;
+        const size_t v0 = whole ? 0 : a, vo = a - v0;  // first op of the view, this sub-batch's position in it
+        const uint32_t *d_kidx = v.d_kidx ? v.d_kidx + vo : nullptr;
+        const uint64_t *d_moff = v.d_moff + vo, *d_coff = v.d_coff ? v.d_coff + vo : nullptr;
+        const uint8_t *mbase = v.d_msgs - msg_off[v0];
+        const uint8_t *cbase = ctx_off ? v.d_ctxs - ctx_off[v0] : nullptr;
+        const size_t kb = key_idx ? 0 : a;  // identity mapping walks the key table with the batch
+        TRY(mldsa_verify(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_tr.dev + kb * 64,
+                         reinterpret_cast<const int32_t *>(hs->k_a.dev) + kb * k * 256, n_keys - kb, d_kidx, mbase, d_moff, cbase,
+                         d_coff, sl.sigs.dev, sl.out.dev, n, hs->comp));
+        HCHECK(hipEventRecord(sl.comp_done, hs->comp));
+        HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
+        TRY(download(sl, sl.out, ok + a, n, pin_ok, hs->down));
+        HCHECK(hipEventRecord(sl.down_done, hs->down));
+        sl.busy = true;
+        return MLDSA_OK;
+    };
+    rc = stage_up(0);
+    for (size_t i = 0; i < n_sub && rc == MLDSA_OK; i++) {
+        if (i + 1 < n_sub) rc = stage_up(i + 1);
+        if (rc == MLDSA_OK) rc = run(i);
     }
     for (auto &sl : hs->slot) {
         const int r2 = reclaim(sl);
@@ -348,8 +381,19 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     int32_t *s1 = reinterpret_cast<int32_t *>(hs->k_a.dev), *s2 = reinterpret_cast<int32_t *>(hs->k_b.dev),
             *t0 = reinterpret_cast<int32_t *>(hs->k_c.dev);
     TRY(mldsa_sk_expand(ctx, set, hs->key_bytes.dev, hs->k_rho.dev, hs->k_capk.dev, hs->k_tr.dev, s1, s2, t0, n_keys, hs->comp));
-    const size_t sub = std::min(n_ops, (size_t)ctx->opt_host_sub_sign);
-    TRY(mldsa_reserve(ctx, set, MLDSA_OP_SIGN, sub));
+    // Sub-batches: signing is compute-bound and its rounds are latency-bound on small batches, so they are as large as the
+    // pipelines' chunk -- except the LAST one, whose signatures come down with nothing left to hide the transfer behind:
+    // ctx->opt_host_sub_sign ops (49 152 + 16 384 for a 65 536-op call: 11.1 ms against 13.4 ms in one piece)
+    std::vector<size_t> cut{0};
+    {
+        const size_t big = 65536, tail = std::max<size_t>(64, (size_t)ctx->opt_host_sub_sign);
+        for (size_t rem = n_ops; rem > 0;) {
+            const size_t take = rem > big + tail ? big : rem > 2 * tail ? rem - tail : rem;
+            cut.push_back(cut.back() + take);
+            rem -= take;
+        }
+    }
+    TRY(mldsa_reserve(ctx, set, MLDSA_OP_SIGN, std::min<size_t>(n_ops, 65536)));
     OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
     const bool pin_rnd = is_pinned(rnd), pin_sigs = is_pinned(sigs);
     // per-op status always comes back: MLDSA_ERR_AGAIN marks the (practically never) ops that need another pass
@@ -358,7 +402,6 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     if (!st) { st_local.resize(n_ops); st = st_local.data(); }
     const bool pin_st = status && is_pinned(status);
     int rc = MLDSA_OK;
-    size_t i = 0;
     // the calls below cannot wait for the device, but an op they leave unfinished is signed again further down: plan the
     // rounds like a synchronous call (three or four empty ~0.2 ms rounds less per sub-batch than the 1e-9 plan)
     struct StopGuard {
@@ -366,31 +409,43 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
         explicit StopGuard(mldsa_ctx *cc) : c(cc), old(cc->async_stop) { c->async_stop = 0.05; }
         ~StopGuard() { c->async_stop = old; }
     } stop_guard(ctx);
-    for (size_t a = 0; a < n_ops && rc == MLDSA_OK; a += sub, i++) {
-        const size_t b = std::min(n_ops, a + sub), n = b - a;
-        Slot &sl = hs->slot[i % N_SLOTS];
-        rc = [&]() -> int {
-            TRY(reclaim(sl));
-            TRY(upload_op_inputs(hs->up, sl, in, a, b));
-            TRY(upload(sl.rnd, rnd + a * 32, n * 32, pin_rnd, hs->up));
-            TRY(grow_dev(sl.out, n * sgl));
-            TRY(grow_dev(sl.status, n * 4));
-            HCHECK(hipEventRecord(sl.up_done, hs->up));
-            HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
-            const uint8_t *mbase = sl.d_msgs - msg_off[a];
-            const uint8_t *cbase = ctx_off ? sl.d_ctxs - ctx_off[a] : nullptr;
-            const size_t kb = key_idx ? 0 : a;
-            TRY(mldsa_sign_async(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_capk.dev + kb * 32, hs->k_tr.dev + kb * 64, s1 + kb * l * 256,
-                                 s2 + kb * k * 256, t0 + kb * k * 256, n_keys - kb, sl.d_kidx, mbase, sl.d_moff, cbase, sl.d_coff,
-                                 sl.rnd.dev, sl.out.dev, reinterpret_cast<int32_t *>(sl.status.dev), n, hs->comp));
-            HCHECK(hipEventRecord(sl.comp_done, hs->comp));
-            HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
-            TRY(download(sl, sl.out, sigs + a * sgl, n * sgl, pin_sigs, hs->down));
-            TRY(download(sl, sl.status, st + a, n * 4, pin_st, hs->down));
-            HCHECK(hipEventRecord(sl.down_done, hs->down));
-            sl.busy = true;
-            return MLDSA_OK;
-        }();
+    // uploads of sub-batch i + 1 are submitted before the download of sub-batch i (copies are served in submission order,
+    // see mldsa_verify_host): otherwise the next sub-batch's few KB of inputs sit behind 100 MB of signatures that are not
+    // even signed yet, and signing waits for both
+    const size_t n_sub = cut.size() - 1;
+    auto stage_up = [&](size_t j) -> int {
+        const size_t a = cut[j], b = cut[j + 1], n = b - a;
+        Slot &sl = hs->slot[j % N_SLOTS];
+        TRY(reclaim(sl));
+        TRY(upload_op_inputs(hs->up, sl, in, a, b));
+        TRY(upload(sl.rnd, rnd + a * 32, n * 32, pin_rnd, hs->up));
+        TRY(grow_dev(sl.out, n * sgl));
+        TRY(grow_dev(sl.status, n * 4));
+        HCHECK(hipEventRecord(sl.up_done, hs->up));
+        return MLDSA_OK;
+    };
+    auto run = [&](size_t j) -> int {
+        const size_t a = cut[j], n = cut[j + 1] - a;
+        Slot &sl = hs->slot[j % N_SLOTS];
+        HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
+        const uint8_t *mbase = sl.d_msgs - msg_off[a];
+        const uint8_t *cbase = ctx_off ? sl.d_ctxs - ctx_off[a] : nullptr;
+        const size_t kb = key_idx ? 0 : a;
+        TRY(mldsa_sign_async(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_capk.dev + kb * 32, hs->k_tr.dev + kb * 64, s1 + kb * l * 256,
+                             s2 + kb * k * 256, t0 + kb * k * 256, n_keys - kb, sl.d_kidx, mbase, sl.d_moff, cbase, sl.d_coff,
+                             sl.rnd.dev, sl.out.dev, reinterpret_cast<int32_t *>(sl.status.dev), n, hs->comp));
+        HCHECK(hipEventRecord(sl.comp_done, hs->comp));
+        HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
+        TRY(download(sl, sl.out, sigs + a * sgl, n * sgl, pin_sigs, hs->down));
+        TRY(download(sl, sl.status, st + a, n * 4, pin_st, hs->down));
+        HCHECK(hipEventRecord(sl.down_done, hs->down));
+        sl.busy = true;
+        return MLDSA_OK;
+    };
+    rc = stage_up(0);
+    for (size_t j = 0; j < n_sub && rc == MLDSA_OK; j++) {
+        if (j + 1 < n_sub) rc = stage_up(j + 1);
+        if (rc == MLDSA_OK) rc = run(j);
     }
     for (auto &sl : hs->slot) {
         const int r2 = reclaim(sl);

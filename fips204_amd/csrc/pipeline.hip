@@ -14,6 +14,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <chrono>
+
 #include "ctx.h"
 
 namespace mldsa {
@@ -108,7 +110,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
         // fork: the small lane-per-op kernels are latency-bound (1-2 Keccak-f per op, <= 1 wave per SIMD) and
         // independent of ExpandA, so they run on the context's second stream underneath it
-        hipStream_t aux = ctx->aux_stream;
+        hipStream_t aux = parallel_stream(ctx, s);
         MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(aux, ctx->fork_ev, 0));
         {
@@ -516,9 +518,9 @@ struct SignLane {
 int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl, SignLane *lanes, int n_lanes, hipStream_t s) {
     lanes[0].st = s;
     if (n_lanes > 1) {
-        lanes[1].st = ctx->aux_stream;
+        lanes[1].st = parallel_stream(ctx, s);
         MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ctx->fork_ev, 0));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(lanes[1].st, ctx->fork_ev, 0));
     }
     for (int i = 0; i < n_lanes; i++) TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st));
     // 10: while (z, h) = bottom                                            ml_dsa.rs:212
@@ -543,7 +545,7 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
         }
     }
     if (n_lanes > 1) {
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, ctx->aux_stream));
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, lanes[1].st));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));
     }
     return MLDSA_OK;
@@ -631,6 +633,57 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         (void)hipStreamSynchronize(s);
     }
     return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// Helper streams that really run beside the caller's stream (see ctx.h).
+__global__ void k_probe_spin(unsigned *p, int iters) {
+    unsigned v = threadIdx.x;
+    for (int i = 0; i < iters; i++) v = v * 1664525u + 1013904223u;
+    if (v == 0x2545F491u) p[0] = v;
+}
+__global__ void k_probe_touch(unsigned *p) {
+    if (threadIdx.x == 0) p[1] = 1;
+}
+
+bool streams_serialise(mldsa_ctx *ctx, hipStream_t a, hipStream_t b) {
+    if (a == b) return true;
+    if (!ctx->d_probe && hipMalloc((void **)&ctx->d_probe, 256) != hipSuccess) return false;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    const double t0 = now();
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, ctx->d_probe, 40000);  // a few hundred microseconds on one wave
+    hipLaunchKernelGGL(k_probe_touch, dim3(1), dim3(64), 0, b, ctx->d_probe);
+    (void)hipStreamSynchronize(b);
+    const double tb = now() - t0;
+    (void)hipStreamSynchronize(a);
+    const double ta = now() - t0;
+    (void)hipGetLastError();
+    return tb > 0.5 * ta;
+}
+
+hipStream_t parallel_stream(mldsa_ctx *ctx, hipStream_t s, hipStream_t avoid) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return ctx->aux_stream;
+    if (!avoid)
+        for (const auto &pr : ctx->parallel_of)
+            if (pr.first == s) return pr.second;
+    if (ctx->helper_streams.empty()) ctx->helper_streams.push_back(ctx->aux_stream);
+    hipStream_t found = nullptr;
+    for (size_t i = 0; i < 8 && !found; i++) {
+        if (i == ctx->helper_streams.size()) {
+            hipStream_t t = nullptr;
+            if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) break;
+            ctx->helper_streams.push_back(t);
+        }
+        hipStream_t c = ctx->helper_streams[i];
+        if (c == s || c == avoid) continue;
+        if (!streams_serialise(ctx, s, c) && (!avoid || !streams_serialise(ctx, avoid, c))) found = c;
+    }
+    if (!found) found = ctx->aux_stream;  // every candidate shares a queue: still correct, just not concurrent
+    if (!avoid) ctx->parallel_of.emplace_back(s, found);
+    return found;
 }
 
 // ------------------------------------------------------------------------------------
