@@ -503,26 +503,35 @@ int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, u
     TRY(mldsa_reserve(ctx, set, MLDSA_OP_KEYGEN, sub));
     const bool pin_xi = is_pinned(xi), pin_pk = is_pinned(pk), pin_sk = is_pinned(sk);
     int rc = MLDSA_OK;
-    size_t i = 0;
-    for (size_t a = 0; a < n_keys && rc == MLDSA_OK; a += sub, i++) {
-        const size_t n = std::min(n_keys, a + sub) - a;
-        Slot &sl = hs->slot[i % N_SLOTS];
-        rc = [&]() -> int {
-            TRY(reclaim(sl));
-            TRY(upload(sl.xi, xi + a * 32, n * 32, pin_xi, hs->up));
-            TRY(grow_dev(sl.pk, n * pkl));
-            TRY(grow_dev(sl.sk, n * skl));
-            HCHECK(hipEventRecord(sl.up_done, hs->up));
-            HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
-            TRY(mldsa_keygen(ctx, set, sl.xi.dev, sl.pk.dev, sl.sk.dev, n, hs->comp));
-            HCHECK(hipEventRecord(sl.comp_done, hs->comp));
-            HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
-            TRY(download(sl, sl.pk, pk + a * pkl, n * pkl, pin_pk, hs->down));
-            TRY(download(sl, sl.sk, sk + a * skl, n * skl, pin_sk, hs->down));
-            HCHECK(hipEventRecord(sl.down_done, hs->down));
-            sl.busy = true;
-            return MLDSA_OK;
-        }();
+    // seeds of sub-batch i + 1 go up before the keys of sub-batch i come down (copies are served in submission order)
+    const size_t n_sub = (n_keys + sub - 1) / sub;
+    auto stage_up = [&](size_t j) -> int {
+        const size_t a = j * sub, n = std::min(n_keys, a + sub) - a;
+        Slot &sl = hs->slot[j % N_SLOTS];
+        TRY(reclaim(sl));
+        TRY(upload(sl.xi, xi + a * 32, n * 32, pin_xi, hs->up));
+        TRY(grow_dev(sl.pk, n * pkl));
+        TRY(grow_dev(sl.sk, n * skl));
+        HCHECK(hipEventRecord(sl.up_done, hs->up));
+        return MLDSA_OK;
+    };
+    auto run = [&](size_t j) -> int {
+        const size_t a = j * sub, n = std::min(n_keys, a + sub) - a;
+        Slot &sl = hs->slot[j % N_SLOTS];
+        HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
+        TRY(mldsa_keygen(ctx, set, sl.xi.dev, sl.pk.dev, sl.sk.dev, n, hs->comp));
+        HCHECK(hipEventRecord(sl.comp_done, hs->comp));
+        HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
+        TRY(download(sl, sl.pk, pk + a * pkl, n * pkl, pin_pk, hs->down));
+        TRY(download(sl, sl.sk, sk + a * skl, n * skl, pin_sk, hs->down));
+        HCHECK(hipEventRecord(sl.down_done, hs->down));
+        sl.busy = true;
+        return MLDSA_OK;
+    };
+    rc = stage_up(0);
+    for (size_t j = 0; j < n_sub && rc == MLDSA_OK; j++) {
+        if (j + 1 < n_sub) rc = stage_up(j + 1);
+        if (rc == MLDSA_OK) rc = run(j);
     }
     for (auto &sl : hs->slot) {
         const int r2 = reclaim(sl);

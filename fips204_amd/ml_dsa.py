@@ -293,12 +293,19 @@ class MlDsa:
             raise ValueError("ML-DSA.Sign: ctx too long")
         return sig[:n_ops]
 
-    def keygen_host(self, xi):
-        """mldsa_keygen_host: seeds [n, 32] in host memory -> (pk [n, PK_LEN], sk [n, SK_LEN]) numpy arrays."""
+    def keygen_host(self, xi, out=None):
+        """mldsa_keygen_host: seeds [n, 32] in host memory -> (pk [n, PK_LEN], sk [n, SK_LEN]) numpy arrays.
+        out: (pk, sk) uint8 arrays to fill (page-locked ones are written by the DMA directly)."""
         x = self._np_u8(xi, 32, "xi")
         n = x.size // 32
-        pk = np.zeros((max(n, 1), self.PK_LEN), dtype=np.uint8)
-        sk = np.zeros((max(n, 1), self.SK_LEN), dtype=np.uint8)
+        if out is not None:
+            pk, sk = out
+            if pk.dtype != np.uint8 or sk.dtype != np.uint8 or pk.size < n * self.PK_LEN or sk.size < n * self.SK_LEN \
+                    or not pk.flags.c_contiguous or not sk.flags.c_contiguous:
+                raise ValueError("keygen_host: out = (pk, sk) contiguous uint8 arrays of at least n keys")
+        else:
+            pk = np.zeros((max(n, 1), self.PK_LEN), dtype=np.uint8)
+            sk = np.zeros((max(n, 1), self.SK_LEN), dtype=np.uint8)
         vp = lambda a: C.c_void_p(a.ctypes.data)
         _lib.check(self.lib.mldsa_keygen_host(self.hp._h, self.pset, vp(x), vp(pk), vp(sk), n))
         return pk[:n], sk[:n]
