@@ -20,7 +20,9 @@
 
 namespace mldsa {
 
-constexpr size_t CHUNK_OPS = 65536;
+// verify / keygen ops resident per pass: 131 072 instead of 65 536 is +0.8 / +3 / +6.5 % for ML-DSA-87 / 65 / 44 on calls of
+// that size or more (the lane-per-op hash and mu kernels run two waves per SIMD instead of one; half as many launch tails)
+constexpr size_t CHUNK_OPS = 131072;
 
 int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return MLDSA_OK;

@@ -377,8 +377,8 @@ def test_config3_ml_dsa_65_sign_at_65536(sets):
 
 
 def test_config4_slice_ml_dsa_87_verify_at_131072(sets):
-    """BASELINE config 4's per-GPU slice: 131 072 ML-DSA-87 verifies = two pipeline chunks, 1 % of the signatures
-    corrupted in a known pattern; the oracle agrees on a sample from both chunks."""
+    """BASELINE config 4's per-GPU slice: 131 072 ML-DSA-87 verifies (one verify chunk, two sign chunks), 1 % of the
+    signatures corrupted in a known pattern; the oracle agrees on a sample from both halves."""
     m = sets[87]
     n = 131072
     b = make_batch(m, n, 1024, b"c4")

@@ -54,11 +54,11 @@ def test_message_and_ctx_length_edges_vs_oracle(sets, pset):
 
 
 def test_identity_key_mapping_and_multichunk(sets):
-    """key_idx = None with one key per op, and a batch larger than one pipeline chunk (65536 ops):
-    verdicts must match a known corruption pattern."""
+    """key_idx = None with one key per op, and a batch larger than one pipeline chunk (65 536 ops for keygen and sign,
+    131 072 for verify): verdicts must match a known corruption pattern."""
     m = sets[44]
     g = torch.Generator(device="cuda").manual_seed(17)
-    n = 70001  # > CHUNK_OPS
+    n = 131072 + 7001  # three sign chunks, two verify chunks, both with ragged ends
     xi = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
     pk, sk = m.keygen_from_seed(xi)
     pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
@@ -73,7 +73,7 @@ def test_identity_key_mapping_and_multichunk(sets):
     assert np.array_equal(got, ~bad)
     # spot-check signatures against the oracle on both sides of the chunk boundary
     skh = host(sk)
-    for i in (0, 1, 65535, 65536, 70000):
+    for i in (0, 1, 65535, 65536, 131071, 131072, n - 1):
         want = orc.sign_internal(44, orc.sk_try_from_bytes(44, skh[i].tobytes()), msgs[i], bytes(32), mode=0)
         assert host(sig)[i].tobytes() == want, i
 
