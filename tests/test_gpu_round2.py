@@ -377,7 +377,7 @@ def test_config3_ml_dsa_65_sign_at_65536(sets):
 
 
 def test_config4_slice_ml_dsa_87_verify_at_131072(sets):
-    """BASELINE config 4's per-GPU slice: 131 072 ML-DSA-87 verifies (one verify chunk, two sign chunks), 1 % of the
+    """BASELINE config 4's per-GPU slice: 131 072 ML-DSA-87 verifies (one pipeline pass), 1 % of the
     signatures corrupted in a known pattern; the oracle agrees on a sample from both halves."""
     m = sets[87]
     n = 131072
@@ -404,15 +404,15 @@ def test_config4_slice_ml_dsa_87_verify_at_131072(sets):
 
 @pytest.mark.parametrize("pset", [65, 87])
 def test_multichunk_sign(sets, pset):
-    """a signing batch larger than one pipeline chunk (65 536 ops): second-chunk signatures byte-exact, all verify"""
+    """a signing batch larger than one pipeline pass (262 144 ops): second-pass signatures byte-exact, all verify"""
     m = sets[pset]
-    n = 65536 + 1500
+    n = 262144 + 1500
     b = make_batch(m, n, 64, b"mc%d" % pset)
     sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
     st = torch.zeros(n, dtype=torch.int32, device="cuda")
     m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st)
     assert int(host(st).max()) == 0
-    idx = [0, 65535, 65536, 65537, n - 1]
+    idx = [0, 65535, 65536, 262143, 262144, 262145, n - 1]
     got = host(sig[idx])
     for row, w in enumerate(oracle_sigs(pset, b, idx)):
         assert got[row].tobytes() == w

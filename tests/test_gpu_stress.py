@@ -54,11 +54,10 @@ def test_message_and_ctx_length_edges_vs_oracle(sets, pset):
 
 
 def test_identity_key_mapping_and_multichunk(sets):
-    """key_idx = None with one key per op, and a batch larger than one pipeline chunk (65 536 ops for keygen and sign,
-    131 072 for verify): verdicts must match a known corruption pattern."""
+    """key_idx = None with one key per op, and a batch larger than one pipeline pass (131 072 ops for keygen and verify): verdicts must match a known corruption pattern."""
     m = sets[44]
     g = torch.Generator(device="cuda").manual_seed(17)
-    n = 131072 + 7001  # three sign chunks, two verify chunks, both with ragged ends
+    n = 131072 + 7001  # two verify / keygen passes with a ragged end (sign: one pass, see test_multichunk_sign)
     xi = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
     pk, sk = m.keygen_from_seed(xi)
     pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
