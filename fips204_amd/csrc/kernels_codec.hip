@@ -8,6 +8,7 @@
 
 #include <cstdlib>
 #include "ctx.h"
+#include "challenge_dev.h"
 #include "sampler_dev.h"
 #include "keccak.h"
 #include "ntt_wave.h"
@@ -306,7 +307,6 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
 // block the wave reads the 64 ops' 136-byte pieces with consecutive lanes on consecutive
 // dwords (coalesced) into an LDS tile, and each lane then absorbs its own row.  la and lb are
 // multiples of 4; ALIGNED = all pointers / strides are multiples of 4 (dword loads).
-constexpr int H_STRIDE = 35;  // dwords per tile row (136 bytes + pad, odd stride)
 
 // With vd.ok != nullptr the kernel is the tail of verify_internal (ml_dsa.rs:429-436): instead of storing the digest it
 // compares it with the signature's c_tilde and writes the verdict, combined with the decode failures that make the
@@ -333,9 +333,6 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* tile = tiles + wave * 64 * H_STRIDE;
     if (n_dev) n_ops = *n_dev;  // the signer's rounds: the count lives on the device, the grid is sized from its expectation
-    const int data = la + lb;              // bytes that come from memory
-    const int total = data + tail_len;     // message length
-    const int n_blocks = total / SHAKE256_RATE + 1;
     for (size_t base_op = (size_t)blockIdx.x * CBLOCK; base_op < n_ops; base_op += (size_t)gridDim.x * CBLOCK) {
         const size_t op = base_op + threadIdx.x;
         const bool valid = op < n_ops;
@@ -346,57 +343,7 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
         ptr_b[wave * 64 + lane] = b ? (unsigned long long)(b + opc * sb) : pa;
         wave_lds_sync_c();
         KeccakState st;
-        keccak_zero(st);
-        // The wave's 64 rows x 34 dwords of one rate block.  Passes 0..31: lanes 0-31 fetch dwords 0..31 of row 2 i, lanes
-        // 32-63 those of row 2 i + 1 (coalesced 128-byte runs); passes 32, 33: lane r fetches dword 32 / 33 of row r.
-        // Branch-free: a dword past the end of the data is fetched from the row start and zeroed.  All 34 loads of a
-        // block are issued back to back, and those of block b + 1 before the permutation of block b, so their latency
-        // hides under it (the hash chain of one op is serial and the kernel runs a single wave per SIMD).
-        uint32_t pre[34];
-        auto issue = [&](int blk) {
-            const int base = blk * SHAKE256_RATE;
-#pragma unroll
-            for (int i = 0; i < 34; i++) {
-                const int row = i < 32 ? 2 * i + (lane >> 5) : lane;
-                const int off = base + 4 * (i < 32 ? (lane & 31) : i);
-                const bool have = off + 4 <= data, in_a = off < la;
-                const unsigned long long pp = in_a ? ptr_a[wave * 64 + row] : ptr_b[wave * 64 + row];
-                const uint8_t* src = reinterpret_cast<const uint8_t*>(pp) + (have ? (in_a ? off : off - la) : 0);
-                const uint32_t v = ALIGNED ? *reinterpret_cast<const uint32_t*>(src) : load_le32(src);
-                pre[i] = have ? v : 0u;
-            }
-        };
-        issue(0);
-        for (int blk = 0; blk < n_blocks; blk++) {
-            const int base = blk * SHAKE256_RATE;
-#pragma unroll
-            for (int i = 0; i < 34; i++) {
-                const int row = i < 32 ? 2 * i + (lane >> 5) : lane;
-                const int wd = i < 32 ? (lane & 31) : i;
-                tile[row * H_STRIDE + wd] = pre[i];
-            }
-            wave_lds_sync_c();
-            static_for_c<0, 17>([&](auto wc) {
-                constexpr int W = decltype(wc)::value;
-                uint32_t lo = tile[lane * H_STRIDE + 2 * W], hi = tile[lane * H_STRIDE + 2 * W + 1];
-                const int off = base + 8 * W;
-                if (off + 8 > data && off <= total) {  // word holds tail bytes and / or the 0x1F pad (lane-uniform)
-                    for (int i = 0; i < 8; i++) {
-                        const int pos = off + i;
-                        uint32_t v = 0;
-                        if (pos >= data && pos < total) v = (tail >> (8 * (pos - data))) & 0xFF;
-                        else if (pos == total) v = 0x1F;
-                        if (i < 4) lo |= v << (8 * i); else hi |= v << (8 * (i - 4));
-                    }
-                }
-                st.lo[W] ^= lo;
-                st.hi[W] ^= hi;
-            });
-            if (blk == n_blocks - 1) st.hi[16] ^= 0x80000000u;
-            wave_lds_sync_c();
-            if (blk + 1 < n_blocks) issue(blk + 1);
-            keccak_f1600(st);
-        }
+        shake256_2_absorb<ALIGNED>(st, tile, ptr_a + wave * 64, ptr_b + wave * 64, la, lb, tail, tail_len, lane);
         if (valid && vd.ok) {
             const uint8_t* c0 = vd.sigs + op * vd.sig_len;  // c_tilde opens the signature (encodings.rs:251)
             uint32_t diff = 0;

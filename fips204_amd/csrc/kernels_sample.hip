@@ -7,6 +7,7 @@
 // cooperatively so that HBM only sees contiguous runs (one coalesced store instruction per
 // stream and flush) instead of 64 lanes scattering single dwords 1 KiB apart.
 #include "ctx.h"
+#include "challenge_dev.h"
 #include "sampler_dev.h"
 
 namespace mldsa {
@@ -209,9 +210,6 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
 // sign bits h; for i = 256 - tau .. 255: draw bytes j until j <= i; c[i] = c[j];
 // c[j] = 1 - 2 * bit(i + tau - 256) of h.  The Fisher-Yates array and the squeezed block
 // live in lane-private LDS rows (dynamic indexing); output c[op] as int32[256].
-constexpr int SIB_C_STRIDE = 65;    // dwords: 256 int8 + pad (odd: conflict-free)
-constexpr int SIB_BLK_STRIDE = 35;  // dwords: 136 bytes + pad
-
 template <int CT>  // c_tilde bytes: 32, 48 or 64
 __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict__ c_tilde, size_t ct_stride,
                                                        int tau, int32_t* __restrict__ c_out, size_t n_ops,
@@ -220,9 +218,7 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
     __shared__ uint32_t b_lds[64 * SIB_BLK_STRIDE];
     const int lane = threadIdx.x;
     if (n_dev) n_ops = *n_dev;
-    int8_t* c = reinterpret_cast<int8_t*>(c_lds + lane * SIB_C_STRIDE);
     uint32_t* bw = b_lds + lane * SIB_BLK_STRIDE;
-    const uint8_t* bb = reinterpret_cast<const uint8_t*>(bw);
     for (size_t wave_base = (size_t)blockIdx.x * 64; wave_base < n_ops; wave_base += (size_t)gridDim.x * 64) {
         const size_t op = wave_base + lane;
         const bool valid = op < n_ops;
@@ -233,32 +229,7 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
             absorb_words<CT / 8>(st, c_tilde + op * ct_stride);
         }
         shake_pad<SHAKE256_RATE, CT>(st);
-#pragma unroll
-        for (int i = 0; i < 64; i++) c_lds[lane * SIB_C_STRIDE + i] = 0;
-
-        keccak_f1600(st);
-        const uint64_t h64 = ((uint64_t)st.hi[0] << 32) | st.lo[0];  // hashing.rs:55-56
-        static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
-        int pos = 8;
-        int i = valid ? 256 - tau : 256;
-        for (;;) {
-            while (i < 256 && pos < SHAKE256_RATE) {
-                const int j = bb[pos++];
-                if (j <= i) {  // hashing.rs:68-83
-                    c[i] = c[j];
-                    const int index = i + tau - 256;
-                    const uint32_t bit = (uint32_t)((h64 >> index) & 1u);
-                    c[j] = (int8_t)(1 - 2 * (int)bit);
-                    i++;
-                }
-            }
-            if (!__any(i < 256)) break;
-            if (i < 256) {  // this lane used up its block (rare): squeeze the next one
-                keccak_f1600(st);
-                static_for<0, 34>([&](auto wc) { constexpr int W = decltype(wc)::value; bw[W] = state_word<W>(st); });
-                pos = 0;
-            }
-        }
+        sample_in_ball_lane(st, tau, valid, c_lds + lane * SIB_C_STRIDE, bw);
         wave_lds_sync();
         for (int row = 0; row < 64; row++) {
             if (wave_base + row >= n_ops) break;
