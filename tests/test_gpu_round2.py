@@ -689,3 +689,18 @@ def test_full_batch_every_signature_and_every_verdict_match_the_oracle(sets, pse
     want_v = orc.verify_batch_mt(pset, pk_o, kidx, msgs, [sig2[i].tobytes() for i in range(n)], 16, 1, mode=0)
     assert np.array_equal(got, np.asarray(want_v, dtype=bool))
     assert int((~got).sum()) == idx.size  # a flipped bit never leaves a signature valid
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_get_public_key_of_arbitrary_secret_key_bytes(sets, pset):
+    """private_to_public_key (ml_dsa.rs:502-559) computes t = A s1 + s2 from whatever expand_private decoded, out-of-range
+    eta fields and a tr that is not H(pk) included: the public key bytes must be the ones the oracle derives."""
+    m = sets[pset]
+    rng = np.random.default_rng(300 + pset)
+    sk = rng.integers(0, 256, (6, m.SK_LEN), dtype=np.uint8)
+    sk[3, 128:] = 0xFF  # every field all-ones
+    sks = m.private_keys_from_bytes(torch.from_numpy(sk).cuda())
+    got = host(m.public_keys_into_bytes(m.get_public_key(sks)))
+    for i in range(len(sk)):
+        want = orc.pk_into_bytes(pset, orc.get_public_key(pset, orc.sk_try_from_bytes(pset, sk[i].tobytes())))
+        assert got[i].tobytes() == want, i
