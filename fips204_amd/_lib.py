@@ -31,7 +31,7 @@ _P, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in (
-        "graphs_captured", "graph_replays", "direct_calls", "workspace_growths", "sign_extra_rounds")]
+        "graphs_captured", "graph_replays", "direct_calls", "workspace_growths", "sign_extra_rounds", "workspace_shrinks")]
 
 
 OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3

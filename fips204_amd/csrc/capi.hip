@@ -93,6 +93,8 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
     ctx->opt_host_sub_verify = env_long("MLDSA_HOST_SUB_VERIFY", 64, 65536, ctx->opt_host_sub_verify);
     ctx->opt_host_sub_sign = env_long("MLDSA_HOST_SUB_SIGN", 64, 65536, ctx->opt_host_sub_sign);
+    ctx->pass_ops = (size_t)env_long("MLDSA_PASS_OPS", 256, 1 << 20, (long)ctx->pass_ops);
+    ctx->pass_ops_sign = (size_t)env_long("MLDSA_PASS_OPS_SIGN", 256, 1 << 20, (long)ctx->pass_ops_sign);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cu = prop.multiProcessorCount;
@@ -113,6 +115,8 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
@@ -147,6 +151,8 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->ws_ev) (void)hipEventDestroy(ctx->ws_ev);
+    if (ctx->zero_fork_ev) (void)hipEventDestroy(ctx->zero_fork_ev);
+    if (ctx->zero_ev) (void)hipEventDestroy(ctx->zero_ev);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
     delete ctx;
@@ -191,7 +197,11 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             return MLDSA_OK;
         case MLDSA_OPT_SIGN_CT0_EXACT:
             REQUIRE(value == 0 || value == 1, "mldsa_set_option: MLDSA_OPT_SIGN_CT0_EXACT is 0 or 1");
-            if (ctx->opt_ct0_exact != value) drop_graphs(ctx);  // the flag is a kernel argument of captured launches
+            if (ctx->opt_ct0_exact != value) {  // the flag is a kernel argument of captured launches
+                DeviceGuard dg(ctx->device);
+                MLDSA_HIP_CHECK(hipDeviceSynchronize());  // a replayed graph may still be running
+                drop_graphs(ctx);
+            }
             ctx->opt_ct0_exact = value;
             return MLDSA_OK;
         default: return set_error(MLDSA_ERR_PARAM, "mldsa_set_option: unknown option");
@@ -225,13 +235,9 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops) {
     ENTER(ctx, "mldsa_reserve");
     const mldsa_params *p = params_of(set);
     REQUIRE(p, "mldsa_reserve: unknown parameter set");
-    size_t bytes = 0;
-    if (op == MLDSA_OP_KEYGEN) bytes = keygen_workspace_bytes(p, n_ops);
-    else if (op == MLDSA_OP_SIGN) bytes = sign_workspace_bytes(ctx, p, n_ops, true);
-    else if (op == MLDSA_OP_VERIFY) bytes = verify_workspace_bytes(p, n_ops, true);
-    else return set_error(MLDSA_ERR_PARAM, "mldsa_reserve: unknown operation");
+    REQUIRE(op == MLDSA_OP_KEYGEN || op == MLDSA_OP_SIGN || op == MLDSA_OP_VERIFY, "mldsa_reserve: unknown operation");
     std::lock_guard<std::mutex> lk(ctx->op_mutex);
-    return n_ops ? ensure_workspace(ctx, bytes) : MLDSA_OK;
+    return n_ops ? reserve_workspace(ctx, p, op, n_ops, true) : MLDSA_OK;
 }
 
 int mldsa_malloc(void **dev_ptr, size_t bytes) {
@@ -438,7 +444,7 @@ static int verify_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, co
     const mldsa_params *p = params_of(set);
     if (n_ops == 0) return MLDSA_OK;
     OpGuard guard(ctx, s);
-    int rc = ensure_workspace(ctx, verify_workspace_bytes(p, n_ops, a_hat == nullptr));
+    int rc = reserve_workspace(ctx, p, MLDSA_OP_VERIFY, n_ops, a_hat == nullptr);
     if (rc != MLDSA_OK) return rc;
     struct { int op, set, mode; const void *rho, *a_hat, *tr, *t1; size_t n_keys; const void *key_idx, *msgs, *msg_off, *ctxs, *ctx_off, *sigs, *ok;
              size_t n_ops; } key;
@@ -520,7 +526,7 @@ int mldsa_get_public_key(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint
             "mldsa_get_public_key: NULL pointer");
     if (n_keys == 0) return MLDSA_OK;
     OpGuard guard(ctx, (hipStream_t)stream);
-    int rc = ensure_workspace(ctx, keygen_workspace_bytes(p, n_keys));
+    int rc = reserve_workspace(ctx, p, MLDSA_OP_KEYGEN, n_keys, true);
     if (rc != MLDSA_OK) return rc;
     return get_public_key_batch(ctx, set, rho, tr, s_1_hat_mont, s_2_hat_mont, pk_rho, pk_tr, pk_t1_d2_hat_mont, n_keys, (hipStream_t)stream);
 }
@@ -533,7 +539,7 @@ int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     if (n_keys == 0) return MLDSA_OK;
     hipStream_t s = (hipStream_t)stream;
     OpGuard guard(ctx, s);
-    int rc = ensure_workspace(ctx, keygen_workspace_bytes(p, n_keys));
+    int rc = reserve_workspace(ctx, p, MLDSA_OP_KEYGEN, n_keys, true);
     if (rc != MLDSA_OK) return rc;
     struct { int op, set; const void *xi, *pk, *sk; size_t n; } key;
     memset(&key, 0, sizeof(key));
@@ -541,18 +547,22 @@ int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     return run_op(ctx, s, MLDSA_OP_KEYGEN, n_keys, &key, sizeof(key), [&](hipStream_t st) { return keygen_batch(ctx, set, xi, pk, sk, n_keys, st); });
 }
 
-static int sign_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,
+}  // extern "C"
+
+int mldsa::sign_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,
                      const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                      const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-                     int32_t *status, size_t n_ops, hipStream_t s, bool async_mode) {
+                     int32_t *status, size_t n_ops, hipStream_t s, bool async_mode, double plan_stop) {
     const mldsa_params *p = params_of(set);
     if (n_ops == 0) return MLDSA_OK;
-    OpGuard guard(ctx, s);
-    int rc = ensure_workspace(ctx, sign_workspace_bytes(ctx, p, n_ops, a_hat == nullptr));
+    OpGuard guard(ctx, s, true);  // sign_batch orders itself after a pending background clearing
+    int rc = reserve_workspace(ctx, p, MLDSA_OP_SIGN, n_ops, a_hat == nullptr);
     if (rc != MLDSA_OK) return rc;
     return sign_batch(ctx, set, mode, rho, cap_k, tr, s1, s2, t0, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, rnd, sigs, status,
-                      n_ops, s, a_hat, async_mode);
+                      n_ops, s, a_hat, async_mode, plan_stop);
 }
+
+extern "C" {
 
 #define SIGN_CHECKS(name, first)                                                                                                  \
     ENTER(ctx, name);                                                                                                             \

@@ -27,6 +27,7 @@ struct GraphEntry {
     std::vector<unsigned char> key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipStream_t last_stream = nullptr;  // where it was last launched (waited for before the graph is destroyed)
     unsigned long long last_use = 0;
 };
 struct HostStage;
@@ -54,6 +55,9 @@ struct mldsa_ctx {
     // op-level pipeline workspace (grown on demand, pipeline.hip)
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // ops resident per pass of a pipeline (= what the workspace is sized for): verify / keygen and sign.  Tuned for a whole
+    // MI355X (pipeline.hip); halved by reserve_workspace when the device cannot hold the workspace of a full pass.
+    size_t pass_ops = 131072, pass_ops_sign = 262144;
     // second stream: the small latency-bound lane-per-op kernels of verify (hint unpack, mu,
     // SampleInBall) run here, concurrently with the VALU-bound ExpandA on the caller's stream
     hipStream_t aux_stream = nullptr;
@@ -77,6 +81,12 @@ struct mldsa_ctx {
     hipEvent_t ws_ev = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_busy = false;
+    // A synchronous signing call clears its secrets (y, w, c, rho'' ...: 1.1 GB for 65 536 ML-DSA-65 ops) on a helper stream
+    // after the signatures are complete; zero_ev marks the end of that, and the next op-level call waits for it on the device
+    // before it touches the workspace (OpGuard) -- a signing call only after its ExpandA, which writes below [zero_lo, zero_hi).
+    hipEvent_t zero_fork_ev = nullptr, zero_ev = nullptr;
+    bool zero_pending = false, zero_wait_after_ea = false;
+    size_t zero_lo = 0, zero_hi = 0;
     // optional per-stage timing: HIP event pairs recorded on the launch stream, resolved
     // only when the caller asks for the report (no synchronisation in the timed region)
     bool prof_on = false;
@@ -125,13 +135,18 @@ struct DeviceGuard {
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
+// orders `s` after the background clearing of the previous signing call's secrets, if one is pending (pipeline.hip)
+int wait_zeroise(mldsa_ctx *, hipStream_t s);
+
 // RAII guard of one op-level call (capi.hip)
 struct OpGuard {
     mldsa_ctx *c;
     hipStream_t s;
     std::unique_lock<std::mutex> lk;
-    OpGuard(mldsa_ctx *ctx, hipStream_t stream) : c(ctx), s(stream), lk(ctx->op_mutex) {
+    // defer_zero: the caller (sign_call) orders itself after the previous call's background clearing
+    OpGuard(mldsa_ctx *ctx, hipStream_t stream, bool defer_zero = false) : c(ctx), s(stream), lk(ctx->op_mutex) {
         if (c->ws_busy && c->ws_stream != s) (void)hipStreamWaitEvent(s, c->ws_ev, 0);
+        if (!defer_zero) (void)wait_zeroise(c, s);
     }
     ~OpGuard() {
         (void)hipEventRecord(c->ws_ev, s);
@@ -214,20 +229,22 @@ int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t
 // the round kernels of the signer: counts come from `ctl` on the device, the *_hint arguments only size the grids
 int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde,
                      const uint32_t *slot_op, const uint32_t *key_idx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
-                     uint16_t *kappa, int32_t *done, uint8_t *sigs, const RoundCtl *ctl, uint8_t *stage, size_t stage_stride,
-                     int32_t *accept, size_t slots_hint, hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr,
-                     const uint8_t *key_oor = nullptr, int oor_by_op = 0);
+                     uint16_t *kappa, int32_t *done, uint8_t *sigs, const RoundCtl *ctl, int32_t *accept, size_t slots_hint,
+                     hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr, const uint8_t *key_oor = nullptr,
+                     int oor_by_op = 0);
 int launch_key_range(mldsa_ctx *, const mldsa_params *, const int32_t *s2, const uint32_t *kidx, size_t n_units, uint8_t *oor, hipStream_t);
 int launch_make_slots(mldsa_ctx *, RoundCtl *ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t *act,
                       const uint16_t *kappa, int l, uint32_t *slot_op, uint16_t *slot_kappa, const uint32_t *key_idx,
                       uint32_t *slot_key, size_t slots_hint, hipStream_t);
+// speculative rounds: builds the signature of each op's first surviving candidate (the candidates' c / y / w / c~ rows)
 int launch_resolve(mldsa_ctx *, const mldsa_params *, const RoundCtl *ctl, const uint32_t *act, const int32_t *accept,
-                   const uint8_t *stage, size_t stage_stride, uint8_t *sigs, int32_t *done, uint16_t *kappa, size_t ops_hint,
-                   hipStream_t);
+                   const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde, const uint32_t *key_idx,
+                   const int32_t *s1, const int32_t *s2, const int32_t *t0, uint8_t *sigs, int32_t *done, uint16_t *kappa,
+                   size_t ops_hint, hipStream_t, const uint8_t *key_oor = nullptr, int oor_by_op = 0);
 int launch_compact(mldsa_ctx *, RoundCtl *ctl, int parity, const uint32_t *act_in, const int32_t *done, uint32_t *act_out,
                    size_t ops_hint, hipStream_t);
 int launch_init_active(mldsa_ctx *, size_t n, const int32_t *bad_op, int32_t *done, uint16_t *kappa, int32_t *status,
-                       uint32_t *act_out, RoundCtl *ctl, hipStream_t);
+                       uint32_t *act_out, RoundCtl *ctl, uint8_t *sigs, size_t sig_len, hipStream_t);
 int launch_mark_unfinished(mldsa_ctx *, const RoundCtl *ctl, int parity, const uint32_t *act, int32_t *status, uint8_t *sigs,
                            size_t sig_len, hipStream_t);
 int launch_sanitize_keys(mldsa_ctx *, const uint32_t *key_idx, size_t n_keys, size_t n_ops, uint32_t *safe, int32_t *bad, hipStream_t);
@@ -260,16 +277,25 @@ int keygen_batch(mldsa_ctx *, int set, const uint8_t *xi, uint8_t *pk, uint8_t *
 int sign_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1,
                const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-               int32_t *status, size_t n_ops, hipStream_t, const int32_t *a_hat_keys, bool async_mode);
+               int32_t *status, size_t n_ops, hipStream_t, const int32_t *a_hat_keys, bool async_mode, double plan_stop = 0.0);
+// mldsa_sign / mldsa_sign_async / mldsa_sign_cached_a behind their argument checks (capi.hip).  plan_stop > 0: expected number of
+// unfinished ops at which the round plan stops, instead of the context's default for the mode (mldsa_sign_host re-signs
+// leftovers itself and plans like a synchronous call).
+int sign_call(mldsa_ctx *, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,
+              const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
+              const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
+              int32_t *status, size_t n_ops, hipStream_t, bool async_mode, double plan_stop = 0.0);
 int verify_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1_d2_hat_mont, size_t n_keys,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
                  const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t,
                  const int32_t *a_hat_keys = nullptr);
 // workspace: sized before a pipeline is enqueued (growing waits for the device and drops the captured graphs)
 int ensure_workspace(mldsa_ctx *, size_t bytes);
-size_t verify_workspace_bytes(const mldsa_params *, size_t n_ops, bool own_a);
+size_t verify_workspace_bytes(const mldsa_ctx *, const mldsa_params *, size_t n_ops, bool own_a);
 size_t sign_workspace_bytes(const mldsa_ctx *, const mldsa_params *, size_t n_ops, bool own_a);
-size_t keygen_workspace_bytes(const mldsa_params *, size_t n_keys);
+size_t keygen_workspace_bytes(const mldsa_ctx *, const mldsa_params *, size_t n_keys);
+// ensure_workspace for n_ops ops of MLDSA_OP_*; on MLDSA_ERR_NOMEM the context's pass size is halved and the request retried
+int reserve_workspace(mldsa_ctx *, const mldsa_params *, int op, size_t n_ops, bool own_a);
 // hipGraph replay of repeated call shapes: `key` = every value that ends up in a kernel parameter
 int run_op(mldsa_ctx *, hipStream_t, int op, size_t n_ops, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue);
 void drop_graphs(mldsa_ctx *);

@@ -393,7 +393,11 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
             rem -= take;
         }
     }
-    TRY(mldsa_reserve(ctx, set, MLDSA_OP_SIGN, std::min<size_t>(n_ops, 65536)));
+    {
+        size_t largest = 0;  // a sub-batch can be larger than `big` (rem <= big + tail goes as rem - tail)
+        for (size_t j = 0; j + 1 < cut.size(); j++) largest = std::max(largest, cut[j + 1] - cut[j]);
+        TRY(mldsa_reserve(ctx, set, MLDSA_OP_SIGN, largest));
+    }
     OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
     const bool pin_rnd = is_pinned(rnd), pin_sigs = is_pinned(sigs);
     // per-op status always comes back: MLDSA_ERR_AGAIN marks the (practically never) ops that need another pass
@@ -403,12 +407,9 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     const bool pin_st = status && is_pinned(status);
     int rc = MLDSA_OK;
     // the calls below cannot wait for the device, but an op they leave unfinished is signed again further down: plan the
-    // rounds like a synchronous call (three or four empty ~0.2 ms rounds less per sub-batch than the 1e-9 plan)
-    struct StopGuard {
-        mldsa_ctx *c; double old;
-        explicit StopGuard(mldsa_ctx *cc) : c(cc), old(cc->async_stop) { c->async_stop = 0.05; }
-        ~StopGuard() { c->async_stop = old; }
-    } stop_guard(ctx);
+    // rounds like a synchronous call (three or four empty ~0.2 ms rounds less per sub-batch than the 1e-9 plan).  Passed per
+    // call: the context's own threshold stays what mldsa_sign_async callers on other threads configured.
+    constexpr double HOST_PLAN_STOP = 0.05;
     // uploads of sub-batch i + 1 are submitted before the download of sub-batch i (copies are served in submission order,
     // see mldsa_verify_host): otherwise the next sub-batch's few KB of inputs sit behind 100 MB of signatures that are not
     // even signed yet, and signing waits for both
@@ -431,9 +432,9 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
         const uint8_t *mbase = sl.d_msgs - msg_off[a];
         const uint8_t *cbase = ctx_off ? sl.d_ctxs - ctx_off[a] : nullptr;
         const size_t kb = key_idx ? 0 : a;
-        TRY(mldsa_sign_async(ctx, set, mode, hs->k_rho.dev + kb * 32, hs->k_capk.dev + kb * 32, hs->k_tr.dev + kb * 64, s1 + kb * l * 256,
-                             s2 + kb * k * 256, t0 + kb * k * 256, n_keys - kb, sl.d_kidx, mbase, sl.d_moff, cbase, sl.d_coff,
-                             sl.rnd.dev, sl.out.dev, reinterpret_cast<int32_t *>(sl.status.dev), n, hs->comp));
+        TRY(sign_call(ctx, set, mode, hs->k_rho.dev + kb * 32, nullptr, hs->k_capk.dev + kb * 32, hs->k_tr.dev + kb * 64, s1 + kb * l * 256,
+                      s2 + kb * k * 256, t0 + kb * k * 256, n_keys - kb, sl.d_kidx, mbase, sl.d_moff, cbase, sl.d_coff, sl.rnd.dev,
+                      sl.out.dev, reinterpret_cast<int32_t *>(sl.status.dev), n, hs->comp, true, HOST_PLAN_STOP));
         HCHECK(hipEventRecord(sl.comp_done, hs->comp));
         HCHECK(hipStreamWaitEvent(hs->down, sl.comp_done, 0));
         TRY(download(sl, sl.out, sigs + a * sgl, n * sgl, pin_sigs, hs->down));

@@ -61,11 +61,11 @@ __device__ __forceinline__ Coef4 ld4(const int32_t* p, int u) {
 }
 
 // ------------------------------------------------------------------------------------
-// Fused tail of one rejection-loop iteration (ml_dsa.rs:243-336): ONE WAVE PER SLOT, looping over
-// the slot's polynomials, so there are no block barriers and no cross-wave reductions:
+// Fused tail of one rejection-loop iteration (ml_dsa.rs:243-336): ONE WAVE PER CANDIDATE, looping over
+// its polynomials, so there are no block barriers and no cross-wave reductions:
 //   z_j  = y_j + inv_ntt(c_hat o s1_hat_j)            ||z||  <  gamma1 - beta ?
 //   r_i  = w_i - inv_ntt(c_hat o s2_hat_i)            ||LowBits(r)|| < gamma2 - beta ?
-//   -- only if both hold (about 1 slot in 5):
+//   -- only if both hold (about 1 candidate in 5):
 //   ct0_i = inv_ntt(c_hat o t0_hat_i)                 ||ct0|| < gamma2 ?
 //   h_i  = MakeHint(-ct0_i, r_i + ct0_i)              weight(h) <= omega ?
 //   (ML-DSA-65 / 87: tau * 2^12 < gamma2, the ct0 test cannot fail, and h_i comes from ONE transform per row:
@@ -74,31 +74,223 @@ __device__ __forceinline__ Coef4 ld4(const int32_t* p, int u) {
 // (c_hat = ntt(c) comes from k_ntt.)  sigEncode (encodings.rs:238-276) is written EAGERLY while the
 // polynomials stream through: z bytes in stage 1, hint bytes in stage 2.  If the attempt is then
 // rejected the bytes are garbage, but the op's next attempt rewrites every byte, and only an
-// accepted attempt sets done[] / accept[] -- so the signature buffer of a finished op always holds
-// the accepted attempt.  The reference's two `continue` stages (ml_dsa.rs:280, 312) stay two stages;
-// stage 1 first transforms only the polynomials that CAN reject (flags from sign_w / ExpandMask, see
-// below), the more selective LowBits test first, and leaves at the first rejection: a rejected
-// ML-DSA-65 attempt costs about 1.5 of the 11 inverse NTTs of stage 1.
+// accepted attempt sets done[] -- so the signature buffer of a finished op always holds the accepted
+// attempt.  The reference's two `continue` stages (ml_dsa.rs:280, 312) stay two stages; stage 1 first
+// transforms only the polynomials that CAN reject (flags from sign_w / ExpandMask, see below), the more
+// selective LowBits test first, and leaves at the first rejection: a rejected ML-DSA-65 attempt costs
+// about 1.5 of the 11 inverse NTTs of stage 1.
+//
+// tail_attempt is that iteration for one candidate, in two forms:
+//   FULL  = the whole iteration with the signature bytes written to `sig` (k_sign_tail in rounds with one candidate
+//           per op, k_resolve for the winner of a speculative round);
+//   !FULL = the tests of the polynomials that can reject, nothing written (k_sign_tail in speculative rounds: most
+//           candidates are rejected, and of the survivors only the FIRST one of each op is ever needed, so bytes,
+//           the remaining z_j and the hint stage are left to k_resolve, which builds exactly one signature per op).
+struct TailPtrs {
+    const int32_t *c_hat, *y, *w;
+    const uint8_t* ctilde;
+    const int32_t *s1, *s2, *t0;
+};
+
+template <int K, int L, bool G2HI, bool FULL>
+__device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, size_t key, uint32_t r_risky, uint32_t z_risky,
+                                             bool s2_oor, uint8_t* sig, int32_t* xp, const LdsTw& itw, int lane, int gb, int beta,
+                                             int omega, int ctilde_len, int ct0_exact) {
+    constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
+    // ||c t0||inf <= tau * 2^12: below gamma2 = (q-1)/32 for ML-DSA-65 / 87 (200 704, 245 760 < 261 888), not for ML-DSA-44
+    constexpr bool CT0_CAN_FAIL = !G2HI;
+    const int32_t gamma1 = 1 << gb;
+    const int cb = gb + 1;
+    const int4 cv = reinterpret_cast<const int4*>(a.c_hat + slot * N)[lane];
+    if (FULL && lane < ctilde_len) sig[lane] = a.ctilde[slot * 64 + lane];
+    // ---- stage 1.  ||c s1||inf and ||c s2||inf are at most beta = tau * eta, so a polynomial of w whose
+    // LowBits all stay below gamma2 - 2 beta cannot fail ||LowBits(w - c s2)||inf < gamma2 - beta, and a
+    // polynomial of y below gamma1 - 2 beta cannot fail ||y + c s1||inf < gamma1 - beta (ml_dsa.rs:280; with
+    // |low| < gamma2 the decomposition of w - c s2 keeps the high part of w).  sign_w and ExpandMask flag the
+    // few polynomials that are NOT below those margins (about 1 in 3 of w, 1 in 6 of y for ML-DSA-65):
+    // pass 0 transforms only those -- the more selective LowBits test first -- and leaves at the first
+    // rejection; pass 1 (FULL) computes the remaining z_j for the attempts that survived (1 in 5), which
+    // need them for the signature bytes.
+    bool ok = true;  // wave-uniform
+    // work list of a pass: bit i < K = r_i (s2 / w), bit K + j = z_j (s1 / y), walked from the low end with the
+    // next polynomial's loads issued before the current inverse NTT
+    uint32_t todo = (1u << (K + L)) - 1u;
+    const uint32_t risky = (r_risky & ((1u << K) - 1u)) | (z_risky << K);
+    auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
+        const bool is_r = idx < K;
+        const int32_t* sp = is_r ? a.s2 + (key * K + idx) * (size_t)N : a.s1 + (key * L + (idx - K)) * (size_t)N;
+        const int32_t* xq = is_r ? a.w + (slot * K + idx) * (size_t)N : a.y + (slot * L + (idx - K)) * (size_t)N;
+        load_packed(v, sp, lane);
+        load_strided(x, xq, lane);
+    };
+#pragma unroll 1
+    for (int pass = 0; pass < (FULL ? 2 : 1) && ok; pass++) {
+        // pass 1 needs only the remaining z_j (signature bytes): stage 2 works from w itself
+        uint32_t work = pass == 0 ? (risky & todo) : (todo & ~((1u << K) - 1u));
+        todo &= ~work;
+        int cur = work ? __ffs((int)work) - 1 : -1;
+        int32_t nv[4] = {0, 0, 0, 0}, nx[4] = {0, 0, 0, 0};
+        if (cur >= 0) issue_loads(cur, nv, nx);
+#pragma unroll 1
+        while (cur >= 0) {
+            work &= work - 1u;
+            const int nxt = work ? __ffs((int)work) - 1 : -1;
+            const int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, x[4] = {nx[0], nx[1], nx[2], nx[3]};
+            if (nxt >= 0) issue_loads(nxt, nv, nx);
+            int32_t r[4];
+            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+            ntt_inv_wave(r, itw, lane, F_MONT);
+            bool bad = false;
+            if (cur < K) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int32_t rr = caddq(x[k] - r[k]);     // w - cs2, canonical (both operands are in [0, q))
+                    int32_t r1, r0;
+                    decompose<G2HI>(rr, r1, r0);
+                    bad |= (r0 < 0 ? -r0 : r0) >= GAMMA2 - beta;
+                }
+                if (__ballot(bad) != 0ull) { ok = false; break; }
+            } else {
+                const int j = cur - K;
+                int32_t zc4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // z mod+- q (ml_dsa.rs:264, 334): y in (-gamma1, gamma1], cs1 in [0, q), so one conditional
+                    // subtraction lands in (-q/2, q/2]
+                    const int32_t zs = x[k] + r[k];
+                    const int32_t zc = zs - ((((Q / 2) - zs) >> 31) & Q);
+                    zc4[k] = zc;
+                    bad |= (zc < 0 ? -zc : zc) >= gamma1 - beta;
+                }
+                if (__ballot(bad) != 0ull) { ok = false; break; }
+                if constexpr (FULL) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) xp[64 * k + lane] = zc4[k];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int4 z4 = reinterpret_cast<const int4*>(xp)[lane];
+                    const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
+                    uint64_t lo = 0;
+                    uint32_t hi = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {  // BitPack(z, gamma1 - 1, gamma1): field = gamma1 - z
+                        const uint64_t f = (uint64_t)(uint32_t)(gamma1 - zz[t]);
+                        const int sh = t * cb;
+                        lo |= f << sh;
+                        if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
+                    }
+                    const int nbytes = cb / 2;
+                    uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * cb) + (size_t)lane * nbytes;
+                    for (int t = 0; t < 8; t++) dst[t] = (uint8_t)(lo >> (8 * t));
+                    for (int t = 8; t < nbytes; t++) dst[t] = (uint8_t)(hi >> (8 * (t - 8)));
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            cur = nxt;
+        }
+    }
+    if constexpr (!FULL) return ok;
+    // ---- stage 2: ct0, hints (HintBitPack, conversion.rs:277-328, written as they are found)
+    if (ok) {
+        uint8_t* hy = sig + ctilde_len + (size_t)L * (32 * cb);
+        for (int i = lane; i < omega + K; i += 64) hy[i] = 0;
+        int32_t dmax = 0;  // ML-DSA-44: largest |centred coefficient| of the rows' transform outputs
+        int index = 0;     // running count of hints, wave-uniform
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+            // The attempt passed the LowBits test, hence HighBits(w - cs2) = HighBits(w) (what makes verification recover
+            // w1), and  h = [HighBits(w - cs2 + ct0) != HighBits(w)],  w - cs2 + ct0 = w + invNTT(c_hat o (t0_hat - s2_hat)):
+            // ONE inverse transform per row instead of the reference's two (cs2 and ct0).
+            int32_t v[4], v2[4], r[4], base[4];
+            load_packed(v, a.t0 + (key * K + i) * (size_t)N, lane);
+            load_packed(v2, a.s2 + (key * K + i) * (size_t)N, lane);
+            load_strided(base, a.w + (slot * K + i) * (size_t)N, lane);
+            if (s2_oor) {
+                // out-of-range s2: the identity is not guaranteed; r_i = w_i - c s2_i explicitly (it passed the LowBits
+                // test in stage 1, where every polynomial counted as risky), then r_i + c t0_i as the reference does
+                r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
+                ntt_inv_wave(r, itw, lane, F_MONT);
+#pragma unroll
+                for (int k = 0; k < 4; k++) base[k] = caddq(base[k] - r[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] -= v2[k];
+            }
+            r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+            ntt_inv_wave(r, itw, lane, F_MONT);  // ct0 - cs2 (ct0 for an out-of-range key), canonical
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if constexpr (CT0_CAN_FAIL) {
+                    int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);  // center_mod of a canonical value
+                    tc = tc < 0 ? -tc : tc;
+                    dmax = tc > dmax ? tc : dmax;
+                }
+                // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
+                int32_t a1, a0, b1, b0;
+                const int32_t sum = base[k] + r[k] - Q;  // both in [0, q)
+                decompose<G2HI>(caddq(sum), a1, a0);
+                decompose<G2HI>(base[k], b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q); same high part as w
+                const bool h = a1 != b1;
+                const unsigned long long mask = __ballot(h);
+                if (h) {
+                    const int rank = index + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (rank < omega) hy[rank] = (uint8_t)(64 * k + lane);
+                }
+                index += __popcll(mask);
+            }
+            if (lane == 0) hy[omega + i] = (uint8_t)(index < 255 ? index : 255);
+        }
+        ok = index <= omega;  // ml_dsa.rs:313-315
+        if constexpr (CT0_CAN_FAIL) {
+            // ||ct0||inf < gamma2 (ml_dsa.rs:312).  The rows gave d = ct0 - cs2 with ||cs2||inf <= beta, so max|d| + beta bounds
+            // it; an out-of-range key gave ct0 itself.  Only if that bound cannot decide (|d| within beta of gamma2: ~1e-7
+            // of the attempts) are the K transforms of ct0 proper spent.
+            auto wave_max = [](int32_t x) {
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const int32_t o = __shfl_xor(x, m);
+                    x = o > x ? o : x;
+                }
+                return x;
+            };
+            dmax = wave_max(dmax);
+            bool ct0_ok = dmax + (s2_oor ? 0 : beta) < GAMMA2;
+            if (!s2_oor && (!ct0_ok || ct0_exact)) {
+                int32_t tmax = 0;
+#pragma unroll 1
+                for (int i = 0; i < K; i++) {
+                    int32_t v[4], r[4];
+                    load_packed(v, a.t0 + (key * K + i) * (size_t)N, lane);
+                    r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+                    ntt_inv_wave(r, itw, lane, F_MONT);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);
+                        tc = tc < 0 ? -tc : tc;
+                        tmax = tc > tmax ? tc : tmax;
+                    }
+                }
+                ct0_ok = wave_max(tmax) < GAMMA2;
+            }
+            ok = ok && ct0_ok;
+        }
+    }
+    return ok;
+}
+
 template <int K, int L, bool G2HI>
 __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_sign_tail(
-    const int32_t* __restrict__ c_hat, const int32_t* __restrict__ y, const int32_t* __restrict__ w,
-    const uint8_t* __restrict__ ctilde, const uint32_t* __restrict__ slot_op, const uint32_t* __restrict__ key_idx,
-    const int32_t* __restrict__ s1, const int32_t* __restrict__ s2, const int32_t* __restrict__ t0,
+    TailPtrs a, const uint32_t* __restrict__ slot_op, const uint32_t* __restrict__ key_idx,
     uint16_t* __restrict__ kappa, int32_t* __restrict__ done, uint8_t* __restrict__ sigs,
-    const RoundCtl* __restrict__ ctl,
-    uint8_t* __restrict__ stage, size_t stage_stride, int32_t* __restrict__ accept, int gb, int beta, int omega,
+    const RoundCtl* __restrict__ ctl, int32_t* __restrict__ accept, int gb, int beta, int omega,
     int ctilde_len, size_t sig_len, const Twiddle* __restrict__ inv_tab,
     const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk, const uint8_t* __restrict__ key_oor, int oor_by_op,
     int ct0_exact) {
-    constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
-    // ||c t0||inf <= tau * 2^12: below gamma2 = (q-1)/32 for ML-DSA-65 / 87 (200 704, 245 760 < 261 888), not for ML-DSA-44
-    constexpr bool CT0_CAN_FAIL = !G2HI;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: slot indices and row pointers stay scalar
-    const int32_t gamma1 = 1 << gb;
-    const int cb = gb + 1;
     // slots and candidates per op of this round: written by k_make_slots (the host never sees them)
     const uint32_t n_slots32 = ctl->ns;
     const int spec = (int)ctl->spec;
@@ -109,7 +301,7 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
     const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES;
 
     // op / key of the next slot are fetched one slot ahead (two dependent loads off the critical path)
-    // ... and so are its risk flags (which polynomials stage 1 has to transform, see below)
+    // ... and so are its risk flags (which polynomials stage 1 has to transform)
     auto risk_flags = [&](uint32_t sl, uint32_t& rr, uint32_t& zr) {
         rr = wrisk ? (uint32_t)wrisk[sl] : (1u << K) - 1u;
         zr = (1u << L) - 1u;
@@ -138,183 +330,17 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
             risk_flags(slot32 + n_waves, rrisk_next, zrisk_next);
             oor_next = key_oor ? key_oor[oor_by_op ? op_next : key_next] : 0u;
         }
-        uint8_t* sig = spec == 1 ? sigs + op * sig_len : stage + slot * stage_stride;
-        const int4 cv = reinterpret_cast<const int4*>(c_hat + slot * N)[lane];
-        if (lane < ctilde_len) sig[lane] = ctilde[slot * 64 + lane];
-        // ---- stage 1.  ||c s1||inf and ||c s2||inf are at most beta = tau * eta, so a polynomial of w whose
-        // LowBits all stay below gamma2 - 2 beta cannot fail ||LowBits(w - c s2)||inf < gamma2 - beta, and a
-        // polynomial of y below gamma1 - 2 beta cannot fail ||y + c s1||inf < gamma1 - beta (ml_dsa.rs:280; with
-        // |low| < gamma2 the decomposition of w - c s2 keeps the high part of w).  sign_w and ExpandMask flag the
-        // few polynomials that are NOT below those margins (about 1 in 3 of w, 1 in 6 of y for ML-DSA-65):
-        // pass 0 transforms only those -- the more selective LowBits test first -- and leaves at the first
-        // rejection; pass 1 computes the remaining r_i and z_j for the attempts that survived (1 in 5), which
-        // need them for the hints and the signature bytes.
-        bool ok = true;  // wave-uniform
-        // work list of a pass: bit i < K = r_i (s2 / w), bit K + j = z_j (s1 / y), walked from the low end with the
-        // next polynomial's loads issued before the current inverse NTT
-        uint32_t todo = (1u << (K + L)) - 1u;
-        const uint32_t risky = (r_risky & ((1u << K) - 1u)) | (z_risky << K);
-        auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
-            const bool is_r = idx < K;
-            const int32_t* sp = is_r ? s2 + (key * K + idx) * (size_t)N : s1 + (key * L + (idx - K)) * (size_t)N;
-            const int32_t* xp = is_r ? w + (slot * K + idx) * (size_t)N : y + (slot * L + (idx - K)) * (size_t)N;
-            load_packed(v, sp, lane);
-            load_strided(x, xp, lane);
-        };
-#pragma unroll 1
-        for (int pass = 0; pass < 2 && ok; pass++) {
-            // pass 1 needs only the remaining z_j (signature bytes): stage 2 works from w itself
-            uint32_t work = pass == 0 ? (risky & todo) : (todo & ~((1u << K) - 1u));
-            todo &= ~work;
-            int cur = work ? __ffs((int)work) - 1 : -1;
-            int32_t nv[4] = {0, 0, 0, 0}, nx[4] = {0, 0, 0, 0};
-            if (cur >= 0) issue_loads(cur, nv, nx);
-#pragma unroll 1
-            while (cur >= 0) {
-                work &= work - 1u;
-                const int nxt = work ? __ffs((int)work) - 1 : -1;
-                const int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, x[4] = {nx[0], nx[1], nx[2], nx[3]};
-                if (nxt >= 0) issue_loads(nxt, nv, nx);
-                int32_t r[4];
-                r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-                ntt_inv_wave(r, itw, lane, F_MONT);
-                bool bad = false;
-                if (cur < K) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int32_t rr = caddq(x[k] - r[k]);     // w - cs2, canonical (both operands are in [0, q))
-                        int32_t r1, r0;
-                        decompose<G2HI>(rr, r1, r0);
-                        bad |= (r0 < 0 ? -r0 : r0) >= GAMMA2 - beta;
-                    }
-                    if (__ballot(bad) != 0ull) { ok = false; break; }
-                } else {
-                    const int j = cur - K;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        // z mod+- q (ml_dsa.rs:264, 334): y in (-gamma1, gamma1], cs1 in [0, q), so one conditional
-                        // subtraction lands in (-q/2, q/2]
-                        const int32_t zs = x[k] + r[k];
-                        const int32_t zc = zs - ((((Q / 2) - zs) >> 31) & Q);
-                        xpose[wave][64 * k + lane] = zc;
-                        bad |= (zc < 0 ? -zc : zc) >= gamma1 - beta;
-                    }
-                    if (__ballot(bad) != 0ull) { ok = false; break; }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int4 z4 = reinterpret_cast<const int4*>(&xpose[wave][0])[lane];
-                    const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
-                    uint64_t lo = 0;
-                    uint32_t hi = 0;
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {  // BitPack(z, gamma1 - 1, gamma1): field = gamma1 - z
-                        const uint64_t f = (uint64_t)(uint32_t)(gamma1 - zz[t]);
-                        const int sh = t * cb;
-                        lo |= f << sh;
-                        if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
-                    }
-                    const int nbytes = cb / 2;
-                    uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * cb) + (size_t)lane * nbytes;
-                    for (int t = 0; t < 8; t++) dst[t] = (uint8_t)(lo >> (8 * t));
-                    for (int t = 8; t < nbytes; t++) dst[t] = (uint8_t)(hi >> (8 * (t - 8)));
-                    __builtin_amdgcn_wave_barrier();
-                }
-                cur = nxt;
-            }
-        }
-        // ---- stage 2: ct0, hints (HintBitPack, conversion.rs:277-328, written as they are found)
-        if (ok) {
-            uint8_t* hy = sig + ctilde_len + (size_t)L * (32 * cb);
-            for (int i = lane; i < omega + K; i += 64) hy[i] = 0;
-            int32_t dmax = 0;  // ML-DSA-44: largest |centred coefficient| of the rows' transform outputs
-            int index = 0;     // running count of hints, wave-uniform
-#pragma unroll 1
-            for (int i = 0; i < K; i++) {
-                // The attempt passed the LowBits test, hence HighBits(w - cs2) = HighBits(w) (what makes verification recover
-                // w1), and  h = [HighBits(w - cs2 + ct0) != HighBits(w)],  w - cs2 + ct0 = w + invNTT(c_hat o (t0_hat - s2_hat)):
-                // ONE inverse transform per row instead of the reference's two (cs2 and ct0).
-                int32_t v[4], v2[4], r[4], base[4];
-                load_packed(v, t0 + (key * K + i) * (size_t)N, lane);
-                load_packed(v2, s2 + (key * K + i) * (size_t)N, lane);
-                load_strided(base, w + (slot * K + i) * (size_t)N, lane);
-                if (s2_oor) {
-                    // out-of-range s2: the identity is not guaranteed; r_i = w_i - c s2_i explicitly (it passed the LowBits
-                    // test in stage 1, where every polynomial counted as risky), then r_i + c t0_i as the reference does
-                    r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
-                    ntt_inv_wave(r, itw, lane, F_MONT);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) base[k] = caddq(base[k] - r[k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) v[k] -= v2[k];
-                }
-                r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-                ntt_inv_wave(r, itw, lane, F_MONT);  // ct0 - cs2 (ct0 for an out-of-range key), canonical
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if constexpr (CT0_CAN_FAIL) {
-                        int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);  // center_mod of a canonical value
-                        tc = tc < 0 ? -tc : tc;
-                        dmax = tc > dmax ? tc : dmax;
-                    }
-                    // make_hint(Q - ct0, partial_reduce32(w - cs2 + ct0)), ml_dsa.rs:298-306
-                    int32_t a1, a0, b1, b0;
-                    const int32_t sum = base[k] + r[k] - Q;  // both in [0, q)
-                    decompose<G2HI>(caddq(sum), a1, a0);
-                    decompose<G2HI>(base[k], b1, b0);  // (w - cs2 + ct0) + (Q - ct0) = w - cs2 (mod q); same high part as w
-                    const bool h = a1 != b1;
-                    const unsigned long long mask = __ballot(h);
-                    if (h) {
-                        const int rank = index + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (rank < omega) hy[rank] = (uint8_t)(64 * k + lane);
-                    }
-                    index += __popcll(mask);
-                }
-                if (lane == 0) hy[omega + i] = (uint8_t)(index < 255 ? index : 255);
-            }
-            ok = index <= omega;  // ml_dsa.rs:313-315
-            if constexpr (CT0_CAN_FAIL) {
-                // ||ct0||inf < gamma2 (ml_dsa.rs:312).  The rows gave d = ct0 - cs2 with ||cs2||inf <= beta, so max|d| + beta bounds
-                // it; an out-of-range key gave ct0 itself.  Only if that bound cannot decide (|d| within beta of gamma2: ~1e-7
-                // of the attempts) are the K transforms of ct0 proper spent.
-                auto wave_max = [](int32_t x) {
-#pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) {
-                        const int32_t o = __shfl_xor(x, m);
-                        x = o > x ? o : x;
-                    }
-                    return x;
-                };
-                dmax = wave_max(dmax);
-                bool ct0_ok = dmax + (s2_oor ? 0 : beta) < GAMMA2;
-                if (!s2_oor && (!ct0_ok || ct0_exact)) {
-                    int32_t tmax = 0;
-#pragma unroll 1
-                    for (int i = 0; i < K; i++) {
-                        int32_t v[4], r[4];
-                        load_packed(v, t0 + (key * K + i) * (size_t)N, lane);
-                        r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
-                        ntt_inv_wave(r, itw, lane, F_MONT);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);
-                            tc = tc < 0 ? -tc : tc;
-                            tmax = tc > tmax ? tc : tmax;
-                        }
-                    }
-                    ct0_ok = wave_max(tmax) < GAMMA2;
-                }
-                ok = ok && ct0_ok;
-            }
-        }
-        if (lane == 0) {
-            if (spec == 1) {
+        if (spec == 1) {
+            const bool ok = tail_attempt<K, L, G2HI, true>(a, slot, key, r_risky, z_risky, s2_oor, sigs + op * sig_len, xpose[wave], itw,
+                                                           lane, gb, beta, omega, ctilde_len, ct0_exact);
+            if (lane == 0) {
                 if (ok) done[op] = 1;
                 else kappa[op] = (uint16_t)(kappa[op] + L);  // ml_dsa.rs:281 / 316
-            } else {
-                accept[slot] = ok ? 1 : 0;
             }
+        } else {
+            const bool ok = tail_attempt<K, L, G2HI, false>(a, slot, key, r_risky, z_risky, s2_oor, nullptr, xpose[wave], itw, lane, gb,
+                                                            beta, omega, ctilde_len, ct0_exact);
+            if (lane == 0) accept[slot] = ok ? 1 : 0;
         }
     }
 }
@@ -361,48 +387,46 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
     }
 }
 
-// One 256-thread block per unfinished op: the first wave finds the first accepted candidate, all four copy its staged
-// signature (16-byte aligned rows) to the op's slot of `sigs` (any alignment: SIG_LEN is odd) as dwords assembled from
-// two aligned source words.
-__global__ __launch_bounds__(256) void k_resolve(const RoundCtl* __restrict__ ctl, const uint32_t* __restrict__ act,
-                                                 const int32_t* __restrict__ accept,
-                                                 const uint8_t* __restrict__ stage, size_t stage_stride,
-                                                 uint8_t* __restrict__ sigs, size_t sig_len, int32_t* __restrict__ done,
-                                                 uint16_t* __restrict__ kappa, int l) {
-    __shared__ int winner;
+// Speculative rounds, second half: one wave per unfinished op.  accept[] holds the verdict of stage 1 for each of the op's
+// candidates; the wave takes the FIRST survivor -- the candidate the sequential loop of ml_dsa.rs:212-330 would have reached --
+// and runs the whole iteration for it with the bytes going straight to the op's signature (tail_attempt<FULL>: all z_j, the
+// hint stage).  Should the hint stage reject it (weight(h) > omega, about 1 %), the next survivor is tried, as the loop would.
+template <int K, int L, bool G2HI>
+__global__ __launch_bounds__(64 * GWAVES) void k_resolve(const RoundCtl* __restrict__ ctl, const uint32_t* __restrict__ act,
+                                                         const int32_t* __restrict__ accept, TailPtrs a,
+                                                         const uint32_t* __restrict__ key_idx, uint8_t* __restrict__ sigs, size_t sig_len,
+                                                         int32_t* __restrict__ done, uint16_t* __restrict__ kappa, int gb, int beta,
+                                                         int omega, int ctilde_len, const Twiddle* __restrict__ inv_tab,
+                                                         const uint8_t* __restrict__ key_oor, int oor_by_op, int ct0_exact) {
+    __shared__ Twiddle tw_lds[INV_TW * 64];
+    __shared__ int32_t xpose[GWAVES][N];
     const int spec = (int)ctl->spec;
-    if (spec == 1) return;  // sign_tail wrote done[] / kappa[] / the signature itself
+    if (spec == 1) return;  // k_sign_tail wrote done[] / kappa[] / the signature itself
     const uint32_t m = ctl->m;
-    const int tid = threadIdx.x;
-    for (uint32_t i = blockIdx.x; i < m; i += gridDim.x) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = inv_tab[i];
+    __syncthreads();
+    const LdsTw itw{tw_lds, lane};
+    const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES;
+    for (uint32_t i = wid; i < m; i += n_waves) {
         const uint32_t op = act[i];
-        if (tid < 64) {
-            const int mine = tid < spec ? accept[(size_t)i * spec + tid] : 0;
-            const unsigned long long mask = __ballot(mine != 0);
-            if (tid == 0) winner = mask ? __ffsll((long long)mask) - 1 : -1;
+        const size_t key = key_idx ? key_idx[op] : op;
+        const bool s2_oor = key_oor ? key_oor[oor_by_op ? op : key] != 0 : false;
+        const int mine = lane < spec ? accept[(size_t)i * spec + lane] : 0;
+        unsigned long long mask = __ballot(mine != 0);
+        bool fin = false;
+        while (mask && !fin) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            // every z_j is wanted (bytes); the r_i were tested by k_sign_tail and are not needed on their own
+            fin = tail_attempt<K, L, G2HI, true>(a, (size_t)i * spec + j, key, 0u, (1u << L) - 1u, s2_oor, sigs + (size_t)op * sig_len,
+                                                 xpose[wave], itw, lane, gb, beta, omega, ctilde_len, ct0_exact);
         }
-        __syncthreads();
-        const int j = winner;
-        __syncthreads();  // everyone has read `winner` before the next op's first wave overwrites it
-        if (j < 0) {
-            if (tid == 0) kappa[op] = (uint16_t)(kappa[op] + spec * l);
-            continue;
+        if (lane == 0) {
+            if (fin) done[op] = 1;
+            else kappa[op] = (uint16_t)(kappa[op] + spec * L);
         }
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(stage + ((size_t)i * spec + j) * stage_stride);
-        uint8_t* dst = sigs + (size_t)op * sig_len;
-        const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);  // bytes until dst is dword aligned
-        const int n_dw = (int)((sig_len - head) / 4);
-        uint32_t* dst4 = reinterpret_cast<uint32_t*>(dst + head);
-        for (int d = tid; d < n_dw; d += 256) {
-            // bytes head + 4 d .. + 3 of the source row: words d and d + 1 funnel-shifted (the row is padded to 16 bytes)
-            const uint32_t lo = src[d], hi = src[d + 1];
-            dst4[d] = head ? __builtin_amdgcn_alignbit(hi, lo, 8 * head) : lo;
-        }
-        const uint8_t* srcb = reinterpret_cast<const uint8_t*>(src);
-        if (tid < head) dst[tid] = srcb[tid];
-        const int tail0 = head + 4 * n_dw;
-        if (tid < (int)sig_len - tail0) dst[tail0 + tid] = srcb[tail0 + tid];
-        if (tid == 0) done[op] = 1;
     }
 }
 
@@ -417,10 +441,12 @@ __global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int
 }
 
 // first active list: every op except those whose ctx is too long (lib.rs:274) or whose key index is out of
-// range (bad: 0 = fine, 1 = ctx too long, 2 = bad key index).  ctl must be zeroed beforehand.
+// range (bad: 0 = fine, 1 = ctx too long, 2 = bad key index); a refused op gets an all-zero signature (the signature buffer
+// as a whole is NOT cleared: every other op's bytes are written by its accepted attempt).  ctl must be zeroed beforehand.
 __global__ __launch_bounds__(256) void k_init_active(size_t n, const int32_t* __restrict__ bad_op, int32_t* __restrict__ done,
                                                      uint16_t* __restrict__ kappa, int32_t* __restrict__ status,
-                                                     uint32_t* __restrict__ act_out, RoundCtl* __restrict__ ctl) {
+                                                     uint32_t* __restrict__ act_out, RoundCtl* __restrict__ ctl,
+                                                     uint8_t* __restrict__ sigs, size_t sig_len) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     kappa[i] = 0;  // ml_dsa.rs:204
@@ -428,6 +454,8 @@ __global__ __launch_bounds__(256) void k_init_active(size_t n, const int32_t* __
     done[i] = bad;
     if (status) status[i] = bad == 0 ? MLDSA_OK : bad == 1 ? MLDSA_ERR_CTX_LEN : MLDSA_ERR_PARAM;
     if (!bad) act_out[atomicAdd(&ctl->cnt[0], 1u)] = (uint32_t)i;
+    else
+        for (size_t b = 0; b < sig_len; b++) sigs[i * sig_len + b] = 0;  // rare: one thread per refused op
 }
 
 // mldsa_sign_async: ops that are still unfinished after the enqueued rounds (parity = rounds & 1) get status
@@ -682,15 +710,15 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
 
 int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde,
                      const uint32_t* slot_op, const uint32_t* key_idx, const int32_t* s1, const int32_t* s2, const int32_t* t0,
-                     uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, uint8_t* stage, size_t stage_stride,
-                     int32_t* accept, size_t slots_hint, hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk,
-                     const uint8_t* key_oor, int oor_by_op) {
+                     uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, int32_t* accept, size_t slots_hint,
+                     hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk, const uint8_t* key_oor, int oor_by_op) {
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
+    const TailPtrs a{c, y, w, ctilde, s1, s2, t0};
     dim3 grid(grid_for(ctx, slots_hint, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
-#define MLDSA_TAIL(KK, LL, G2)                                                                                              \
-    hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, c, y, w, ctilde, slot_op, key_idx, s1, s2, t0, kappa, \
-                       done, sigs, ctl, stage, stage_stride, accept, gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len,   \
-                       ctx->d_inv_tw, wrisk, yrisk, key_oor, oor_by_op, (int)ctx->opt_ct0_exact)
+#define MLDSA_TAIL(KK, LL, G2)                                                                                                    \
+    hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, a, slot_op, key_idx, kappa, done, sigs, ctl, accept, \
+                       gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len, ctx->d_inv_tw, wrisk, yrisk, key_oor, oor_by_op,  \
+                       (int)ctx->opt_ct0_exact)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_TAIL(6, 5, true);
     else MLDSA_TAIL(8, 7, true);
@@ -719,11 +747,20 @@ int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_targe
     return MLDSA_OK;
 }
 
-int launch_resolve(mldsa_ctx*, const mldsa_params* p, const RoundCtl* ctl, const uint32_t* act, const int32_t* accept,
-                   const uint8_t* stage, size_t stage_stride, uint8_t* sigs, int32_t* done, uint16_t* kappa, size_t ops_hint,
-                   hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)(ops_hint ? ops_hint : 1)), dim3(256), 0, s, ctl, act, accept, stage, stage_stride, sigs,
-                       (size_t)p->sig_len, done, kappa, p->l);
+int launch_resolve(mldsa_ctx* ctx, const mldsa_params* p, const RoundCtl* ctl, const uint32_t* act, const int32_t* accept,
+                   const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde, const uint32_t* key_idx,
+                   const int32_t* s1, const int32_t* s2, const int32_t* t0, uint8_t* sigs, int32_t* done, uint16_t* kappa,
+                   size_t ops_hint, hipStream_t s, const uint8_t* key_oor, int oor_by_op) {
+    const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
+    const TailPtrs a{c, y, w, ctilde, s1, s2, t0};
+    dim3 grid(grid_for(ctx, ops_hint, GWAVES, 8));
+#define MLDSA_RES(KK, LL, G2)                                                                                                      \
+    hipLaunchKernelGGL((k_resolve<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, ctl, act, accept, a, key_idx, sigs, (size_t)p->sig_len, \
+                       done, kappa, gb, p->beta, p->omega, p->ctilde_len, ctx->d_inv_tw, key_oor, oor_by_op, (int)ctx->opt_ct0_exact)
+    if (p->set == MLDSA_44) MLDSA_RES(4, 4, false);
+    else if (p->set == MLDSA_65) MLDSA_RES(6, 5, true);
+    else MLDSA_RES(8, 7, true);
+#undef MLDSA_RES
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
@@ -736,9 +773,9 @@ int launch_compact(mldsa_ctx*, RoundCtl* ctl, int parity, const uint32_t* act_in
 }
 
 int launch_init_active(mldsa_ctx*, size_t n, const int32_t* bad_op, int32_t* done, uint16_t* kappa, int32_t* status,
-                       uint32_t* act_out, RoundCtl* ctl, hipStream_t s) {
+                       uint32_t* act_out, RoundCtl* ctl, uint8_t* sigs, size_t sig_len, hipStream_t s) {
     if (n == 0) return MLDSA_OK;
-    hipLaunchKernelGGL(k_init_active, dim3(blocks256(n)), dim3(256), 0, s, n, bad_op, done, kappa, status, act_out, ctl);
+    hipLaunchKernelGGL(k_init_active, dim3(blocks256(n)), dim3(256), 0, s, n, bad_op, done, kappa, status, act_out, ctl, sigs, sig_len);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

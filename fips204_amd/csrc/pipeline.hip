@@ -22,7 +22,25 @@ namespace mldsa {
 
 // verify / keygen ops resident per pass: 131 072 instead of 65 536 is +0.8 / +3 / +6.5 % for ML-DSA-87 / 65 / 44 on calls of
 // that size or more (the lane-per-op hash and mu kernels run two waves per SIMD instead of one; half as many launch tails)
-constexpr size_t CHUNK_OPS = 131072;
+// (the default of mldsa_ctx::pass_ops: a context whose device cannot hold that workspace halves it, reserve_workspace)
+// MLDSA_OPT_GRAPHS = 1 replays signing calls of up to this many ops (run_op)
+constexpr size_t GRAPH_AUTO_MAX_OPS = 16384;
+
+// Workspace for `n_ops` ops of operation `op`.  The pass sizes above are tuned for a whole MI355X (a 262 144-op ML-DSA-87 signing
+// pass takes 15 GB of the 288); on a device that cannot give that much -- smaller, partitioned, or shared with other work --
+// the context falls back to smaller passes (more of them per call, results identical) instead of failing the call.
+int reserve_workspace(mldsa_ctx *ctx, const mldsa_params *p, int op, size_t n_ops, bool own_a) {
+    for (;;) {
+        const size_t bytes = op == MLDSA_OP_SIGN ? sign_workspace_bytes(ctx, p, n_ops, own_a)
+                             : op == MLDSA_OP_VERIFY ? verify_workspace_bytes(ctx, p, n_ops, own_a)
+                                                     : keygen_workspace_bytes(ctx, p, n_ops);
+        const int rc = ensure_workspace(ctx, bytes);
+        size_t &pass = op == MLDSA_OP_SIGN ? ctx->pass_ops_sign : ctx->pass_ops;
+        if (rc != MLDSA_ERR_NOMEM || pass <= 1024 || n_ops <= pass / 2) return rc;
+        pass /= 2;
+        ctx->stats.workspace_shrinks++;
+    }
+}
 
 int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return MLDSA_OK;
@@ -79,8 +97,8 @@ struct VerifyWs {
 #define TRY(expr) do { int _rc = (expr); if (_rc != MLDSA_OK) return _rc; } while (0)
 #define STAGE(name, expr) do { ProfScope _ps(ctx, s, name); TRY(expr); } while (0)
 
-size_t verify_workspace_bytes(const mldsa_params *p, size_t n_ops, bool own_a) {
-    return VerifyWs(nullptr, p, n_ops < CHUNK_OPS ? n_ops : CHUNK_OPS, own_a).bytes;
+size_t verify_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a) {
+    return VerifyWs(nullptr, p, std::min(n_ops, ctx->pass_ops), own_a).bytes;
 }
 
 // verify_internal (ml_dsa.rs:351-437) for n_ops independent (key, message, signature) triples
@@ -91,7 +109,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "verify: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
-    const size_t chunk = n_ops < CHUNK_OPS ? n_ops : CHUNK_OPS;
+    const size_t chunk = std::min(n_ops, ctx->pass_ops);
     if (ctx->ws_bytes < VerifyWs(nullptr, p, chunk, a_hat_keys == nullptr).bytes)
         return set_error(MLDSA_ERR_NOMEM, "verify: workspace not reserved");
     const size_t mw = (size_t)(64 + p->w1_len);
@@ -220,15 +238,15 @@ struct KeygenWs {
 };
 }  // namespace
 
-size_t keygen_workspace_bytes(const mldsa_params *p, size_t n_keys) {
-    return KeygenWs(nullptr, p, n_keys < CHUNK_OPS ? n_keys : CHUNK_OPS).bytes;
+size_t keygen_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_keys) {
+    return KeygenWs(nullptr, p, std::min(n_keys, ctx->pass_ops)).bytes;
 }
 
 int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys, hipStream_t s) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "keygen: unknown parameter set");
     if (n_keys == 0) return MLDSA_OK;
-    const size_t chunk = n_keys < CHUNK_OPS ? n_keys : CHUNK_OPS;
+    const size_t chunk = std::min(n_keys, ctx->pass_ops);
     if (ctx->ws_bytes < KeygenWs(nullptr, p, chunk).bytes) return set_error(MLDSA_ERR_NOMEM, "keygen: workspace not reserved");
     const size_t pkl = (size_t)p->pk_len, skl = (size_t)p->sk_len;
     KeygenWs w(ctx->ws, p, chunk);
@@ -260,7 +278,7 @@ int get_public_key_batch(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "get_public_key: unknown parameter set");
     if (n_keys == 0) return MLDSA_OK;
-    const size_t chunk = n_keys < CHUNK_OPS ? n_keys : CHUNK_OPS;
+    const size_t chunk = std::min(n_keys, ctx->pass_ops);
     if (ctx->ws_bytes < KeygenWs(nullptr, p, chunk).bytes) return set_error(MLDSA_ERR_NOMEM, "get_public_key: workspace not reserved");
     KeygenWs w(ctx->ws, p, chunk);
     const int k = p->k, l = p->l;
@@ -293,21 +311,20 @@ namespace {
 // sign ops resident per pass (workspace size).  The rounds' fixed costs (the lane-per-slot hash / SampleInBall at one wave per
 // SIMD, launch tails) are paid per pass, so a larger pass signs faster: 7.7 M/s at 65 536 ops, 8.6 M/s at 131 072, 9.1 M/s at
 // 262 144 (ML-DSA-65; the workspace of a 262 144-op ML-DSA-87 pass is 15 GB of the 288)
-constexpr size_t SIGN_CHUNK_OPS = 262144;
+// = the default of mldsa_ctx::pass_ops_sign
 
 struct SignWs {
     int32_t *a_hat, *y, *w, *c, *done, *bad_op, *key_bad, *accept;
-    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *stage, *wrisk, *yrisk, *key_oor;
+    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk, *key_oor;
     uint16_t *kappa, *slot_kappa;
     uint32_t *act[2], *slot_op, *slot_key, *kidx;
     RoundCtl *ctl;
-    size_t bytes = 0, stage_stride = 0;
+    size_t bytes = 0;
     uint8_t *base = nullptr;
     SignWs() = default;
     // n = ops of the chunk, ns = most candidate slots of a round
     SignWs(void *base_, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat) : base(static_cast<uint8_t *>(base_)) {
         Carver cv(base_);
-        stage_stride = ((size_t)p->sig_len + 15) & ~(size_t)15;
         a_hat = cv.take<int32_t>(own_a_hat ? n * (size_t)(p->k * p->l) * N : 0);
         key_bad = cv.take<int32_t>(n);
         kidx = cv.take<uint32_t>(n);
@@ -324,7 +341,6 @@ struct SignWs {
         wrisk = cv.take<uint8_t>(ns);
         yrisk = cv.take<uint8_t>(ns * (size_t)p->l);
         key_oor = cv.take<uint8_t>(n);  // per key of the table, or per op when the table is larger than the chunk
-        stage = cv.take<uint8_t>(ns * stage_stride);
         kappa = cv.take<uint16_t>(n);
         slot_kappa = cv.take<uint16_t>(ns);
         act[0] = cv.take<uint32_t>(n);
@@ -349,7 +365,7 @@ struct SignPlan {
     std::vector<size_t> m_hint, ns_hint;  // per round: ops / slots the grids are sized for
 };
 
-SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode) {
+SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, double plan_stop = 0.0) {
     SignPlan pl;
     pl.spec_max = (uint32_t)ctx->opt_spec_max;
     // a small batch cannot fill the target however many candidates each op gets: cap it so that the
@@ -362,7 +378,7 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode) {
     // a synchronous call looks at the device once anyway and adds rounds if an op is left, so its plan stops when that is
     // unlikely (< 5 % of the calls: a planned round for 0.002 expected ops costs every call the ~0.2 ms latency chain of an
     // empty round, two extra rounds cost the rare call ~0.5 ms); an asynchronous call cannot look, and plans until < 1e-9
-    const double stop = async_mode ? ctx->async_stop : 0.05;
+    const double stop = plan_stop > 0.0 ? plan_stop : async_mode ? ctx->async_stop : 0.05;
     for (int r = 0; r < 64 && m > stop; r++) {
         // grids follow mean + 6 sigma of the binomial count (a round that still finds more just loops)
         const double m_hi = std::min((double)n, m + 6.0 * std::sqrt(m) + 1.0);
@@ -389,7 +405,7 @@ static int sign_lanes_for(const mldsa_ctx *ctx, size_t chunk) { return (ctx->opt
 static size_t lane_ops(size_t chunk, int n_lanes) { return n_lanes == 1 ? chunk : ((chunk + 1) / 2 + 255) & ~(size_t)255; }
 
 size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a) {
-    const size_t chunk = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
+    const size_t chunk = std::min(n_ops, ctx->pass_ops_sign);
     const int n_lanes = sign_lanes_for(ctx, chunk);
     const size_t n = lane_ops(chunk, n_lanes);
     return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a).bytes;
@@ -417,11 +433,13 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     // 17: c_hat <- NTT(c), in place                                   :240
     STAGE("ntt_c", launch_ntt(ctx, w.c, w.c, ns_hint, s, ns_dev));
     // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
-    STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.stage,
-                                        w.stage_stride, w.accept, ns_hint, s, w.wrisk, w.yrisk, w.key_oor, oor_by_op ? 1 : 0));
-    // speculative rounds only (the kernel leaves at once when the device chose one candidate per op)
-    STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.stage, w.stage_stride, sg, w.done, w.kappa,
-                                    std::min<size_t>(m_hint, 4096), s));
+    // (in a speculative round: only the tests that can reject, one verdict per candidate)
+    STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
+                                        ns_hint, s, w.wrisk, w.yrisk, w.key_oor, oor_by_op ? 1 : 0));
+    // speculative rounds only (the kernel leaves at once when the device chose one candidate per op): the whole iteration
+    // for each op's first surviving candidate, bytes straight into the op's signature
+    STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, w.y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
+                                    m_hint, s, w.key_oor, oor_by_op ? 1 : 0));
     STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s));
     return MLDSA_OK;
 }
@@ -486,10 +504,18 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     }
     const ChunkKeys c = chunk_keys(p, w, a);
     const size_t key_base = a.key_idx ? 0 : o;
-    TRY(launch_zero(ctx, c.sg, n * (size_t)p->sig_len, s));
-    TRY(launch_zero(ctx, w.ctl, sizeof(RoundCtl), s));
     // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
     if (own_a) STAGE("expand_a", launch_expand_a(ctx, a.set, a.rho + key_base * 32, 32, c.kidx, w.a_hat, n, s, true));
+    // the previous signing call may still be clearing its secrets on a helper stream (sign_batch): ExpandA (public, below the
+    // cleared span) was allowed to start beside it, everything from here on writes into that span
+    if (ctx->zero_wait_after_ea) {
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
+        ctx->zero_wait_after_ea = false;
+        ctx->zero_pending = false;
+    }
+    // the signature buffer is not cleared: every op's bytes come from its accepted attempt, a refused op (k_init_active) or
+    // one an asynchronous call leaves unfinished (k_mark_unfinished) gets its zeros there
+    TRY(launch_zero(ctx, w.ctl, sizeof(RoundCtl), s));
     // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
     STAGE("mu", launch_mu(ctx, a.tr + key_base * 64, 64, c.kidx, a.mode, a.msgs, a.msg_off + o, a.ctxs, a.ctx_off ? a.ctx_off + o : nullptr,
                           w.rnd_mu + 32, 96, w.bad_op, n, s, key_bad));
@@ -506,7 +532,7 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
         TRY(launch_key_range(ctx, p, c.s2k, by_op ? c.kidx : nullptr, units, w.key_oor, s));
     }
     // 8: kappa <- 0; active = all ops with a legal ctx and key index
-    TRY(launch_init_active(ctx, n, w.bad_op, w.done, w.kappa, st, w.act[0], w.ctl, s));
+    TRY(launch_init_active(ctx, n, w.bad_op, w.done, w.kappa, st, w.act[0], w.ctl, c.sg, (size_t)p->sig_len, s));
     return MLDSA_OK;
 }
 
@@ -591,18 +617,41 @@ int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl,
 
 }  // namespace
 
+// would run_op replay / capture this call (then nothing may be waited for in the middle of its enqueue function)?
+static bool op_uses_graph(const mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return true;
+    if (ctx->prof_on) return false;
+    return ctx->opt_graphs == 2 || (ctx->opt_graphs == 1 && op == MLDSA_OP_SIGN && n_ops <= GRAPH_AUTO_MAX_OPS);
+}
+
+int wait_zeroise(mldsa_ctx *ctx, hipStream_t s) {
+    if (!ctx->zero_pending) return MLDSA_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        // the caller is capturing `s` into a graph of its own: an event recorded outside the capture cannot become a
+        // dependency of it, so the (sub-millisecond) clearing is waited for on the host
+        if (hipEventQuery(ctx->zero_ev) != hipSuccess) MLDSA_HIP_CHECK(hipEventSynchronize(ctx->zero_ev));
+    } else {
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
+    }
+    ctx->zero_pending = false;
+    return MLDSA_OK;
+}
+
 int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr,
                const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx,
                const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd,
-               uint8_t *sigs, int32_t *status, size_t n_ops, hipStream_t s, const int32_t *a_hat_keys, bool async_mode) {
+               uint8_t *sigs, int32_t *status, size_t n_ops, hipStream_t s, const int32_t *a_hat_keys, bool async_mode,
+               double plan_stop) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sign: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
     const bool own_a = a_hat_keys == nullptr;
-    const size_t chunk = n_ops < SIGN_CHUNK_OPS ? n_ops : SIGN_CHUNK_OPS;
+    const size_t chunk = std::min(n_ops, ctx->pass_ops_sign);
     const int n_lanes = sign_lanes_for(ctx, chunk);
     const size_t per_lane = lane_ops(chunk, n_lanes);
-    const SignPlan pl = plan_sign(ctx, set, per_lane, async_mode);
+    const SignPlan pl = plan_sign(ctx, set, per_lane, async_mode, plan_stop);
     SignLane lanes[2];
     size_t ws_off = 0;
     for (int i = 0; i < n_lanes; i++) {
@@ -610,6 +659,15 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         ws_off += lanes[i].w.bytes;
     }
     if (ctx->ws_bytes < ws_off) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
+    if (ctx->zero_pending) {
+        // The previous synchronous call is (perhaps) still clearing its secrets on a helper stream.  This call's ExpandA may run
+        // beside that -- one is integer-issue-bound, the other a stream of stores -- when it is launched directly on one lane
+        // and everything the prologue touches before its wait (A_hat, the key-index scratch) lies below the span being cleared.
+        const size_t public_end = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
+        const bool defer = own_a && n_lanes == 1 && !op_uses_graph(ctx, s, MLDSA_OP_SIGN, chunk) && public_end <= ctx->zero_lo;
+        if (defer) ctx->zero_wait_after_ea = true;
+        else TRY(wait_zeroise(ctx, s));
+    }
     ctx->last_sign_slots = 0;
     int rc = MLDSA_OK;
     for (size_t o = 0; o < n_ops && rc == MLDSA_OK; o += chunk) {
@@ -633,9 +691,26 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         rc = run_op(ctx, s, MLDSA_OP_SIGN, n_chunk, &key, sizeof(key), [&](hipStream_t st) { return sign_chunk_enqueue(ctx, p, pl, lanes, live, st); });
         if (rc == MLDSA_OK && !async_mode) rc = sign_chunk_finish(ctx, p, pl, lanes, live, s);
     }
-    if (!async_mode || rc != MLDSA_OK) {
+    if (ctx->zero_wait_after_ea) {  // the call failed before its prologue got there
+        ctx->zero_wait_after_ea = false;
+        (void)wait_zeroise(ctx, s);
+    }
+    if (rc != MLDSA_OK) {
         for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, s);  // also on the error path
         (void)hipStreamSynchronize(s);
+    } else if (!async_mode) {
+        // Every signature is in place (sign_chunk_finish waited for the stream).  y, w, c, rho'' ... are cleared on a helper
+        // stream, off the caller's critical path (1.1 GB for a 65 536-op ML-DSA-65 call: ~0.2 ms of an 8 ms call): the next
+        // op-level call on this context waits for zero_ev on the device before it touches the workspace, destroy / regrow
+        // wait for the whole device.
+        hipStream_t z = parallel_stream(ctx, s);
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_fork_ev, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(z, ctx->zero_fork_ev, 0));
+        for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, z);
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_ev, z));
+        ctx->zero_pending = true;
+        ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
+        ctx->zero_hi = ws_off;
     }
     return rc;
 }
@@ -693,6 +768,8 @@ hipStream_t parallel_stream(mldsa_ctx *ctx, hipStream_t s, hipStream_t avoid) {
 
 // ------------------------------------------------------------------------------------
 // hipGraph replay.  A call shape = the operation and every argument that ends up in a kernel parameter.
+// callers make sure nothing of the context still runs (ensure_workspace and mldsa_ctx_destroy wait for the device,
+// mldsa_set_option does the same before it gets here)
 void drop_graphs(mldsa_ctx *ctx) {
     for (auto &g : ctx->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -707,7 +784,6 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
     // work, where the 0.15-0.4 ms of host time a directly launched call costs is a sizeable share of the call; 2 every
     // op-level call.  A replayed graph is NOT faster on the device (the device-driven loop never waits for the host):
     // it costs the call 20-50 us of launch latency and saves the host thread 5-25x of its time per call.
-    constexpr size_t GRAPH_AUTO_MAX_OPS = 16384;
     const bool wanted = ctx->opt_graphs == 2 || (ctx->opt_graphs == 1 && op == MLDSA_OP_SIGN && n_ops <= GRAPH_AUTO_MAX_OPS);
     if (!wanted || ctx->prof_on) {  // per-stage timing needs the individual launches
         ctx->stats.direct_calls++;
@@ -729,7 +805,11 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
         if ((long)ctx->graphs.size() >= ctx->opt_graph_cache) {
             auto lru = std::min_element(ctx->graphs.begin(), ctx->graphs.end(),
                                         [](const GraphEntry &a, const GraphEntry &b) { return a.last_use < b.last_use; });
-            if (lru->exec) (void)hipGraphExecDestroy(lru->exec);
+            // the evicted graph may still be executing (asynchronous calls, the *_host paths): wait for the stream it ran on
+            if (lru->exec) {
+                (void)hipStreamSynchronize(lru->last_stream);
+                (void)hipGraphExecDestroy(lru->exec);
+            }
             if (lru->graph) (void)hipGraphDestroy(lru->graph);
             ctx->graphs.erase(lru);
         }
@@ -772,6 +852,7 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
         ctx->stats.graph_replays++;
     }
     MLDSA_HIP_CHECK(hipGraphLaunch(hit->exec, gs));
+    hit->last_stream = gs;
     if (!s) {
         MLDSA_HIP_CHECK(hipEventRecord(ctx->graph_join_ev, gs));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->graph_join_ev, 0));

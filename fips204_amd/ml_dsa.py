@@ -255,6 +255,37 @@ class MlDsa:
         flat = np.frombuffer(b"".join(bytes(b) for b in items) or b"\0", dtype=np.uint8)
         return flat, off
 
+    @staticmethod
+    def _host_strings(items, n_ops, what):
+        """list of byte strings or (flat uint8, uint64 offsets[n_ops + 1]) -> validated contiguous (flat, offsets).
+        The library walks offsets[0 .. n_ops] and reads flat[offsets[0] .. offsets[n_ops]): both are checked here, so a
+        short list or a truncated buffer is a ValueError and never an out-of-bounds read on the C side."""
+        if isinstance(items, tuple):
+            flat, off = items
+            flat = np.ascontiguousarray(flat, dtype=np.uint8)
+            off = np.ascontiguousarray(off)
+            if off.dtype != np.uint64:
+                if off.size and (not np.issubdtype(off.dtype, np.integer) or int(off.min()) < 0):
+                    raise ValueError(f"{what}: offsets must be non-negative integers")
+                off = off.astype(np.uint64)
+        else:
+            if len(items) != n_ops:
+                raise ValueError(f"{what}: {len(items)} entries for {n_ops} operations")
+            flat, off = MlDsa._cat_host(items)
+        if off.ndim != 1 or off.size != n_ops + 1:
+            raise ValueError(f"{what}: offsets must have n_ops + 1 = {n_ops + 1} entries, got {off.size}")
+        if n_ops and bool(np.any(off[1:] < off[:-1])):
+            raise ValueError(f"{what}: offsets must be non-decreasing")
+        if int(off[-1]) > flat.size:
+            raise ValueError(f"{what}: offsets run past the end of the byte buffer ({int(off[-1])} > {flat.size})")
+        return flat, off
+
+    @staticmethod
+    def _host_out(a, dtype, n_items, what):
+        if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags.c_contiguous or not a.flags.writeable or a.size < n_items:
+            raise ValueError(f"{what}: a writable C-contiguous {np.dtype(dtype).name} array of at least {n_items} elements is required")
+        return a
+
     def verify_host(self, pk_bytes, messages, sigs, ctxs=None, key_idx=None, mode=MODE_PURE, out=None):
         """mldsa_verify_host: wire-format public keys [n_keys, PK_LEN], signatures [n_ops, SIG_LEN] and messages
         in HOST memory (numpy); returns a bool array.  `messages` / `ctxs`: list of byte strings, or a
@@ -262,12 +293,13 @@ class MlDsa:
         pk = self._np_u8(pk_bytes, self.PK_LEN, "pk")
         sg = self._np_u8(sigs, self.SIG_LEN, "sigs")
         n_keys, n_ops = pk.size // self.PK_LEN, sg.size // self.SIG_LEN
-        mflat, moff = messages if isinstance(messages, tuple) else self._cat_host(messages)
+        mflat, moff = self._host_strings(messages, n_ops, "messages")
         cflat = coff = None
         if ctxs is not None:
-            cflat, coff = ctxs if isinstance(ctxs, tuple) else self._cat_host(ctxs)
+            cflat, coff = self._host_strings(ctxs, n_ops, "ctxs")
         kidx = _check_key_idx(key_idx, n_keys, n_ops)
-        ok = out if out is not None else np.zeros(max(n_ops, 1), dtype=np.uint8)  # out: caller's (page-locked) uint8[n_ops]
+        # out: caller's (page-locked) uint8[n_ops]
+        ok = self._host_out(out, np.uint8, n_ops, "verify_host: out") if out is not None else np.zeros(max(n_ops, 1), dtype=np.uint8)
         vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
         _lib.check(self.lib.mldsa_verify_host(self.hp._h, self.pset, mode, vp(pk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
                                               vp(coff), vp(sg), vp(ok), n_ops))
@@ -279,13 +311,21 @@ class MlDsa:
         sk = self._np_u8(sk_bytes, self.SK_LEN, "sk")
         rn = self._np_u8(rnd, 32, "rnd")
         n_keys, n_ops = sk.size // self.SK_LEN, rn.size // 32
-        mflat, moff = messages if isinstance(messages, tuple) else self._cat_host(messages)
+        mflat, moff = self._host_strings(messages, n_ops, "messages")
         cflat = coff = None
         if ctxs is not None:
-            cflat, coff = ctxs if isinstance(ctxs, tuple) else self._cat_host(ctxs)
+            cflat, coff = self._host_strings(ctxs, n_ops, "ctxs")
         kidx = _check_key_idx(key_idx, n_keys, n_ops)
-        sig, status = out if out is not None else (np.zeros((max(n_ops, 1), self.SIG_LEN), dtype=np.uint8),
-                                                     np.zeros(max(n_ops, 1), dtype=np.int32))
+        if out is not None:
+            if not isinstance(out, tuple) or len(out) != 2:
+                raise ValueError("sign_host: out = (sig uint8[n_ops, SIG_LEN], status int32[n_ops])")
+            sig = self._host_out(out[0], np.uint8, n_ops * self.SIG_LEN, "sign_host: out[0] (signatures)")
+            status = self._host_out(out[1], np.int32, n_ops, "sign_host: out[1] (status)")
+            if sig.ndim == 2 and sig.shape[1] != self.SIG_LEN:
+                raise ValueError(f"sign_host: out[0] rows must be SIG_LEN = {self.SIG_LEN} bytes")
+            sig = sig.reshape(-1)[:n_ops * self.SIG_LEN].reshape(n_ops, self.SIG_LEN) if n_ops else sig
+        else:
+            sig, status = np.zeros((max(n_ops, 1), self.SIG_LEN), dtype=np.uint8), np.zeros(max(n_ops, 1), dtype=np.int32)
         vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
         _lib.check(self.lib.mldsa_sign_host(self.hp._h, self.pset, mode, vp(sk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
                                             vp(coff), vp(rn), vp(sig), vp(status), n_ops))

@@ -112,9 +112,11 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
                                        left over in about 1 call in 500) */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
-/* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths */
+/* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,
+ * extra signing rounds, and workspace_shrinks = how often the context halved its pass size because the device could not hold
+ * the workspace of a full pass (the call then runs in more passes; results are identical) */
 typedef struct {
-    unsigned long long graphs_captured, graph_replays, direct_calls, workspace_growths, sign_extra_rounds;
+    unsigned long long graphs_captured, graph_replays, direct_calls, workspace_growths, sign_extra_rounds, workspace_shrinks;
 } mldsa_stats;
 int mldsa_get_stats(mldsa_ctx *ctx, mldsa_stats *out);
 

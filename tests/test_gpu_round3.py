@@ -1,0 +1,273 @@
+"""GPU parity derived from the reference's fuzz targets and soak test (round 3):
+
+  * fuzz/fuzz_targets/fuzz_all.rs:14-15   a good signature XOR an arbitrary mask is verified
+  * fuzz/fuzz_targets/fuzz_all.rs:25-37   arbitrary PUBLIC-KEY bytes are deserialised and garbage signatures verified under them
+  * fuzz/fuzz_targets/fuzz_verify.rs:17-31 arbitrary (pk, sig) byte strings through try_from_bytes + verify
+  * fuzz/fuzz_targets/fuzz_sign.rs         arbitrary SECRET-KEY bytes sign
+  * tests/integration.rs:22-53 (`forever`) randomized keygen / sign / verify / flip loop
+
+Every verdict and every signature is compared with the oracle's (bit-exact), at BASELINE batch sizes for the verifier."""
+import hashlib
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from fips204_amd.hotpath import HotPath
+    h = HotPath(0)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def sets(hp):
+    from fips204_amd.ml_dsa import MlDsa
+    return {s: MlDsa(s, hotpath=hp) for s in (44, 65, 87)}
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def shake(tag, i, n=32):
+    return hashlib.shake_256(tag + int(i).to_bytes(8, "little")).digest(n)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# mask classes of the fuzzed verify batch (op i gets class i % len(CLASSES))
+CLASSES = ("good", "bit", "byte", "dense1pct", "dense50pct", "random_sig", "mask_ctilde", "mask_z", "mask_hints",
+           "random_pk", "random_pk_random_sig")
+
+
+def fuzz_batch(m, pset, n, nk, seed):
+    """(pk bytes [2 nk], key_idx, msgs, sigs [n]) -- keys 0 .. nk-1 are generated keys, nk .. 2 nk-1 are random bytes."""
+    rng = np.random.default_rng(seed)
+    p = m.params
+    xi = [shake(b"fuzz-key%d" % pset, i) for i in range(nk)]
+    pk, sk = m.keygen_from_seed(xi)
+    sks = m.private_keys_from_bytes(sk)
+    msgs = [shake(b"fuzz-msg", i) for i in range(n)]
+    rnd = [shake(b"fuzz-rnd", i) for i in range(n)]
+    kidx = (np.arange(n) * 5 % nk).astype(np.uint32)
+    sig = host(m.try_sign_with_seed(sks, msgs, rnd, key_idx=kidx, mode=0)).copy()
+    pk_all = np.concatenate([host(pk), rng.integers(0, 256, (nk, m.PK_LEN), dtype=np.uint8)])
+    cls = np.arange(n) % len(CLASSES)
+    L = m.SIG_LEN
+    cb = 18 if p.gamma1 == (1 << 17) else 20
+    z0, h0 = p.ctilde_len, p.ctilde_len + p.l * 32 * cb  # sigEncode sections: c~ | z | hints (encodings.rs:238-276)
+    def xor_mask(rows, lo, hi, density):
+        mask = (rng.random((rows.size, hi - lo, 8)) < density)
+        sig[rows, lo:hi] ^= np.packbits(mask, axis=2, bitorder="little")[:, :, 0]
+    for c, name in enumerate(CLASSES):
+        rows = np.nonzero(cls == c)[0]
+        if name == "bit":
+            sig[rows, rng.integers(0, L, rows.size)] ^= (1 << rng.integers(0, 8, rows.size)).astype(np.uint8)
+        elif name == "byte":
+            sig[rows, rng.integers(0, L, rows.size)] ^= rng.integers(1, 256, rows.size).astype(np.uint8)
+        elif name == "dense1pct":
+            xor_mask(rows, 0, L, 0.01)
+        elif name == "dense50pct":
+            xor_mask(rows, 0, L, 0.5)
+        elif name in ("random_sig", "random_pk_random_sig"):
+            sig[rows] = rng.integers(0, 256, (rows.size, L), dtype=np.uint8)
+        elif name == "mask_ctilde":
+            xor_mask(rows, 0, z0, 0.02)
+        elif name == "mask_z":
+            xor_mask(rows, z0, h0, 0.0005)
+        elif name == "mask_hints":
+            xor_mask(rows, h0, L, 0.01)
+        if name.startswith("random_pk"):
+            kidx[rows] += nk  # verified under arbitrary public-key bytes
+    return pk_all, kidx, msgs, sig, cls
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_fuzzed_signatures_and_arbitrary_public_keys_full_batch(sets, pset):
+    """65 536 verifications per parameter set: good signatures XOR masks of every density, masks confined to each
+    section of the encoding, random signatures, and random PUBLIC-KEY bytes through mldsa_pk_expand -- all verdicts
+    equal the oracle's (fuzz_all.rs:14-37, fuzz_verify.rs:17-31)."""
+    m = sets[pset]
+    n, nk = 65536, 256
+    pk_all, kidx, msgs, sig, cls = fuzz_batch(m, pset, n, nk, 7000 + pset)
+    pks = m.public_keys_from_bytes(dev(pk_all))
+    got = m.verify(pks, msgs, dev(sig), key_idx=kidx, mode=0)
+    pk_o = [orc.pk_try_from_bytes(pset, pk_all[i].tobytes()) for i in range(2 * nk)]
+    want = np.asarray(orc.verify_batch_mt(pset, pk_o, kidx, msgs, [sig[i].tobytes() for i in range(n)], 16, 1, mode=0), dtype=bool)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, [(int(i), CLASSES[cls[i]]) for i in bad[:8]]
+    assert got[cls == 0].all()  # the untouched signatures verify
+    # the same batch through the host-memory entry point (wire-format keys expanded inside the call)
+    got_h = m.verify_host(pk_all, msgs, sig, key_idx=kidx, mode=0)
+    assert np.array_equal(got_h, want)
+    # a fuzz batch that only ever says "False" for the altered classes proves little: at least the z-section masks must sometimes
+    # survive the norm test and reach the hash comparison (they still fail there)
+    assert not got[cls != 0].any()
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_arbitrary_secret_key_bytes_sign_like_the_oracle(sets, pset):
+    """fuzz_sign.rs: PrivateKey::try_from_bytes accepts any bytes (conversion.rs:259-260 never rejects) and the signer computes
+    with them -- out-of-range eta fields, a tr that is no hash of anything.  Signatures must be the oracle's byte for byte,
+    and the verdict under the matching get_public_key() must be the oracle's too."""
+    m = sets[pset]
+    rng = np.random.default_rng(8000 + pset)
+    nk, n = 48, 1536
+    sk = rng.integers(0, 256, (nk, m.SK_LEN), dtype=np.uint8)
+    sk[0, 128:] = 0xFF
+    sk[1, 128:] = 0x00
+    sks = m.private_keys_from_bytes(dev(sk))
+    msgs = [shake(b"rsk-msg", i, 1 + i % 90) for i in range(n)]
+    rnd = [shake(b"rsk-rnd", i) if i % 3 else bytes(32) for i in range(n)]
+    ctxs = [shake(b"rsk-ctx", i, i % 7) for i in range(n)]
+    kidx = (np.arange(n) % nk).astype(np.uint32)
+    sig = host(m.try_sign_with_seed(sks, msgs, rnd, ctxs=ctxs, key_idx=kidx, mode=0))
+    sk_o = [orc.sk_try_from_bytes(pset, sk[i].tobytes()) for i in range(nk)]
+    for i in range(n):
+        want = orc.sign_internal(pset, sk_o[kidx[i]], msgs[i], rnd[i], ctx=ctxs[i], mode=0)
+        assert sig[i].tobytes() == want, i
+    pks = m.get_public_key(sks)
+    pkb = host(m.public_keys_into_bytes(pks))
+    got = m.verify(pks, msgs, dev(sig), ctxs=ctxs, key_idx=kidx, mode=0)
+    for i in range(n):
+        pk_o = orc.get_public_key(pset, sk_o[kidx[i]])
+        if i < nk:
+            assert pkb[i].tobytes() == orc.pk_into_bytes(pset, pk_o), i
+        assert bool(got[i]) == orc.verify_internal(pset, pk_o, msgs[i], sig[i].tobytes(), ctx=ctxs[i], mode=0), i
+
+
+def test_small_passes_give_identical_results(sets):
+    """A context whose device cannot hold the workspace of a full pass falls back to smaller passes (reserve_workspace);
+    MLDSA_PASS_OPS / MLDSA_PASS_OPS_SIGN force that: 3 000 ops in passes of 512 must give the bytes of the one-pass call."""
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    m = sets[65]
+    n, nk = 3000, 40
+    xi = [shake(b"pass-key", i) for i in range(nk)]
+    msgs = [shake(b"pass-msg", i, 40) for i in range(n)]
+    rnd = [shake(b"pass-rnd", i) for i in range(n)]
+    kidx = (np.arange(n) * 3 % nk).astype(np.uint32)
+    def run(mm):
+        pk, sk = mm.keygen_from_seed(xi)
+        sig = mm.try_sign_with_seed(mm.private_keys_from_bytes(sk), msgs, rnd, key_idx=kidx)
+        bad = sig.clone()
+        bad[::3, 100] ^= 1
+        return host(pk), host(sk), host(sig), mm.verify(mm.public_keys_from_bytes(pk), msgs, bad, key_idx=kidx)
+    want = run(m)
+    old = {k: os.environ.get(k) for k in ("MLDSA_PASS_OPS", "MLDSA_PASS_OPS_SIGN")}
+    os.environ["MLDSA_PASS_OPS"] = "512"
+    os.environ["MLDSA_PASS_OPS_SIGN"] = "512"
+    try:
+        h2 = HotPath(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        got = run(MlDsa(65, hotpath=h2))
+    finally:
+        h2.close()
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    assert (~want[3][::3]).all() and want[3][1::3].all()
+
+
+# ------------------------------------------------------------------------------ soak (tests/integration.rs:22-53 `forever`)
+def test_soak_random_shapes_knobs_and_modes_against_the_oracle(hp, sets):
+    """A seeded, time-bounded version of the reference's `forever` loop: random parameter set, batch size (1 ... 70 000,
+    log-uniform), key count, message / ctx lengths, interface mode and library knobs (graph replay, speculation target and
+    width, planned rounds -> the extra-round path, signing lanes, synchronous / asynchronous signing), keygen -> sign ->
+    verify -> flip -> verify on the device, with a sample of every iteration's keys, signatures and verdicts compared with
+    the oracle.  Shapes repeat and alternate on ONE context, so workspace regrowth, the graph cache and the loop's control
+    block are exercised the way a long-running service would."""
+    seconds = float(os.environ.get("MLDSA_SOAK_SECONDS", "60"))
+    seed = int(os.environ.get("MLDSA_SOAK_SEED", "20260203"))
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + seconds
+    defaults = {o: hp.get_option(o) for o in (1, 2, 3, 6, 7)}
+    it = 0
+    shapes = []
+    try:
+        while time.time() < t_end:
+            it += 1
+            pset = int(rng.choice([44, 65, 87]))
+            m = sets[pset]
+            if shapes and rng.random() < 0.3:
+                n, nk = shapes[int(rng.integers(len(shapes)))]  # a shape seen before: graph-cache hits
+            else:
+                n = int(np.exp(rng.uniform(0, np.log(70000))))
+                nk = int(min(n, np.exp(rng.uniform(0, np.log(600)))))
+                shapes.append((n, nk))
+            mode = int(rng.choice([0, 0, 1, 2]))
+            knobs = {1: int(rng.choice([0, 1, 2])), 2: int(rng.choice([1024, 8192, 40000, 65536, 150000])),
+                     3: int(rng.choice([1, 4, 32, 64])), 6: int(rng.choice([0, 0, 1, 3])), 7: int(rng.choice([1, 1, 2]))}
+            for o, v in knobs.items():
+                hp.set_option(o, v)
+            tag = b"soak%d-" % it
+            what = f"seed {seed} iteration {it}: set {pset} n {n} keys {nk} mode {mode} knobs {knobs}"
+            xi = [shake(tag + b"k", i) for i in range(nk)]
+            pk, sk = m.keygen_from_seed(xi)
+            pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+            max_len = int(rng.choice([0, 32, 300, 3000])) if n < 5000 else 48
+            msgs = [shake(tag + b"m", i, int(rng.integers(0, max_len + 1))) if mode != 2 else
+                    orc.hash_message(shake(tag + b"m", i, 20), "SHA512") for i in range(n)]
+            ctxs = None if (mode == 1 or rng.random() < 0.5) else [shake(tag + b"c", i, int(rng.integers(0, 256))) for i in range(n)]
+            rnd = [shake(tag + b"r", i) for i in range(n)]
+            kidx = rng.integers(0, nk, n).astype(np.uint32)
+            if rng.random() < 0.5:
+                sig = m.try_sign_with_seed(sks, msgs, rnd, ctxs=ctxs, key_idx=kidx, mode=mode)
+            else:  # asynchronous: re-sign what the enqueued rounds left (status -5), as a service would
+                from fips204_amd.ml_dsa import _cat_with_offsets
+                mb, mo = _cat_with_offsets(msgs, m.device)
+                cb = co = None
+                if ctxs is not None:
+                    cb, co = _cat_with_offsets(ctxs, m.device)
+                rn = dev(np.frombuffer(b"".join(rnd), dtype=np.uint8).reshape(n, 32))
+                sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+                st = torch.zeros(n, dtype=torch.int32, device="cuda")
+                kd = dev(kidx.view(np.int32))
+                m.sign_device(sks, mb, mo, rn, sig, n, cb, co, kd, mode, st, wait=False)
+                st_h = host(st)
+                assert set(np.unique(st_h)) <= {0, -5}, what
+                for i in np.nonzero(st_h == -5)[0]:
+                    assert not host(sig[i]).any(), what
+                    one = m.try_sign_with_seed(sks, [msgs[i]], [rnd[i]], ctxs=None if ctxs is None else [ctxs[i]],
+                                               key_idx=kidx[i:i + 1], mode=mode)
+                    sig[i] = one[0]
+            ok = m.verify(pks, msgs, sig, ctxs=ctxs, key_idx=kidx, mode=mode)
+            assert ok.all(), what
+            sig_h = host(sig).copy()
+            flip = rng.random(n) < 0.3
+            rows = np.nonzero(flip)[0]
+            sig_h[rows, rng.integers(0, m.SIG_LEN, rows.size)] ^= (1 << rng.integers(0, 8, rows.size)).astype(np.uint8)
+            ok2 = m.verify(pks, msgs, dev(sig_h), ctxs=ctxs, key_idx=kidx, mode=mode)
+            assert np.array_equal(ok2, ~flip), what
+            # the oracle on a sample: keys, signatures (before the flips), verdicts (after)
+            pkb, skb = host(pk), host(sk)
+            sig_good = host(sig)
+            for i in rng.choice(n, min(n, 12), replace=False):
+                ki = int(kidx[i])
+                pk_o, sk_o = orc.keygen_from_seed(pset, xi[ki])
+                assert pkb[ki].tobytes() == orc.pk_into_bytes(pset, pk_o) and skb[ki].tobytes() == orc.sk_into_bytes(pset, sk_o), what
+                c = b"" if ctxs is None else ctxs[i]
+                assert sig_good[i].tobytes() == orc.sign_internal(pset, sk_o, msgs[i], rnd[i], ctx=c, mode=mode), (what, int(i))
+                assert bool(ok2[i]) == orc.verify_internal(pset, pk_o, msgs[i], sig_h[i].tobytes(), ctx=c, mode=mode), (what, int(i))
+    finally:
+        for o, v in defaults.items():
+            hp.set_option(o, v)
+    assert it >= 3, f"only {it} iterations in {seconds} s"
+    print(f"soak: {it} iterations in {seconds:.0f} s, stats {hp.stats()}")
