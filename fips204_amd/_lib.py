@@ -36,7 +36,7 @@ class Stats(C.Structure):
 
 OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
 OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE, OPT_SIGN_ROUNDS = 1, 2, 3, 4, 5, 6
-OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP = 7, 8, 9
+OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_MASK_AHEAD = 7, 8, 9, 10
 ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
@@ -91,8 +91,18 @@ _SIGNATURES = {
     "mldsa_verify_host": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ],
     "mldsa_sign_host": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ],
     "mldsa_keygen_host": [_P, _I, _P, _P, _P, _SZ],
+    "mldsa_group_create": [C.POINTER(_I), _I, C.POINTER(_P)],
+    "mldsa_group_destroy": [_P],
+    "mldsa_group_size": [_P],
+    "mldsa_group_ctx": [_P, _I],
+    "mldsa_group_shard": [_SZ, _I, _I, C.POINTER(_SZ), C.POINTER(_SZ)],
+    "mldsa_verify_host_group": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ],
+    "mldsa_sign_host_group": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ],
+    "mldsa_keygen_host_group": [_P, _I, _P, _P, _P, _SZ],
+    "mldsa_group_allgather": [_P, C.POINTER(_P), _SZ, _I],
 }
-_RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p, "mldsa_get_option": C.c_long}
+_RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p, "mldsa_get_option": C.c_long,
+             "mldsa_group_destroy": None, "mldsa_group_ctx": _P}
 
 _lib = None
 

@@ -18,6 +18,8 @@ struct RoundCtl {
     uint32_t cnt[2];       // unfinished ops entering a round of parity 0 / 1
     uint32_t m, spec, ns;  // this round: unfinished ops, candidates per op, candidate slots = m * spec
     uint32_t rounds;       // rounds that found work (statistics)
+    uint32_t spec_par[2];  // candidates per op of the last round of parity 0 / 1 (k_make_slots of the next round reads the other one)
+    uint32_t use_pre;      // this round's masks were generated one round ahead (k_expand_mask role 2): slot s reads y row slot_y[s]
     unsigned long long slots_total;  // candidate slots of all rounds of the call (statistics)
     unsigned long long ops_total;    // sum over the rounds of the unfinished ops entering them (statistics)
 };
@@ -38,7 +40,7 @@ struct mldsa_ctx {
     int n_cu = 256;
     // tuning knobs (mldsa_set_option)
     long opt_graphs = 1, opt_spec_target = 65536, opt_spec_max = 32, opt_va_blocks = 16, opt_graph_cache = 24;
-    long opt_sign_rounds = 0, opt_sign_lanes = 1, opt_ct0_exact = 0;
+    long opt_sign_rounds = 0, opt_sign_lanes = 1, opt_ct0_exact = 0, opt_mask_ahead = 0;
     // expected number of unfinished ops at which an ASYNCHRONOUS sign call stops planning rounds (1e-9: practically never an
     // MLDSA_ERR_AGAIN); mldsa_sign_host, which re-signs such ops anyway, raises it to the synchronous plan's 0.05 for its calls
     double async_stop = 1e-9;
@@ -62,12 +64,15 @@ struct mldsa_ctx {
     // SampleInBall) run here, concurrently with the VALU-bound ExpandA on the caller's stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipEvent_t pre_fork_ev = nullptr, pre_join_ev = nullptr;  // sign: the helper ExpandMask launch of a round (pipeline.hip)
     // HIP maps streams onto a handful of hardware queues (four here, handed out 0 1 2 3 3 2 1 0 ...: tools/ubench_queues.hip);
     // two streams on one queue run their kernels strictly one after the other.  parallel_stream() therefore PROBES which of
     // the context's helper streams really runs beside a given stream (a spin kernel on one, an empty kernel on the other)
     // and remembers the answer per stream handle.
     std::vector<hipStream_t> helper_streams;             // aux_stream first, more created on demand
     std::vector<std::pair<hipStream_t, hipStream_t>> parallel_of;  // (stream, helper that does not share its queue)
+    std::vector<hipStream_t> prio_streams;                          // high-priority helpers (priority_stream)
+    std::vector<std::pair<hipStream_t, hipStream_t>> prio_of;
     unsigned *d_probe = nullptr;
     // graphs of calls made on the legacy default stream run here (that stream cannot be captured)
     hipStream_t graph_stream = nullptr;
@@ -199,9 +204,10 @@ int launch_expand_a(mldsa_ctx *, int set, const uint8_t *rho, size_t rho_stride,
                     bool pack24 = false);
 int launch_expand_s(mldsa_ctx *, int set, const uint8_t *rho_prime, size_t rho_stride, int32_t *s12, size_t n_ops, hipStream_t);
 // yrisk (optional): one byte per polynomial, 1 = some |y| >= gamma1 - 2 beta (see k_sign_tail)
+// ctl / role / kappa_add: the signer's two launches per round, see k_expand_mask
 int launch_expand_mask(mldsa_ctx *, int set, const uint8_t *rho_pp, size_t rho_stride, const uint16_t *kappa, int kappa_by_slot,
                        const uint32_t *op_idx, int32_t *y, size_t n_ops, hipStream_t, uint8_t *yrisk = nullptr,
-                       const uint32_t *n_dev = nullptr);
+                       const uint32_t *n_dev = nullptr, const RoundCtl *ctl = nullptr, int role = 0, uint32_t kappa_add = 0);
 int launch_sample_in_ball(mldsa_ctx *, int set, const uint8_t *c_tilde, size_t ct_stride, int32_t *c, size_t n_ops, hipStream_t,
                           const uint32_t *n_dev = nullptr);
 
@@ -221,9 +227,11 @@ int launch_ctilde_verdict(mldsa_ctx *, const mldsa_params *, const uint8_t *mu_w
 
 // ---- launchers (kernels_sign.hip, kernels_poly.hip) ----
 // y_polys_per_op: distance between consecutive ops' y vectors in polynomials (0 = L, contiguous)
+// y_idx (optional): slot -> row of y (the signer's rounds may use masks generated one round ahead, laid out by the previous
+// round's slots)
 int launch_sign_w(mldsa_ctx *, int set, const int32_t *a_hat, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
                   size_t w1_stride, size_t n_ops, hipStream_t, size_t y_polys_per_op = 0, uint8_t *wrisk = nullptr,
-                  bool a_packed = false, const uint32_t *n_dev = nullptr);
+                  bool a_packed = false, const uint32_t *n_dev = nullptr, const uint32_t *y_idx = nullptr);
 int launch_unpack_ntt(mldsa_ctx *, const uint8_t *src, size_t key_stride, size_t poly_off, int bits, int b, int32_t scale,
                       int32_t *out, int polys_per_key, size_t n_keys, hipStream_t);
 // the round kernels of the signer: counts come from `ctl` on the device, the *_hint arguments only size the grids
@@ -231,18 +239,21 @@ int launch_sign_tail(mldsa_ctx *, const mldsa_params *, const int32_t *c, const 
                      const uint32_t *slot_op, const uint32_t *key_idx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
                      uint16_t *kappa, int32_t *done, uint8_t *sigs, const RoundCtl *ctl, int32_t *accept, size_t slots_hint,
                      hipStream_t, const uint8_t *wrisk = nullptr, const uint8_t *yrisk = nullptr, const uint8_t *key_oor = nullptr,
-                     int oor_by_op = 0);
+                     int oor_by_op = 0, const uint32_t *slot_y = nullptr);
 int launch_key_range(mldsa_ctx *, const mldsa_params *, const int32_t *s2, const uint32_t *kidx, size_t n_units, uint8_t *oor, hipStream_t);
+// pre_enqueued: the previous round launched k_expand_mask role 2 (its rows are indexed by ypos = the op's position in that round)
 int launch_make_slots(mldsa_ctx *, RoundCtl *ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t *act,
                       const uint16_t *kappa, int l, uint32_t *slot_op, uint16_t *slot_kappa, const uint32_t *key_idx,
-                      uint32_t *slot_key, size_t slots_hint, hipStream_t);
+                      uint32_t *slot_key, size_t slots_hint, hipStream_t, int pre_enqueued = 0, const uint32_t *ypos = nullptr,
+                      uint32_t *slot_y = nullptr);
 // speculative rounds: builds the signature of each op's first surviving candidate (the candidates' c / y / w / c~ rows)
 int launch_resolve(mldsa_ctx *, const mldsa_params *, const RoundCtl *ctl, const uint32_t *act, const int32_t *accept,
                    const int32_t *c, const int32_t *y, const int32_t *w, const uint8_t *ctilde, const uint32_t *key_idx,
                    const int32_t *s1, const int32_t *s2, const int32_t *t0, uint8_t *sigs, int32_t *done, uint16_t *kappa,
-                   size_t ops_hint, hipStream_t, const uint8_t *key_oor = nullptr, int oor_by_op = 0);
+                   size_t ops_hint, hipStream_t, const uint8_t *key_oor = nullptr, int oor_by_op = 0, const uint32_t *slot_y = nullptr);
+// ypos_out (optional): position each surviving op had in act_in (= its slot in a one-candidate round)
 int launch_compact(mldsa_ctx *, RoundCtl *ctl, int parity, const uint32_t *act_in, const int32_t *done, uint32_t *act_out,
-                   size_t ops_hint, hipStream_t);
+                   size_t ops_hint, hipStream_t, uint32_t *ypos_out = nullptr);
 int launch_init_active(mldsa_ctx *, size_t n, const int32_t *bad_op, int32_t *done, uint16_t *kappa, int32_t *status,
                        uint32_t *act_out, RoundCtl *ctl, uint8_t *sigs, size_t sig_len, hipStream_t);
 int launch_mark_unfinished(mldsa_ctx *, const RoundCtl *ctl, int parity, const uint32_t *act, int32_t *status, uint8_t *sigs,
@@ -254,6 +265,7 @@ bool streams_serialise(mldsa_ctx *, hipStream_t a, hipStream_t b);
 // a context-owned stream whose kernels run beside those of `s` (probed once per stream handle; `avoid`: a second stream it
 // must not share a queue with either, or nullptr).  Falls back to aux_stream while `s` is being captured.
 hipStream_t parallel_stream(mldsa_ctx *, hipStream_t s, hipStream_t avoid = nullptr);
+hipStream_t priority_stream(mldsa_ctx *, hipStream_t s);  // the same, with the device's highest stream priority
 int launch_copy_rows(mldsa_ctx *, void *dst, size_t dst_stride, const void *src, size_t src_stride, int row_bytes, size_t n_rows,
                      hipStream_t);
 int launch_key_intt(mldsa_ctx *, const int32_t *src, int polys_per_key, size_t n_keys, int bits, int b, uint8_t *dst, size_t key_stride,

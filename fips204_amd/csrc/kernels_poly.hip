@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
     int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
     uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op, uint8_t *__restrict__ wrisk, int32_t risk_bound,
-    const uint32_t *__restrict__ n_dev) {
+    const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ z_idx) {
     constexpr int NZ = HAS_C ? L + 1 : L;
     __shared__ int4 zh[AW][NZ][64];
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
@@ -210,12 +210,13 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
         if constexpr (HAS_C) tv = reinterpret_cast<const int4 *>(t1 + (key * K) * (size_t)N)[lane];
         // ---- forward transforms, next polynomial loaded one ahead
         int32_t nr[4];
-        load_strided(nr, z + (op * z_polys_per_op) * (size_t)N, lane);
+        const size_t zrow = (z_idx ? (size_t)z_idx[op] : op) * z_polys_per_op;  // first polynomial of the op's z / y vector
+        load_strided(nr, z + zrow * (size_t)N, lane);
 #pragma unroll 1
         for (int j = 0; j < NZ; j++) {
             asm volatile("" ::: "memory");  // keep the LDS twiddle reads at their point of use (no hoisting into registers)
             int32_t r[4] = {reduce32(nr[0]), reduce32(nr[1]), reduce32(nr[2]), reduce32(nr[3])};
-            if (j + 1 < L) load_strided(nr, z + (op * z_polys_per_op + j + 1) * (size_t)N, lane);
+            if (j + 1 < L) load_strided(nr, z + (zrow + j + 1) * (size_t)N, lane);
             else if (HAS_C && j + 1 == L) load_strided(nr, c + op * (size_t)N, lane);
             ntt_fwd_wave(r, ftw, lane);
             if (HAS_C && j == L) {
@@ -346,9 +347,9 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
     const uint32_t *no_idx = nullptr;
     dim3 gw(grid_for(ctx, n_ops, AW, (unsigned)ctx->opt_va_blocks));
     uint8_t *nw1 = nullptr;
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0, no_idx);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0, no_idx);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0, no_idx);
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0, no_idx, no_idx);
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0, no_idx, no_idx);
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0, no_idx, no_idx);
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -358,7 +359,7 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 // w1Encode(HighBits(w)) (ml_dsa.rs:225-232)
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
                   size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op, uint8_t *wrisk, bool a_packed,
-                  const uint32_t *n_dev) {
+                  const uint32_t *n_dev, const uint32_t *y_idx) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
@@ -367,7 +368,7 @@ int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_i
     dim3 gw(grid_for(ctx, n_ops, AW, 16));
 #define MLDSA_SW2(KK, LL, W1M, AP)                                                                                               \
     hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M, AP>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
-                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound, n_dev)
+                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound, n_dev, y_idx)
 #define MLDSA_SW(KK, LL, W1M) do { if (a_packed) MLDSA_SW2(KK, LL, W1M, true); else MLDSA_SW2(KK, LL, W1M, false); } while (0)
     if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
     else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 2); else MLDSA_SW(6, 5, 0); }

@@ -93,7 +93,7 @@ struct TailPtrs {
 };
 
 template <int K, int L, bool G2HI, bool FULL>
-__device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, size_t key, uint32_t r_risky, uint32_t z_risky,
+__device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, size_t yrow, size_t key, uint32_t r_risky, uint32_t z_risky,
                                              bool s2_oor, uint8_t* sig, int32_t* xp, const LdsTw& itw, int lane, int gb, int beta,
                                              int omega, int ctilde_len, int ct0_exact) {
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
@@ -119,7 +119,7 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
     auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
         const bool is_r = idx < K;
         const int32_t* sp = is_r ? a.s2 + (key * K + idx) * (size_t)N : a.s1 + (key * L + (idx - K)) * (size_t)N;
-        const int32_t* xq = is_r ? a.w + (slot * K + idx) * (size_t)N : a.y + (slot * L + (idx - K)) * (size_t)N;
+        const int32_t* xq = is_r ? a.w + (slot * K + idx) * (size_t)N : a.y + (yrow * L + (idx - K)) * (size_t)N;
         load_packed(v, sp, lane);
         load_strided(x, xq, lane);
     };
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
     const RoundCtl* __restrict__ ctl, int32_t* __restrict__ accept, int gb, int beta, int omega,
     int ctilde_len, size_t sig_len, const Twiddle* __restrict__ inv_tab,
     const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk, const uint8_t* __restrict__ key_oor, int oor_by_op,
-    int ct0_exact) {
+    int ct0_exact, const uint32_t* __restrict__ slot_y) {
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
     const int lane = threadIdx.x & 63;
@@ -302,43 +302,47 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
 
     // op / key of the next slot are fetched one slot ahead (two dependent loads off the critical path)
     // ... and so are its risk flags (which polynomials stage 1 has to transform)
-    auto risk_flags = [&](uint32_t sl, uint32_t& rr, uint32_t& zr) {
+    // (y and its flags are addressed by the slot's y row: the slot itself, or where the previous round put the mask it
+    //  generated ahead of time)
+    auto risk_flags = [&](uint32_t sl, uint32_t yr, uint32_t& rr, uint32_t& zr) {
         rr = wrisk ? (uint32_t)wrisk[sl] : (1u << K) - 1u;
         zr = (1u << L) - 1u;
         if (yrisk) {
             zr = 0;
 #pragma unroll
-            for (int j = 0; j < L; j++) zr |= (yrisk[(size_t)sl * L + j] ? 1u : 0u) << j;
+            for (int j = 0; j < L; j++) zr |= (yrisk[(size_t)yr * L + j] ? 1u : 0u) << j;
         }
     };
-    uint32_t op_next = 0, key_next = 0, rrisk_next = 0, zrisk_next = 0, oor_next = 0;
+    uint32_t op_next = 0, key_next = 0, rrisk_next = 0, zrisk_next = 0, oor_next = 0, yrow_next = 0;
     if (wid < n_slots32) {
         op_next = slot_op[wid];
+        yrow_next = slot_y ? slot_y[wid] : wid;
         key_next = key_idx ? key_idx[op_next] : op_next;
-        risk_flags(wid, rrisk_next, zrisk_next);
+        risk_flags(wid, yrow_next, rrisk_next, zrisk_next);
         oor_next = key_oor ? key_oor[oor_by_op ? op_next : key_next] : 0u;
     }
     for (uint32_t slot32 = wid; slot32 < n_slots32; slot32 += n_waves) {
-        const size_t slot = slot32, op = op_next, key = key_next;
+        const size_t slot = slot32, op = op_next, key = key_next, yrow = yrow_next;
         // a key whose s2 leaves [-eta, eta] (k_key_range) voids ||c s2||inf <= beta: every polynomial can reject and the
         // hint stage takes the reference's two-transform form
         const bool s2_oor = oor_next != 0;  // wave-uniform
         const uint32_t r_risky = s2_oor ? (1u << K) - 1u : rrisk_next, z_risky = zrisk_next;
         if (slot32 + n_waves < n_slots32) {
             op_next = slot_op[slot32 + n_waves];
+            yrow_next = slot_y ? slot_y[slot32 + n_waves] : slot32 + n_waves;
             key_next = key_idx ? key_idx[op_next] : op_next;
-            risk_flags(slot32 + n_waves, rrisk_next, zrisk_next);
+            risk_flags(slot32 + n_waves, yrow_next, rrisk_next, zrisk_next);
             oor_next = key_oor ? key_oor[oor_by_op ? op_next : key_next] : 0u;
         }
         if (spec == 1) {
-            const bool ok = tail_attempt<K, L, G2HI, true>(a, slot, key, r_risky, z_risky, s2_oor, sigs + op * sig_len, xpose[wave], itw,
+            const bool ok = tail_attempt<K, L, G2HI, true>(a, slot, yrow, key, r_risky, z_risky, s2_oor, sigs + op * sig_len, xpose[wave], itw,
                                                            lane, gb, beta, omega, ctilde_len, ct0_exact);
             if (lane == 0) {
                 if (ok) done[op] = 1;
                 else kappa[op] = (uint16_t)(kappa[op] + L);  // ml_dsa.rs:281 / 316
             }
         } else {
-            const bool ok = tail_attempt<K, L, G2HI, false>(a, slot, key, r_risky, z_risky, s2_oor, nullptr, xpose[wave], itw, lane, gb,
+            const bool ok = tail_attempt<K, L, G2HI, false>(a, slot, yrow, key, r_risky, z_risky, s2_oor, nullptr, xpose[wave], itw, lane, gb,
                                                             beta, omega, ctilde_len, ct0_exact);
             if (lane == 0) accept[slot] = ok ? 1 : 0;
         }
@@ -359,10 +363,18 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
 // round kernel walks its units with a grid-stride loop bounded by those device values, so the host can
 // enqueue any number of rounds ahead of time (or replay them from a hipGraph) with grids sized from the
 // EXPECTED counts: a round that finds more work loops, a round that finds none exits at once.
+//
+// Masks one round ahead: while a round with one candidate per op runs its HBM-bound sign_w, a helper stream generates the NEXT
+// round's first candidate (kappa + l) for all of its ops (k_expand_mask role 2; a fifth of them will have finished and their
+// masks are never read).  The rows are laid out by this round's slots; k_compact records the position each surviving op had
+// (ypos), and if the next round is again a one-candidate round its slot s reads y row slot_y[s] = ypos[s] and its own
+// ExpandMask launch returns at once (ctl->use_pre).  The decision is made here, on the device, from the spec the previous
+// round really used (spec_par[]) and the one this round gets: the host only says whether it enqueued the helper launch.
 __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, int parity, uint32_t spec_target, uint32_t spec_max,
                                                     const uint32_t* __restrict__ act, const uint16_t* __restrict__ kappa, int l,
                                                     uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa,
-                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key) {
+                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key,
+                                                    int pre_enqueued, const uint32_t* __restrict__ ypos, uint32_t* __restrict__ slot_y) {
     const uint32_t m = ctl->cnt[parity];
     uint32_t spec = 1;
     if (m > 0 && m * 2 <= spec_target) {
@@ -370,10 +382,13 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
         if (spec > spec_max) spec = spec_max;
     }
     const uint32_t ns = m * spec;
+    const bool use_pre = pre_enqueued && spec == 1u && ctl->spec_par[parity ^ 1] == 1u;  // spec_par[parity ^ 1]: not written here
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->cnt[parity ^ 1] = 0;
         ctl->m = m;
         ctl->spec = spec;
+        ctl->spec_par[parity] = spec;
+        ctl->use_pre = use_pre ? 1u : 0u;
         ctl->ns = ns;
         ctl->slots_total += ns;
         ctl->ops_total += m;
@@ -384,6 +399,7 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
         slot_op[sidx] = op;
         if (slot_key) slot_key[sidx] = key_idx ? key_idx[op] : op;  // row of a per-key A_hat table
         slot_kappa[sidx] = (uint16_t)(kappa[op] + (sidx % spec) * (uint32_t)l);
+        if (slot_y) slot_y[sidx] = use_pre ? ypos[sidx] : sidx;
     }
 }
 
@@ -397,7 +413,8 @@ __global__ __launch_bounds__(64 * GWAVES) void k_resolve(const RoundCtl* __restr
                                                          const uint32_t* __restrict__ key_idx, uint8_t* __restrict__ sigs, size_t sig_len,
                                                          int32_t* __restrict__ done, uint16_t* __restrict__ kappa, int gb, int beta,
                                                          int omega, int ctilde_len, const Twiddle* __restrict__ inv_tab,
-                                                         const uint8_t* __restrict__ key_oor, int oor_by_op, int ct0_exact) {
+                                                         const uint8_t* __restrict__ key_oor, int oor_by_op, int ct0_exact,
+                                                         const uint32_t* __restrict__ slot_y) {
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];
     const int spec = (int)ctl->spec;
@@ -420,8 +437,9 @@ __global__ __launch_bounds__(64 * GWAVES) void k_resolve(const RoundCtl* __restr
             const int j = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
             // every z_j is wanted (bytes); the r_i were tested by k_sign_tail and are not needed on their own
-            fin = tail_attempt<K, L, G2HI, true>(a, (size_t)i * spec + j, key, 0u, (1u << L) - 1u, s2_oor, sigs + (size_t)op * sig_len,
-                                                 xpose[wave], itw, lane, gb, beta, omega, ctilde_len, ct0_exact);
+            const size_t slot = (size_t)i * spec + j;
+            fin = tail_attempt<K, L, G2HI, true>(a, slot, slot_y ? (size_t)slot_y[slot] : slot, key, 0u, (1u << L) - 1u, s2_oor,
+                                                 sigs + (size_t)op * sig_len, xpose[wave], itw, lane, gb, beta, omega, ctilde_len, ct0_exact);
         }
         if (lane == 0) {
             if (fin) done[op] = 1;
@@ -432,11 +450,16 @@ __global__ __launch_bounds__(64 * GWAVES) void k_resolve(const RoundCtl* __restr
 
 // keep the unfinished ops for the next round (order is irrelevant: ops are independent)
 __global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int parity, const uint32_t* __restrict__ act_in,
-                                                 const int32_t* __restrict__ done, uint32_t* __restrict__ act_out) {
+                                                 const int32_t* __restrict__ done, uint32_t* __restrict__ act_out,
+                                                 uint32_t* __restrict__ ypos_out) {
     const uint32_t m = ctl->m;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
         const uint32_t op = act_in[i];
-        if (!done[op]) act_out[atomicAdd(&ctl->cnt[parity ^ 1], 1u)] = op;
+        if (!done[op]) {
+            const uint32_t j = atomicAdd(&ctl->cnt[parity ^ 1], 1u);
+            act_out[j] = op;
+            if (ypos_out) ypos_out[j] = i;  // where this round kept the op (= the row of a mask generated ahead for it)
+        }
     }
 }
 
@@ -711,14 +734,15 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
 int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde,
                      const uint32_t* slot_op, const uint32_t* key_idx, const int32_t* s1, const int32_t* s2, const int32_t* t0,
                      uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, int32_t* accept, size_t slots_hint,
-                     hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk, const uint8_t* key_oor, int oor_by_op) {
+                     hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk, const uint8_t* key_oor, int oor_by_op,
+                     const uint32_t* slot_y) {
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
     const TailPtrs a{c, y, w, ctilde, s1, s2, t0};
     dim3 grid(grid_for(ctx, slots_hint, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
 #define MLDSA_TAIL(KK, LL, G2)                                                                                                    \
     hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, a, slot_op, key_idx, kappa, done, sigs, ctl, accept, \
                        gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len, ctx->d_inv_tw, wrisk, yrisk, key_oor, oor_by_op,  \
-                       (int)ctx->opt_ct0_exact)
+                       (int)ctx->opt_ct0_exact, slot_y)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_TAIL(6, 5, true);
     else MLDSA_TAIL(8, 7, true);
@@ -740,9 +764,9 @@ int launch_key_range(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s2, c
 
 int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t* act,
                       const uint16_t* kappa, int l, uint32_t* slot_op, uint16_t* slot_kappa, const uint32_t* key_idx,
-                      uint32_t* slot_key, size_t slots_hint, hipStream_t s) {
+                      uint32_t* slot_key, size_t slots_hint, hipStream_t s, int pre_enqueued, const uint32_t* ypos, uint32_t* slot_y) {
     hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, spec_target, spec_max, act, kappa, l,
-                       slot_op, slot_kappa, key_idx, slot_key);
+                       slot_op, slot_kappa, key_idx, slot_key, pre_enqueued, ypos, slot_y);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }
@@ -750,13 +774,13 @@ int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_targe
 int launch_resolve(mldsa_ctx* ctx, const mldsa_params* p, const RoundCtl* ctl, const uint32_t* act, const int32_t* accept,
                    const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde, const uint32_t* key_idx,
                    const int32_t* s1, const int32_t* s2, const int32_t* t0, uint8_t* sigs, int32_t* done, uint16_t* kappa,
-                   size_t ops_hint, hipStream_t s, const uint8_t* key_oor, int oor_by_op) {
+                   size_t ops_hint, hipStream_t s, const uint8_t* key_oor, int oor_by_op, const uint32_t* slot_y) {
     const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
     const TailPtrs a{c, y, w, ctilde, s1, s2, t0};
     dim3 grid(grid_for(ctx, ops_hint, GWAVES, 8));
 #define MLDSA_RES(KK, LL, G2)                                                                                                      \
     hipLaunchKernelGGL((k_resolve<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, ctl, act, accept, a, key_idx, sigs, (size_t)p->sig_len, \
-                       done, kappa, gb, p->beta, p->omega, p->ctilde_len, ctx->d_inv_tw, key_oor, oor_by_op, (int)ctx->opt_ct0_exact)
+                       done, kappa, gb, p->beta, p->omega, p->ctilde_len, ctx->d_inv_tw, key_oor, oor_by_op, (int)ctx->opt_ct0_exact, slot_y)
     if (p->set == MLDSA_44) MLDSA_RES(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_RES(6, 5, true);
     else MLDSA_RES(8, 7, true);
@@ -766,8 +790,8 @@ int launch_resolve(mldsa_ctx* ctx, const mldsa_params* p, const RoundCtl* ctl, c
 }
 
 int launch_compact(mldsa_ctx*, RoundCtl* ctl, int parity, const uint32_t* act_in, const int32_t* done, uint32_t* act_out,
-                   size_t ops_hint, hipStream_t s) {
-    hipLaunchKernelGGL(k_compact, dim3(blocks256(ops_hint)), dim3(256), 0, s, ctl, parity, act_in, done, act_out);
+                   size_t ops_hint, hipStream_t s, uint32_t* ypos_out) {
+    hipLaunchKernelGGL(k_compact, dim3(blocks256(ops_hint)), dim3(256), 0, s, ctl, parity, act_in, done, act_out, ypos_out);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

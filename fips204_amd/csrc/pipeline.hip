@@ -314,21 +314,23 @@ namespace {
 // = the default of mldsa_ctx::pass_ops_sign
 
 struct SignWs {
-    int32_t *a_hat, *y, *w, *c, *done, *bad_op, *key_bad, *accept;
-    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk, *key_oor;
+    int32_t *a_hat, *y[2], *w, *c, *done, *bad_op, *key_bad, *accept;  // y[round & 1]: the round's masks (one may be filled a round ahead)
+    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk[2], *key_oor;
     uint16_t *kappa, *slot_kappa;
-    uint32_t *act[2], *slot_op, *slot_key, *kidx;
+    uint32_t *act[2], *ypos[2], *slot_op, *slot_key, *slot_y, *kidx;
     RoundCtl *ctl;
     size_t bytes = 0;
     uint8_t *base = nullptr;
     SignWs() = default;
     // n = ops of the chunk, ns = most candidate slots of a round
-    SignWs(void *base_, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat) : base(static_cast<uint8_t *>(base_)) {
+    // two_y: a second mask buffer for "masks one round ahead" (MLDSA_OPT_SIGN_MASK_AHEAD)
+    SignWs(void *base_, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat, bool two_y) : base(static_cast<uint8_t *>(base_)) {
         Carver cv(base_);
         a_hat = cv.take<int32_t>(own_a_hat ? n * (size_t)(p->k * p->l) * N : 0);
         key_bad = cv.take<int32_t>(n);
         kidx = cv.take<uint32_t>(n);
-        y = cv.take<int32_t>(ns * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
+        y[0] = cv.take<int32_t>(ns * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
+        y[1] = two_y ? cv.take<int32_t>(ns * (size_t)p->l * N) : y[0];
         w = cv.take<int32_t>(ns * (size_t)p->k * N);
         c = cv.take<int32_t>(ns * (size_t)N);
         done = cv.take<int32_t>(n);
@@ -339,14 +341,18 @@ struct SignWs {
         w1 = cv.take<uint8_t>(ns * (size_t)p->w1_len);
         ctilde = cv.take<uint8_t>(ns * 64);
         wrisk = cv.take<uint8_t>(ns);
-        yrisk = cv.take<uint8_t>(ns * (size_t)p->l);
+        yrisk[0] = cv.take<uint8_t>(ns * (size_t)p->l);
+        yrisk[1] = two_y ? cv.take<uint8_t>(ns * (size_t)p->l) : yrisk[0];
         key_oor = cv.take<uint8_t>(n);  // per key of the table, or per op when the table is larger than the chunk
         kappa = cv.take<uint16_t>(n);
         slot_kappa = cv.take<uint16_t>(ns);
         act[0] = cv.take<uint32_t>(n);
         act[1] = cv.take<uint32_t>(n);
+        ypos[0] = cv.take<uint32_t>(n);
+        ypos[1] = cv.take<uint32_t>(n);
         slot_op = cv.take<uint32_t>(ns);
         slot_key = cv.take<uint32_t>(ns);
+        slot_y = cv.take<uint32_t>(ns);
         ctl = cv.take<RoundCtl>(1);
         bytes = (cv.off + 511) & ~(size_t)255;
     }
@@ -363,6 +369,7 @@ struct SignPlan {
     uint32_t spec_target = 1, spec_max = 1;
     size_t ns_max = 0;
     std::vector<size_t> m_hint, ns_hint;  // per round: ops / slots the grids are sized for
+    std::vector<int> one_cand;            // per round: the plan expects one candidate per op (the device decides for itself)
 };
 
 SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, double plan_stop = 0.0) {
@@ -389,12 +396,14 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
         const size_t mm = (size_t)std::max(1.0, std::floor(m));
         if (mm * 2 <= tgt) spec_mean = (double)std::min<size_t>(tgt / mm, pl.spec_max);
         pl.m_hint.push_back(mh);
+        pl.one_cand.push_back(spec_mean == 1.0 && spec == 1 ? 1 : 0);
         pl.ns_hint.push_back(std::min(pl.ns_max, std::max(mh * spec, (size_t)std::ceil(m_hi * spec_mean))));
         m *= std::pow(q, spec_mean);
     }
     if (ctx->opt_sign_rounds > 0 && (size_t)ctx->opt_sign_rounds < pl.m_hint.size()) {
         pl.m_hint.resize((size_t)ctx->opt_sign_rounds);
         pl.ns_hint.resize((size_t)ctx->opt_sign_rounds);
+        pl.one_cand.resize((size_t)ctx->opt_sign_rounds);
     }
     return pl;
 }
@@ -408,23 +417,45 @@ size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t 
     const size_t chunk = std::min(n_ops, ctx->pass_ops_sign);
     const int n_lanes = sign_lanes_for(ctx, chunk);
     const size_t n = lane_ops(chunk, n_lanes);
-    return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a).bytes;
+    return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a, ctx->opt_mask_ahead != 0).bytes;
 }
 
+// batches below this size keep the plain sequence: their sign_w is not HBM-bound, and a fork / join per round costs latency
+constexpr size_t MASK_AHEAD_MIN_OPS = 16384;
+
 // One round of the rejection loop (steps 10-33 of Algorithm 7), counts read from the device
+// pre_in: the previous round launched the helper ExpandMask for this one; pre_out: launch it for the next one (pre_stream)
 static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, int round, size_t m_hint,
                               size_t ns_hint, const uint32_t *kidx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
-                              const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s, bool oor_by_op) {
+                              const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s, bool oor_by_op, bool pre_in = false,
+                              bool pre_out = false, hipStream_t pre_stream = nullptr) {
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
     const uint32_t *ns_dev = &w.ctl->ns;
+    int32_t *y = w.y[par];
+    uint8_t *yrisk = w.yrisk[par];
+    if (pre_in) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->pre_join_ev, 0));  // the helper launch read this round's slot arrays-to-be
     STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.spec_target, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
-                                          w.slot_kappa, kidx, own_a ? nullptr : w.slot_key, ns_hint, s));
-    // 11: y <- ExpandMask(rho'', kappa)                               :215
-    STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y, ns_hint, s, w.yrisk, ns_dev));
+                                          w.slot_kappa, kidx, own_a ? nullptr : w.slot_key, ns_hint, s, pre_in ? 1 : 0, w.ypos[par],
+                                          w.slot_y));
+    // 11: y <- ExpandMask(rho'', kappa)                               :215   (returns at once when the round uses masks made ahead)
+    STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, y, ns_hint, s, yrisk, ns_dev, w.ctl, 1, 0));
+    if (pre_out) {
+        // Masks one round ahead (k_make_slots): the next round's first candidate for every op of this round, on a helper stream
+        // underneath this round's sign_w -- that kernel re-reads A_hat per op and is HBM-bound with half of the integer issue
+        // slots idle (tools/ubench_overlap2.py: 880 us back to back, 730 us side by side at 65 536 ops).
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->pre_fork_ev, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(pre_stream, ctx->pre_fork_ev, 0));
+        {
+            ProfScope ps(ctx, pre_stream, "expand_mask_ahead");
+            TRY(launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y[par ^ 1], ns_hint, pre_stream, w.yrisk[par ^ 1],
+                                   ns_dev, w.ctl, 2, (uint32_t)p->l));
+        }
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->pre_join_ev, pre_stream));
+    }
     // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-    STAGE("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys, own_a ? w.slot_op : w.slot_key, w.y, w.w, w.w1,
-                                  (size_t)p->w1_len, ns_hint, s, 0, w.wrisk, own_a, ns_dev));
+    STAGE("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys, own_a ? w.slot_op : w.slot_key, y, w.w, w.w1,
+                                  (size_t)p->w1_len, ns_hint, s, 0, w.wrisk, own_a, ns_dev, w.slot_y));
     // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
     STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
                                            w.ctilde, 64, ns_hint, s, ns_dev));
@@ -434,13 +465,13 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     STAGE("ntt_c", launch_ntt(ctx, w.c, w.c, ns_hint, s, ns_dev));
     // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
     // (in a speculative round: only the tests that can reject, one verdict per candidate)
-    STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
-                                        ns_hint, s, w.wrisk, w.yrisk, w.key_oor, oor_by_op ? 1 : 0));
+    STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
+                                        ns_hint, s, w.wrisk, yrisk, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
     // speculative rounds only (the kernel leaves at once when the device chose one candidate per op): the whole iteration
     // for each op's first surviving candidate, bytes straight into the op's signature
-    STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, w.y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
-                                    m_hint, s, w.key_oor, oor_by_op ? 1 : 0));
-    STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s));
+    STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
+                                    m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
+    STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1]));
     return MLDSA_OK;
 }
 
@@ -488,7 +519,7 @@ bool oor_by_op(const SignArgs &a) { return a.key_idx && a.n_keys > a.n; }
 void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
     // y, rho'', cs1 / cs2, staged signatures are secret-dependent (the reference zeroizes on drop, types.rs:19);
     // A_hat = ExpandA(rho) is public and is the first and largest carve: skipped.
-    uint8_t *secrets = reinterpret_cast<uint8_t *>(w.y);
+    uint8_t *secrets = reinterpret_cast<uint8_t *>(w.y[0]);
     (void)launch_zero(ctx, secrets, (size_t)(w.base + w.bytes - secrets), s);
 }
 
@@ -556,15 +587,23 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
     for (int i = 0; i < n_lanes; i++) TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st));
     // 10: while (z, h) = bottom                                            ml_dsa.rs:212
     const int rounds = (int)pl.m_hint.size();
+    // masks one round ahead (enqueue_sign_round): where the plan expects two one-candidate rounds in a row, on a batch large
+    // enough for sign_w to be HBM-bound; one lane only (the helper stream is the second lane's stream)
+    const bool ahead = ctx->opt_mask_ahead != 0 && n_lanes == 1 && lanes[0].a.n >= MASK_AHEAD_MIN_OPS;
+    hipStream_t pre_stream = ahead ? (ctx->opt_mask_ahead == 2 ? parallel_stream(ctx, s) : priority_stream(ctx, s)) : nullptr;
+    bool pre_prev = false;
     for (int round = 0; round < rounds; round++) {
+        const bool pre_out = ahead && round + 1 < rounds && pl.one_cand[round] && pl.one_cand[round + 1];
         for (int i = 0; i < n_lanes; i++) {
             const SignLane &L = lanes[i];
             const ChunkKeys c = chunk_keys(p, L.w, L.a);
             // the plan is for a full slice; a short last one only makes its grids generous
             TRY(enqueue_sign_round(ctx, p, L.w, pl, round, std::min(pl.m_hint[round], L.a.n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k,
-                                   c.ak, c.sg, L.st, oor_by_op(L.a)));
+                                   c.ak, c.sg, L.st, oor_by_op(L.a), pre_prev, pre_out, pre_stream));
         }
+        pre_prev = pre_out;
     }
+    if (pre_prev) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->pre_join_ev, 0));  // (cannot happen: the last round never launches ahead)
     for (int i = 0; i < n_lanes; i++) {
         const SignLane &L = lanes[i];
         if (L.a.async_mode) {
@@ -655,7 +694,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     SignLane lanes[2];
     size_t ws_off = 0;
     for (int i = 0; i < n_lanes; i++) {
-        lanes[i].w = SignWs(static_cast<uint8_t *>(ctx->ws) + ws_off, p, per_lane, pl.ns_max, own_a);
+        lanes[i].w = SignWs(static_cast<uint8_t *>(ctx->ws) + ws_off, p, per_lane, pl.ns_max, own_a, ctx->opt_mask_ahead != 0);
         ws_off += lanes[i].w.bytes;
     }
     if (ctx->ws_bytes < ws_off) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
@@ -663,7 +702,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         // The previous synchronous call is (perhaps) still clearing its secrets on a helper stream.  This call's ExpandA may run
         // beside that -- one is integer-issue-bound, the other a stream of stores -- when it is launched directly on one lane
         // and everything the prologue touches before its wait (A_hat, the key-index scratch) lies below the span being cleared.
-        const size_t public_end = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
+        const size_t public_end = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y[0]) - static_cast<uint8_t *>(ctx->ws));
         const bool defer = own_a && n_lanes == 1 && !op_uses_graph(ctx, s, MLDSA_OP_SIGN, chunk) && public_end <= ctx->zero_lo;
         if (defer) ctx->zero_wait_after_ea = true;
         else TRY(wait_zeroise(ctx, s));
@@ -672,10 +711,11 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     int rc = MLDSA_OK;
     for (size_t o = 0; o < n_ops && rc == MLDSA_OK; o += chunk) {
         const size_t n_chunk = (n_ops - o) < chunk ? (n_ops - o) : chunk;
-        struct { int op, n_lanes; long spec_target, spec_max, rounds; SignArgs a[2]; } key;
+        struct { int op, n_lanes; long spec_target, spec_max, rounds, ahead; SignArgs a[2]; } key;
         memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
         key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_max = ctx->opt_spec_max;
         key.rounds = (long)pl.m_hint.size();  // the planned rounds (options, the asynchronous stop threshold) shape the launch sequence
+        key.ahead = ctx->opt_mask_ahead;
         int live = 0;
         for (int i = 0; i < n_lanes; i++) {
             const size_t lo = std::min(n_chunk, (size_t)i * per_lane), hi = std::min(n_chunk, lo + per_lane);
@@ -709,7 +749,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, z);
         MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_ev, z));
         ctx->zero_pending = true;
-        ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
+        ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y[0]) - static_cast<uint8_t *>(ctx->ws));
         ctx->zero_hi = ws_off;
     }
     return rc;
@@ -763,6 +803,31 @@ hipStream_t parallel_stream(mldsa_ctx *ctx, hipStream_t s, hipStream_t avoid) {
     }
     if (!found) found = ctx->aux_stream;  // every candidate shares a queue: still correct, just not concurrent
     if (!avoid) ctx->parallel_of.emplace_back(s, found);
+    return found;
+}
+
+// Like parallel_stream, but a HIGH-PRIORITY stream: work placed there is dispatched ahead of the caller's stream's work when
+// both have workgroups waiting.  The signer's "masks one round ahead" launch runs here: it must finish inside the HBM-bound
+// sign_w it hides under, not trail behind it into the latency-bound hash that follows.
+hipStream_t priority_stream(mldsa_ctx *ctx, hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return ctx->aux_stream;
+    for (const auto &pr : ctx->prio_of)
+        if (pr.first == s) return pr.second;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    hipStream_t found = nullptr;
+    for (size_t i = 0; i < 8 && !found; i++) {
+        if (i == ctx->prio_streams.size()) {
+            hipStream_t t = nullptr;
+            if (hipStreamCreateWithPriority(&t, hipStreamNonBlocking, greatest) != hipSuccess) break;
+            ctx->prio_streams.push_back(t);
+        }
+        hipStream_t c = ctx->prio_streams[i];
+        if (!streams_serialise(ctx, s, c)) found = c;
+    }
+    if (!found) found = parallel_stream(ctx, s);
+    ctx->prio_of.emplace_back(s, found);
     return found;
 }
 

@@ -240,6 +240,12 @@ class MlDsa:
         return PublicKeys(self.pset, rho, tr, t1)
 
     # ---- host-memory entry points (numpy arrays in, numpy arrays out; staging inside the library) --------
+    def _host_fn(self, op):
+        return getattr(self.lib, f"mldsa_{op}_host")
+
+    def _host_handle(self):
+        return self.hp._h
+
     @staticmethod
     def _np_u8(a, row, what):
         a = np.ascontiguousarray(a, dtype=np.uint8)
@@ -301,8 +307,8 @@ class MlDsa:
         # out: caller's (page-locked) uint8[n_ops]
         ok = self._host_out(out, np.uint8, n_ops, "verify_host: out") if out is not None else np.zeros(max(n_ops, 1), dtype=np.uint8)
         vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
-        _lib.check(self.lib.mldsa_verify_host(self.hp._h, self.pset, mode, vp(pk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
-                                              vp(coff), vp(sg), vp(ok), n_ops))
+        _lib.check(self._host_fn("verify")(self._host_handle(), self.pset, mode, vp(pk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
+                                           vp(coff), vp(sg), vp(ok), n_ops))
         return ok[:n_ops].astype(bool)
 
     def sign_host(self, sk_bytes, messages, rnd, ctxs=None, key_idx=None, mode=MODE_PURE, out=None):
@@ -327,8 +333,8 @@ class MlDsa:
         else:
             sig, status = np.zeros((max(n_ops, 1), self.SIG_LEN), dtype=np.uint8), np.zeros(max(n_ops, 1), dtype=np.int32)
         vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
-        _lib.check(self.lib.mldsa_sign_host(self.hp._h, self.pset, mode, vp(sk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
-                                            vp(coff), vp(rn), vp(sig), vp(status), n_ops))
+        _lib.check(self._host_fn("sign")(self._host_handle(), self.pset, mode, vp(sk), n_keys, vp(kidx), vp(mflat), vp(moff), vp(cflat),
+                                         vp(coff), vp(rn), vp(sig), vp(status), n_ops))
         if n_ops and int(status[:n_ops].min()) < 0:
             raise ValueError("ML-DSA.Sign: ctx too long")
         return sig[:n_ops]
@@ -347,7 +353,7 @@ class MlDsa:
             pk = np.zeros((max(n, 1), self.PK_LEN), dtype=np.uint8)
             sk = np.zeros((max(n, 1), self.SK_LEN), dtype=np.uint8)
         vp = lambda a: C.c_void_p(a.ctypes.data)
-        _lib.check(self.lib.mldsa_keygen_host(self.hp._h, self.pset, vp(x), vp(pk), vp(sk), n))
+        _lib.check(self._host_fn("keygen")(self._host_handle(), self.pset, vp(x), vp(pk), vp(sk), n))
         return pk[:n], sk[:n]
 
     # ---- KeyGen (src/traits.rs:8-114; src/lib.rs:247-250) ------------------------------
@@ -440,3 +446,58 @@ class MlDsa:
             _ptr(ctx_off) if ctx_off is not None else null, _ptr(rnd), _ptr(sigs),
             _ptr(status) if status is not None else null, n_ops, _stream()))
         return sigs
+
+
+class MlDsaGroup(MlDsa):
+    """The host-memory entry points over SEVERAL GPUs of one node: mldsa_group_create(device_ids) + mldsa_*_host_group
+    (include/mldsa_hip.h "several GPUs of one node").  verify_host / sign_host / keygen_host take exactly the arguments of
+    MlDsa's and return byte-identical results: the library cuts the batch into contiguous slices of ceil(B / N) ops, one
+    worker thread and context per entry of `device_ids` (a device may be listed twice: two contexts on one GPU), results
+    land directly in the caller's arrays.  Needs no torch: every pointer is host memory."""
+
+    def __init__(self, pset, device_ids):
+        self.pset = pset
+        self.lib = _lib.load()
+        p = _lib.get_params(pset)
+        self.params = p
+        self.PK_LEN, self.SK_LEN, self.SIG_LEN = p.pk_len, p.sk_len, p.sig_len
+        self.device_ids = [int(d) for d in device_ids]
+        ids = (C.c_int * len(self.device_ids))(*self.device_ids)
+        g = C.c_void_p()
+        _lib.check(self.lib.mldsa_group_create(ids, len(self.device_ids), C.byref(g)))
+        self._g = g
+        self.hp = None
+
+    def __len__(self):
+        return len(self.device_ids)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self.lib.mldsa_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _host_fn(self, op):
+        return getattr(self.lib, f"mldsa_{op}_host_group")
+
+    def _host_handle(self):
+        return self._g
+
+    def ctx(self, i):
+        """the i-th context of the group as a raw handle (mldsa_set_option / mldsa_reserve)"""
+        return C.c_void_p(self.lib.mldsa_group_ctx(self._g, i))
+
+    def set_option(self, option, value):
+        for i in range(len(self)):
+            _lib.check(self.lib.mldsa_set_option(self.ctx(i), option, value))
+
+    def shard(self, n_ops, part):
+        """(first, count) of the slice part `part` owns: mldsa_group_shard (= multi_gpu.shard)"""
+        a, c = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.mldsa_group_shard(n_ops, len(self), part, C.byref(a), C.byref(c)))
+        return a.value, c.value

@@ -110,6 +110,10 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
                                        10^-value (1..12, default 9: practically never an MLDSA_ERR_AGAIN).  A caller that re-signs such
                                        ops anyway can lower it: 2 plans like the synchronous call (three ~0.2 ms rounds less, an op
                                        left over in about 1 call in 500) */
+#define MLDSA_OPT_SIGN_MASK_AHEAD 10 /* sign: 1 = in the early rounds (one candidate per op, >= 16384 ops) the next round's masks are generated
+                                       on a high-priority helper stream underneath the HBM-bound w = A y kernel of the current round; 0
+                                       (default) = plain sequence.  Signatures are identical; measured on MI355X the helper launch slows
+                                       the kernels it runs beside by what it saves, hence off */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,
@@ -326,6 +330,36 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
                     const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                     const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops);
 int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys);
+
+/* ---- several GPUs of one node -------------------------------------------------------------
+ * The reference's operations are independent pure functions of their arguments (src/traits.rs:118-308,
+ * 330-362), so a batch shards trivially: contiguous slices of ceil(n_ops / N) ops, one per device (SURVEY.md
+ * 8e), no exchange on the data path.  A group owns one context and one host worker thread per entry of
+ * device_ids (a device may be listed more than once: several contexts on one GPU).  The *_host_group calls
+ * take exactly the arguments of mldsa_verify_host / mldsa_sign_host / mldsa_keygen_host, hand slice i to
+ * worker i -- which runs the ordinary host-memory entry point of its context on its part of the caller's
+ * arrays -- and return when every slice's results are in the caller's buffers.  Results are byte-identical
+ * to the single-context call.  mldsa_group_ctx(g, i) gives the i-th context (options, reserve, the device-
+ * resident entry points on the caller's own streams). */
+typedef struct mldsa_group mldsa_group;
+int mldsa_group_create(const int *device_ids, int n, mldsa_group **out);
+void mldsa_group_destroy(mldsa_group *g);
+int mldsa_group_size(const mldsa_group *g);
+mldsa_ctx *mldsa_group_ctx(mldsa_group *g, int i);
+/* the slice of an n_ops batch that part `part` of `n_parts` owns: first = min(n_ops, part * ceil(n_ops / n_parts)) */
+int mldsa_group_shard(size_t n_ops, int n_parts, int part, size_t *first, size_t *count);
+int mldsa_verify_host_group(mldsa_group *g, int set, int mode, const uint8_t *pk, size_t n_keys, const uint32_t *key_idx,
+                            const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                            const uint8_t *sigs, uint8_t *ok, size_t n_ops);
+int mldsa_sign_host_group(mldsa_group *g, int set, int mode, const uint8_t *sk, size_t n_keys, const uint32_t *key_idx,
+                          const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
+                          const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops);
+int mldsa_keygen_host_group(mldsa_group *g, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys);
+/* Device-resident verdicts (each device ran mldsa_verify on its slice): the one exchange SURVEY 8e names.
+ * bufs[i] = device pointer on device i of the group, N * ceil(n_ops / N) bytes, slice i of it filled; afterwards
+ * every buffer holds all n_ops bytes.  use_rccl: 1 = ncclAllGather over xGMI (librccl.so is loaded on first
+ * use; the devices must be distinct), 0 = device-to-device copies, -1 = RCCL if possible, copies otherwise. */
+int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, int use_rccl);
 
 #ifdef __cplusplus
 }

@@ -109,3 +109,25 @@ def test_bench_refuses_a_world_that_disagrees_with_gpus(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises(SystemExit):
         bench.dist_setup(bench.parse(["--gpus", "8"]))
+
+
+def test_library_slice_math_matches_the_python_split():
+    """mldsa_group_shard (the C ABI's in-library batch split, csrc/group.hip) = multi_gpu.shard for every (n, world, rank):
+    contiguous ceil(n / world) slices, ragged and empty tails included.  Pure host arithmetic: runs without a GPU."""
+    import ctypes as C
+    from fips204_amd import _lib
+    from fips204_amd.multi_gpu import shard
+    lib = _lib.load()
+    for world in (1, 2, 3, 7, 8):
+        for n in (0, 1, 5, 8, 63, 64, 65, 65536, 65537, 1 << 20, (1 << 20) + 3):
+            covered = 0
+            for rank in range(world):
+                a, c = C.c_size_t(), C.c_size_t()
+                assert lib.mldsa_group_shard(n, world, rank, C.byref(a), C.byref(c)) == 0
+                assert (a.value, c.value) == shard(n, rank, world), (n, world, rank)
+                assert a.value == covered or c.value == 0
+                covered += c.value
+            assert covered == n
+    a, c = C.c_size_t(), C.c_size_t()
+    assert lib.mldsa_group_shard(10, 2, 2, C.byref(a), C.byref(c)) != 0   # part outside the group
+    assert lib.mldsa_group_shard(10, 0, 0, C.byref(a), C.byref(c)) != 0
