@@ -107,6 +107,13 @@ class DevBuf {
     size_t n_ = 0;
 };
 
+// first byte of a vector of fixed-size byte arrays (std::array is contiguous and has no header); nullptr for an empty vector --
+// `v.data()->data()` would be a member call on a null pointer there (found by the UBSan run of tests/cpp/test_mirror_asan.cpp)
+template <class A>
+inline const uint8_t* raw_bytes(const std::vector<A>& v) { return reinterpret_cast<const uint8_t*>(v.data()); }
+template <class A>
+inline uint8_t* raw_bytes(std::vector<A>& v) { return reinterpret_cast<uint8_t*>(v.data()); }
+
 // concatenate byte strings + u64 offsets (the msgs / ctxs arguments of the C ABI)
 struct Packed {
     DevBuf bytes, offsets;
@@ -262,7 +269,7 @@ struct ParamSet {
     static std::pair<std::vector<PkBytes>, std::vector<SkBytes>> keygen_host(const std::vector<std::array<uint8_t, 32>>& xi) {
         std::vector<PkBytes> pk(xi.size());
         std::vector<SkBytes> sk(xi.size());
-        check(mldsa_keygen_host(Device::get().ctx(), SET, xi.data()->data(), pk.data()->data(), sk.data()->data(), xi.size()),
+        check(mldsa_keygen_host(Device::get().ctx(), SET, raw_bytes(xi), raw_bytes(pk), raw_bytes(sk), xi.size()),
               "mldsa_keygen_host");
         return {std::move(pk), std::move(sk)};
     }
@@ -274,8 +281,8 @@ struct ParamSet {
         HostBytes m(msgs), c(ctxs);
         std::vector<Signature> sig(n);
         std::vector<int32_t> st(n, 0);
-        check(mldsa_sign_host(Device::get().ctx(), SET, mode, sk.data()->data(), sk.size(), key_idx.data(), m.flat.data(), m.off.data(),
-                              c.flat.data(), c.off.data(), rnd.data()->data(), sig.data()->data(), st.data(), n), "mldsa_sign_host");
+        check(mldsa_sign_host(Device::get().ctx(), SET, mode, raw_bytes(sk), sk.size(), key_idx.data(), m.flat.data(), m.off.data(),
+                              c.flat.data(), c.off.data(), raw_bytes(rnd), raw_bytes(sig), st.data(), n), "mldsa_sign_host");
         for (int32_t s : st)
             if (s == MLDSA_ERR_CTX_LEN) throw Error("ML-DSA.Sign: ctx too long");
             else if (s != MLDSA_OK) throw Error("ML-DSA.Sign: key index out of range");
@@ -288,10 +295,61 @@ struct ParamSet {
         if (ctxs.size() != n || sigs.size() != n || key_idx.size() != n) throw Error("verify_host: argument lengths differ");
         HostBytes m(msgs), c(ctxs);
         std::vector<uint8_t> ok(n, 0);
-        check(mldsa_verify_host(Device::get().ctx(), SET, mode, pk.data()->data(), pk.size(), key_idx.data(), m.flat.data(), m.off.data(),
-                                c.flat.data(), c.off.data(), sigs.data()->data(), ok.data(), n), "mldsa_verify_host");
+        check(mldsa_verify_host(Device::get().ctx(), SET, mode, raw_bytes(pk), pk.size(), key_idx.data(), m.flat.data(), m.off.data(),
+                                c.flat.data(), c.off.data(), raw_bytes(sigs), ok.data(), n), "mldsa_verify_host");
         return std::vector<bool>(ok.begin(), ok.end());
     }
+
+    // ---- the same host-memory operations split over several GPUs (mldsa_group_*, include/mldsa_hip.h) ----------
+    // Group({0, 1, ..., 7}): one context and one worker thread per device; contiguous ceil(B / N) slices; results identical
+    // to the single-device calls above.
+    class Group {
+      public:
+        explicit Group(const std::vector<int>& device_ids) {
+            check(mldsa_group_create(device_ids.data(), (int)device_ids.size(), &g_), "mldsa_group_create");
+        }
+        ~Group() { mldsa_group_destroy(g_); }
+        Group(const Group&) = delete;
+        Group& operator=(const Group&) = delete;
+        int size() const { return mldsa_group_size(g_); }
+        mldsa_ctx* ctx(int i) const { return mldsa_group_ctx(g_, i); }
+        std::pair<std::vector<PkBytes>, std::vector<SkBytes>> keygen_host(const std::vector<std::array<uint8_t, 32>>& xi) const {
+            std::vector<PkBytes> pk(xi.size());
+            std::vector<SkBytes> sk(xi.size());
+            check(mldsa_keygen_host_group(g_, SET, raw_bytes(xi), raw_bytes(pk), raw_bytes(sk), xi.size()),
+                  "mldsa_keygen_host_group");
+            return {std::move(pk), std::move(sk)};
+        }
+        std::vector<Signature> sign_host(const std::vector<SkBytes>& sk, const std::vector<uint32_t>& key_idx,
+                                         const std::vector<std::vector<uint8_t>>& msgs, const std::vector<std::vector<uint8_t>>& ctxs,
+                                         const std::vector<std::array<uint8_t, 32>>& rnd, int mode = MLDSA_MODE_PURE) const {
+            const size_t n = msgs.size();
+            if (ctxs.size() != n || rnd.size() != n || key_idx.size() != n) throw Error("sign_host: argument lengths differ");
+            HostBytes m(msgs), c(ctxs);
+            std::vector<Signature> sig(n);
+            std::vector<int32_t> st(n, 0);
+            check(mldsa_sign_host_group(g_, SET, mode, raw_bytes(sk), sk.size(), key_idx.data(), m.flat.data(), m.off.data(),
+                                        c.flat.data(), c.off.data(), raw_bytes(rnd), raw_bytes(sig), st.data(), n),
+                  "mldsa_sign_host_group");
+            for (int32_t s : st)
+                if (s == MLDSA_ERR_CTX_LEN) throw Error("ML-DSA.Sign: ctx too long");
+                else if (s != MLDSA_OK) throw Error("ML-DSA.Sign: key index out of range");
+            return sig;
+        }
+        std::vector<bool> verify_host(const std::vector<PkBytes>& pk, const std::vector<uint32_t>& key_idx,
+                                      const std::vector<std::vector<uint8_t>>& msgs, const std::vector<Signature>& sigs,
+                                      const std::vector<std::vector<uint8_t>>& ctxs, int mode = MLDSA_MODE_PURE) const {
+            const size_t n = msgs.size();
+            if (ctxs.size() != n || sigs.size() != n || key_idx.size() != n) throw Error("verify_host: argument lengths differ");
+            HostBytes m(msgs), c(ctxs);
+            std::vector<uint8_t> ok(n, 0);
+            check(mldsa_verify_host_group(g_, SET, mode, raw_bytes(pk), pk.size(), key_idx.data(), m.flat.data(), m.off.data(),
+                                          c.flat.data(), c.off.data(), raw_bytes(sigs), ok.data(), n), "mldsa_verify_host_group");
+            return std::vector<bool>(ok.begin(), ok.end());
+        }
+      private:
+        mldsa_group* g_ = nullptr;
+    };
 
     // ---- single-key objects with the reference's method names -------------------------------------
     class PublicKey {

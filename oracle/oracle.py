@@ -11,7 +11,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# MLDSA_ORACLE_LIB: load another build of the same source instead -- tests/test_sanitizers_cpu.py points it at
+# liboracle_asan.so (oracle/Makefile) in a subprocess that has the ASan runtime preloaded
+_LIB_PATH = os.environ.get("MLDSA_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 Q = 8380417
 N = 256
@@ -24,7 +26,7 @@ def build(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB_PATH)], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

@@ -1,0 +1,88 @@
+"""Sanitizer leg (the reference fuzzes with debug-assertions + overflow-checks, fuzz/Cargo.toml:31-35).
+GPU AddressSanitizer does not exist on the pool, so the CPU-side code runs under ASan + UBSan here:
+
+  * the oracle (oracle/mldsa_oracle.c built as liboracle_asan.so, oracle/Makefile) through the reference's ACVP KATs and
+    through arbitrary / out-of-range key bytes, in a subprocess with the ASan runtime preloaded;
+  * the C++ host mirror (fips204_amd/host/fips204_hip.hpp: argument packing, RAII device buffers, group calls) and its
+    SHA-256 / SHA-512 / SHAKE128 (prehash.hpp) over a stub C ABI whose buffers are exactly sized (tests/cpp/stub_cabi.cpp).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _runtime(name):
+    out = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+    return out if os.path.isabs(out) and os.path.exists(out) else None
+
+
+def test_cpp_mirror_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "test_mirror_asan"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wall",
+                           os.path.join(ROOT, "tests", "cpp", "test_mirror_asan.cpp"), os.path.join(ROOT, "tests", "cpp", "stub_cabi.cpp"),
+                           "-o", str(exe)])
+    oid = bytes([0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02])
+    lines = []
+    for n in (0, 1, 3, 55, 56, 63, 64, 65, 111, 112, 119, 120, 127, 128, 129, 167, 168, 169, 335, 336, 337, 1000, 5000):
+        m = bytes((i * 7 + n) & 255 for i in range(n))
+        for ph, suffix, h in (("SHA256", b"\x01", lambda x: hashlib.sha256(x).digest()), ("SHA512", b"\x03", lambda x: hashlib.sha512(x).digest()),
+                              ("SHAKE128", b"\x0b", lambda x: hashlib.shake_128(x).digest(32))):
+            lines.append(f"{ph} {m.hex() or '-'} {(oid + suffix + h(m)).hex()}")
+    out = subprocess.run([str(exe)], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    assert out.stdout.startswith("OK 69 hash vectors"), out.stdout
+
+
+_ARBITRARY_KEYS = r"""
+import numpy as np
+from oracle import oracle as orc
+rng = np.random.default_rng(5)
+orc.lib()
+maps = open("/proc/self/maps").read()
+assert "liboracle_asan.so" in maps and "libasan" in maps, "the sanitizer build is not what is loaded"
+for pset in (44, 65, 87):
+    p = orc.params(pset)
+    for trial in range(6):
+        skb = rng.integers(0, 256, p.sk_len, dtype=np.uint8).tobytes()
+        if trial == 0: skb = skb[:128] + b"\xff" * (p.sk_len - 128)      # every field all-ones: eta / t0 out of range
+        if trial == 1: skb = skb[:128] + b"\x00" * (p.sk_len - 128)
+        sk = orc.sk_try_from_bytes(pset, skb)
+        pk = orc.get_public_key(pset, sk)
+        assert len(orc.pk_into_bytes(pset, pk)) == p.pk_len and len(orc.sk_into_bytes(pset, sk)) == p.sk_len
+        msg = bytes(range(trial * 9))
+        sig = orc.sign_internal(pset, sk, msg, bytes(32), ctx=b"c" * trial, mode=0)
+        orc.verify_internal(pset, pk, msg, sig, ctx=b"c" * trial, mode=0)
+        # arbitrary public-key and signature bytes (fuzz_all.rs:25-37): every failure is just False
+        pk2 = orc.pk_try_from_bytes(pset, rng.integers(0, 256, p.pk_len, dtype=np.uint8).tobytes())
+        assert orc.verify_internal(pset, pk2, msg, sig, mode=0) is False
+        assert orc.verify_internal(pset, pk, msg, rng.integers(0, 256, p.sig_len, dtype=np.uint8).tobytes(), mode=0) is False
+    try:
+        orc.sign_internal(pset, sk, b"m", bytes(32), ctx=b"x" * 256, mode=0)
+        raise SystemExit("ctx of 256 bytes accepted")
+    except ValueError:
+        pass
+print("arbitrary keys OK")
+"""
+
+
+def test_oracle_kats_and_arbitrary_keys_under_asan_ubsan():
+    asan = _runtime("libasan.so")
+    if not asan:
+        pytest.skip("no libasan.so next to gcc")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle_asan.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               MLDSA_ORACLE_LIB=os.path.join(ROOT, "oracle", "liboracle_asan.so"), PYTHONPATH=ROOT)
+    # the reference's ACVP keyGen / sigGen / sigVer vectors, messages.rs, bad_sig and the unit pins through the sanitizer build
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_kat.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])
+    assert "passed" in out.stdout and "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
+    out = subprocess.run([sys.executable, "-c", _ARBITRARY_KEYS], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "arbitrary keys OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
