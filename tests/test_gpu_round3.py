@@ -346,3 +346,32 @@ def test_group_allgather_of_device_resident_verdicts(hp):
                 assert lib.mldsa_group_allgather(g, arr, n, 1) != 0  # RCCL + duplicate devices: refused, not attempted
         finally:
             lib.mldsa_group_destroy(g)
+
+
+# ------------------------------------------------------------------------------ BASELINE config 5 at its specified request mix
+def test_config5_request_mix_against_the_oracle(hp):
+    """SURVEY 8(d') C5: request i -> set (44, 65, 87)[i mod 3], keygen / sign / verify by i mod 10 (10 / 40 / 50 %), bucketed into
+    per-set calls on one context with asynchronous signing (bench.py MixedStream = `--workload mixed`).  EVERY generated key,
+    signature and verdict of a step is compared with the oracle (ml_dsa.rs:57, 153, 351 are the three callers)."""
+    import bench
+    old = hp.get_option(9)
+    try:
+        wl = bench.MixedStream(hp, 1200, 0)
+        n = wl.ops_per_step
+        assert n == 3600 and wl.count == {"keygen": 360, "sign": 1440, "verify": 1800}
+        for pset in (44, 65, 87):
+            r = wl.req[pset]
+            ids = np.concatenate([r["keygen"], r["sign"], r["verify"]])
+            assert len(ids) == 1200 and (ids % 3 == (44, 65, 87).index(pset)).all()
+            assert (r["keygen"] % 10 == 0).all() and ((r["sign"] % 10 >= 1) & (r["sign"] % 10 <= 4)).all() and (r["verify"] % 10 >= 5).all()
+        wl.check(n_oracle=10 ** 9)
+        # a second step on the same buffers (graph replay for the shapes the policy covers) gives the same bytes
+        before = [d["sign"]["sig"].clone() for d in wl.sets]
+        for d in wl.sets:
+            d["sign"]["sig"].zero_()
+        wl.step(1)
+        wl.finish_steps()
+        for d, b in zip(wl.sets, before):
+            assert torch.equal(d["sign"]["sig"], b)
+    finally:
+        hp.set_option(9, old)

@@ -3,7 +3,7 @@
 #   bench JSON lines, rocprofv3 kernel stats, HBM-traffic and SQ PMC passes (separate --pmc runs with --kernel-trace only,
 #   the program itself directly after `--`).  Everything lands in gpurun_out/final_$R/ and, summarised, in profiles/.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/final_$R
 mkdir -p "$OUT"
 export TMPDIR=/tmp
