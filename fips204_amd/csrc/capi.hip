@@ -94,6 +94,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
     ctx->opt_host_sub_verify = env_long("MLDSA_HOST_SUB_VERIFY", 64, 65536, ctx->opt_host_sub_verify);
     ctx->opt_host_sub_sign = env_long("MLDSA_HOST_SUB_SIGN", 64, 65536, ctx->opt_host_sub_sign);
+    ctx->opt_host_direct = env_long("MLDSA_HOST_DIRECT", 0, 1, ctx->opt_host_direct);
     ctx->pass_ops = (size_t)env_long("MLDSA_PASS_OPS", 256, 1 << 20, (long)ctx->pass_ops);
     ctx->pass_ops_sign = (size_t)env_long("MLDSA_PASS_OPS_SIGN", 256, 1 << 20, (long)ctx->pass_ops_sign);
     hipDeviceProp_t prop;
@@ -115,6 +116,8 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->exp_fork_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->exp_join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pre_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pre_join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_ev, hipEventDisableTiming);
@@ -146,6 +149,8 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    if (ctx->exp_fork_ev) (void)hipEventDestroy(ctx->exp_fork_ev);
+    if (ctx->exp_join_ev) (void)hipEventDestroy(ctx->exp_join_ev);
     if (ctx->pre_fork_ev) (void)hipEventDestroy(ctx->pre_fork_ev);
     if (ctx->pre_join_ev) (void)hipEventDestroy(ctx->pre_join_ev);
     for (size_t i = 1; i < ctx->helper_streams.size(); i++) (void)hipStreamDestroy(ctx->helper_streams[i]);  // [0] is aux_stream
@@ -563,14 +568,14 @@ int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
 int mldsa::sign_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,
                      const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                      const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-                     int32_t *status, size_t n_ops, hipStream_t s, bool async_mode, double plan_stop) {
+                     int32_t *status, size_t n_ops, hipStream_t s, bool async_mode, double plan_stop, uint8_t *export_sigs) {
     const mldsa_params *p = params_of(set);
     if (n_ops == 0) return MLDSA_OK;
     OpGuard guard(ctx, s, true);  // sign_batch orders itself after a pending background clearing
     int rc = reserve_workspace(ctx, p, MLDSA_OP_SIGN, n_ops, a_hat == nullptr);
     if (rc != MLDSA_OK) return rc;
     return sign_batch(ctx, set, mode, rho, cap_k, tr, s1, s2, t0, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, rnd, sigs, status,
-                      n_ops, s, a_hat, async_mode, plan_stop);
+                      n_ops, s, a_hat, async_mode, plan_stop, export_sigs);
 }
 
 extern "C" {

@@ -13,11 +13,15 @@
 #include "ntt_wave.h"
 
 namespace mldsa {
+#define MLDSA_EXP_RING 64
 // Device-resident control block of the signer's rejection loop (kernels_sign.hip: k_make_slots).
 struct RoundCtl {
     uint32_t cnt[2];       // unfinished ops entering a round of parity 0 / 1
     uint32_t m, spec, ns;  // this round: unfinished ops, candidates per op, candidate slots = m * spec
     uint32_t rounds;       // rounds that found work (statistics)
+    uint32_t m_par[2];     // unfinished ops that entered the last round of parity 0 / 1
+    uint32_t exp_cnt;      // ops appended to the completion-order list so far (k_compact; mldsa_sign_host's direct export)
+    uint32_t exp_hi[64];   // exp_cnt at the end of round r (ring, r mod 64): round r's export copies [exp_hi[r - 1], exp_hi[r])
     uint32_t spec_par[2];  // candidates per op of the last round of parity 0 / 1 (k_make_slots of the next round reads the other one)
     uint32_t use_pre;      // this round's masks were generated one round ahead (k_expand_mask role 2): slot s reads y row slot_y[s]
     unsigned long long slots_total;  // candidate slots of all rounds of the call (statistics)
@@ -44,6 +48,7 @@ struct mldsa_ctx {
     // expected number of unfinished ops at which an ASYNCHRONOUS sign call stops planning rounds (1e-9: practically never an
     // MLDSA_ERR_AGAIN); mldsa_sign_host, which re-signs such ops anyway, raises it to the synchronous plan's 0.05 for its calls
     double async_stop = 1e-9;
+    long opt_host_direct = 1;  // mldsa_sign_host: finished signatures are written into a page-locked caller buffer round by round
     long opt_host_sub_verify = 8192, opt_host_sub_sign = 16384;  // *_host entry points: ops per sub-batch (verify), ops of the LAST sub-batch (sign)
     mldsa_stats stats = {};
     // hipGraph replay of repeated op-level call shapes
@@ -64,6 +69,7 @@ struct mldsa_ctx {
     // SampleInBall) run here, concurrently with the VALU-bound ExpandA on the caller's stream
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipEvent_t exp_fork_ev = nullptr, exp_join_ev = nullptr;  // sign: the per-round export of finished signatures to host memory
     hipEvent_t pre_fork_ev = nullptr, pre_join_ev = nullptr;  // sign: the helper ExpandMask launch of a round (pipeline.hip)
     // HIP maps streams onto a handful of hardware queues (four here, handed out 0 1 2 3 3 2 1 0 ...: tools/ubench_queues.hip);
     // two streams on one queue run their kernels strictly one after the other.  parallel_stream() therefore PROBES which of
@@ -253,7 +259,12 @@ int launch_resolve(mldsa_ctx *, const mldsa_params *, const RoundCtl *ctl, const
                    size_t ops_hint, hipStream_t, const uint8_t *key_oor = nullptr, int oor_by_op = 0, const uint32_t *slot_y = nullptr);
 // ypos_out (optional): position each surviving op had in act_in (= its slot in a one-candidate round)
 int launch_compact(mldsa_ctx *, RoundCtl *ctl, int parity, const uint32_t *act_in, const int32_t *done, uint32_t *act_out,
-                   size_t ops_hint, hipStream_t, uint32_t *ypos_out = nullptr);
+                   size_t ops_hint, hipStream_t, uint32_t *ypos_out = nullptr, uint32_t *exp_list = nullptr);
+// mldsa_sign_host's direct export (kernels_sign.hip k_export_done): snapshot of the completion-order list at the end of a round
+// (on the call's stream), then the copy of that round's finished signatures to host memory (device-visible pointer; helper stream)
+int launch_export_snap(mldsa_ctx *, RoundCtl *ctl, int round, hipStream_t);
+int launch_export_done(mldsa_ctx *, RoundCtl *ctl, int round, const uint32_t *exp_list, const uint8_t *sigs, uint8_t *host, size_t sig_len,
+                       size_t ops_hint, hipStream_t snap_stream, hipStream_t);
 int launch_init_active(mldsa_ctx *, size_t n, const int32_t *bad_op, int32_t *done, uint16_t *kappa, int32_t *status,
                        uint32_t *act_out, RoundCtl *ctl, uint8_t *sigs, size_t sig_len, hipStream_t);
 int launch_mark_unfinished(mldsa_ctx *, const RoundCtl *ctl, int parity, const uint32_t *act, int32_t *status, uint8_t *sigs,
@@ -289,14 +300,15 @@ int keygen_batch(mldsa_ctx *, int set, const uint8_t *xi, uint8_t *pk, uint8_t *
 int sign_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1,
                const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-               int32_t *status, size_t n_ops, hipStream_t, const int32_t *a_hat_keys, bool async_mode, double plan_stop = 0.0);
+               int32_t *status, size_t n_ops, hipStream_t, const int32_t *a_hat_keys, bool async_mode, double plan_stop = 0.0,
+               uint8_t *export_sigs = nullptr);
 // mldsa_sign / mldsa_sign_async / mldsa_sign_cached_a behind their argument checks (capi.hip).  plan_stop > 0: expected number of
 // unfinished ops at which the round plan stops, instead of the context's default for the mode (mldsa_sign_host re-signs
 // leftovers itself and plans like a synchronous call).
 int sign_call(mldsa_ctx *, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,
               const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
               const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-              int32_t *status, size_t n_ops, hipStream_t, bool async_mode, double plan_stop = 0.0);
+              int32_t *status, size_t n_ops, hipStream_t, bool async_mode, double plan_stop = 0.0, uint8_t *export_sigs = nullptr);
 int verify_batch(mldsa_ctx *, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1_d2_hat_mont, size_t n_keys,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
                  const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t,
@@ -309,7 +321,8 @@ size_t keygen_workspace_bytes(const mldsa_ctx *, const mldsa_params *, size_t n_
 // ensure_workspace for n_ops ops of MLDSA_OP_*; on MLDSA_ERR_NOMEM the context's pass size is halved and the request retried
 int reserve_workspace(mldsa_ctx *, const mldsa_params *, int op, size_t n_ops, bool own_a);
 // hipGraph replay of repeated call shapes: `key` = every value that ends up in a kernel parameter
-int run_op(mldsa_ctx *, hipStream_t, int op, size_t n_ops, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue);
+int run_op(mldsa_ctx *, hipStream_t, int op, size_t n_ops, const void *key, size_t key_len, const std::function<int(hipStream_t)> &enqueue,
+           bool allow_graph = true);
 void drop_graphs(mldsa_ctx *);
 void host_stage_destroy(mldsa_ctx *);  // host_api.hip
 

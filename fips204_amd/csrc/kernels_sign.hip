@@ -2,6 +2,7 @@
 // of the rejection loop of sign_internal (src/ml_dsa.rs:212-330), sig_encode, and the
 // keygen tail (power2round, pk / sk encode).  Everything is integer, element-wise or one
 // wave per polynomial; the NTT work goes through ntt_wave.h.
+#include <algorithm>
 #include <cstdlib>
 #include "ctx.h"
 #include "keccak.h"
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->cnt[parity ^ 1] = 0;
         ctl->m = m;
+        ctl->m_par[parity] = m;  // for the round's export launch, which may run after the next round's k_make_slots changed ctl->m
         ctl->spec = spec;
         ctl->spec_par[parity] = spec;
         ctl->use_pre = use_pre ? 1u : 0u;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(64 * GWAVES) void k_resolve(const RoundCtl* __restr
 // keep the unfinished ops for the next round (order is irrelevant: ops are independent)
 __global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int parity, const uint32_t* __restrict__ act_in,
                                                  const int32_t* __restrict__ done, uint32_t* __restrict__ act_out,
-                                                 uint32_t* __restrict__ ypos_out) {
+                                                 uint32_t* __restrict__ ypos_out, uint32_t* __restrict__ exp_list) {
     const uint32_t m = ctl->m;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
         const uint32_t op = act_in[i];
@@ -459,7 +461,53 @@ __global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int
             const uint32_t j = atomicAdd(&ctl->cnt[parity ^ 1], 1u);
             act_out[j] = op;
             if (ypos_out) ypos_out[j] = i;  // where this round kept the op (= the row of a mask generated ahead for it)
+        } else if (exp_list) {
+            exp_list[atomicAdd(&ctl->exp_cnt, 1u)] = op;  // finished in this round: its signature is complete (k_export_done)
         }
+    }
+}
+
+// Signatures straight into the caller's HOST memory (mldsa_sign_host with page-locked buffers): after every round the ops that
+// finished in it are copied from the device-side signature buffer (which the tail kernels write byte by byte) to `host` -- a
+// device-visible pointer to the caller's page-locked array -- so the signatures cross PCIe while later rounds still run, instead
+// of in one trailing 217 MB copy.  k_compact appends every op that finished to exp_list (completion order) and k_export_snap
+// records how far the list had grown at the end of round r (exp_hi[r]); the export launch of round r, on a helper stream,
+// copies the ops exp_list[exp_hi[r - 1] .. exp_hi[r]) -- it shares nothing with later rounds, so the round chain never waits
+// for it.  One wave per row; 16-byte aligned stores (tools/ubench_d2h.hip: dwordx4 stores reach the DMA engines' 53 GB/s,
+// dword stores a third of that), the source words funnel-shifted to the destination's alignment.
+__global__ void k_export_snap(RoundCtl* __restrict__ ctl, int round) {
+    ctl->exp_hi[round & (MLDSA_EXP_RING - 1)] = ctl->exp_cnt;
+}
+
+__global__ __launch_bounds__(256) void k_export_done(const RoundCtl* __restrict__ ctl, int round, const uint32_t* __restrict__ exp_list,
+                                                     const uint8_t* __restrict__ sigs, uint8_t* __restrict__ host, size_t sig_len) {
+    const uint32_t lo = round > 0 ? ctl->exp_hi[(round - 1) & (MLDSA_EXP_RING - 1)] : 0u, hi = ctl->exp_hi[round & (MLDSA_EXP_RING - 1)];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (uint32_t i = lo + wid; i < hi; i += n_waves) {
+        const uint32_t op = exp_list[i];
+        const uint8_t* src = sigs + (size_t)op * sig_len;
+        uint8_t* dst = host + (size_t)op * sig_len;
+        const int head = (int)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15);  // bytes until dst is 16-byte aligned
+        const int n_q = ((int)sig_len - head) / 16 - 1;                                  // the last quad goes byte-wise: no read past the row
+        uint4* dst16 = reinterpret_cast<uint4*>(dst + head);
+        const uintptr_t sa0 = reinterpret_cast<uintptr_t>(src + head);
+        const uint32_t* src4 = reinterpret_cast<const uint32_t*>(sa0 & ~(uintptr_t)3);
+        const int sh = (int)(sa0 & 3) * 8;
+        for (int q = lane; q < n_q; q += 64) {
+            const uint32_t* w = src4 + 4 * q;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            uint4 v = make_uint4(w0, w1, w2, w3);
+            if (sh) {
+                const uint32_t w4 = w[4];
+                v = make_uint4(__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), __builtin_amdgcn_alignbit(w3, w2, sh),
+                               __builtin_amdgcn_alignbit(w4, w3, sh));
+            }
+            dst16[q] = v;
+        }
+        if (lane < head) dst[lane] = src[lane];
+        const int tail0 = head + 16 * (n_q > 0 ? n_q : 0);
+        for (int t = tail0 + lane; t < (int)sig_len; t += 64) dst[t] = src[t];
     }
 }
 
@@ -790,8 +838,27 @@ int launch_resolve(mldsa_ctx* ctx, const mldsa_params* p, const RoundCtl* ctl, c
 }
 
 int launch_compact(mldsa_ctx*, RoundCtl* ctl, int parity, const uint32_t* act_in, const int32_t* done, uint32_t* act_out,
-                   size_t ops_hint, hipStream_t s, uint32_t* ypos_out) {
-    hipLaunchKernelGGL(k_compact, dim3(blocks256(ops_hint)), dim3(256), 0, s, ctl, parity, act_in, done, act_out, ypos_out);
+                   size_t ops_hint, hipStream_t s, uint32_t* ypos_out, uint32_t* exp_list) {
+    hipLaunchKernelGGL(k_compact, dim3(blocks256(ops_hint)), dim3(256), 0, s, ctl, parity, act_in, done, act_out, ypos_out, exp_list);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_export_done(mldsa_ctx* ctx, RoundCtl* ctl, int round, const uint32_t* exp_list, const uint8_t* sigs, uint8_t* host, size_t sig_len,
+                       size_t ops_hint, hipStream_t snap_stream, hipStream_t s) {
+    (void)snap_stream;
+    // SIXTEEN workgroups, whatever the round's size: a kernel that stores to host memory slows everything that runs beside it
+    // once it has more than that in flight (tools/ubench_d2h2.hip: 16 workgroups reach 44 GB/s and cost a neighbouring
+    // kernel 0-15 %; 32 reach 52 GB/s and cost it 75 %; 128 make an HBM fill beside them 12 times slower)
+    (void)ctx;
+    const unsigned blocks = (unsigned)std::min<size_t>(16, std::max<size_t>(1, (ops_hint + 3) / 4));
+    hipLaunchKernelGGL(k_export_done, dim3(blocks), dim3(256), 0, s, ctl, round, exp_list, sigs, host, sig_len);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_export_snap(mldsa_ctx*, RoundCtl* ctl, int round, hipStream_t s) {
+    hipLaunchKernelGGL(k_export_snap, dim3(1), dim3(1), 0, s, ctl, round);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -317,7 +317,7 @@ struct SignWs {
     int32_t *a_hat, *y[2], *w, *c, *done, *bad_op, *key_bad, *accept;  // y[round & 1]: the round's masks (one may be filled a round ahead)
     uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk[2], *key_oor;
     uint16_t *kappa, *slot_kappa;
-    uint32_t *act[2], *ypos[2], *slot_op, *slot_key, *slot_y, *kidx;
+    uint32_t *act[2], *ypos[2], *slot_op, *slot_key, *slot_y, *kidx, *exp_list;
     RoundCtl *ctl;
     size_t bytes = 0;
     uint8_t *base = nullptr;
@@ -350,6 +350,7 @@ struct SignWs {
         act[1] = cv.take<uint32_t>(n);
         ypos[0] = cv.take<uint32_t>(n);
         ypos[1] = cv.take<uint32_t>(n);
+        exp_list = cv.take<uint32_t>(n);
         slot_op = cv.take<uint32_t>(ns);
         slot_key = cv.take<uint32_t>(ns);
         slot_y = cv.take<uint32_t>(ns);
@@ -424,11 +425,26 @@ size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t 
 constexpr size_t MASK_AHEAD_MIN_OPS = 16384;
 
 // One round of the rejection loop (steps 10-33 of Algorithm 7), counts read from the device
+// mldsa_sign_host's direct export: round `round`'s finished signatures (k_export_done) on exp_stream, ordered after everything
+// enqueued on `s` so far
+static int enqueue_export(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, int round, size_t ops_hint, const uint8_t *sg, uint8_t *export_sg,
+                          hipStream_t s, hipStream_t exp_stream) {
+    MLDSA_HIP_CHECK(hipEventRecord(ctx->exp_fork_ev, s));
+    MLDSA_HIP_CHECK(hipStreamWaitEvent(exp_stream, ctx->exp_fork_ev, 0));
+    {
+        ProfScope ps(ctx, exp_stream, "export_to_host");
+        TRY(launch_export_done(ctx, w.ctl, round, w.exp_list, sg, export_sg, (size_t)p->sig_len, ops_hint, s, exp_stream));
+    }
+    MLDSA_HIP_CHECK(hipEventRecord(ctx->exp_join_ev, exp_stream));
+    return MLDSA_OK;
+}
+
 // pre_in: the previous round launched the helper ExpandMask for this one; pre_out: launch it for the next one (pre_stream)
 static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, int round, size_t m_hint,
                               size_t ns_hint, const uint32_t *kidx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
                               const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s, bool oor_by_op, bool pre_in = false,
-                              bool pre_out = false, hipStream_t pre_stream = nullptr) {
+                              bool pre_out = false, hipStream_t pre_stream = nullptr, uint8_t *export_sg = nullptr,
+                              hipStream_t exp_stream = nullptr, bool exp_pending = false) {
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
     const uint32_t *ns_dev = &w.ctl->ns;
@@ -440,6 +456,10 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
                                           w.slot_y));
     // 11: y <- ExpandMask(rho'', kappa)                               :215   (returns at once when the round uses masks made ahead)
     STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, y, ns_hint, s, yrisk, ns_dev, w.ctl, 1, 0));
+    // the PREVIOUS round's finished signatures -> the caller's host memory, on a helper stream (a small, fixed number of
+    // workgroups: see launch_export_done).  The launch reads only its own range of the completion-order list, which no later
+    // round touches, so nothing of the round chain ever waits for it.
+    if (export_sg && exp_pending) TRY(enqueue_export(ctx, p, w, round - 1, m_hint, sg, export_sg, s, exp_stream));
     if (pre_out) {
         // Masks one round ahead (k_make_slots): the next round's first candidate for every op of this round, on a helper stream
         // underneath this round's sign_w -- that kernel re-reads A_hat per op and is HBM-bound with half of the integer issue
@@ -471,7 +491,9 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     // for each op's first surviving candidate, bytes straight into the op's signature
     STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
                                     m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
-    STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1]));
+    STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1],
+                                    export_sg ? w.exp_list : nullptr));
+    if (export_sg) TRY(launch_export_snap(ctx, w.ctl, round, s));  // how far the completion-order list has grown: this round's range
     return MLDSA_OK;
 }
 
@@ -490,6 +512,7 @@ struct SignArgs {
     uint8_t *sigs;
     int32_t *status;
     const int32_t *a_hat_keys;
+    uint8_t *export_sigs;  // optional: the caller's page-locked host array (device-visible), finished signatures are copied there round by round
     size_t offset, n;   // this chunk: first op and number of ops
     size_t chunk;       // ops the workspace / plan is laid out for
     int async_mode;
@@ -498,7 +521,7 @@ struct SignArgs {
 struct ChunkKeys {  // per-chunk views of the key tables (identity mapping walks with the chunk)
     const uint32_t *kidx;
     const int32_t *s1k, *s2k, *t0k, *ak;
-    uint8_t *sg;
+    uint8_t *sg, *xsg;
 };
 
 ChunkKeys chunk_keys(const mldsa_params *p, const SignWs &w, const SignArgs &a) {
@@ -510,6 +533,7 @@ ChunkKeys chunk_keys(const mldsa_params *p, const SignWs &w, const SignArgs &a) 
     c.t0k = a.t0 + key_base * (size_t)p->k * N;
     c.ak = a.a_hat_keys ? a.a_hat_keys + key_base * (size_t)(p->k * p->l) * N : nullptr;
     c.sg = a.sigs + a.offset * (size_t)p->sig_len;
+    c.xsg = a.export_sigs ? a.export_sigs + a.offset * (size_t)p->sig_len : nullptr;
     return c;
 }
 
@@ -592,6 +616,9 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
     const bool ahead = ctx->opt_mask_ahead != 0 && n_lanes == 1 && lanes[0].a.n >= MASK_AHEAD_MIN_OPS;
     hipStream_t pre_stream = ahead ? (ctx->opt_mask_ahead == 2 ? parallel_stream(ctx, s) : priority_stream(ctx, s)) : nullptr;
     bool pre_prev = false;
+    // export of finished signatures to host memory (mldsa_sign_host): one lane only (the lanes would share the events)
+    const bool exporting = lanes[0].a.export_sigs != nullptr && n_lanes == 1;
+    hipStream_t exp_stream = exporting ? parallel_stream(ctx, s) : nullptr;
     for (int round = 0; round < rounds; round++) {
         const bool pre_out = ahead && round + 1 < rounds && pl.one_cand[round] && pl.one_cand[round + 1];
         for (int i = 0; i < n_lanes; i++) {
@@ -599,9 +626,16 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
             const ChunkKeys c = chunk_keys(p, L.w, L.a);
             // the plan is for a full slice; a short last one only makes its grids generous
             TRY(enqueue_sign_round(ctx, p, L.w, pl, round, std::min(pl.m_hint[round], L.a.n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k,
-                                   c.ak, c.sg, L.st, oor_by_op(L.a), pre_prev, pre_out, pre_stream));
+                                   c.ak, c.sg, L.st, oor_by_op(L.a), pre_prev, pre_out, pre_stream, exporting ? c.xsg : nullptr, exp_stream,
+                                   round > 0));
         }
         pre_prev = pre_out;
+    }
+    if (exporting && rounds > 0) {  // the last round's export; the call's stream ends after it
+        const SignLane &L = lanes[0];
+        const ChunkKeys c = chunk_keys(p, L.w, L.a);
+        TRY(enqueue_export(ctx, p, L.w, rounds - 1, std::min(pl.m_hint[rounds - 1], L.a.n), c.sg, c.xsg, s, exp_stream));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->exp_join_ev, 0));
     }
     if (pre_prev) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->pre_join_ev, 0));  // (cannot happen: the last round never launches ahead)
     for (int i = 0; i < n_lanes; i++) {
@@ -644,8 +678,14 @@ int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl,
             TRY(launch_zero(ctx, &L.w.ctl->slots_total, 2 * sizeof(unsigned long long), s));
             for (int e = 0; e < 2; e++) {
                 ctx->stats.sign_extra_rounds++;
+                const bool exporting = L.a.export_sigs != nullptr && n_lanes == 1;
                 TRY(enqueue_sign_round(ctx, p, L.w, pl, round + e, 64, std::min<size_t>(pl.ns_max, 2048), c.kidx, c.s1k, c.s2k, c.t0k, c.ak,
-                                       c.sg, s, oor_by_op(L.a)));
+                                       c.sg, s, oor_by_op(L.a), false, false, nullptr, exporting ? c.xsg : nullptr,
+                                       exporting ? parallel_stream(ctx, s) : nullptr, false));
+                if (exporting) {  // an extra round exports its own finishers right away
+                    TRY(enqueue_export(ctx, p, L.w, round + e, 64, c.sg, c.xsg, s, parallel_stream(ctx, s)));
+                    MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->exp_join_ev, 0));
+                }
             }
             MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], L.w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
         }
@@ -682,7 +722,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
                const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx,
                const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd,
                uint8_t *sigs, int32_t *status, size_t n_ops, hipStream_t s, const int32_t *a_hat_keys, bool async_mode,
-               double plan_stop) {
+               double plan_stop, uint8_t *export_sigs) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sign: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
@@ -723,12 +763,15 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
             SignArgs &a = key.a[live];
             a.set = set; a.mode = mode; a.rho = rho; a.cap_k = cap_k; a.tr = tr; a.s1 = s1; a.s2 = s2; a.t0 = t0; a.n_keys = n_keys;
             a.key_idx = key_idx; a.msgs = msgs; a.msg_off = msg_off; a.ctxs = ctxs; a.ctx_off = ctx_off; a.rnd = rnd; a.sigs = sigs;
-            a.status = status; a.a_hat_keys = a_hat_keys; a.offset = o + lo; a.n = hi - lo; a.chunk = per_lane;
+            a.status = status; a.a_hat_keys = a_hat_keys; a.export_sigs = export_sigs; a.offset = o + lo; a.n = hi - lo; a.chunk = per_lane;
             a.async_mode = async_mode ? 1 : 0;
             lanes[live].a = a;
             live++;
         }
-        rc = run_op(ctx, s, MLDSA_OP_SIGN, n_chunk, &key, sizeof(key), [&](hipStream_t st) { return sign_chunk_enqueue(ctx, p, pl, lanes, live, st); });
+        // a call that exports its signatures to host memory forks a helper launch off every round; replaying that shape crashed
+        // inside hipGraphLaunch (hip::Graph::UpdateStreams, ROCm 7.0 runtime of this image) for some round counts: launched directly
+        rc = run_op(ctx, s, MLDSA_OP_SIGN, n_chunk, &key, sizeof(key), [&](hipStream_t st) { return sign_chunk_enqueue(ctx, p, pl, lanes, live, st); },
+                    export_sigs == nullptr);
         if (rc == MLDSA_OK && !async_mode) rc = sign_chunk_finish(ctx, p, pl, lanes, live, s);
     }
     if (ctx->zero_wait_after_ea) {  // the call failed before its prologue got there
@@ -844,13 +887,13 @@ void drop_graphs(mldsa_ctx *ctx) {
 }
 
 int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key, size_t key_len,
-           const std::function<int(hipStream_t)> &enqueue) {
+           const std::function<int(hipStream_t)> &enqueue, bool allow_graph) {
     // MLDSA_OPT_GRAPHS: 0 never; 1 signing calls of up to GRAPH_AUTO_MAX_OPS ops -- ~100 launches for a few ms of device
     // work, where the 0.15-0.4 ms of host time a directly launched call costs is a sizeable share of the call; 2 every
     // op-level call.  A replayed graph is NOT faster on the device (the device-driven loop never waits for the host):
     // it costs the call 20-50 us of launch latency and saves the host thread 5-25x of its time per call.
     const bool wanted = ctx->opt_graphs == 2 || (ctx->opt_graphs == 1 && op == MLDSA_OP_SIGN && n_ops <= GRAPH_AUTO_MAX_OPS);
-    if (!wanted || ctx->prof_on) {  // per-stage timing needs the individual launches
+    if (!wanted || !allow_graph || ctx->prof_on) {  // per-stage timing needs the individual launches
         ctx->stats.direct_calls++;
         return enqueue(s);
     }

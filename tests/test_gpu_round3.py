@@ -375,3 +375,69 @@ def test_config5_request_mix_against_the_oracle(hp):
             assert torch.equal(d["sign"]["sig"], b)
     finally:
         hp.set_option(9, old)
+
+
+# ------------------------------------------------------------------------------ mldsa_sign_host: signatures written to host memory round by round
+def _pinned(shape, dtype):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    t = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=True)
+    a = t.numpy()[:n].view(dtype).reshape(shape)
+    a[...] = 0xA5 if dtype == np.uint8 else -7   # stale bytes: every row must be overwritten
+    return t, a
+
+
+@pytest.mark.parametrize("n,nk,passes", [(40000, 300, 0), (700, 9, 0), (20000, 64, 4096)])
+def test_sign_host_writes_page_locked_signatures_directly(sets, n, nk, passes):
+    """With a page-locked signature buffer mldsa_sign_host signs the whole batch in ONE call and k_export_done copies the
+    signatures that finished in each round to the caller's memory (lib.rs:268-296 is the per-op contract: same bytes).
+    Cases: a call in the direct path's size range (16 385 ... 131 072 ops), a small one (sub-batch path, captured and replayed
+    as a hipGraph: three calls on the same buffers), and a direct call cut into several passes (export offsets per pass);
+    refused ops get zero rows and their status."""
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    env = {"MLDSA_PASS_OPS_SIGN": str(passes)} if passes else {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        h2 = HotPath(0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    try:
+        m = MlDsa(65, hotpath=h2)
+        rng = np.random.default_rng(n)
+        xi = np.frombuffer(b"".join(shake(b"dir-key", i) for i in range(nk)), dtype=np.uint8)
+        pk, sk = m.keygen_host(xi)
+        msgs = [shake(b"dir-msg", i, int(rng.integers(0, 120))) for i in range(n)]
+        ctxs = [shake(b"dir-ctx", i, i % 5) for i in range(n)]
+        rnd = np.frombuffer(b"".join(shake(b"dir-rnd", i) for i in range(n)), dtype=np.uint8)
+        kidx = rng.integers(0, nk, n).astype(np.uint32)
+        want = m.sign_host(sk, msgs, rnd, ctxs=ctxs, key_idx=kidx)          # pageable output: the sub-batch path
+        keep_s, sig = _pinned((n, m.SIG_LEN), np.uint8)
+        keep_t, st = _pinned((n,), np.int32)
+        for rep in range(3):
+            sig[...] = 0xA5
+            got = m.sign_host(sk, msgs, rnd, ctxs=ctxs, key_idx=kidx, out=(sig, st))
+            assert got.ctypes.data == sig.ctypes.data and np.array_equal(got, want), rep
+            assert not st.any()
+        stats = h2.stats()
+        if n <= 16384:
+            assert stats["graph_replays"] >= 1
+        sk_o = [orc.sk_try_from_bytes(65, sk[i].tobytes()) for i in range(nk)]
+        for i in rng.choice(n, 8, replace=False):
+            assert sig[i].tobytes() == orc.sign_internal(65, sk_o[kidx[i]], msgs[i], rnd[32 * i:32 * i + 32].tobytes(), ctx=ctxs[i], mode=0)
+        assert m.verify_host(pk, msgs, sig, ctxs=ctxs, key_idx=kidx).all()
+        # refused ops: an over-long ctx in the middle of the batch
+        ctxs2 = list(ctxs)
+        bad = [1, n // 2, n - 1]
+        for i in bad:
+            ctxs2[i] = b"z" * 256
+        sig[...] = 0xA5
+        with pytest.raises(ValueError):
+            m.sign_host(sk, msgs, rnd, ctxs=ctxs2, key_idx=kidx, out=(sig, st))
+        good = np.ones(n, dtype=bool)
+        good[bad] = False
+        assert np.array_equal(sig[good], want[good]) and not sig[bad].any()
+        assert (st[bad] == -2).all() and not st[good].any()
+    finally:
+        h2.close()
