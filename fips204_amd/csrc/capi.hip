@@ -95,6 +95,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_host_sub_verify = env_long("MLDSA_HOST_SUB_VERIFY", 64, 65536, ctx->opt_host_sub_verify);
     ctx->opt_host_sub_sign = env_long("MLDSA_HOST_SUB_SIGN", 64, 65536, ctx->opt_host_sub_sign);
     ctx->opt_host_direct = env_long("MLDSA_HOST_DIRECT", 0, 1, ctx->opt_host_direct);
+    ctx->opt_side_prologue = env_long("MLDSA_SIDE_PROLOGUE", 0, 1, ctx->opt_side_prologue);
     ctx->pass_ops = (size_t)env_long("MLDSA_PASS_OPS", 256, 1 << 20, (long)ctx->pass_ops);
     ctx->pass_ops_sign = (size_t)env_long("MLDSA_PASS_OPS_SIGN", 256, 1 << 20, (long)ctx->pass_ops_sign);
     hipDeviceProp_t prop;

@@ -48,6 +48,7 @@ struct mldsa_ctx {
     // expected number of unfinished ops at which an ASYNCHRONOUS sign call stops planning rounds (1e-9: practically never an
     // MLDSA_ERR_AGAIN); mldsa_sign_host, which re-signs such ops anyway, raises it to the synchronous plan's 0.05 for its calls
     double async_stop = 1e-9;
+    long opt_side_prologue = 0;  // sign: mu / rho'' / key-range / first active list on the helper stream underneath ExpandA (experiment knob; measured: no gain, 8.25 vs 8.19 ms per 65 536 ML-DSA-65 signatures)
     long opt_host_direct = 1;  // mldsa_sign_host: finished signatures are written into a page-locked caller buffer round by round
     long opt_host_sub_verify = 8192, opt_host_sub_sign = 16384;  // *_host entry points: ops per sub-batch (verify), ops of the LAST sub-batch (sign)
     mldsa_stats stats = {};

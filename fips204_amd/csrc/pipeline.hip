@@ -548,7 +548,11 @@ void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
 }
 
 // steps 1-8 of Algorithm 7 for one lane's slice of a chunk: enqueue only (capturable)
-int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignArgs &a, hipStream_t s) {
+// side_ok: the lane-per-op kernels of the prologue (mu, rho'', the key-range check, the first active list: latency-bound, one wave
+// per SIMD or less) may run on the context's helper stream underneath ExpandA, like the verifier's (one lane only: the helper
+// stream is the second lane's)
+int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignArgs &a, hipStream_t s, bool side_ok) {
+    hipStream_t const main_stream = s;
     const bool own_a = a.a_hat_keys == nullptr;
     const size_t o = a.offset, n = a.n;
     int32_t *st = a.status ? a.status + o : nullptr;
@@ -559,15 +563,23 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     }
     const ChunkKeys c = chunk_keys(p, w, a);
     const size_t key_base = a.key_idx ? 0 : o;
+    const bool fork = side_ok && own_a && n >= 4096 && ctx->opt_side_prologue;
+    hipStream_t side = s;
+    if (fork) {
+        side = parallel_stream(ctx, s);
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(side, ctx->fork_ev, 0));
+    }
     // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
     if (own_a) STAGE("expand_a", launch_expand_a(ctx, a.set, a.rho + key_base * 32, 32, c.kidx, w.a_hat, n, s, true));
     // the previous signing call may still be clearing its secrets on a helper stream (sign_batch): ExpandA (public, below the
     // cleared span) was allowed to start beside it, everything from here on writes into that span
     if (ctx->zero_wait_after_ea) {
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(side, ctx->zero_ev, 0));
         ctx->zero_wait_after_ea = false;
         ctx->zero_pending = false;
     }
+    s = side;  // ---- the small kernels below: on the helper stream when forked, joined at the end
     // the signature buffer is not cleared: every op's bytes come from its accepted attempt, a refused op (k_init_active) or
     // one an asynchronous call leaves unfinished (k_mark_unfinished) gets its zeros there
     TRY(launch_zero(ctx, w.ctl, sizeof(RoundCtl), s));
@@ -588,6 +600,10 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     }
     // 8: kappa <- 0; active = all ops with a legal ctx and key index
     TRY(launch_init_active(ctx, n, w.bad_op, w.done, w.kappa, st, w.act[0], w.ctl, c.sg, (size_t)p->sig_len, s));
+    if (fork) {
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, side));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->join_ev, 0));
+    }
     return MLDSA_OK;
 }
 
@@ -608,7 +624,7 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
         MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(lanes[1].st, ctx->fork_ev, 0));
     }
-    for (int i = 0; i < n_lanes; i++) TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st));
+    for (int i = 0; i < n_lanes; i++) TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st, n_lanes == 1));
     // 10: while (z, h) = bottom                                            ml_dsa.rs:212
     const int rounds = (int)pl.m_hint.size();
     // masks one round ahead (enqueue_sign_round): where the plan expects two one-candidate rounds in a row, on a batch large
