@@ -22,7 +22,13 @@ python bench.py --workload mixed --batch 65536 --no-cpu-baseline --steps 5 --war
 python bench.py --gpus 2 --backend gloo --workload verify87 --batch 32768 --no-cpu-baseline --steps 5 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_gpus2_gloo_shared_gpu.json"
 # and the RCCL code path with a world of one (torchrun-style environment)
 MLDSA_BENCH_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 python bench.py --gpus 1 --workload verify87 --batch 32768 --no-cpu-baseline --steps 5 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_rccl_world1.json"
+# the C ABI's in-library multi-GPU path (mldsa_group_*): two contexts on this box's one GPU, host-fed
+python bench.py --inproc --gpus 2 --workload verify65 --batch 32768 --steps 5 --warmup 1 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_inproc_group2_verify65.json"
+python bench.py --inproc --gpus 2 --workload sign65 --batch 32768 --steps 3 --warmup 1 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/bench_inproc_group2_sign65.json"
 ./tools/ubench_graph 90 > "$OUT/ubench_graph.txt" 2>&1
+./tools/ubench_d2h2 > "$OUT/ubench_d2h2.txt" 2>&1
+python tools/ubench_overlap2.py > "$OUT/ubench_overlap2.txt" 2>&1
+for n in 32768 65536 131072; do python tools/hostfed_sign.py $n 4 2>&1 | grep sign_host; MLDSA_HOST_DIRECT=0 python tools/hostfed_sign.py $n 4 2>&1 | grep sign_host; done > "$OUT/hostfed_sign.txt"
 # rocprofv3 per-kernel summaries of the commands whose kernel times bench.py reports: the headline workload on its own (every
 # k_expand_a / k_verify_main launch is a 65536-op launch: the averages must agree with roofline.kernel_ms), sign65 on its
 # own, and the whole default run (which also contains the smaller launches of the host-fed passes)
