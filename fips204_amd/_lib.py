@@ -36,7 +36,7 @@ class Stats(C.Structure):
 
 OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
 OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE, OPT_SIGN_ROUNDS = 1, 2, 3, 4, 5, 6
-OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_MASK_AHEAD = 7, 8, 9, 10
+OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD = 7, 8, 9, 10
 ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
 
 # name -> argtypes (all return int unless listed in _RESTYPES)

@@ -90,7 +90,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 524288, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
     ctx->opt_sign_lanes = env_long("MLDSA_SIGN_LANES", 1, 2, ctx->opt_sign_lanes);
-    ctx->opt_mask_ahead = env_long("MLDSA_MASK_AHEAD", 0, 2, ctx->opt_mask_ahead);  // 2 (experiment): helper stream without priority
+    ctx->opt_lookahead = env_long("MLDSA_LOOKAHEAD", 0, 2, ctx->opt_lookahead);
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
     ctx->opt_host_sub_verify = env_long("MLDSA_HOST_SUB_VERIFY", 64, 65536, ctx->opt_host_sub_verify);
     ctx->opt_host_sub_sign = env_long("MLDSA_HOST_SUB_SIGN", 64, 65536, ctx->opt_host_sub_sign);
@@ -119,8 +119,6 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->exp_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->exp_join_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pre_fork_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pre_join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_ev, hipEventDisableTiming);
@@ -152,8 +150,6 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
     if (ctx->exp_fork_ev) (void)hipEventDestroy(ctx->exp_fork_ev);
     if (ctx->exp_join_ev) (void)hipEventDestroy(ctx->exp_join_ev);
-    if (ctx->pre_fork_ev) (void)hipEventDestroy(ctx->pre_fork_ev);
-    if (ctx->pre_join_ev) (void)hipEventDestroy(ctx->pre_join_ev);
     for (size_t i = 1; i < ctx->helper_streams.size(); i++) (void)hipStreamDestroy(ctx->helper_streams[i]);  // [0] is aux_stream
     for (hipStream_t t : ctx->prio_streams) (void)hipStreamDestroy(t);
     if (ctx->d_probe) (void)hipFree(ctx->d_probe);
@@ -207,9 +203,9 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             REQUIRE(value >= 1 && value <= 12, "mldsa_set_option: MLDSA_OPT_SIGN_ASYNC_EXP is 1 .. 12");
             ctx->async_stop = std::pow(10.0, -(double)value);
             return MLDSA_OK;
-        case MLDSA_OPT_SIGN_MASK_AHEAD:
-            REQUIRE(value == 0 || value == 1, "mldsa_set_option: MLDSA_OPT_SIGN_MASK_AHEAD is 0 or 1");
-            ctx->opt_mask_ahead = value;
+        case MLDSA_OPT_SIGN_LOOKAHEAD:
+            REQUIRE(value >= 0 && value <= 2, "mldsa_set_option: MLDSA_OPT_SIGN_LOOKAHEAD is 0, 1 or 2");
+            ctx->opt_lookahead = value;  // changes the workspace layout: the next signing call reserves for it
             return MLDSA_OK;
         case MLDSA_OPT_SIGN_CT0_EXACT:
             REQUIRE(value == 0 || value == 1, "mldsa_set_option: MLDSA_OPT_SIGN_CT0_EXACT is 0 or 1");
@@ -235,7 +231,7 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option) {
         case MLDSA_OPT_SIGN_ROUNDS: return ctx->opt_sign_rounds;
         case MLDSA_OPT_SIGN_LANES: return ctx->opt_sign_lanes;
         case MLDSA_OPT_SIGN_CT0_EXACT: return ctx->opt_ct0_exact;
-        case MLDSA_OPT_SIGN_MASK_AHEAD: return ctx->opt_mask_ahead;
+        case MLDSA_OPT_SIGN_LOOKAHEAD: return ctx->opt_lookahead;
         case MLDSA_OPT_SIGN_ASYNC_EXP: return std::lround(-std::log10(ctx->async_stop));
         default: return MLDSA_ERR_PARAM;
     }

@@ -327,7 +327,8 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
                                                        const uint8_t* __restrict__ b, size_t sb, int lb,
                                                        uint32_t tail, int tail_len,
                                                        uint8_t* __restrict__ out, size_t so, size_t n_ops,
-                                                       const uint32_t* __restrict__ n_dev, VerdictArgs vd) {
+                                                       const uint32_t* __restrict__ n_dev, VerdictArgs vd,
+                                                       const uint32_t* __restrict__ b_idx) {
     __shared__ uint32_t tiles[CWAVES * 64 * H_STRIDE];
     __shared__ unsigned long long ptr_a[CWAVES * 64], ptr_b[CWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
         const size_t opc = valid ? op : base_op;
         const unsigned long long pa = (unsigned long long)(a + (a_idx ? a_idx[opc] : opc) * sa);
         ptr_a[wave * 64 + lane] = pa;
-        ptr_b[wave * 64 + lane] = b ? (unsigned long long)(b + opc * sb) : pa;
+        ptr_b[wave * 64 + lane] = b ? (unsigned long long)(b + (b_idx ? b_idx[opc] : opc) * sb) : pa;
         wave_lds_sync_c();
         KeccakState st;
         shake256_2_absorb<ALIGNED>(st, tile, ptr_a + wave * 64, ptr_b + wave * 64, la, lb, tail, tail_len, lane);
@@ -402,13 +403,13 @@ int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* k
 
 static int launch_shake256_2v(int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                               size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
-                              const uint32_t* n_dev, const VerdictArgs& vd);
+                              const uint32_t* n_dev, const VerdictArgs& vd, const uint32_t* b_idx = nullptr);
 
 int launch_shake256_2(mldsa_ctx*, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                       size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
-                      const uint32_t* n_dev) {
+                      const uint32_t* n_dev, const uint32_t* b_idx) {
     VerdictArgs none{};
-    return launch_shake256_2v(out_len, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, s, n_dev, none);
+    return launch_shake256_2v(out_len, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, s, n_dev, none, b_idx);
 }
 
 // c_tilde' = H(mu | w1Encode(w1')) and the final verdict of verify_internal in one kernel (ml_dsa.rs:429-436)
@@ -420,15 +421,15 @@ int launch_ctilde_verdict(mldsa_ctx*, const mldsa_params* p, const uint8_t* mu_w
 
 static int launch_shake256_2v(int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                               size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
-                              const uint32_t* n_dev, const VerdictArgs& vd) {
+                              const uint32_t* n_dev, const VerdictArgs& vd, const uint32_t* b_idx) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     dim3 grid(lane_blocks(n_ops ? n_ops : 1)), block(CBLOCK);
     if ((la & 3) != 0 || (lb & 3) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: segment lengths must be multiples of 4 bytes");
     const bool al = (((uintptr_t)a | (uintptr_t)sa | (uintptr_t)b | (uintptr_t)sb) & 3) == 0;
 #define MLDSA_SHAKE_CASE(O)                                                                                              \
     case O:                                                                                                              \
-        if (al) hipLaunchKernelGGL((k_shake256_2<O, true>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd); \
-        else hipLaunchKernelGGL((k_shake256_2<O, false>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd);   \
+        if (al) hipLaunchKernelGGL((k_shake256_2<O, true>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd, b_idx); \
+        else hipLaunchKernelGGL((k_shake256_2<O, false>), grid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd, b_idx);   \
         break;
     switch (out_len) {
         MLDSA_SHAKE_CASE(32)

@@ -112,18 +112,13 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
 // ExpandMask (hashing.rs:281-313): stream (op, r < L): v = SHAKE256(rho'' || (kappa + r) LE16),
 // y[r][i] = gamma1 - (c-bit field i of v), c = 1 + bitlen(gamma1 - 1) (bit_unpack,
 // conversion.rs:227-262).  No rejection: all lanes advance in lock step.
-// The signer's rounds launch it in two roles (ctl != nullptr, pipeline.hip "masks one round ahead"):
-//   role 1 = this round's masks, skipped when the round uses the masks generated ahead of time (ctl->use_pre);
-//   role 2 = the NEXT round's first candidate (kappa + kappa_add) for every op of this round, only when this round has
-//            one candidate per op (ctl->spec == 1) -- runs on a helper stream underneath this round's HBM-bound sign_w.
 template <int GB>  // gamma1 = 2^GB, GB = 17 or 19
 __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_expand_mask(const uint8_t* __restrict__ rho_pp, size_t rho_stride,
                                                              const uint16_t* __restrict__ kappa, int kappa_by_slot,
                                                              const uint32_t* __restrict__ op_idx,
                                                              int32_t* __restrict__ y, int l, size_t n_ops,
                                                              const uint32_t* __restrict__ n_dev,
-                                                             uint8_t* __restrict__ yrisk, int32_t risk_bound,
-                                                             const RoundCtl* __restrict__ ctl, int role, uint32_t kappa_add) {
+                                                             uint8_t* __restrict__ yrisk, int32_t risk_bound) {
     constexpr int CB = GB + 1;
     constexpr uint32_t MASK = (1u << CB) - 1u;
     __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
@@ -131,10 +126,6 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
     uint32_t* stage = lds + wave * 64 * STAGE_STRIDE;
     uint32_t* my = stage + lane * STAGE_STRIDE;
     if (n_dev) n_ops = *n_dev;  // the signer's rounds: slots of this round, known only on the device
-    if (ctl) {
-        if (role == 1 && ctl->use_pre) return;
-        if (role == 2 && ctl->spec != 1u) return;
-    }
     const size_t n_streams = n_ops * (size_t)l;
     // tiles of 256 streams, grid-stride (the grid is sized from the expected count)
     for (size_t tile = (size_t)blockIdx.x * (64 * SWAVES); tile < n_streams; tile += (size_t)gridDim.x * (64 * SWAVES)) {
@@ -151,7 +142,7 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
     keccak_zero(st);
     {
         absorb_words<8>(st, rho_pp + op * rho_stride);
-        const uint32_t nn = ((uint32_t)kappa[kappa_by_slot ? slot : op] + kappa_add + r) & 0xFFFFu;  // hashing.rs:293 (u16 arithmetic)
+        const uint32_t nn = ((uint32_t)kappa[kappa_by_slot ? slot : op] + r) & 0xFFFFu;  // hashing.rs:293 (u16 arithmetic)
         st.lo[8] = nn | (0x1Fu << 16);
         st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
     }
@@ -287,14 +278,13 @@ int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_st
 
 // n_dev != nullptr: the op count is read from the device (the signer's rounds) and n_ops only sizes the grid
 int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_stride, const uint16_t* kappa, int kappa_by_slot,
-                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s, uint8_t* yrisk, const uint32_t* n_dev,
-                       const RoundCtl* ctl, int role, uint32_t kappa_add) {
+                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s, uint8_t* yrisk, const uint32_t* n_dev) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
     dim3 grid(stream_blocks((n_ops ? n_ops : 1) * (size_t)p->l)), block(64 * SWAVES);
-    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta, ctl, role, kappa_add);
-    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta, ctl, role, kappa_add);
+    if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta);
+    else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -120,7 +120,7 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
     auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
         const bool is_r = idx < K;
         const int32_t* sp = is_r ? a.s2 + (key * K + idx) * (size_t)N : a.s1 + (key * L + (idx - K)) * (size_t)N;
-        const int32_t* xq = is_r ? a.w + (slot * K + idx) * (size_t)N : a.y + (yrow * L + (idx - K)) * (size_t)N;
+        const int32_t* xq = is_r ? a.w + (yrow * K + idx) * (size_t)N : a.y + (yrow * L + (idx - K)) * (size_t)N;
         load_packed(v, sp, lane);
         load_strided(x, xq, lane);
     };
@@ -206,7 +206,7 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
             int32_t v[4], v2[4], r[4], base[4];
             load_packed(v, a.t0 + (key * K + i) * (size_t)N, lane);
             load_packed(v2, a.s2 + (key * K + i) * (size_t)N, lane);
-            load_strided(base, a.w + (slot * K + i) * (size_t)N, lane);
+            load_strided(base, a.w + (yrow * K + i) * (size_t)N, lane);
             if (s2_oor) {
                 // out-of-range s2: the identity is not guaranteed; r_i = w_i - c s2_i explicitly (it passed the LowBits
                 // test in stage 1, where every polynomial counted as risky), then r_i + c t0_i as the reference does
@@ -303,10 +303,11 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
 
     // op / key of the next slot are fetched one slot ahead (two dependent loads off the critical path)
     // ... and so are its risk flags (which polynomials stage 1 has to transform)
-    // (y and its flags are addressed by the slot's y row: the slot itself, or where the previous round put the mask it
-    //  generated ahead of time)
+    // (y, w and their flags are addressed by the slot's ROW: the slot itself, or where a round that generated two candidates
+    //  per op put this one)
     auto risk_flags = [&](uint32_t sl, uint32_t yr, uint32_t& rr, uint32_t& zr) {
-        rr = wrisk ? (uint32_t)wrisk[sl] : (1u << K) - 1u;
+        (void)sl;
+        rr = wrisk ? (uint32_t)wrisk[yr] : (1u << K) - 1u;
         zr = (1u << L) - 1u;
         if (yrisk) {
             zr = 0;
@@ -365,17 +366,19 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
 // enqueue any number of rounds ahead of time (or replay them from a hipGraph) with grids sized from the
 // EXPECTED counts: a round that finds more work loops, a round that finds none exits at once.
 //
-// Masks one round ahead: while a round with one candidate per op runs its HBM-bound sign_w, a helper stream generates the NEXT
-// round's first candidate (kappa + l) for all of its ops (k_expand_mask role 2; a fifth of them will have finished and their
-// masks are never read).  The rows are laid out by this round's slots; k_compact records the position each surviving op had
-// (ypos), and if the next round is again a one-candidate round its slot s reads y row slot_y[s] = ypos[s] and its own
-// ExpandMask launch returns at once (ctl->use_pre).  The decision is made here, on the device, from the spec the previous
-// round really used (spec_par[]) and the one this round gets: the host only says whether it enqueued the helper launch.
+// Two candidates per op generated at once (rounds with one candidate per op, i.e. the first four of a large batch).  There
+// sign_w is bound by re-reading each op's A_hat from HBM (23 KB per op and round against 12 KB of y / w per candidate), so a round
+// may produce the rows of TWO candidates per op -- kappa and kappa + l, adjacent rows that share the A_hat read -- while testing only
+// the first: hash, SampleInBall and the tail run on row 2 i of op i.  The next round then generates nothing: k_compact recorded the
+// position each surviving op had (ypos), its slot s tests row 2 ypos[s] + 1 (use_pre) and its ExpandMask / sign_w launches find
+// ns_gen = 0.  A fifth of the second candidates belong to ops that finished and are never read.  Decided here, on the device:
+// the host only says what its plan allows (may_gen2 / may_use_pre); gen_par[] carries what the previous round really did.
 __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, int parity, uint32_t spec_target, uint32_t spec_max,
                                                     const uint32_t* __restrict__ act, const uint16_t* __restrict__ kappa, int l,
                                                     uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa,
-                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ slot_key,
-                                                    int pre_enqueued, const uint32_t* __restrict__ ypos, uint32_t* __restrict__ slot_y) {
+                                                    const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ gen_op,
+                                                    uint16_t* __restrict__ gen_kappa, uint32_t* __restrict__ gen_key, int may_use_pre,
+                                                    int may_gen2, const uint32_t* __restrict__ ypos, uint32_t* __restrict__ slot_y) {
     const uint32_t m = ctl->cnt[parity];
     uint32_t spec = 1;
     if (m > 0 && m * 2 <= spec_target) {
@@ -383,25 +386,37 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
         if (spec > spec_max) spec = spec_max;
     }
     const uint32_t ns = m * spec;
-    const bool use_pre = pre_enqueued && spec == 1u && ctl->spec_par[parity ^ 1] == 1u;  // spec_par[parity ^ 1]: not written here
+    const bool use_pre = may_use_pre && spec == 1u && ctl->gen_par[parity ^ 1] == 2u;  // gen_par[parity ^ 1]: not written here
+    const uint32_t gen = use_pre ? 0u : (may_gen2 && spec == 1u) ? 2u : 1u;
+    const uint32_t ns_gen = gen == 2u ? 2u * m : gen == 1u ? ns : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->cnt[parity ^ 1] = 0;
         ctl->m = m;
-        ctl->m_par[parity] = m;  // for the round's export launch, which may run after the next round's k_make_slots changed ctl->m
+        ctl->m_par[parity] = m;
         ctl->spec = spec;
-        ctl->spec_par[parity] = spec;
+        ctl->gen_par[parity] = gen;
         ctl->use_pre = use_pre ? 1u : 0u;
         ctl->ns = ns;
-        ctl->slots_total += ns;
-        ctl->ops_total += m;
+        ctl->ns_gen = ns_gen;
+        ctl->slots_total += ns_gen;  // candidates generated (statistics: a second candidate counts whether or not it is ever tested)
+        ctl->ops_total += gen ? m : 0u;
         ctl->rounds += m ? 1u : 0u;
     }
-    for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < ns; sidx += gridDim.x * 256) {
-        const uint32_t op = act[sidx / spec];
-        slot_op[sidx] = op;
-        if (slot_key) slot_key[sidx] = key_idx ? key_idx[op] : op;  // row of a per-key A_hat table
-        slot_kappa[sidx] = (uint16_t)(kappa[op] + (sidx % spec) * (uint32_t)l);
-        if (slot_y) slot_y[sidx] = use_pre ? ypos[sidx] : sidx;
+    const uint32_t top = ns > ns_gen ? ns : ns_gen;
+    for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < top; sidx += gridDim.x * 256) {
+        if (sidx < ns) {  // the candidates this round tests
+            const uint32_t op = act[sidx / spec];
+            slot_op[sidx] = op;
+            slot_kappa[sidx] = (uint16_t)(kappa[op] + (sidx % spec) * (uint32_t)l);
+            slot_y[sidx] = use_pre ? 2u * ypos[sidx] + 1u : gen == 2u ? 2u * sidx : sidx;
+        }
+        if (sidx < ns_gen) {  // the rows this round generates
+            const uint32_t per = gen == 2u ? 2u : spec;
+            const uint32_t op = act[sidx / per];
+            gen_op[sidx] = op;
+            gen_kappa[sidx] = (uint16_t)(kappa[op] + (sidx % per) * (uint32_t)l);
+            if (gen_key) gen_key[sidx] = key_idx ? key_idx[op] : op;  // row of a per-key A_hat table
+        }
     }
 }
 
@@ -812,9 +827,10 @@ int launch_key_range(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s2, c
 
 int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t* act,
                       const uint16_t* kappa, int l, uint32_t* slot_op, uint16_t* slot_kappa, const uint32_t* key_idx,
-                      uint32_t* slot_key, size_t slots_hint, hipStream_t s, int pre_enqueued, const uint32_t* ypos, uint32_t* slot_y) {
+                      uint32_t* gen_op, uint16_t* gen_kappa, uint32_t* gen_key, size_t slots_hint, hipStream_t s, int may_use_pre,
+                      int may_gen2, const uint32_t* ypos, uint32_t* slot_y) {
     hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, spec_target, spec_max, act, kappa, l,
-                       slot_op, slot_kappa, key_idx, slot_key, pre_enqueued, ypos, slot_y);
+                       slot_op, slot_kappa, key_idx, gen_op, gen_kappa, gen_key, may_use_pre, may_gen2, ypos, slot_y);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -314,35 +314,36 @@ namespace {
 // = the default of mldsa_ctx::pass_ops_sign
 
 struct SignWs {
-    int32_t *a_hat, *y[2], *w, *c, *done, *bad_op, *key_bad, *accept;  // y[round & 1]: the round's masks (one may be filled a round ahead)
-    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk[2], *key_oor;
-    uint16_t *kappa, *slot_kappa;
-    uint32_t *act[2], *ypos[2], *slot_op, *slot_key, *slot_y, *kidx, *exp_list;
+    // y / w / w1 / wrisk / yrisk are ROWS (one per generated candidate: `rows` = ns, or 2 ns when two candidates per op may be
+    // generated at once); c / ctilde / accept are per TESTED candidate (slot)
+    int32_t *a_hat, *y, *w, *c, *done, *bad_op, *key_bad, *accept;
+    uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk, *key_oor;
+    uint16_t *kappa, *slot_kappa, *gen_kappa;
+    uint32_t *act[2], *ypos[2], *slot_op, *gen_op, *gen_key, *slot_y, *kidx, *exp_list;
     RoundCtl *ctl;
     size_t bytes = 0;
     uint8_t *base = nullptr;
     SignWs() = default;
     // n = ops of the chunk, ns = most candidate slots of a round
-    // two_y: a second mask buffer for "masks one round ahead" (MLDSA_OPT_SIGN_MASK_AHEAD)
-    SignWs(void *base_, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat, bool two_y) : base(static_cast<uint8_t *>(base_)) {
+    // two_rows: room for two generated candidates per op (MLDSA_OPT_SIGN_LOOKAHEAD)
+    SignWs(void *base_, const mldsa_params *p, size_t n, size_t ns, bool own_a_hat, bool two_rows) : base(static_cast<uint8_t *>(base_)) {
         Carver cv(base_);
+        const size_t rows = two_rows ? std::max(ns, 2 * n) : ns;
         a_hat = cv.take<int32_t>(own_a_hat ? n * (size_t)(p->k * p->l) * N : 0);
         key_bad = cv.take<int32_t>(n);
         kidx = cv.take<uint32_t>(n);
-        y[0] = cv.take<int32_t>(ns * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
-        y[1] = two_y ? cv.take<int32_t>(ns * (size_t)p->l * N) : y[0];
-        w = cv.take<int32_t>(ns * (size_t)p->k * N);
+        y = cv.take<int32_t>(rows * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
+        w = cv.take<int32_t>(rows * (size_t)p->k * N);
         c = cv.take<int32_t>(ns * (size_t)N);
         done = cv.take<int32_t>(n);
         bad_op = cv.take<int32_t>(n);
         accept = cv.take<int32_t>(ns);
         rnd_mu = cv.take<uint8_t>(n * 96);  // rnd || mu per op: H(K || rnd || mu) input, ml_dsa.rs:199
         rho_pp = cv.take<uint8_t>(n * 64);
-        w1 = cv.take<uint8_t>(ns * (size_t)p->w1_len);
+        w1 = cv.take<uint8_t>(rows * (size_t)p->w1_len);
         ctilde = cv.take<uint8_t>(ns * 64);
-        wrisk = cv.take<uint8_t>(ns);
-        yrisk[0] = cv.take<uint8_t>(ns * (size_t)p->l);
-        yrisk[1] = two_y ? cv.take<uint8_t>(ns * (size_t)p->l) : yrisk[0];
+        wrisk = cv.take<uint8_t>(rows);
+        yrisk = cv.take<uint8_t>(rows * (size_t)p->l);
         key_oor = cv.take<uint8_t>(n);  // per key of the table, or per op when the table is larger than the chunk
         kappa = cv.take<uint16_t>(n);
         slot_kappa = cv.take<uint16_t>(ns);
@@ -352,7 +353,9 @@ struct SignWs {
         ypos[1] = cv.take<uint32_t>(n);
         exp_list = cv.take<uint32_t>(n);
         slot_op = cv.take<uint32_t>(ns);
-        slot_key = cv.take<uint32_t>(ns);
+        gen_op = cv.take<uint32_t>(rows);
+        gen_key = cv.take<uint32_t>(rows);
+        gen_kappa = cv.take<uint16_t>(rows);
         slot_y = cv.take<uint32_t>(ns);
         ctl = cv.take<RoundCtl>(1);
         bytes = (cv.off + 511) & ~(size_t)255;
@@ -414,15 +417,24 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
 static int sign_lanes_for(const mldsa_ctx *ctx, size_t chunk) { return (ctx->opt_sign_lanes >= 2 && chunk >= 8192) ? 2 : 1; }
 static size_t lane_ops(size_t chunk, int n_lanes) { return n_lanes == 1 ? chunk : ((chunk + 1) / 2 + 255) & ~(size_t)255; }
 
+static bool lookahead_on(const mldsa_ctx *ctx, const mldsa_params *p);
+
 size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a) {
     const size_t chunk = std::min(n_ops, ctx->pass_ops_sign);
     const int n_lanes = sign_lanes_for(ctx, chunk);
     const size_t n = lane_ops(chunk, n_lanes);
-    return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a, ctx->opt_mask_ahead != 0).bytes;
+    return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a, lookahead_on(ctx, p)).bytes;
 }
 
-// batches below this size keep the plain sequence: their sign_w is not HBM-bound, and a fork / join per round costs latency
-constexpr size_t MASK_AHEAD_MIN_OPS = 16384;
+// batches below this size generate one candidate per op and round: their sign_w is not bound by re-reading A_hat
+constexpr size_t LOOKAHEAD_MIN_OPS = 8192;
+// Two candidates per op generated at once (k_make_slots).  Measured at 65 536 ops, same-box A/B: ML-DSA-65 7.81 / 7.93 ms against
+// 8.00 / 8.18 ms per signing step (sign_w 2.11-2.21 instead of 2.44-2.61 ms; 6.8 instead of 6.5 generated candidates per signature);
+// ML-DSA-44 and ML-DSA-87 within 1 % either way (their ExpandMask launches quantise worse at twice the rows), so the default
+// (option value 1) applies it to ML-DSA-65 only
+static bool lookahead_on(const mldsa_ctx *ctx, const mldsa_params *p) {
+    return ctx->opt_lookahead == 2 || (ctx->opt_lookahead == 1 && p->set == MLDSA_65);
+}
 
 // One round of the rejection loop (steps 10-33 of Algorithm 7), counts read from the device
 // mldsa_sign_host's direct export: round `round`'s finished signatures (k_export_done) on exp_stream, ordered after everything
@@ -439,46 +451,35 @@ static int enqueue_export(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w
     return MLDSA_OK;
 }
 
-// pre_in: the previous round launched the helper ExpandMask for this one; pre_out: launch it for the next one (pre_stream)
+// pre_in: the plan lets this round test the rows the previous one generated; gen2: the plan lets this round generate two
+// candidates per op (k_make_slots decides on the device)
 static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignPlan &pl, int round, size_t m_hint,
                               size_t ns_hint, const uint32_t *kidx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
                               const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s, bool oor_by_op, bool pre_in = false,
-                              bool pre_out = false, hipStream_t pre_stream = nullptr, uint8_t *export_sg = nullptr,
-                              hipStream_t exp_stream = nullptr, bool exp_pending = false) {
+                              bool gen2 = false, uint8_t *export_sg = nullptr, hipStream_t exp_stream = nullptr,
+                              bool exp_pending = false) {
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
-    const uint32_t *ns_dev = &w.ctl->ns;
-    int32_t *y = w.y[par];
-    uint8_t *yrisk = w.yrisk[par];
-    if (pre_in) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->pre_join_ev, 0));  // the helper launch read this round's slot arrays-to-be
+    const uint32_t *ns_dev = &w.ctl->ns, *ns_gen_dev = &w.ctl->ns_gen;
+    const size_t gen_hint = gen2 ? 2 * ns_hint : ns_hint;  // grids of the generating kernels (a round that tests ready rows finds ns_gen = 0)
     STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.spec_target, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
-                                          w.slot_kappa, kidx, own_a ? nullptr : w.slot_key, ns_hint, s, pre_in ? 1 : 0, w.ypos[par],
-                                          w.slot_y));
-    // 11: y <- ExpandMask(rho'', kappa)                               :215   (returns at once when the round uses masks made ahead)
-    STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, y, ns_hint, s, yrisk, ns_dev, w.ctl, 1, 0));
+                                          w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
+                                          pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
+    // 11: y <- ExpandMask(rho'', kappa)                               :215
+    STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.gen_kappa, 1, w.gen_op, w.y, gen_hint, s, w.yrisk, ns_gen_dev));
     // the PREVIOUS round's finished signatures -> the caller's host memory, on a helper stream (a small, fixed number of
     // workgroups: see launch_export_done).  The launch reads only its own range of the completion-order list, which no later
     // round touches, so nothing of the round chain ever waits for it.
     if (export_sg && exp_pending) TRY(enqueue_export(ctx, p, w, round - 1, m_hint, sg, export_sg, s, exp_stream));
-    if (pre_out) {
-        // Masks one round ahead (k_make_slots): the next round's first candidate for every op of this round, on a helper stream
-        // underneath this round's sign_w -- that kernel re-reads A_hat per op and is HBM-bound with half of the integer issue
-        // slots idle (tools/ubench_overlap2.py: 880 us back to back, 730 us side by side at 65 536 ops).
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->pre_fork_ev, s));
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(pre_stream, ctx->pre_fork_ev, 0));
-        {
-            ProfScope ps(ctx, pre_stream, "expand_mask_ahead");
-            TRY(launch_expand_mask(ctx, set, w.rho_pp, 64, w.slot_kappa, 1, w.slot_op, w.y[par ^ 1], ns_hint, pre_stream, w.yrisk[par ^ 1],
-                                   ns_dev, w.ctl, 2, (uint32_t)p->l));
-        }
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->pre_join_ev, pre_stream));
-    }
-    // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222
-    STAGE("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys, own_a ? w.slot_op : w.slot_key, y, w.w, w.w1,
-                                  (size_t)p->w1_len, ns_hint, s, 0, w.wrisk, own_a, ns_dev, w.slot_y));
-    // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
+    // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222   (one row per generated candidate; the two
+    // candidates of an op are adjacent rows and share the A_hat read)
+    STAGE("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys, own_a ? w.gen_op : w.gen_key, w.y, w.w, w.w1,
+                                  (size_t)p->w1_len, gen_hint, s, 0, w.wrisk, own_a, ns_gen_dev));
+    // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234   (w1 of the slot's row)
     STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
-                                           w.ctilde, 64, ns_hint, s, ns_dev));
+                                           w.ctilde, 64, ns_hint, s, ns_dev, w.slot_y));
+    int32_t *y = w.y;
+    uint8_t *yrisk = w.yrisk;
     // 16: c <- SampleInBall(c_tilde)                                  :237
     STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns_hint, s, ns_dev));
     // 17: c_hat <- NTT(c), in place                                   :240
@@ -543,7 +544,7 @@ bool oor_by_op(const SignArgs &a) { return a.key_idx && a.n_keys > a.n; }
 void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
     // y, rho'', cs1 / cs2, staged signatures are secret-dependent (the reference zeroizes on drop, types.rs:19);
     // A_hat = ExpandA(rho) is public and is the first and largest carve: skipped.
-    uint8_t *secrets = reinterpret_cast<uint8_t *>(w.y[0]);
+    uint8_t *secrets = reinterpret_cast<uint8_t *>(w.y);
     (void)launch_zero(ctx, secrets, (size_t)(w.base + w.bytes - secrets), s);
 }
 
@@ -627,25 +628,23 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
     for (int i = 0; i < n_lanes; i++) TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st, n_lanes == 1));
     // 10: while (z, h) = bottom                                            ml_dsa.rs:212
     const int rounds = (int)pl.m_hint.size();
-    // masks one round ahead (enqueue_sign_round): where the plan expects two one-candidate rounds in a row, on a batch large
-    // enough for sign_w to be HBM-bound; one lane only (the helper stream is the second lane's stream)
-    const bool ahead = ctx->opt_mask_ahead != 0 && n_lanes == 1 && lanes[0].a.n >= MASK_AHEAD_MIN_OPS;
-    hipStream_t pre_stream = ahead ? (ctx->opt_mask_ahead == 2 ? parallel_stream(ctx, s) : priority_stream(ctx, s)) : nullptr;
-    bool pre_prev = false;
+    // Two candidates per op generated at once (k_make_slots): where the plan expects two one-candidate rounds in a row, on a batch
+    // large enough for sign_w to be bound by re-reading A_hat.  Rounds pair up: (generate two, test the first) then (test the second).
+    const bool look = lookahead_on(ctx, p) && lanes[0].a.n >= LOOKAHEAD_MIN_OPS;
+    bool gen2_prev = false;
     // export of finished signatures to host memory (mldsa_sign_host): one lane only (the lanes would share the events)
     const bool exporting = lanes[0].a.export_sigs != nullptr && n_lanes == 1;
     hipStream_t exp_stream = exporting ? parallel_stream(ctx, s) : nullptr;
     for (int round = 0; round < rounds; round++) {
-        const bool pre_out = ahead && round + 1 < rounds && pl.one_cand[round] && pl.one_cand[round + 1];
+        const bool gen2 = look && !gen2_prev && round + 1 < rounds && pl.one_cand[round] && pl.one_cand[round + 1];
         for (int i = 0; i < n_lanes; i++) {
             const SignLane &L = lanes[i];
             const ChunkKeys c = chunk_keys(p, L.w, L.a);
             // the plan is for a full slice; a short last one only makes its grids generous
             TRY(enqueue_sign_round(ctx, p, L.w, pl, round, std::min(pl.m_hint[round], L.a.n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k,
-                                   c.ak, c.sg, L.st, oor_by_op(L.a), pre_prev, pre_out, pre_stream, exporting ? c.xsg : nullptr, exp_stream,
-                                   round > 0));
+                                   c.ak, c.sg, L.st, oor_by_op(L.a), gen2_prev, gen2, exporting ? c.xsg : nullptr, exp_stream, round > 0));
         }
-        pre_prev = pre_out;
+        gen2_prev = gen2;
     }
     if (exporting && rounds > 0) {  // the last round's export; the call's stream ends after it
         const SignLane &L = lanes[0];
@@ -653,7 +652,6 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
         TRY(enqueue_export(ctx, p, L.w, rounds - 1, std::min(pl.m_hint[rounds - 1], L.a.n), c.sg, c.xsg, s, exp_stream));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->exp_join_ev, 0));
     }
-    if (pre_prev) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->pre_join_ev, 0));  // (cannot happen: the last round never launches ahead)
     for (int i = 0; i < n_lanes; i++) {
         const SignLane &L = lanes[i];
         if (L.a.async_mode) {
@@ -696,7 +694,7 @@ int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl,
                 ctx->stats.sign_extra_rounds++;
                 const bool exporting = L.a.export_sigs != nullptr && n_lanes == 1;
                 TRY(enqueue_sign_round(ctx, p, L.w, pl, round + e, 64, std::min<size_t>(pl.ns_max, 2048), c.kidx, c.s1k, c.s2k, c.t0k, c.ak,
-                                       c.sg, s, oor_by_op(L.a), false, false, nullptr, exporting ? c.xsg : nullptr,
+                                       c.sg, s, oor_by_op(L.a), false, false, exporting ? c.xsg : nullptr,
                                        exporting ? parallel_stream(ctx, s) : nullptr, false));
                 if (exporting) {  // an extra round exports its own finishers right away
                     TRY(enqueue_export(ctx, p, L.w, round + e, 64, c.sg, c.xsg, s, parallel_stream(ctx, s)));
@@ -750,7 +748,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     SignLane lanes[2];
     size_t ws_off = 0;
     for (int i = 0; i < n_lanes; i++) {
-        lanes[i].w = SignWs(static_cast<uint8_t *>(ctx->ws) + ws_off, p, per_lane, pl.ns_max, own_a, ctx->opt_mask_ahead != 0);
+        lanes[i].w = SignWs(static_cast<uint8_t *>(ctx->ws) + ws_off, p, per_lane, pl.ns_max, own_a, lookahead_on(ctx, p));
         ws_off += lanes[i].w.bytes;
     }
     if (ctx->ws_bytes < ws_off) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
@@ -758,7 +756,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         // The previous synchronous call is (perhaps) still clearing its secrets on a helper stream.  This call's ExpandA may run
         // beside that -- one is integer-issue-bound, the other a stream of stores -- when it is launched directly on one lane
         // and everything the prologue touches before its wait (A_hat, the key-index scratch) lies below the span being cleared.
-        const size_t public_end = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y[0]) - static_cast<uint8_t *>(ctx->ws));
+        const size_t public_end = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
         const bool defer = own_a && n_lanes == 1 && !op_uses_graph(ctx, s, MLDSA_OP_SIGN, chunk) && public_end <= ctx->zero_lo;
         if (defer) ctx->zero_wait_after_ea = true;
         else TRY(wait_zeroise(ctx, s));
@@ -771,7 +769,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
         key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_max = ctx->opt_spec_max;
         key.rounds = (long)pl.m_hint.size();  // the planned rounds (options, the asynchronous stop threshold) shape the launch sequence
-        key.ahead = ctx->opt_mask_ahead;
+        key.ahead = ctx->opt_lookahead;
         int live = 0;
         for (int i = 0; i < n_lanes; i++) {
             const size_t lo = std::min(n_chunk, (size_t)i * per_lane), hi = std::min(n_chunk, lo + per_lane);
@@ -808,7 +806,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, z);
         MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_ev, z));
         ctx->zero_pending = true;
-        ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y[0]) - static_cast<uint8_t *>(ctx->ws));
+        ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
         ctx->zero_hi = ws_off;
     }
     return rc;

@@ -110,10 +110,11 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
                                        10^-value (1..12, default 9: practically never an MLDSA_ERR_AGAIN).  A caller that re-signs such
                                        ops anyway can lower it: 2 plans like the synchronous call (three ~0.2 ms rounds less, an op
                                        left over in about 1 call in 500) */
-#define MLDSA_OPT_SIGN_MASK_AHEAD 10 /* sign: 1 = in the early rounds (one candidate per op, >= 16384 ops) the next round's masks are generated
-                                       on a high-priority helper stream underneath the HBM-bound w = A y kernel of the current round; 0
-                                       (default) = plain sequence.  Signatures are identical; measured on MI355X the helper launch slows
-                                       the kernels it runs beside by what it saves, hence off */
+#define MLDSA_OPT_SIGN_LOOKAHEAD 10  /* sign: in the early rounds of a batch of >= 8192 ops (one candidate tested per op) a round may generate the
+                                       masks and w = A y of TWO candidates per op, which share the read of the op's A_hat -- the kernel is bound
+                                       by re-reading A_hat from HBM there --, and the next round tests the second one without generating
+                                       anything.  0 = never, 1 (default) = for the parameter sets where it measured faster (ML-DSA-65: +2.7 %),
+                                       2 = for every set.  Signatures are identical */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,
