@@ -102,8 +102,10 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
     constexpr bool CT0_CAN_FAIL = !G2HI;
     const int32_t gamma1 = 1 << gb;
     const int cb = gb + 1;
-    const int4 cv = reinterpret_cast<const int4*>(a.c_hat + slot * N)[lane];
-    if (FULL && lane < ctilde_len) sig[lane] = a.ctilde[slot * 64 + lane];
+    // everything a candidate owns -- y, w, c_hat, c~ and the risk flags -- lives in its ROW (k_make_slots)
+    (void)slot;
+    const int4 cv = reinterpret_cast<const int4*>(a.c_hat + yrow * N)[lane];
+    if (FULL && lane < ctilde_len) sig[lane] = a.ctilde[yrow * 64 + lane];
     // ---- stage 1.  ||c s1||inf and ||c s2||inf are at most beta = tau * eta, so a polynomial of w whose
     // LowBits all stay below gamma2 - 2 beta cannot fail ||LowBits(w - c s2)||inf < gamma2 - beta, and a
     // polynomial of y below gamma1 - 2 beta cannot fail ||y + c s1||inf < gamma1 - beta (ml_dsa.rs:280; with

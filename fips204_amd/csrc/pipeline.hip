@@ -314,8 +314,8 @@ namespace {
 // = the default of mldsa_ctx::pass_ops_sign
 
 struct SignWs {
-    // y / w / w1 / wrisk / yrisk are ROWS (one per generated candidate: `rows` = ns, or 2 ns when two candidates per op may be
-    // generated at once); c / ctilde / accept are per TESTED candidate (slot)
+    // y / w / w1 / wrisk / yrisk / c / ctilde are ROWS (one per generated candidate: `rows` = ns, or 2 n when two candidates per op
+    // may be generated at once); accept is per TESTED candidate (slot)
     int32_t *a_hat, *y, *w, *c, *done, *bad_op, *key_bad, *accept;
     uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk, *key_oor;
     uint16_t *kappa, *slot_kappa, *gen_kappa;
@@ -334,14 +334,14 @@ struct SignWs {
         kidx = cv.take<uint32_t>(n);
         y = cv.take<int32_t>(rows * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
         w = cv.take<int32_t>(rows * (size_t)p->k * N);
-        c = cv.take<int32_t>(ns * (size_t)N);
+        c = cv.take<int32_t>(rows * (size_t)N);
         done = cv.take<int32_t>(n);
         bad_op = cv.take<int32_t>(n);
         accept = cv.take<int32_t>(ns);
         rnd_mu = cv.take<uint8_t>(n * 96);  // rnd || mu per op: H(K || rnd || mu) input, ml_dsa.rs:199
         rho_pp = cv.take<uint8_t>(n * 64);
         w1 = cv.take<uint8_t>(rows * (size_t)p->w1_len);
-        ctilde = cv.take<uint8_t>(ns * 64);
+        ctilde = cv.take<uint8_t>(rows * 64);
         wrisk = cv.take<uint8_t>(rows);
         yrisk = cv.take<uint8_t>(rows * (size_t)p->l);
         key_oor = cv.take<uint8_t>(n);  // per key of the table, or per op when the table is larger than the chunk
@@ -460,7 +460,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
                               bool exp_pending = false) {
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
-    const uint32_t *ns_dev = &w.ctl->ns, *ns_gen_dev = &w.ctl->ns_gen;
+    const uint32_t *ns_gen_dev = &w.ctl->ns_gen;  // rows generated this round (the tail kernels read ctl->ns themselves)
     const size_t gen_hint = gen2 ? 2 * ns_hint : ns_hint;  // grids of the generating kernels (a round that tests ready rows finds ns_gen = 0)
     STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.spec_target, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
                                           w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
@@ -475,15 +475,18 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     // candidates of an op are adjacent rows and share the A_hat read)
     STAGE("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys, own_a ? w.gen_op : w.gen_key, w.y, w.w, w.w1,
                                   (size_t)p->w1_len, gen_hint, s, 0, w.wrisk, own_a, ns_gen_dev));
-    // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234   (w1 of the slot's row)
-    STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.slot_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
-                                           w.ctilde, 64, ns_hint, s, ns_dev, w.slot_y));
+    // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
+    // The challenge of EVERY generated row, also of the second candidates a two-candidate round makes for the next round: these
+    // lane-per-row kernels cost the same for 65 536 and 131 072 rows' worth of latency chains (one or two waves per SIMD), and
+    // the next round then consists of the tail alone.
+    STAGE("ctilde_hash", launch_shake256_2(ctx, p->ctilde_len, w.rnd_mu + 32, 96, 64, w.gen_op, w.w1, (size_t)p->w1_len, p->w1_len, 0, 0,
+                                           w.ctilde, 64, gen_hint, s, ns_gen_dev));
     int32_t *y = w.y;
     uint8_t *yrisk = w.yrisk;
     // 16: c <- SampleInBall(c_tilde)                                  :237
-    STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, ns_hint, s, ns_dev));
+    STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, gen_hint, s, ns_gen_dev));
     // 17: c_hat <- NTT(c), in place                                   :240
-    STAGE("ntt_c", launch_ntt(ctx, w.c, w.c, ns_hint, s, ns_dev));
+    STAGE("ntt_c", launch_ntt(ctx, w.c, w.c, gen_hint, s, ns_gen_dev));
     // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
     // (in a speculative round: only the tests that can reject, one verdict per candidate)
     STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
