@@ -89,6 +89,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_graphs = env_long("MLDSA_GRAPHS", 0, 2, ctx->opt_graphs);
     ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 524288, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
+    ctx->opt_spec_rows = env_long("MLDSA_SPEC_ROWS", 1, 524288, ctx->opt_spec_rows);
     ctx->opt_sign_lanes = env_long("MLDSA_SIGN_LANES", 1, 2, ctx->opt_sign_lanes);
     ctx->opt_lookahead = env_long("MLDSA_LOOKAHEAD", 0, 2, ctx->opt_lookahead);
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
@@ -122,6 +123,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_head_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
@@ -161,6 +163,7 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->ws_ev) (void)hipEventDestroy(ctx->ws_ev);
     if (ctx->zero_fork_ev) (void)hipEventDestroy(ctx->zero_fork_ev);
     if (ctx->zero_ev) (void)hipEventDestroy(ctx->zero_ev);
+    if (ctx->zero_head_ev) (void)hipEventDestroy(ctx->zero_head_ev);
     if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
     delete ctx;
@@ -551,7 +554,7 @@ int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     REQUIRE(n_keys == 0 || (xi && pk && sk), "mldsa_keygen: NULL pointer");
     if (n_keys == 0) return MLDSA_OK;
     hipStream_t s = (hipStream_t)stream;
-    OpGuard guard(ctx, s);
+    OpGuard guard(ctx, s, true);  // keygen_batch orders itself after a pending background clearing
     int rc = reserve_workspace(ctx, p, MLDSA_OP_KEYGEN, n_keys, true);
     if (rc != MLDSA_OK) return rc;
     struct { int op, set; const void *xi, *pk, *sk; size_t n; } key;

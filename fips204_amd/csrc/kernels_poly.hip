@@ -170,16 +170,25 @@ __global__ __launch_bounds__(BLOCK) void k_infinity_norm(const int32_t *__restri
 // a_idx then maps a candidate slot to the A_hat it uses.
 // W1 = 1 / 2 additionally emits w1Encode(HighBits(w)) (6-bit / 4-bit fields) per op: the signer's
 // commitment bytes (ml_dsa.rs:225-232), so no separate pass re-reads w.
+// KG = true is key generation's t = A s1 + s2 (ml_dsa.rs:86-92): s1 and s2 are rows of one (L + K)-polynomial vector per key
+// (`z`, z_polys_per_op = L + K), and instead of storing A s1 the epilogue adds s2_i, applies Power2Round (high_low.rs:15-48) and
+// packs t1 into the key's pk and t0 into its sk (encodings.rs:18-40, 136-152): A s1 and t never travel through HBM.
+struct KeygenOut {
+    uint8_t *pk, *sk;
+    size_t pk_len, sk_len, t0_off;  // t0_off: byte offset of the t0 section inside sk
+    int eta, ebits;                 // BitPack(s, eta, eta): `ebits`-wide fields eta - s (the s1 / s2 sections of sk, from byte 128)
+};
 constexpr int AW = 4;  // waves per block
-template <int K, int L, bool HAS_C, int W1 = 0, bool APACK = false>
+template <int K, int L, bool HAS_C, int W1 = 0, bool APACK = false, bool KG = false>
 __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
     int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
     uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op, uint8_t *__restrict__ wrisk, int32_t risk_bound,
-    const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ z_idx) {
+    const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ z_idx, KeygenOut kg) {
     constexpr int NZ = HAS_C ? L + 1 : L;
     __shared__ int4 zh[AW][NZ][64];
+    __shared__ int32_t xp_kg[KG ? AW : 1][KG ? N : 1];  // strided -> four consecutive coefficients per lane (t1 / t0 packing)
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -219,6 +228,17 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
         for (int j = 0; j < NZ; j++) {
             asm volatile("" ::: "memory");  // keep the LDS twiddle reads at their point of use (no hoisting into registers)
             int32_t r[4] = {reduce32(nr[0]), reduce32(nr[1]), reduce32(nr[2]), reduce32(nr[3])};
+            if constexpr (KG) {  // s1_j passes through here: its section of sk (encodings.rs:118-134) is packed on the way
+#pragma unroll
+                for (int k = 0; k < 4; k++) xp_kg[wave][64 * k + lane] = r[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int4 s4 = reinterpret_cast<const int4 *>(&xp_kg[wave][0])[lane];
+                const uint32_t f[4] = {(uint32_t)(kg.eta - s4.x), (uint32_t)(kg.eta - s4.y), (uint32_t)(kg.eta - s4.z), (uint32_t)(kg.eta - s4.w)};
+                store_fields(kg.sk + op * kg.sk_len + 128 + (size_t)j * (32 * kg.ebits), f, kg.ebits, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
             if (j + 1 < L) load_strided(nr, z + (zrow + j + 1) * (size_t)N, lane);
             else if (HAS_C && j + 1 == L) load_strided(nr, c + op * (size_t)N, lane);
             ntt_fwd_wave(r, ftw, lane);
@@ -261,6 +281,40 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
 #pragma unroll
             for (int k = 0; k < 4; k++) acc[k] = mont_reduce64(acc64[k]);  // (-q, q): the inverse transform's input range
             ntt_inv_wave(acc, itw, lane, F_MONT2);
+            if constexpr (KG) {
+                int32_t s2v[4];
+                load_strided(s2v, z + (zrow + L + i) * (size_t)N, lane);  // s2_i: centred coefficients in [-eta, eta]
+                {   // ... and its section of sk
+#pragma unroll
+                    for (int k = 0; k < 4; k++) xp_kg[wave][64 * k + lane] = s2v[k];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int4 s4 = reinterpret_cast<const int4 *>(&xp_kg[wave][0])[lane];
+                    const uint32_t f[4] = {(uint32_t)(kg.eta - s4.x), (uint32_t)(kg.eta - s4.y), (uint32_t)(kg.eta - s4.z), (uint32_t)(kg.eta - s4.w)};
+                    store_fields(kg.sk + op * kg.sk_len + 128 + (size_t)(L + i) * (32 * kg.ebits), f, kg.ebits, lane);
+                    __builtin_amdgcn_wave_barrier();
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) xp_kg[wave][64 * k + lane] = freeze(acc[k] + s2v[k]);  // t = A s1 + s2 (ml_dsa.rs:88-91)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int4 t4 = reinterpret_cast<const int4 *>(&xp_kg[wave][0])[lane];
+                const int32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+                uint32_t f1[4], f0[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int32_t r1 = (tt[c] + (1 << 12) - 1) >> 13;       // power2round, high_low.rs:26-31
+                    const int32_t r0 = tt[c] - (r1 << 13);
+                    f1[c] = (uint32_t)r1;
+                    f0[c] = (uint32_t)((1 << 12) - r0);                     // BitPack(t0, 2^12 - 1, 2^12)
+                }
+                store_fields(kg.pk + op * kg.pk_len + 32 + (size_t)i * 320, f1, 10, lane);
+                store_fields(kg.sk + op * kg.sk_len + kg.t0_off + (size_t)i * 416, f0, 13, lane);
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             store_strided(acc, w_out + (op * K + i) * (size_t)N, lane);
             if constexpr (W1 != 0) {
                 constexpr bool G2HI = W1 == 2;
@@ -350,9 +404,9 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
     const uint32_t *no_idx = nullptr;
     dim3 gw(grid_for(ctx, n_ops, AW, (unsigned)ctx->opt_va_blocks));
     uint8_t *nw1 = nullptr;
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0, no_idx, no_idx);
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0, no_idx, no_idx);
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0, no_idx, no_idx);
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0, no_idx, no_idx, KeygenOut{});
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0, no_idx, no_idx, KeygenOut{});
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0, no_idx, no_idx, KeygenOut{});
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -371,7 +425,7 @@ int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_i
     dim3 gw(grid_for(ctx, n_ops, AW, 16));
 #define MLDSA_SW2(KK, LL, W1M, AP)                                                                                               \
     hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M, AP>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
-                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound, n_dev, y_idx)
+                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound, n_dev, y_idx, KeygenOut{})
 #define MLDSA_SW(KK, LL, W1M) do { if (a_packed) MLDSA_SW2(KK, LL, W1M, true); else MLDSA_SW2(KK, LL, W1M, false); } while (0)
     if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
     else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 2); else MLDSA_SW(6, 5, 0); }
@@ -379,6 +433,28 @@ int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_i
     else return set_error(MLDSA_ERR_PARAM, "sign_w: unknown parameter set");
 #undef MLDSA_SW2
 #undef MLDSA_SW
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+// key generation's t = A s1 + s2 with Power2Round and the t1 / t0 packing in the epilogue (k_verify_arith<.., KG = true>);
+// s1s2[key][L + K] = ExpandS output, a_hat in the pipelines' 24-bit form
+int launch_keygen_t(mldsa_ctx *ctx, const mldsa_params *p, const int32_t *a_hat, const int32_t *s1s2, uint8_t *pk, uint8_t *sk, size_t n_keys,
+                    hipStream_t s) {
+    if (n_keys == 0) return MLDSA_OK;
+    const int32_t *none = nullptr;
+    const uint32_t *no_idx = nullptr;
+    uint8_t *nw1 = nullptr;
+    const int eb = p->eta == 2 ? 3 : 4;
+    const KeygenOut kg{pk, sk, (size_t)p->pk_len, (size_t)p->sk_len, (size_t)128 + (size_t)(p->l + p->k) * 32 * eb, p->eta, eb};
+    dim3 gw(grid_for(ctx, n_keys, AW, 16));
+#define MLDSA_KGT(KK, LL)                                                                                                              \
+    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, 0, true, true>), gw, dim3(64 * AW), 0, s, a_hat, no_idx, s1s2, none, none, no_idx,   \
+                       (int32_t *)nullptr, n_keys, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)(LL + KK), nw1, 0, no_idx, no_idx, kg)
+    if (p->set == MLDSA_44) MLDSA_KGT(4, 4);
+    else if (p->set == MLDSA_65) MLDSA_KGT(6, 5);
+    else MLDSA_KGT(8, 7);
+#undef MLDSA_KGT
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -375,7 +375,8 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
 // position each surviving op had (ypos), its slot s tests row 2 ypos[s] + 1 (use_pre) and its ExpandMask / sign_w launches find
 // ns_gen = 0.  A fifth of the second candidates belong to ops that finished and are never read.  Decided here, on the device:
 // the host only says what its plan allows (may_gen2 / may_use_pre); gen_par[] carries what the previous round really did.
-__global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, int parity, uint32_t spec_target, uint32_t spec_max,
+__global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, int parity, uint32_t spec_target, uint32_t spec_rows,
+                                                    uint32_t spec_max,
                                                     const uint32_t* __restrict__ act, const uint16_t* __restrict__ kappa, int l,
                                                     uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa,
                                                     const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ gen_op,
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
     const uint32_t m = ctl->cnt[parity];
     uint32_t spec = 1;
     if (m > 0 && m * 2 <= spec_target) {
-        spec = spec_target / m;
+        spec = spec_rows / m;
         if (spec > spec_max) spec = spec_max;
     }
     const uint32_t ns = m * spec;
@@ -603,77 +604,19 @@ __global__ __launch_bounds__(256) void k_copy_rows(uint8_t* __restrict__ dst, si
 // keygen tail (ml_dsa.rs:88-101 + encodings.rs:18-40, 94-152): t = inv_ntt(A s1_hat) + s2,
 // (t1, t0) = power2round(t); pk = rho | SimpleBitPack(t1, 10 bits); and the s1 / s2 / t0
 // sections of sk.  One wave per polynomial, 4 consecutive coefficients per lane.
-__device__ __forceinline__ void store_fields(uint8_t* dst, const uint32_t f[4], int bits, int lane) {
-    uint64_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) v |= (uint64_t)f[i] << (i * bits);
-    const int nbytes = bits / 2;  // 4 * bits / 8; bits in {3, 4, 10, 13} -> handle odd sizes below
-    if (bits == 3) {  // 12 bits per lane: pair lanes -> 3 bytes per 2 lanes
-        const uint32_t other = __shfl_xor((uint32_t)v, 1);
-        if (!(lane & 1)) {
-            const uint32_t both = (uint32_t)v | (other << 12);
-            uint8_t* d = dst + (lane >> 1) * 3;
-            d[0] = (uint8_t)both; d[1] = (uint8_t)(both >> 8); d[2] = (uint8_t)(both >> 16);
-        }
-    } else if (bits == 13) {  // 52 bits per lane: pair lanes -> 13 bytes per 2 lanes
-        const uint64_t other = __shfl_xor((unsigned long long)v, 1);
-        if (!(lane & 1)) {
-            uint8_t* d = dst + (lane >> 1) * 13;
-            const uint64_t lo = v | (other << 52);
-            const uint64_t hi = other >> 12;
-            for (int i = 0; i < 8; i++) d[i] = (uint8_t)(lo >> (8 * i));
-            for (int i = 0; i < 5; i++) d[8 + i] = (uint8_t)(hi >> (8 * i));
-        }
-    } else {
-        uint8_t* d = dst + lane * nbytes;
-        for (int i = 0; i < nbytes; i++) d[i] = (uint8_t)(v >> (8 * i));
-    }
-}
-
-// polys: s1s2[key][L + K] (ExpandS output), as1[key][K] = inv_ntt(A * ntt(s1)) canonical
-// seeds[key] = rho (32) | rho' (64) | K (32): rho opens pk and sk, K follows in sk (encodings.rs:27-31, 118-121)
-__global__ __launch_bounds__(GBLOCK) void k_keygen_encode(const int32_t* __restrict__ s1s2, const int32_t* __restrict__ as1,
-                                                          const uint8_t* __restrict__ seeds,
-                                                          uint8_t* __restrict__ pk, uint8_t* __restrict__ sk, int k, int l,
-                                                          int eta, size_t pk_len, size_t sk_len, size_t n_keys) {
-    const int lane = threadIdx.x & 63;
-    const size_t wave = (size_t)blockIdx.x * GWAVES + (threadIdx.x >> 6);
-    const size_t n_waves = (size_t)gridDim.x * GWAVES;
-    const int ebits = eta == 2 ? 3 : 4;
-    const size_t per_key = (size_t)(l + 2 * k);  // l + k eta-polys, k t-polys
-    for (size_t p = wave; p < n_keys * per_key; p += n_waves) {
-        const size_t key = p / per_key;
-        const int j = (int)(p % per_key);
-        uint8_t* skp = sk + key * sk_len;
-        if (j == 0 && lane < 32) {
-            const uint8_t r = seeds[key * 128 + lane];
-            pk[key * pk_len + lane] = r;
-            skp[lane] = r;
-            skp[32 + lane] = seeds[key * 128 + 96 + lane];
-        }
-        if (j < l + k) {  // skEncode: BitPack(s, eta, eta): field = eta - s   (encodings.rs:118-134)
-            const Coef4 s = ld4(s1s2 + (key * (l + k) + j) * (size_t)N, lane);
-            uint32_t f[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) f[i] = (uint32_t)(eta - s.v[i]);
-            store_fields(skp + 128 + (size_t)j * (32 * ebits), f, ebits, lane);
-        } else {
-            const int i = j - (l + k);
-            const Coef4 a = ld4(as1 + (key * k + i) * (size_t)N, lane);
-            const Coef4 s2 = ld4(s1s2 + (key * (l + k) + l + i) * (size_t)N, lane);
-            uint32_t f1[4], f0[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int32_t tt = freeze(a.v[c] + s2.v[c]);          // ml_dsa.rs:88-91
-                const int32_t r1 = (tt + (1 << 12) - 1) >> 13;        // power2round, high_low.rs:26-31
-                const int32_t r0 = tt - (r1 << 13);
-                f1[c] = (uint32_t)r1;
-                f0[c] = (uint32_t)((1 << 12) - r0);                   // BitPack(t0, 2^12 - 1, 2^12)
-            }
-            store_fields(pk + key * pk_len + 32 + (size_t)i * 320, f1, 10, lane);
-            store_fields(skp + 128 + (size_t)(l + k) * (32 * ebits) + (size_t)i * 416, f0, 13, lane);
-        }
-    }
+// The seeds of a generated key pair: seeds[key] = rho (32) | rho' (64) | K (32); rho opens pk and sk, K follows in sk
+// (encodings.rs:27-31, 118-121).  Everything else of pk / sk is written by the matrix-vector kernel's epilogue
+// (kernels_poly.hip k_verify_arith<.., KG = true>: the s1 / s2 sections on the way in, t1 / t0 on the way out).
+__global__ __launch_bounds__(256) void k_keygen_seeds(const uint8_t* __restrict__ seeds, uint8_t* __restrict__ pk, uint8_t* __restrict__ sk,
+                                                      size_t pk_len, size_t sk_len, size_t n_keys) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t key = t >> 5;
+    const int b = (int)(t & 31);
+    if (key >= n_keys) return;
+    const uint8_t r = seeds[key * 128 + b];
+    pk[key * pk_len + b] = r;
+    sk[key * sk_len + b] = r;
+    sk[key * sk_len + 32 + b] = seeds[key * 128 + 96 + b];
 }
 
 // ------------------------------------------------------------------------------------
@@ -827,11 +770,11 @@ int launch_key_range(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s2, c
     return MLDSA_OK;
 }
 
-int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_target, uint32_t spec_max, const uint32_t* act,
+int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, uint32_t spec_target, uint32_t spec_rows, uint32_t spec_max, const uint32_t* act,
                       const uint16_t* kappa, int l, uint32_t* slot_op, uint16_t* slot_kappa, const uint32_t* key_idx,
                       uint32_t* gen_op, uint16_t* gen_kappa, uint32_t* gen_key, size_t slots_hint, hipStream_t s, int may_use_pre,
                       int may_gen2, const uint32_t* ypos, uint32_t* slot_y) {
-    hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, spec_target, spec_max, act, kappa, l,
+    hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, spec_target, spec_rows, spec_max, act, kappa, l,
                        slot_op, slot_kappa, key_idx, gen_op, gen_kappa, gen_key, may_use_pre, may_gen2, ypos, slot_y);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -939,11 +882,9 @@ int launch_t1_hat(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* as1, con
     return MLDSA_OK;
 }
 
-int launch_keygen_encode(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s1s2, const int32_t* as1, const uint8_t* seeds,
-                         uint8_t* pk, uint8_t* sk, size_t n_keys, hipStream_t s) {
+int launch_keygen_seeds(mldsa_ctx*, const mldsa_params* p, const uint8_t* seeds, uint8_t* pk, uint8_t* sk, size_t n_keys, hipStream_t s) {
     if (n_keys == 0) return MLDSA_OK;
-    hipLaunchKernelGGL(k_keygen_encode, dim3(grid_for(ctx, n_keys * (size_t)(p->l + 2 * p->k), GWAVES, 8)), dim3(GBLOCK), 0, s, s1s2,
-                       as1, seeds, pk, sk, p->k, p->l, p->eta, (size_t)p->pk_len, (size_t)p->sk_len, n_keys);
+    hipLaunchKernelGGL(k_keygen_seeds, dim3(blocks256(n_keys * 32)), dim3(256), 0, s, seeds, pk, sk, (size_t)p->pk_len, (size_t)p->sk_len, n_keys);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

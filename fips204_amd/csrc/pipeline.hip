@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include <chrono>
+#include <thread>
 
 #include "ctx.h"
 
@@ -250,25 +251,63 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     if (ctx->ws_bytes < KeygenWs(nullptr, p, chunk).bytes) return set_error(MLDSA_ERR_NOMEM, "keygen: workspace not reserved");
     const size_t pkl = (size_t)p->pk_len, skl = (size_t)p->sk_len;
     KeygenWs w(ctx->ws, p, chunk);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    // what this call will clear at its end: rho' / K (hbuf), s1, s2 -- A s1 is no longer stored
+    const size_t z_lo = (size_t)(w.hbuf - static_cast<uint8_t *>(ctx->ws));
+    const size_t z_mid = (size_t)(reinterpret_cast<uint8_t *>(w.s1s2) - static_cast<uint8_t *>(ctx->ws));
+    const size_t z_hi = (size_t)(reinterpret_cast<uint8_t *>(w.as1) - static_cast<uint8_t *>(ctx->ws));
+    // The previous call's clearing may still run on a helper stream (below).  A key-generation call of the SAME layout may start
+    // beside it: its seed hash needs only the (small) seed block, cleared first (zero_head_ev); its ExpandA writes below the
+    // cleared span; ExpandS, the first kernel that writes into the big part, waits for the rest (zero_ev).
+    bool wait_head = false, wait_rest = false;
+    if (ctx->zero_pending) {
+        if (!capturing && ctx->zero_head_valid && ctx->zero_lo == z_lo && ctx->zero_mid == z_mid && ctx->zero_hi == z_hi) wait_head = wait_rest = true;
+        else TRY(wait_zeroise(ctx, s));
+    }
     int rc = MLDSA_OK;
     for (size_t o = 0; o < n_keys && rc == MLDSA_OK; o += chunk) {
         const size_t n = (n_keys - o) < chunk ? (n_keys - o) : chunk;
         uint8_t *pko = pk + o * pkl, *sko = sk + o * skl;
         rc = [&]() -> int {
+            if (wait_head) { MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_head_ev, 0)); wait_head = false; }
             // 1: (rho, rho', K) <- H(xi || k || l, 128)                          ml_dsa.rs:68-74
             STAGE("seed_hash", launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
                                                  w.hbuf, 128, n, s));
-            STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
             STAGE("expand_a", launch_expand_a(ctx, set, w.hbuf, 128, nullptr, w.a_hat, n, s, true));          // :85 (24-bit form)
-            // :86-88 inv_ntt(A * ntt(s1)); s1 is read in place from the (s1, s2) rows ExpandS wrote
-            STAGE("sign_w", launch_sign_w(ctx, set, w.a_hat, nullptr, w.s1s2, w.as1, nullptr, 0, n, s, (size_t)(p->l + p->k), nullptr, true));
-            STAGE("keygen_encode", launch_keygen_encode(ctx, p, w.s1s2, w.as1, w.hbuf, pko, sko, n, s));  // :88-92, pk/sk encode incl. rho, K
+            if (wait_rest) {
+                MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
+                wait_rest = false;
+                ctx->zero_pending = false;
+            }
+            STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
+            // :86-92 t = inv_ntt(A * ntt(s1)) + s2, Power2Round and the whole encoding of the polynomials: the matrix-vector kernel
+            // packs s1 and s2 into sk as it reads them (in place, from the rows ExpandS wrote) and t1 -> pk, t0 -> sk in its
+            // epilogue; A s1 and t never exist in HBM
+            STAGE("keygen_t", launch_keygen_t(ctx, p, w.a_hat, w.s1s2, pko, sko, n, s));
+            TRY(launch_keygen_seeds(ctx, p, w.hbuf, pko, sko, n, s));  // rho -> pk, sk; K -> sk
             STAGE("tr_hash", launch_shake256_2(ctx, 64, pko, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, sko + 64, skl, n, s));  // tr = H(pk), :99-101
             return MLDSA_OK;
         }();
     }
-    // rho' / K, s1, s2 and A s1 are secret: cleared on every path out, like the reference's zeroize-on-drop (types.rs:19)
-    (void)launch_zero(ctx, w.hbuf, w.secret_bytes, s);
+    if (wait_head || wait_rest) (void)wait_zeroise(ctx, s);  // the call failed before it got there
+    // rho' / K, s1 and s2 are secret: cleared on every path out, like the reference's zeroize-on-drop (types.rs:19).  Off the
+    // caller's critical path: on a helper stream, the seed block first; the next op-level call of the context waits for it on
+    // the device (OpGuard / above), destroy and regrow wait for the whole device.
+    if (capturing || rc != MLDSA_OK) {
+        (void)launch_zero(ctx, w.hbuf, z_hi - z_lo, s);
+    } else {
+        hipStream_t z = parallel_stream(ctx, s);
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_fork_ev, s));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(z, ctx->zero_fork_ev, 0));
+        (void)launch_zero(ctx, w.hbuf, z_mid - z_lo, z);
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_head_ev, z));
+        (void)launch_zero(ctx, w.s1s2, z_hi - z_mid, z);
+        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_ev, z));
+        ctx->zero_pending = true;
+        ctx->zero_head_valid = true;
+        ctx->zero_lo = z_lo; ctx->zero_mid = z_mid; ctx->zero_hi = z_hi;
+    }
     return rc;
 }
 
@@ -370,7 +409,7 @@ double accept_prob(int set) { return set == MLDSA_44 ? 1.0 / 4.25 : set == MLDSA
 // many rounds to enqueue.  Rounds continue until the expected number of unfinished ops is below a threshold (by
 // Markov's inequality the probability that an op is left is below it too).
 struct SignPlan {
-    uint32_t spec_target = 1, spec_max = 1;
+    uint32_t spec_target = 1, spec_rows = 1, spec_max = 1;
     size_t ns_max = 0;
     std::vector<size_t> m_hint, ns_hint;  // per round: ops / slots the grids are sized for
     std::vector<int> one_cand;            // per round: the plan expects one candidate per op (the device decides for itself)
@@ -383,7 +422,10 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
     // workspace and the grids follow the batch
     const size_t tgt = std::min<size_t>((size_t)ctx->opt_spec_target, std::max<size_t>(n * pl.spec_max, 1));
     pl.spec_target = (uint32_t)tgt;
-    pl.ns_max = std::max(n, tgt);
+    // candidates per speculative round (>= the threshold above): rows = what such a round generates
+    const size_t rows = std::max(tgt, std::min<size_t>((size_t)ctx->opt_spec_rows, std::max<size_t>(n * pl.spec_max, 1)));
+    pl.spec_rows = (uint32_t)rows;
+    pl.ns_max = std::max(n, rows);
     const double q = 1.0 - accept_prob(set);
     double m = (double)n;
     // a synchronous call looks at the device once anyway and adds rounds if an op is left, so its plan stops when that is
@@ -395,10 +437,10 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
         const double m_hi = std::min((double)n, m + 6.0 * std::sqrt(m) + 1.0);
         const size_t mh = (size_t)std::ceil(m_hi);
         size_t spec = 1;
-        if (mh * 2 <= tgt) spec = std::min<size_t>(tgt / mh, pl.spec_max);
+        if (mh * 2 <= tgt) spec = std::min<size_t>(rows / mh, pl.spec_max);
         double spec_mean = 1;  // the rule applied to the mean (what the device will mostly see)
         const size_t mm = (size_t)std::max(1.0, std::floor(m));
-        if (mm * 2 <= tgt) spec_mean = (double)std::min<size_t>(tgt / mm, pl.spec_max);
+        if (mm * 2 <= tgt) spec_mean = (double)std::min<size_t>(rows / mm, pl.spec_max);
         pl.m_hint.push_back(mh);
         pl.one_cand.push_back(spec_mean == 1.0 && spec == 1 ? 1 : 0);
         pl.ns_hint.push_back(std::min(pl.ns_max, std::max(mh * spec, (size_t)std::ceil(m_hi * spec_mean))));
@@ -462,7 +504,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     const bool own_a = a_hat_keys == nullptr;
     const uint32_t *ns_gen_dev = &w.ctl->ns_gen;  // rows generated this round (the tail kernels read ctl->ns themselves)
     const size_t gen_hint = gen2 ? 2 * ns_hint : ns_hint;  // grids of the generating kernels (a round that tests ready rows finds ns_gen = 0)
-    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.spec_target, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
+    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.spec_target, pl.spec_rows, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
                                           w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
                                           pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
     // 11: y <- ExpandMask(rho'', kappa)                               :215
@@ -725,9 +767,12 @@ int wait_zeroise(mldsa_ctx *ctx, hipStream_t s) {
     if (!ctx->zero_pending) return MLDSA_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
-        // the caller is capturing `s` into a graph of its own: an event recorded outside the capture cannot become a
-        // dependency of it, so the (sub-millisecond) clearing is waited for on the host
-        if (hipEventQuery(ctx->zero_ev) != hipSuccess) MLDSA_HIP_CHECK(hipEventSynchronize(ctx->zero_ev));
+        // the caller is capturing `s` into a graph of its own: an event recorded outside the capture cannot become a dependency
+        // of it, and the runtime refuses host waits from a capturing thread -- so the (sub-millisecond) clearing is polled for.
+        // (run_op waits on the stream BEFORE it begins a capture of its own: this branch is for callers' captures only.)
+        hipError_t e;
+        while ((e = hipEventQuery(ctx->zero_ev)) == hipErrorNotReady) std::this_thread::yield();
+        if (e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "waiting for the previous call's background clearing inside a stream capture", e);
     } else {
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
     }
@@ -768,9 +813,9 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     int rc = MLDSA_OK;
     for (size_t o = 0; o < n_ops && rc == MLDSA_OK; o += chunk) {
         const size_t n_chunk = (n_ops - o) < chunk ? (n_ops - o) : chunk;
-        struct { int op, n_lanes; long spec_target, spec_max, rounds, ahead; SignArgs a[2]; } key;
+        struct { int op, n_lanes; long spec_target, spec_rows, spec_max, rounds, ahead; SignArgs a[2]; } key;
         memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
-        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_max = ctx->opt_spec_max;
+        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_rows = ctx->opt_spec_rows; key.spec_max = ctx->opt_spec_max;
         key.rounds = (long)pl.m_hint.size();  // the planned rounds (options, the asynchronous stop threshold) shape the launch sequence
         key.ahead = ctx->opt_lookahead;
         int live = 0;
@@ -809,6 +854,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, z);
         MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_ev, z));
         ctx->zero_pending = true;
+        ctx->zero_head_valid = false;
         ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
         ctx->zero_hi = ws_off;
     }
@@ -949,6 +995,12 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
     // The legacy default stream (NULL) can neither be captured nor take a graph launch that overlaps properly: graphs
     // of calls made on it run on a context-owned stream, ordered after and before the default stream by events.
     hipStream_t gs = s ? s : ctx->graph_stream;
+    // a previous call's background clearing of the workspace: ordered here, on the real stream, before any capture begins
+    // (an event recorded outside a capture cannot be waited for inside it)
+    {
+        const int rcz = wait_zeroise(ctx, s);
+        if (rcz != MLDSA_OK) return rcz;
+    }
     if (!s) {
         MLDSA_HIP_CHECK(hipEventRecord(ctx->graph_fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(gs, ctx->graph_fork_ev, 0));

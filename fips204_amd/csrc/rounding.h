@@ -75,4 +75,33 @@ __device__ __forceinline__ void pack_w1_strided(const uint32_t v[4], uint8_t* ds
     }
 }
 
+// BitPack / SimpleBitPack of four CONSECUTIVE coefficients per lane (encodings.rs, conversion.rs:143-196): f[i] = the `bits`-wide field
+// of coefficient 4 lane + i; `dst` = first byte of the polynomial's 32 * bits bytes.  bits in {3, 4, 10, 13}.
+__device__ __forceinline__ void store_fields(uint8_t* dst, const uint32_t f[4], int bits, int lane) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v |= (uint64_t)f[i] << (i * bits);
+    const int nbytes = bits / 2;  // 4 * bits / 8; bits in {3, 4, 10, 13} -> handle odd sizes below
+    if (bits == 3) {  // 12 bits per lane: pair lanes -> 3 bytes per 2 lanes
+        const uint32_t other = __shfl_xor((uint32_t)v, 1);
+        if (!(lane & 1)) {
+            const uint32_t both = (uint32_t)v | (other << 12);
+            uint8_t* d = dst + (lane >> 1) * 3;
+            d[0] = (uint8_t)both; d[1] = (uint8_t)(both >> 8); d[2] = (uint8_t)(both >> 16);
+        }
+    } else if (bits == 13) {  // 52 bits per lane: pair lanes -> 13 bytes per 2 lanes
+        const uint64_t other = __shfl_xor((unsigned long long)v, 1);
+        if (!(lane & 1)) {
+            uint8_t* d = dst + (lane >> 1) * 13;
+            const uint64_t lo = v | (other << 52);
+            const uint64_t hi = other >> 12;
+            for (int i = 0; i < 8; i++) d[i] = (uint8_t)(lo >> (8 * i));
+            for (int i = 0; i < 5; i++) d[8 + i] = (uint8_t)(hi >> (8 * i));
+        }
+    } else {
+        uint8_t* d = dst + lane * nbytes;
+        for (int i = 0; i < nbytes; i++) d[i] = (uint8_t)(v >> (8 * i));
+    }
+}
+
 }  // namespace mldsa
