@@ -90,6 +90,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 524288, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
     ctx->opt_spec_rows = env_long("MLDSA_SPEC_ROWS", 1, 524288, ctx->opt_spec_rows);
+    ctx->opt_spec_alpha = env_long("MLDSA_SPEC_ALPHA", 10, 100, ctx->opt_spec_alpha);
     ctx->opt_sign_lanes = env_long("MLDSA_SIGN_LANES", 1, 2, ctx->opt_sign_lanes);
     ctx->opt_lookahead = env_long("MLDSA_LOOKAHEAD", 0, 2, ctx->opt_lookahead);
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);

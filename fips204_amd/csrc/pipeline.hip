@@ -410,6 +410,7 @@ double accept_prob(int set) { return set == MLDSA_44 ? 1.0 / 4.25 : set == MLDSA
 // Markov's inequality the probability that an op is left is below it too).
 struct SignPlan {
     uint32_t spec_target = 1, spec_rows = 1, spec_max = 1;
+    SpecRule rule;  // the same table goes to k_make_slots
     size_t ns_max = 0;
     std::vector<size_t> m_hint, ns_hint;  // per round: ops / slots the grids are sized for
     std::vector<int> one_cand;            // per round: the plan expects one candidate per op (the device decides for itself)
@@ -426,6 +427,29 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
     const size_t rows = std::max(tgt, std::min<size_t>((size_t)ctx->opt_spec_rows, std::max<size_t>(n * pl.spec_max, 1)));
     pl.spec_rows = (uint32_t)rows;
     pl.ns_max = std::max(n, rows);
+    // candidates per op for m unfinished ops: 1 while m * 2 > tgt, then round((rows / m) ^ alpha), at most spec_max.  alpha = 1
+    // fills every speculative round to `rows` candidates; alpha < 1 gives mid-size rounds fewer (more, smaller rounds: fewer
+    // wasted candidates and ExpandMask launches that fit whole layers, against one more round's fixed cost)
+    {
+        const double alpha = (double)ctx->opt_spec_alpha / 100.0;
+        auto spec_of = [&](double m) -> uint32_t {
+            if (m < 1 || m * 2 > (double)tgt) return 1;
+            const double s = std::floor(std::pow((double)rows / m, alpha) + (alpha < 1.0 ? 0.5 : 0.0));
+            return (uint32_t)std::max(1.0, std::min((double)pl.spec_max, s));
+        };
+        for (uint32_t s = 0; s < 64; s++) {
+            // thr[s] = largest m that still gets more than s candidates (0 if none): spec_of is non-increasing in m
+            uint32_t lo = 0, hi = (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu);
+            if (s == 0) { pl.rule.thr[0] = 0xFFFFFFFFu; continue; }
+            if (spec_of(1) <= s) { pl.rule.thr[s] = 0; continue; }
+            lo = 1;  // spec_of(lo) > s
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo + 1) / 2;
+                if (spec_of((double)mid) > s) lo = mid; else hi = mid - 1;
+            }
+            pl.rule.thr[s] = lo;
+        }
+    }
     const double q = 1.0 - accept_prob(set);
     double m = (double)n;
     // a synchronous call looks at the device once anyway and adds rounds if an op is left, so its plan stops when that is
@@ -436,15 +460,24 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
         // grids follow mean + 6 sigma of the binomial count (a round that still finds more just loops)
         const double m_hi = std::min((double)n, m + 6.0 * std::sqrt(m) + 1.0);
         const size_t mh = (size_t)std::ceil(m_hi);
-        size_t spec = 1;
-        if (mh * 2 <= tgt) spec = std::min<size_t>(rows / mh, pl.spec_max);
-        double spec_mean = 1;  // the rule applied to the mean (what the device will mostly see)
+        const size_t spec = pl.rule.spec((uint32_t)mh, pl.spec_max);
         const size_t mm = (size_t)std::max(1.0, std::floor(m));
-        if (mm * 2 <= tgt) spec_mean = (double)std::min<size_t>(rows / mm, pl.spec_max);
+        const double spec_mean = (double)pl.rule.spec((uint32_t)mm, pl.spec_max);  // the rule applied to the mean (what the device will mostly see)
         pl.m_hint.push_back(mh);
         pl.one_cand.push_back(spec_mean == 1.0 && spec == 1 ? 1 : 0);
-        pl.ns_hint.push_back(std::min(pl.ns_max, std::max(mh * spec, (size_t)std::ceil(m_hi * spec_mean))));
-        m *= std::pow(q, spec_mean);
+        // slots the round may have: m * spec(m) over the whole range the count can fall in (spec steps UP as m falls below a
+        // threshold, so the largest product sits at m_hi or just below one of the thresholds inside the range)
+        const double m_lo = std::max(1.0, m - 6.0 * std::sqrt(m) - 1.0);
+        size_t ns_top = std::max(mh * spec, (size_t)std::ceil(m_hi * spec_mean));
+        for (uint32_t sidx = 1; sidx < 64 && sidx < pl.spec_max; sidx++) {
+            const double t = (double)pl.rule.thr[sidx];
+            if (t >= m_lo && t <= m_hi) ns_top = std::max(ns_top, (size_t)t * pl.rule.spec(pl.rule.thr[sidx], pl.spec_max));
+        }
+        pl.ns_hint.push_back(std::min(pl.ns_max, ns_top));
+        // progress is planned with the FEWER candidates of the two (the count sitting just above a threshold of the rule must not
+        // leave the call short of rounds: a synchronous call would pay two extra rounds and a host round trip, an asynchronous
+        // one would report MLDSA_ERR_AGAIN)
+        m *= std::pow(q, (double)std::min<size_t>(spec, (size_t)spec_mean));
     }
     if (ctx->opt_sign_rounds > 0 && (size_t)ctx->opt_sign_rounds < pl.m_hint.size()) {
         pl.m_hint.resize((size_t)ctx->opt_sign_rounds);
@@ -504,7 +537,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     const bool own_a = a_hat_keys == nullptr;
     const uint32_t *ns_gen_dev = &w.ctl->ns_gen;  // rows generated this round (the tail kernels read ctl->ns themselves)
     const size_t gen_hint = gen2 ? 2 * ns_hint : ns_hint;  // grids of the generating kernels (a round that tests ready rows finds ns_gen = 0)
-    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.spec_target, pl.spec_rows, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
+    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.rule, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
                                           w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
                                           pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
     // 11: y <- ExpandMask(rho'', kappa)                               :215
@@ -813,9 +846,9 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     int rc = MLDSA_OK;
     for (size_t o = 0; o < n_ops && rc == MLDSA_OK; o += chunk) {
         const size_t n_chunk = (n_ops - o) < chunk ? (n_ops - o) : chunk;
-        struct { int op, n_lanes; long spec_target, spec_rows, spec_max, rounds, ahead; SignArgs a[2]; } key;
+        struct { int op, n_lanes; long spec_target, spec_rows, spec_alpha, spec_max, rounds, ahead; SignArgs a[2]; } key;
         memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
-        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_rows = ctx->opt_spec_rows; key.spec_max = ctx->opt_spec_max;
+        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_rows = ctx->opt_spec_rows; key.spec_alpha = ctx->opt_spec_alpha; key.spec_max = ctx->opt_spec_max;
         key.rounds = (long)pl.m_hint.size();  // the planned rounds (options, the asynchronous stop threshold) shape the launch sequence
         key.ahead = ctx->opt_lookahead;
         int live = 0;
