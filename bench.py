@@ -815,7 +815,7 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
         line["verdict_gather"] = gather
     if whole:
         # stages that run on a helper stream UNDERNEATH a kernel of the call's stream (verify: mu and SampleInBall under ExpandA;
-        # sign: the optional masks-ahead launch under sign_w) are not on the critical path: they are listed, but neither the
+        # sign: the optional side-stream prologue) are not on the critical path: they are listed, but neither the
         # busy fraction nor the gap adds them to the critical stream's time
         overlapped = {"mu", "sample_in_ball"} if wl.kind == "verify" else {"expand_mask_ahead", "mu", "rho_pp_hash"}
         total_ms = sum(v["ms"] for k, v in stages.items() if k not in overlapped)

@@ -441,3 +441,36 @@ def test_sign_host_writes_page_locked_signatures_directly(sets, n, nk, passes):
         assert (st[bad] == -2).all() and not st[good].any()
     finally:
         h2.close()
+
+
+# ------------------------------------------------------------------------------ two candidates per op generated at once
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_two_candidate_generation_and_the_speculation_table_do_not_change_a_signature(hp, sets, pset):
+    """MLDSA_OPT_SIGN_LOOKAHEAD (rounds that generate kappa and kappa + l of every op at once and test them in two rounds,
+    rows addressed through slot_y) and the candidates-per-op rule are scheduling only: the same 20 000 signatures, byte for
+    byte, whatever they are set to -- and those are the oracle's (ml_dsa.rs:212-330: the FIRST accepted kappa wins)."""
+    m = sets[pset]
+    n, nk = 20000, 50
+    xi = [shake(b"look-key%d" % pset, i) for i in range(nk)]
+    pk, sk = m.keygen_from_seed(xi)
+    sks = m.private_keys_from_bytes(sk)
+    msgs = [shake(b"look-msg", i, 33) for i in range(n)]
+    rnd = [shake(b"look-rnd", i) for i in range(n)]
+    kidx = (np.arange(n) * 11 % nk).astype(np.uint32)
+    old = {o: hp.get_option(o) for o in (2, 3, 10)}
+    got = {}
+    try:
+        for look in (0, 1, 2):
+            for target, smax in ((65536, 32), (30000, 5)):
+                hp.set_option(10, look); hp.set_option(2, target); hp.set_option(3, smax)
+                got[(look, target)] = host(m.try_sign_with_seed(sks, msgs, rnd, key_idx=kidx)).copy()
+    finally:
+        for o, v in old.items():
+            hp.set_option(o, v)
+    ref = got[(0, 65536)]
+    for k, v in got.items():
+        assert np.array_equal(v, ref), k
+    skb = host(sk)
+    sk_o = [orc.sk_try_from_bytes(pset, skb[i].tobytes()) for i in range(nk)]
+    want = orc.sign_batch_mt(pset, sk_o, kidx, msgs, rnd, 16, 1, mode=0)
+    assert all(ref[i].tobytes() == want[i] for i in range(n))

@@ -11,7 +11,7 @@
       SQ_* counters -> profiles/<round>_sq_<name>.json: per kernel, mean per dispatch, and the derived ratios
       (VALU instructions per wave-cycle, share of wave cycles with a VALU instruction active / waiting to issue).
 """
-import csv, glob, json, os, statistics, sys
+import csv, glob, json, os, re, statistics, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE_KERNELS = {  # pipeline stage -> substring of the kernel name that runs it
@@ -28,8 +28,9 @@ def rows(d):
 
 
 def stage_of(kernel):
-    if "k_verify_arith<" in kernel:
-        return "sign_w" if ", false," in kernel else "verify_arith"
+    m = re.search(r"k_verify_arith<\d+, \d+, (true|false)(?:, \d+, (?:true|false), (true|false))?", kernel)
+    if m:  # <K, L, HAS_C, W1, APACK, KG>: HAS_C = the config-2 / verify form, KG = key generation's t = A s1 + s2
+        return "verify_arith" if m.group(1) == "true" else "keygen_t" if m.group(2) == "true" else "sign_w"
     for st, sub in STAGE_KERNELS.items():
         if sub in kernel:
             return st
