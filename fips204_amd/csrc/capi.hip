@@ -154,7 +154,6 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->exp_fork_ev) (void)hipEventDestroy(ctx->exp_fork_ev);
     if (ctx->exp_join_ev) (void)hipEventDestroy(ctx->exp_join_ev);
     for (size_t i = 1; i < ctx->helper_streams.size(); i++) (void)hipStreamDestroy(ctx->helper_streams[i]);  // [0] is aux_stream
-    for (hipStream_t t : ctx->prio_streams) (void)hipStreamDestroy(t);
     if (ctx->d_probe) (void)hipFree(ctx->d_probe);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->graph_fork_ev) (void)hipEventDestroy(ctx->graph_fork_ev);

@@ -945,31 +945,6 @@ hipStream_t parallel_stream(mldsa_ctx *ctx, hipStream_t s, hipStream_t avoid) {
     return found;
 }
 
-// Like parallel_stream, but a HIGH-PRIORITY stream: work placed there is dispatched ahead of the caller's stream's work when
-// both have workgroups waiting.  The signer's "masks one round ahead" launch runs here: it must finish inside the HBM-bound
-// sign_w it hides under, not trail behind it into the latency-bound hash that follows.
-hipStream_t priority_stream(mldsa_ctx *ctx, hipStream_t s) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return ctx->aux_stream;
-    for (const auto &pr : ctx->prio_of)
-        if (pr.first == s) return pr.second;
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    hipStream_t found = nullptr;
-    for (size_t i = 0; i < 8 && !found; i++) {
-        if (i == ctx->prio_streams.size()) {
-            hipStream_t t = nullptr;
-            if (hipStreamCreateWithPriority(&t, hipStreamNonBlocking, greatest) != hipSuccess) break;
-            ctx->prio_streams.push_back(t);
-        }
-        hipStream_t c = ctx->prio_streams[i];
-        if (!streams_serialise(ctx, s, c)) found = c;
-    }
-    if (!found) found = parallel_stream(ctx, s);
-    ctx->prio_of.emplace_back(s, found);
-    return found;
-}
-
 // ------------------------------------------------------------------------------------
 // hipGraph replay.  A call shape = the operation and every argument that ends up in a kernel parameter.
 // callers make sure nothing of the context still runs (ensure_workspace and mldsa_ctx_destroy wait for the device,
