@@ -568,14 +568,15 @@ int mldsa_keygen(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
 int mldsa::sign_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr,
                      const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                      const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd, uint8_t *sigs,
-                     int32_t *status, size_t n_ops, hipStream_t s, bool async_mode, double plan_stop, uint8_t *export_sigs) {
+                     int32_t *status, size_t n_ops, hipStream_t s, bool async_mode, double plan_stop, uint8_t *export_sigs,
+                     hipEvent_t inputs_ev) {
     const mldsa_params *p = params_of(set);
     if (n_ops == 0) return MLDSA_OK;
     OpGuard guard(ctx, s, true);  // sign_batch orders itself after a pending background clearing
     int rc = reserve_workspace(ctx, p, MLDSA_OP_SIGN, n_ops, a_hat == nullptr);
     if (rc != MLDSA_OK) return rc;
     return sign_batch(ctx, set, mode, rho, cap_k, tr, s1, s2, t0, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, rnd, sigs, status,
-                      n_ops, s, a_hat, async_mode, plan_stop, export_sigs);
+                      n_ops, s, a_hat, async_mode, plan_stop, export_sigs, inputs_ev);
 }
 
 extern "C" {

@@ -369,6 +369,31 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     HostStage *hs;
     TRY(stage_get(ctx, &hs));
     const size_t skl = (size_t)p->sk_len, sgl = (size_t)p->sig_len, k = (size_t)p->k, l = (size_t)p->l;
+    // Page-locked signature buffer: the signing rounds write finished signatures straight into it (k_export_done after every
+    // round, pipeline.hip) -- the 3.3 KB per signature cross PCIe while later rounds still run, so the whole batch is ONE signing
+    // call (its rounds' fixed costs paid once) with nothing left to download but the statuses.  Pageable buffers, or a runtime
+    // that cannot map the buffer, take the sub-batch path below.
+    // Used for calls of 16 385 ... 98 304 ops (measured, ML-DSA-65: 5.7 instead of 7.3 ms at 32 768, 10.3 instead of 11.1 ms at 65 536, 20.5 instead of 19.6 ms at 131 072; smaller calls replay as
+    // hipGraphs on the sub-batch path, larger ones amortise their rounds anyway and lose more to the export's interference).
+    // (One lane only: the export hangs off lane 0's rounds.)
+    const bool pin_sigs = is_pinned(sigs);
+    uint8_t *sigs_dev_view = nullptr;
+    const bool direct_size = n_ops > HOST_DIRECT_MIN_OPS && n_ops <= HOST_DIRECT_MAX_OPS;
+    if (pin_sigs && direct_size && ctx->opt_host_direct && ctx->opt_sign_lanes < 2) {
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&sigs_dev_view), sigs, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            sigs_dev_view = nullptr;
+        }
+    }
+    // the direct path's signing call starts with ExpandA as soon as the keys and key_idx are there, the other inputs follow
+    // beside it: key_idx goes up first, on its own
+    const uint32_t *d_kidx_early = nullptr;
+    if (sigs_dev_view && key_idx) {
+        Slot &sl = hs->slot[0];
+        TRY(reclaim(sl));
+        TRY(upload(sl.key_idx, key_idx, n_ops * 4, is_pinned(key_idx), hs->up));
+        d_kidx_early = reinterpret_cast<const uint32_t *>(sl.key_idx.dev);
+    }
     // keys: upload once, expand once (PrivateKey::try_from_bytes, ml_dsa.rs:445-469)
     TRY(upload(hs->key_bytes, sk, n_keys * skl, is_pinned(sk), hs->up));
     TRY(grow_dev(hs->k_rho, n_keys * 32));
@@ -397,12 +422,11 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     {
         size_t largest = 0;  // a sub-batch can be larger than `big` (rem <= big + tail goes as rem - tail)
         for (size_t j = 0; j + 1 < cut.size(); j++) largest = std::max(largest, cut[j + 1] - cut[j]);
-        if (ctx->opt_host_direct && is_pinned(sigs) && n_ops > HOST_DIRECT_MIN_OPS && n_ops <= HOST_DIRECT_MAX_OPS)
-            largest = n_ops;  // one signing call for the whole batch (see below)
+        if (sigs_dev_view) largest = n_ops;  // one signing call for the whole batch (see above)
         TRY(mldsa_reserve(ctx, set, MLDSA_OP_SIGN, largest));
     }
     OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
-    const bool pin_rnd = is_pinned(rnd), pin_sigs = is_pinned(sigs);
+    const bool pin_rnd = is_pinned(rnd);
     // per-op status always comes back: MLDSA_ERR_AGAIN marks the (practically never) ops that need another pass
     std::vector<int32_t> st_local;
     int32_t *st = status;
@@ -413,35 +437,23 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     // rounds like a synchronous call (three or four empty ~0.2 ms rounds less per sub-batch than the 1e-9 plan).  Passed per
     // call: the context's own threshold stays what mldsa_sign_async callers on other threads configured.
     constexpr double HOST_PLAN_STOP = 0.05;
-    // Page-locked signature buffer: the signing rounds write finished signatures straight into it (k_export_done after every
-    // round, pipeline.hip) -- the 3.3 KB per signature cross PCIe while later rounds still run, so the whole batch is ONE signing
-    // call (its rounds' fixed costs paid once) with nothing left to download but the statuses.  Pageable buffers, or a runtime
-    // that cannot map the buffer, take the sub-batch path below.
-    // Used for calls of 16 385 ... 98 304 ops (measured, ML-DSA-65: 5.7 instead of 7.3 ms at 32 768, 10.3 instead of 11.1 ms at 65 536, 20.5 instead of 19.6 ms at 131 072; smaller calls replay as
-    // hipGraphs on the sub-batch path, larger ones amortise their rounds anyway and lose more to the export's interference).
-    uint8_t *sigs_dev_view = nullptr;
-    const bool direct_size = n_ops > HOST_DIRECT_MIN_OPS && n_ops <= HOST_DIRECT_MAX_OPS;
-    if (pin_sigs && direct_size && ctx->opt_host_direct) {
-        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&sigs_dev_view), sigs, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            sigs_dev_view = nullptr;
-        }
-    }
     if (sigs_dev_view) {
         Slot &sl = hs->slot[0];
         rc = [&]() -> int {
             TRY(reclaim(sl));
-            TRY(upload_op_inputs(hs->up, sl, in, 0, n_ops));
+            OpInputs rest = in;  // key_idx is up already
+            rest.key_idx = nullptr;
+            TRY(upload_op_inputs(hs->up, sl, rest, 0, n_ops));
+            sl.d_kidx = d_kidx_early;
             TRY(upload(sl.rnd, rnd, n_ops * 32, pin_rnd, hs->up));
             TRY(grow_dev(sl.out, n_ops * sgl));
             TRY(grow_dev(sl.status, n_ops * 4));
-            HCHECK(hipEventRecord(sl.up_done, hs->up));
-            HCHECK(hipStreamWaitEvent(hs->comp, sl.up_done, 0));
+            HCHECK(hipEventRecord(sl.up_done, hs->up));  // the signing call waits for it itself, after its ExpandA
             const uint8_t *mbase = sl.d_msgs - msg_off[0];
             const uint8_t *cbase = ctx_off ? sl.d_ctxs - ctx_off[0] : nullptr;
             TRY(sign_call(ctx, set, mode, hs->k_rho.dev, nullptr, hs->k_capk.dev, hs->k_tr.dev, s1, s2, t0, n_keys, sl.d_kidx, mbase, sl.d_moff,
                           cbase, sl.d_coff, sl.rnd.dev, sl.out.dev, reinterpret_cast<int32_t *>(sl.status.dev), n_ops, hs->comp, true,
-                          HOST_PLAN_STOP, sigs_dev_view));
+                          HOST_PLAN_STOP, sigs_dev_view, sl.up_done));
             HCHECK(hipMemcpyAsync(st, sl.status.dev, n_ops * 4, hipMemcpyDeviceToHost, hs->comp));
             HCHECK(hipStreamSynchronize(hs->comp));
             // a refused op (ctx too long, key index out of range) never entered a round: its signature is all zero

@@ -591,6 +591,7 @@ struct SignArgs {
     uint8_t *sigs;
     int32_t *status;
     const int32_t *a_hat_keys;
+    hipEvent_t inputs_ev;  // optional (mldsa_sign_host): msgs / ctxs / rnd are on the device once this event has fired; waited for after ExpandA
     uint8_t *export_sigs;  // optional: the caller's page-locked host array (device-visible), finished signatures are copied there round by round
     size_t offset, n;   // this chunk: first op and number of ops
     size_t chunk;       // ops the workspace / plan is laid out for
@@ -657,6 +658,10 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
         MLDSA_HIP_CHECK(hipStreamWaitEvent(side, ctx->zero_ev, 0));
         ctx->zero_wait_after_ea = false;
         ctx->zero_pending = false;
+    }
+    if (a.inputs_ev) {  // the host path's uploads of everything but the keys ran beside ExpandA
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, a.inputs_ev, 0));
+        if (side != s) MLDSA_HIP_CHECK(hipStreamWaitEvent(side, a.inputs_ev, 0));
     }
     s = side;  // ---- the small kernels below: on the helper stream when forked, joined at the end
     // the signature buffer is not cleared: every op's bytes come from its accepted attempt, a refused op (k_init_active) or
@@ -737,7 +742,9 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
             const ChunkKeys c = chunk_keys(p, L.w, L.a);
             TRY(launch_mark_unfinished(ctx, L.w.ctl, rounds & 1, L.w.act[rounds & 1], L.a.status ? L.a.status + L.a.offset : nullptr, c.sg,
                                        (size_t)p->sig_len, L.st));
-            zeroise_sign_ws(ctx, L.w, L.st);
+            // (the exporting call of mldsa_sign_host is launched directly, never captured: sign_batch clears its workspace on
+            //  the helper stream like a synchronous call's, 0.3 ms that the caller does not wait for)
+            if (!exporting) zeroise_sign_ws(ctx, L.w, L.st);
         }
     }
     if (n_lanes > 1) {
@@ -817,7 +824,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
                const int32_t *s1, const int32_t *s2, const int32_t *t0, size_t n_keys, const uint32_t *key_idx,
                const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *rnd,
                uint8_t *sigs, int32_t *status, size_t n_ops, hipStream_t s, const int32_t *a_hat_keys, bool async_mode,
-               double plan_stop, uint8_t *export_sigs) {
+               double plan_stop, uint8_t *export_sigs, hipEvent_t inputs_ev) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sign: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
@@ -858,7 +865,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
             SignArgs &a = key.a[live];
             a.set = set; a.mode = mode; a.rho = rho; a.cap_k = cap_k; a.tr = tr; a.s1 = s1; a.s2 = s2; a.t0 = t0; a.n_keys = n_keys;
             a.key_idx = key_idx; a.msgs = msgs; a.msg_off = msg_off; a.ctxs = ctxs; a.ctx_off = ctx_off; a.rnd = rnd; a.sigs = sigs;
-            a.status = status; a.a_hat_keys = a_hat_keys; a.export_sigs = export_sigs; a.offset = o + lo; a.n = hi - lo; a.chunk = per_lane;
+            a.status = status; a.a_hat_keys = a_hat_keys; a.export_sigs = export_sigs; a.inputs_ev = inputs_ev; a.offset = o + lo; a.n = hi - lo; a.chunk = per_lane;
             a.async_mode = async_mode ? 1 : 0;
             lanes[live].a = a;
             live++;
@@ -876,8 +883,9 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     if (rc != MLDSA_OK) {
         for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, s);  // also on the error path
         (void)hipStreamSynchronize(s);
-    } else if (!async_mode) {
-        // Every signature is in place (sign_chunk_finish waited for the stream).  y, w, c, rho'' ... are cleared on a helper
+    } else if (!async_mode || export_sigs) {
+        // Every signature is in place (sign_chunk_finish waited for the stream; mldsa_sign_host's exporting call is asynchronous
+        // and ordered on the device: zero_fork_ev follows its last round and its last export).  y, w, c, rho'' ... are cleared on a helper
         // stream, off the caller's critical path (1.1 GB for a 65 536-op ML-DSA-65 call: ~0.2 ms of an 8 ms call): the next
         // op-level call on this context waits for zero_ev on the device before it touches the workspace, destroy / regrow
         // wait for the whole device.

@@ -386,16 +386,19 @@ def _pinned(shape, dtype):
     return t, a
 
 
-@pytest.mark.parametrize("n,nk,passes", [(40000, 300, 0), (700, 9, 0), (20000, 64, 4096)])
-def test_sign_host_writes_page_locked_signatures_directly(sets, n, nk, passes):
+@pytest.mark.parametrize("n,nk,passes,lanes", [(40000, 300, 0, 1), (700, 9, 0, 1), (20000, 64, 4096, 1), (20000, 64, 0, 2)])
+def test_sign_host_writes_page_locked_signatures_directly(sets, n, nk, passes, lanes):
     """With a page-locked signature buffer mldsa_sign_host signs the whole batch in ONE call and k_export_done copies the
     signatures that finished in each round to the caller's memory (lib.rs:268-296 is the per-op contract: same bytes).
     Cases: a call in the direct path's size range (16 385 ... 131 072 ops), a small one (sub-batch path, captured and replayed
-    as a hipGraph: three calls on the same buffers), and a direct call cut into several passes (export offsets per pass);
+    as a hipGraph: three calls on the same buffers), a direct call cut into several passes (export offsets per pass), and a
+    context set to two signing lanes (the export hangs off ONE lane's rounds: such a context takes the sub-batch path);
     refused ops get zero rows and their status."""
     from fips204_amd.hotpath import HotPath
     from fips204_amd.ml_dsa import MlDsa
     env = {"MLDSA_PASS_OPS_SIGN": str(passes)} if passes else {}
+    if lanes != 1:
+        env["MLDSA_SIGN_LANES"] = str(lanes)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -439,6 +442,34 @@ def test_sign_host_writes_page_locked_signatures_directly(sets, n, nk, passes):
         good[bad] = False
         assert np.array_equal(sig[good], want[good]) and not sig[bad].any()
         assert (st[bad] == -2).all() and not st[good].any()
+    finally:
+        h2.close()
+
+
+def test_sign_host_direct_with_one_key_per_op(sets):
+    """The direct path without key_idx (op i signs with key i; nothing goes up ahead of the keys) and with it naming the same
+    keys: the same signatures, equal to the device-resident call's."""
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    n = 16500
+    h2 = HotPath(0)
+    try:
+        m = MlDsa(44, hotpath=h2)
+        xi = np.frombuffer(b"".join(shake(b"d1-key", i) for i in range(n)), dtype=np.uint8)
+        pk, sk = m.keygen_host(xi)
+        msgs = [shake(b"d1-msg", i, i % 77) for i in range(n)]
+        rnd = np.frombuffer(b"".join(shake(b"d1-rnd", i) for i in range(n)), dtype=np.uint8)
+        keep_s, sig = _pinned((n, m.SIG_LEN), np.uint8)
+        keep_t, st = _pinned((n,), np.int32)
+        m.sign_host(sk, msgs, rnd, out=(sig, st))
+        assert not st.any() and m.verify_host(pk, msgs, sig).all()
+        first = sig.copy()
+        sig[...] = 0xA5
+        m.sign_host(sk, msgs, rnd, key_idx=np.arange(n, dtype=np.uint32), out=(sig, st))
+        assert np.array_equal(sig, first)
+        sk_o = [orc.sk_try_from_bytes(44, sk[i].tobytes()) for i in (0, 1, n - 1)]
+        for o, i in zip(sk_o, (0, 1, n - 1)):
+            assert sig[i].tobytes() == orc.sign_internal(44, o, msgs[i], rnd[32 * i:32 * i + 32].tobytes(), ctx=b"", mode=0)
     finally:
         h2.close()
 
