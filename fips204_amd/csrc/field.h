@@ -17,6 +17,18 @@ constexpr int32_t F_MONT = 16382;         // 256^-1 * 2^32 mod q (ntt.rs:88)
 constexpr int32_t F_MONT2 = 41978;        // 256^-1 * 2^64 mod q (inverse NTT of R^-1-scaled input)
 constexpr int N = 256;
 
+// The pipelines' private 24-bit form of a polynomial with canonical coefficients (A_hat from ExpandA, the signer's w): 768 bytes,
+// four coefficients in three dwords.
+struct Packed3 { uint32_t a, b, c; };
+constexpr int PACKED_POLY_DWORDS = 192;  // 256 * 24 bits
+__device__ __forceinline__ int4 unpack24(const Packed3& p) {
+    return make_int4((int)(p.a & 0xFFFFFFu), (int)(__builtin_amdgcn_alignbit(p.b, p.a, 24) & 0xFFFFFFu),
+                     (int)(__builtin_amdgcn_alignbit(p.c, p.b, 16) & 0xFFFFFFu), (int)(p.c >> 8));
+}
+__device__ __forceinline__ Packed3 pack24(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {  // all < 2^24
+    return Packed3{c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8)};
+}
+
 // a * b * 2^-32 mod q, result in (-q, q); |a*b| < 2^31 * q.  Same computation as the reference's
 // mont_reduce (helpers.rs:156-165); hipcc lowers it to v_mad_i64_i32, v_mul_lo_u32,
 // v_mad_i64_i32 -- three full-rate instructions on gfx950 (profiles/r01_ubench_valu.txt), with

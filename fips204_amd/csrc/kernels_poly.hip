@@ -315,7 +315,18 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
-            store_strided(acc, w_out + (op * K + i) * (size_t)N, lane);
+            if constexpr (W1 != 0) {
+                // the signer's w is read back by k_sign_tail / k_resolve only: 24-bit fields (canonical coefficients < 2^23), the
+                // lane's four strided coefficients in three dwords, dword t of every lane in plane t (64 dwords) -- 768 bytes per
+                // polynomial instead of 1 024, stored and loaded like the first three quarters of a strided polynomial
+                const Packed3 pw = pack24((uint32_t)acc[0], (uint32_t)acc[1], (uint32_t)acc[2], (uint32_t)acc[3]);
+                uint32_t *wp = reinterpret_cast<uint32_t *>(w_out) + (op * K + i) * (size_t)PACKED_POLY_DWORDS;
+                wp[lane] = pw.a;
+                wp[64 + lane] = pw.b;
+                wp[128 + lane] = pw.c;
+            } else {
+                store_strided(acc, w_out + (op * K + i) * (size_t)N, lane);
+            }
             if constexpr (W1 != 0) {
                 constexpr bool G2HI = W1 == 2;
                 uint8_t *dst = w1 + op * w1_stride + (size_t)i * (32 * (G2HI ? 4 : 6));

@@ -7,6 +7,7 @@
 #include "ctx.h"
 #include "keccak.h"
 #include "rounding.h"
+#include "sampler_dev.h"
 
 namespace mldsa {
 
@@ -122,9 +123,13 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
     auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
         const bool is_r = idx < K;
         const int32_t* sp = is_r ? a.s2 + (key * K + idx) * (size_t)N : a.s1 + (key * L + (idx - K)) * (size_t)N;
-        const int32_t* xq = is_r ? a.w + (yrow * K + idx) * (size_t)N : a.y + (yrow * L + (idx - K)) * (size_t)N;
+        // y_j: four strided dwords; w_i (sign_w's 24-bit form): three planes of 64 dwords, unpacked where it is used
+        const int32_t* xq = is_r ? a.w + (yrow * K + idx) * (size_t)PACKED_POLY_DWORDS : a.y + (yrow * L + (idx - K)) * (size_t)N;
         load_packed(v, sp, lane);
-        load_strided(x, xq, lane);
+        x[0] = xq[lane];
+        x[1] = xq[64 + lane];
+        x[2] = xq[128 + lane];
+        x[3] = xq[(is_r ? 0 : 192) + lane];  // (w: unused)
     };
 #pragma unroll 1
     for (int pass = 0; pass < (FULL ? 2 : 1) && ok; pass++) {
@@ -138,7 +143,12 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
         while (cur >= 0) {
             work &= work - 1u;
             const int nxt = work ? __ffs((int)work) - 1 : -1;
-            const int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]}, x[4] = {nx[0], nx[1], nx[2], nx[3]};
+            const int32_t v[4] = {nv[0], nv[1], nv[2], nv[3]};
+            int32_t x[4] = {nx[0], nx[1], nx[2], nx[3]};
+            if (cur < K) {  // w_i arrives as three dwords of 24-bit fields
+                const int4 w4 = unpack24(Packed3{(uint32_t)nx[0], (uint32_t)nx[1], (uint32_t)nx[2]});
+                x[0] = w4.x; x[1] = w4.y; x[2] = w4.z; x[3] = w4.w;
+            }
             if (nxt >= 0) issue_loads(nxt, nv, nx);
             int32_t r[4];
             r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
@@ -208,20 +218,26 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
             int32_t v[4], v2[4], r[4], base[4];
             load_packed(v, a.t0 + (key * K + i) * (size_t)N, lane);
             load_packed(v2, a.s2 + (key * K + i) * (size_t)N, lane);
-            load_strided(base, a.w + (yrow * K + i) * (size_t)N, lane);
+            // w_i stays in its three packed dwords across the transform
+            const uint32_t* wq = reinterpret_cast<const uint32_t*>(a.w) + (yrow * K + i) * (size_t)PACKED_POLY_DWORDS;
+            const Packed3 wp{wq[lane], wq[64 + lane], wq[128 + lane]};
             if (s2_oor) {
                 // out-of-range s2: the identity is not guaranteed; r_i = w_i - c s2_i explicitly (it passed the LowBits
                 // test in stage 1, where every polynomial counted as risky), then r_i + c t0_i as the reference does
                 r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
                 ntt_inv_wave(r, itw, lane, F_MONT);
-#pragma unroll
-                for (int k = 0; k < 4; k++) base[k] = caddq(base[k] - r[k]);
+                const int4 w4 = unpack24(wp);
+                base[0] = caddq(w4.x - r[0]); base[1] = caddq(w4.y - r[1]); base[2] = caddq(w4.z - r[2]); base[3] = caddq(w4.w - r[3]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) v[k] -= v2[k];
             }
             r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
             ntt_inv_wave(r, itw, lane, F_MONT);  // ct0 - cs2 (ct0 for an out-of-range key), canonical
+            if (!s2_oor) {
+                const int4 w4 = unpack24(wp);
+                base[0] = w4.x; base[1] = w4.y; base[2] = w4.z; base[3] = w4.w;
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if constexpr (CT0_CAN_FAIL) {

@@ -372,7 +372,7 @@ struct SignWs {
         key_bad = cv.take<int32_t>(n);
         kidx = cv.take<uint32_t>(n);
         y = cv.take<int32_t>(rows * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
-        w = cv.take<int32_t>(rows * (size_t)p->k * N);
+        w = cv.take<int32_t>(rows * (size_t)p->k * PACKED_POLY_DWORDS);  // 24-bit fields (sign_w)
         c = cv.take<int32_t>(rows * (size_t)N);
         done = cv.take<int32_t>(n);
         bad_op = cv.take<int32_t>(n);

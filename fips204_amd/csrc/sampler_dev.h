@@ -50,8 +50,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 // polynomial instead of 1024: four coefficients = three dwords, so a flush piece is one dwordx3 store.
 // The A_hat the op-level pipelines keep for themselves uses this form (a quarter less HBM traffic in
 // the kernels that stream it); the seam-level mldsa_expand_a keeps the reference's int32 layout.
-struct Packed3 { uint32_t a, b, c; };
-constexpr int PACKED_POLY_DWORDS = 192;  // 256 * 24 bits
 
 template <bool PACK24 = false>
 __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
@@ -88,12 +86,6 @@ __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int
         }
     }
     wave_lds_sync();
-}
-
-// four 24-bit fields (three dwords of a PACK24 polynomial) -> coefficients
-__device__ __forceinline__ int4 unpack24(const Packed3& p) {
-    return make_int4((int)(p.a & 0xFFFFFFu), (int)(__builtin_amdgcn_alignbit(p.b, p.a, 24) & 0xFFFFFFu),
-                     (int)(__builtin_amdgcn_alignbit(p.c, p.b, 16) & 0xFFFFFFu), (int)(p.c >> 8));
 }
 
 // after flush_rows4: move the (at most 3) unflushed coefficients my[fc .. fc + 2] to the row front
