@@ -25,6 +25,18 @@ __device__ __forceinline__ int4 unpack24(const Packed3& p) {
     return make_int4((int)(p.a & 0xFFFFFFu), (int)(__builtin_amdgcn_alignbit(p.b, p.a, 24) & 0xFFFFFFu),
                      (int)(__builtin_amdgcn_alignbit(p.c, p.b, 16) & 0xFFFFFFu), (int)(p.c >> 8));
 }
+// The signer's y between ExpandMask and its users: the squeezed bytes themselves, BitPack(y, gamma1 - 1, gamma1) with c = 18 / 20 bit
+// fields (conversion.rs:227-262), 32 c bytes per polynomial.  Field i starts at bit c i: ONE dword load at its byte (no alignment
+// needed on gfx950) holds it, shifted by (c i) & 7 -- which for i = 64 k + lane depends on the lane only.
+typedef uint32_t __attribute__((aligned(1))) u32_any;
+template <int CB>
+__device__ __forceinline__ uint32_t y_raw_dword(const uint8_t* poly, int k, int lane) {
+    return *reinterpret_cast<const u32_any*>(poly + 8 * CB * k + ((lane * CB) >> 3));
+}
+template <int CB>
+__device__ __forceinline__ int32_t y_from_raw(uint32_t raw, int lane) {
+    return (1 << (CB - 1)) - (int32_t)((raw >> ((lane * CB) & 7)) & ((1u << CB) - 1u));
+}
 __device__ __forceinline__ Packed3 pack24(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {  // all < 2^24
     return Packed3{c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8)};
 }

@@ -178,15 +178,23 @@ struct KeygenOut {
     size_t pk_len, sk_len, t0_off;  // t0_off: byte offset of the t0 section inside sk
     int eta, ebits;                 // BitPack(s, eta, eta): `ebits`-wide fields eta - s (the s1 / s2 sections of sk, from byte 128)
 };
+// YGB != 0 (the signer's rounds): y arrives as ExpandMask's squeezed bytes (field.h y_raw_dword, gamma1 = 2^YGB) and the kernel
+// also flags the polynomials of y that can fail ||z||inf < gamma1 - beta (yr.flags: some |y| >= yr.bound = gamma1 - 2 beta).
+struct YRisk {
+    uint8_t *flags;
+    int32_t bound;
+};
 constexpr int AW = 4;  // waves per block
-template <int K, int L, bool HAS_C, int W1 = 0, bool APACK = false, bool KG = false>
+template <int K, int L, bool HAS_C, int W1 = 0, bool APACK = false, bool KG = false, int YGB = 0>
 __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     const int32_t *__restrict__ a_hat, const uint32_t *__restrict__ a_idx, const int32_t *__restrict__ z,
     const int32_t *__restrict__ c, const int32_t *__restrict__ t1, const uint32_t *__restrict__ key_idx,
     int32_t *__restrict__ w_out, size_t n_ops, const Twiddle *__restrict__ fwd_tab, const Twiddle *__restrict__ inv_tab,
     uint8_t *__restrict__ w1, size_t w1_stride, size_t z_polys_per_op, uint8_t *__restrict__ wrisk, int32_t risk_bound,
-    const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ z_idx, KeygenOut kg) {
+    const uint32_t *__restrict__ n_dev, const uint32_t *__restrict__ z_idx, KeygenOut kg, YRisk yr) {
     constexpr int NZ = HAS_C ? L + 1 : L;
+    constexpr bool YRAW = YGB != 0;
+    constexpr int YCB = YGB + 1;
     __shared__ int4 zh[AW][NZ][64];
     __shared__ int32_t xp_kg[KG ? AW : 1][KG ? N : 1];  // strided -> four consecutive coefficients per lane (t1 / t0 packing)
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
@@ -223,11 +231,33 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
         // ---- forward transforms, next polynomial loaded one ahead
         int32_t nr[4];
         const size_t zrow = (z_idx ? (size_t)z_idx[op] : op) * z_polys_per_op;  // first polynomial of the op's z / y vector
-        load_strided(nr, z + zrow * (size_t)N, lane);
+        auto load_z = [&](size_t poly) {
+            if constexpr (YRAW) {
+                const uint8_t *src = reinterpret_cast<const uint8_t *>(z) + poly * (size_t)(32 * YCB);
+#pragma unroll
+                for (int k = 0; k < 4; k++) nr[k] = (int32_t)y_raw_dword<YCB>(src, k, lane);
+            } else {
+                load_strided(nr, z + poly * (size_t)N, lane);
+            }
+        };
+        load_z(zrow);
 #pragma unroll 1
         for (int j = 0; j < NZ; j++) {
             asm volatile("" ::: "memory");  // keep the LDS twiddle reads at their point of use (no hoisting into registers)
-            int32_t r[4] = {reduce32(nr[0]), reduce32(nr[1]), reduce32(nr[2]), reduce32(nr[3])};
+            int32_t r[4];
+            if constexpr (YRAW) {
+                bool near = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    r[k] = y_from_raw<YCB>((uint32_t)nr[k], lane);  // |y| <= gamma1 < q: no reduction
+                    near |= (r[k] < 0 ? -r[k] : r[k]) >= yr.bound;
+                }
+                const bool any_near = __ballot(near) != 0ull;
+                if (yr.flags && lane == 0) yr.flags[zrow + j] = any_near ? 1 : 0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = reduce32(nr[k]);
+            }
             if constexpr (KG) {  // s1_j passes through here: its section of sk (encodings.rs:118-134) is packed on the way
 #pragma unroll
                 for (int k = 0; k < 4; k++) xp_kg[wave][64 * k + lane] = r[k];
@@ -239,7 +269,7 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
                 store_fields(kg.sk + op * kg.sk_len + 128 + (size_t)j * (32 * kg.ebits), f, kg.ebits, lane);
                 __builtin_amdgcn_wave_barrier();
             }
-            if (j + 1 < L) load_strided(nr, z + (zrow + j + 1) * (size_t)N, lane);
+            if (j + 1 < L) load_z(zrow + j + 1);
             else if (HAS_C && j + 1 == L) load_strided(nr, c + op * (size_t)N, lane);
             ntt_fwd_wave(r, ftw, lane);
             if (HAS_C && j == L) {
@@ -415,9 +445,9 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
     const uint32_t *no_idx = nullptr;
     dim3 gw(grid_for(ctx, n_ops, AW, (unsigned)ctx->opt_va_blocks));
     uint8_t *nw1 = nullptr;
-    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0, no_idx, no_idx, KeygenOut{});
-    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0, no_idx, no_idx, KeygenOut{});
-    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0, no_idx, no_idx, KeygenOut{});
+    if (set == MLDSA_44) hipLaunchKernelGGL((k_verify_arith<4, 4, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)4, nw1, 0, no_idx, no_idx, KeygenOut{}, YRisk{});
+    else if (set == MLDSA_65) hipLaunchKernelGGL((k_verify_arith<6, 5, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)5, nw1, 0, no_idx, no_idx, KeygenOut{}, YRisk{});
+    else if (set == MLDSA_87) hipLaunchKernelGGL((k_verify_arith<8, 7, true>), gw, dim3(64 * AW), 0, s, a, no_idx, z, c, t1, key_idx, w, n_ops, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)7, nw1, 0, no_idx, no_idx, KeygenOut{}, YRisk{});
     else return set_error(MLDSA_ERR_PARAM, "verify_arith: unknown parameter set");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -427,22 +457,32 @@ int launch_verify_arith(mldsa_ctx *ctx, int set, const int32_t *a, const int32_t
 // w1Encode(HighBits(w)) (ml_dsa.rs:225-232)
 int launch_sign_w(mldsa_ctx *ctx, int set, const int32_t *a, const uint32_t *a_idx, const int32_t *y, int32_t *w, uint8_t *w1,
                   size_t w1_stride, size_t n_ops, hipStream_t s, size_t y_polys_per_op, uint8_t *wrisk, bool a_packed,
-                  const uint32_t *n_dev, const uint32_t *y_idx) {
+                  const uint32_t *n_dev, const uint32_t *y_idx, bool y_raw, uint8_t *yrisk) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const int32_t *none = nullptr;
     const uint32_t *no_idx = nullptr;
     const mldsa_params *pp = params_of(set);
     const int32_t risk_bound = pp ? pp->gamma2 - 2 * pp->beta : 0;
+    const YRisk yr{yrisk, pp ? pp->gamma1 - 2 * pp->beta : 0};
+    if (y_raw && !w1) return set_error(MLDSA_ERR_PARAM, "sign_w: raw y is the signer's form (with w1)");
     dim3 gw(grid_for(ctx, n_ops, AW, 16));
-#define MLDSA_SW2(KK, LL, W1M, AP)                                                                                               \
-    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M, AP>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
-                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound, n_dev, y_idx, KeygenOut{})
-#define MLDSA_SW(KK, LL, W1M) do { if (a_packed) MLDSA_SW2(KK, LL, W1M, true); else MLDSA_SW2(KK, LL, W1M, false); } while (0)
-    if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
+#define MLDSA_SW3(KK, LL, W1M, AP, YG)                                                                                                    \
+    hipLaunchKernelGGL((k_verify_arith<KK, LL, false, W1M, AP, false, YG>), gw, dim3(64 * AW), 0, s, a, a_idx, y, none, none, no_idx, w, n_ops, \
+                       ctx->d_fwd_tw, ctx->d_inv_tw, w1, w1_stride, y_polys_per_op ? y_polys_per_op : (size_t)LL, wrisk, risk_bound, n_dev, y_idx, KeygenOut{}, yr)
+#define MLDSA_SW(KK, LL, W1M) do { if (a_packed) MLDSA_SW3(KK, LL, W1M, true, 0); else MLDSA_SW3(KK, LL, W1M, false, 0); } while (0)
+#define MLDSA_SWR(KK, LL, W1M, YG) do { if (a_packed) MLDSA_SW3(KK, LL, W1M, true, YG); else MLDSA_SW3(KK, LL, W1M, false, YG); } while (0)
+    if (y_raw) {
+        if (set == MLDSA_44) MLDSA_SWR(4, 4, 1, 17);
+        else if (set == MLDSA_65) MLDSA_SWR(6, 5, 2, 19);
+        else if (set == MLDSA_87) MLDSA_SWR(8, 7, 2, 19);
+        else return set_error(MLDSA_ERR_PARAM, "sign_w: unknown parameter set");
+    }
+    else if (set == MLDSA_44) { if (w1) MLDSA_SW(4, 4, 1); else MLDSA_SW(4, 4, 0); }
     else if (set == MLDSA_65) { if (w1) MLDSA_SW(6, 5, 2); else MLDSA_SW(6, 5, 0); }
     else if (set == MLDSA_87) { if (w1) MLDSA_SW(8, 7, 2); else MLDSA_SW(8, 7, 0); }
     else return set_error(MLDSA_ERR_PARAM, "sign_w: unknown parameter set");
-#undef MLDSA_SW2
+#undef MLDSA_SWR
+#undef MLDSA_SW3
 #undef MLDSA_SW
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -461,7 +501,7 @@ int launch_keygen_t(mldsa_ctx *ctx, const mldsa_params *p, const int32_t *a_hat,
     dim3 gw(grid_for(ctx, n_keys, AW, 16));
 #define MLDSA_KGT(KK, LL)                                                                                                              \
     hipLaunchKernelGGL((k_verify_arith<KK, LL, false, 0, true, true>), gw, dim3(64 * AW), 0, s, a_hat, no_idx, s1s2, none, none, no_idx,   \
-                       (int32_t *)nullptr, n_keys, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)(LL + KK), nw1, 0, no_idx, no_idx, kg)
+                       (int32_t *)nullptr, n_keys, ctx->d_fwd_tw, ctx->d_inv_tw, nw1, (size_t)0, (size_t)(LL + KK), nw1, 0, no_idx, no_idx, kg, YRisk{})
     if (p->set == MLDSA_44) MLDSA_KGT(4, 4);
     else if (p->set == MLDSA_65) MLDSA_KGT(6, 5);
     else MLDSA_KGT(8, 7);

@@ -112,7 +112,10 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
 // ExpandMask (hashing.rs:281-313): stream (op, r < L): v = SHAKE256(rho'' || (kappa + r) LE16),
 // y[r][i] = gamma1 - (c-bit field i of v), c = 1 + bitlen(gamma1 - 1) (bit_unpack,
 // conversion.rs:227-262).  No rejection: all lanes advance in lock step.
-template <int GB>  // gamma1 = 2^GB, GB = 17 or 19
+// RAW (the signer's rounds): y is kept as the squeezed bytes themselves -- 32 c bytes per polynomial (576 / 640 instead of 1 024),
+// BitUnpack happens where y is used (sign_w's forward transforms, k_sign_tail / k_resolve), and the flags of the polynomials that
+// can fail the ||z|| test (yrisk) come from sign_w.
+template <int GB, bool RAW = false>  // gamma1 = 2^GB, GB = 17 or 19
 __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_expand_mask(const uint8_t* __restrict__ rho_pp, size_t rho_stride,
                                                              const uint16_t* __restrict__ kappa, int kappa_by_slot,
                                                              const uint32_t* __restrict__ op_idx,
@@ -150,6 +153,8 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
     uint64_t acc = 0;
     int nbits = 0, n = 0, carry = 0;  // n = coefficients already stored (multiple of 4), carry < 4 wait in the row
     int32_t ymax = 0;
+    // units of a stream's output row: coefficients, or (RAW) the dwords of its 32 c bytes
+    constexpr int UNITS = RAW ? 8 * CB : N;
 #pragma unroll
     for (int blk = 0; blk < 5; blk++) {
         keccak_f1600(st);
@@ -158,6 +163,12 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
             int cnt = carry;
             static_for<0, 17>([&](auto wc) {
                 constexpr int W = 17 * H + decltype(wc)::value;
+                if constexpr (RAW) {
+                    if (n + cnt < UNITS) {
+                        my[cnt] = state_word<W>(st);
+                        cnt++;
+                    }
+                } else
                 if (n + cnt < N) {  // the reference squeezes 640 bytes but unpacks only 32*c (hashing.rs:297-301)
                     acc |= (uint64_t)state_word<W>(st) << nbits;
                     nbits += 32;
@@ -176,13 +187,13 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
             });
             // uniform counts: every row holds cnt coefficients continuing at n; store the multiple-of-4
             // part as dwordx4 (8 lanes per row, 8 rows per store), keep the rest for the next flush
-            const int fc = (n + cnt == N) ? cnt : (cnt & ~3);
+            const int fc = (n + cnt == UNITS) ? cnt : (cnt & ~3);
             if (fc > 0) {
                 wave_lds_sync();
                 const int grp = lane >> 3, j4 = (lane & 7) * 4;
                 // wave-uniform base + 32-bit byte offsets (see flush_rows4)
-                char* base = reinterpret_cast<char*>(y) + wave_base_u * (size_t)(N * 4);
-                const uint32_t lane_b = (uint32_t)(grp * N + n + j4) * 4u;
+                char* base = reinterpret_cast<char*>(y) + wave_base_u * (size_t)(UNITS * 4);
+                const uint32_t lane_b = (uint32_t)(grp * UNITS + n + j4) * 4u;
                 // rolled on purpose: unrolled, the eight row addresses stay live across the permutations and cost the
                 // kernel its fourth wave per SIMD (142 -> 118 VGPRs)
 #pragma unroll 1
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
                     const int row = 8 * i + grp;
                     if (j4 < fc && wave_base + row < n_streams) {
                         const uint32_t* src = stage + row * STAGE_STRIDE + j4;
-                        *reinterpret_cast<int4*>(base + (lane_b + (uint32_t)i * (8u * N * 4u))) =
+                        *reinterpret_cast<int4*>(base + (lane_b + (uint32_t)i * (8u * UNITS * 4u))) =
                             make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
                     }
                 }
@@ -201,7 +212,9 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
             n += fc;
         });
     }
-    if (yrisk && valid) yrisk[g] = ymax >= risk_bound ? 1 : 0;
+    if constexpr (!RAW) {
+        if (yrisk && valid) yrisk[g] = ymax >= risk_bound ? 1 : 0;
+    }
     }
 }
 
@@ -278,11 +291,17 @@ int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_st
 
 // n_dev != nullptr: the op count is read from the device (the signer's rounds) and n_ops only sizes the grid
 int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_stride, const uint16_t* kappa, int kappa_by_slot,
-                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s, uint8_t* yrisk, const uint32_t* n_dev) {
+                       const uint32_t* op_idx, int32_t* y, size_t n_ops, hipStream_t s, uint8_t* yrisk, const uint32_t* n_dev, bool raw) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
     dim3 grid(stream_blocks((n_ops ? n_ops : 1) * (size_t)p->l)), block(64 * SWAVES);
+    if (raw) {
+        if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17, true>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, 0);
+        else hipLaunchKernelGGL((k_expand_mask<19, true>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, 0);
+        MLDSA_HIP_CHECK(hipGetLastError());
+        return MLDSA_OK;
+    }
     if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask<17>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta);
     else hipLaunchKernelGGL((k_expand_mask<19>), grid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev, yrisk, p->gamma1 - 2 * p->beta);
     MLDSA_HIP_CHECK(hipGetLastError());

@@ -103,6 +103,7 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
     constexpr bool CT0_CAN_FAIL = !G2HI;
     const int32_t gamma1 = 1 << gb;
     const int cb = gb + 1;
+    constexpr int YCB = G2HI ? 20 : 18;  // = cb: gamma2 = (q - 1) / 32 goes with gamma1 = 2^19, (q - 1) / 88 with 2^17
     // everything a candidate owns -- y, w, c_hat, c~ and the risk flags -- lives in its ROW (k_make_slots)
     (void)slot;
     const int4 cv = reinterpret_cast<const int4*>(a.c_hat + yrow * N)[lane];
@@ -123,13 +124,15 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
     auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
         const bool is_r = idx < K;
         const int32_t* sp = is_r ? a.s2 + (key * K + idx) * (size_t)N : a.s1 + (key * L + (idx - K)) * (size_t)N;
-        // y_j: four strided dwords; w_i (sign_w's 24-bit form): three planes of 64 dwords, unpacked where it is used
-        const int32_t* xq = is_r ? a.w + (yrow * K + idx) * (size_t)PACKED_POLY_DWORDS : a.y + (yrow * L + (idx - K)) * (size_t)N;
+        // One load shape for both: w_i (sign_w's 24-bit form) is three planes of 64 dwords, y_j (ExpandMask's squeezed bytes, field.h)
+        // four dwords at byte granularity; both are decoded where they are used.  (The fourth dword of a w_i is the next
+        // polynomial's first plane -- the carve after w follows the last one -- and is not used.)
+        const uint8_t* xb = is_r ? reinterpret_cast<const uint8_t*>(a.w) + (yrow * K + idx) * (size_t)(PACKED_POLY_DWORDS * 4)
+                                 : reinterpret_cast<const uint8_t*>(a.y) + (yrow * L + (idx - K)) * (size_t)(32 * YCB);
+        const int kstride = is_r ? 256 : 8 * YCB, lane_off = is_r ? 4 * lane : (lane * YCB) >> 3;
         load_packed(v, sp, lane);
-        x[0] = xq[lane];
-        x[1] = xq[64 + lane];
-        x[2] = xq[128 + lane];
-        x[3] = xq[(is_r ? 0 : 192) + lane];  // (w: unused)
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = (int32_t) * reinterpret_cast<const u32_any*>(xb + k * kstride + lane_off);
     };
 #pragma unroll 1
     for (int pass = 0; pass < (FULL ? 2 : 1) && ok; pass++) {
@@ -170,7 +173,7 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
                 for (int k = 0; k < 4; k++) {
                     // z mod+- q (ml_dsa.rs:264, 334): y in (-gamma1, gamma1], cs1 in [0, q), so one conditional
                     // subtraction lands in (-q/2, q/2]
-                    const int32_t zs = x[k] + r[k];
+                    const int32_t zs = y_from_raw<YCB>((uint32_t)x[k], lane) + r[k];
                     const int32_t zc = zs - ((((Q / 2) - zs) >> 31) & Q);
                     zc4[k] = zc;
                     bad |= (zc < 0 ? -zc : zc) >= gamma1 - beta;

@@ -371,7 +371,8 @@ struct SignWs {
         a_hat = cv.take<int32_t>(own_a_hat ? n * (size_t)(p->k * p->l) * N : 0);
         key_bad = cv.take<int32_t>(n);
         kidx = cv.take<uint32_t>(n);
-        y = cv.take<int32_t>(rows * (size_t)p->l * N);  // first secret-dependent carve: everything from here on is zeroised
+        // ExpandMask's squeezed bytes, 32 c per polynomial (k_expand_mask<.., RAW>); first secret-dependent carve: everything from here on is zeroised
+        y = cv.take<int32_t>(rows * (size_t)p->l * (size_t)(8 * (p->gamma1 == (1 << 17) ? 18 : 20)));
         w = cv.take<int32_t>(rows * (size_t)p->k * PACKED_POLY_DWORDS);  // 24-bit fields (sign_w)
         c = cv.take<int32_t>(rows * (size_t)N);
         done = cv.take<int32_t>(n);
@@ -541,7 +542,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
                                           w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
                                           pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
     // 11: y <- ExpandMask(rho'', kappa)                               :215
-    STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.gen_kappa, 1, w.gen_op, w.y, gen_hint, s, w.yrisk, ns_gen_dev));
+    STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.gen_kappa, 1, w.gen_op, w.y, gen_hint, s, nullptr, ns_gen_dev, true));
     // the PREVIOUS round's finished signatures -> the caller's host memory, on a helper stream (a small, fixed number of
     // workgroups: see launch_export_done).  The launch reads only its own range of the completion-order list, which no later
     // round touches, so nothing of the round chain ever waits for it.
@@ -549,7 +550,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     // 12: w <- invNTT(A_hat o NTT(y))                                 :218-222   (one row per generated candidate; the two
     // candidates of an op are adjacent rows and share the A_hat read)
     STAGE("sign_w", launch_sign_w(ctx, set, own_a ? w.a_hat : a_hat_keys, own_a ? w.gen_op : w.gen_key, w.y, w.w, w.w1,
-                                  (size_t)p->w1_len, gen_hint, s, 0, w.wrisk, own_a, ns_gen_dev));
+                                  (size_t)p->w1_len, gen_hint, s, 0, w.wrisk, own_a, ns_gen_dev, nullptr, true, w.yrisk));
     // 13-15: w1 <- HighBits(w), w1Encode: in the epilogue of sign_w; c_tilde <- H(mu || w1)   :225-234
     // The challenge of EVERY generated row, also of the second candidates a two-candidate round makes for the next round: these
     // lane-per-row kernels cost the same for 65 536 and 131 072 rows' worth of latency chains (one or two waves per SIMD), and
