@@ -387,14 +387,16 @@ class WholeOp:
         # sign_w needs an op's A_hat once per ROUND (its speculative candidates share the rows), so its A_hat term is
         # counted per op-round, the y / w / w1 terms per candidate slot (see run_one).
         self.a_poly_bytes = 768
+        self.y_poly_bytes = 32 * (18 if pset == 44 else 20)                 # the signer's y as ExpandMask squeezed it
         self.stage_bytes = {
             "expand_a": 32 + self.a_poly_bytes * kl,
             "verify_arith": 1024 * (kl + self.l + 1 + 2 * self.k),
-            "sign_w": 1024 * (self.l + self.k) + p.w1_len + 1,              # per candidate slot: y in, w + w1 + risk flag out
+            # per candidate slot: y in (the squeezed bytes, 32 c per polynomial), w (24-bit fields) + w1 + the risk flags out
+            "sign_w": self.y_poly_bytes * self.l + 768 * self.k + p.w1_len + 1 + self.l,
             "sign_w_per_op_round": self.a_poly_bytes * kl,                  # per unfinished op and round: A_hat in
-            "expand_mask": 66 * self.l + 1024 * self.l,
+            "expand_mask": 66 * self.l + self.y_poly_bytes * self.l,
             # A_hat + signature bytes + c + t1 row block + hint masks in, w1 bytes out
-            "verify_main": self.a_poly_bytes * kl + 1024 * (1 + self.k) + p.sig_len + 32 * self.k + p.w1_len,
+            "verify_main": self.a_poly_bytes * kl + 256 + 1024 * self.k + p.sig_len + 32 * self.k + p.w1_len,   # (c: one byte per coefficient)
         }
         # Keccak-f[1600] permutations per unit of the SHAKE-bound stages (5 SHAKE128 blocks per A_hat
         # polynomial, 5 SHAKE256 blocks per mask polynomial): their ceiling is integer-ALU issue

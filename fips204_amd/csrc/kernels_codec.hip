@@ -159,8 +159,9 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
                     mx = a > mx ? a : mx;
                 }
                 zbad |= mx >= zbound;
-            } else {
-                load_strided(r, c + op * (size_t)N, lane);
+            } else {  // c: k_sample_in_ball<.., C8>'s bytes, the lane's four coefficients in its dword
+                const uint32_t d = reinterpret_cast<const uint32_t*>(c)[op * 64 + ul];
+                r[0] = (int8_t)(d & 0xFF); r[1] = (int8_t)((d >> 8) & 0xFF); r[2] = (int8_t)((d >> 16) & 0xFF); r[3] = (int8_t)(d >> 24);
             }
             ntt_fwd_wave(r, ftw, lane);
             if (j == L) {

@@ -41,6 +41,27 @@ __global__ __launch_bounds__(BLOCK) void k_ntt(const int32_t *__restrict__ in, i
     }
 }
 
+// c_hat = NTT(c) for the signer's rounds: c arrives as k_sample_in_ball<.., C8>'s 256 bytes per row (the lane's four coefficients
+// in its dword), c_hat leaves as int32[256] like k_ntt's output
+__global__ __launch_bounds__(BLOCK) void k_ntt_c8(const uint32_t *__restrict__ in, int32_t *__restrict__ out, size_t n_polys,
+                                                  const Twiddle *__restrict__ tab, const uint32_t *__restrict__ n_dev) {
+    const int lane = threadIdx.x & 63;
+    if (n_dev) n_polys = *n_dev;
+    const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
+    FwdTw tw;
+    load_fwd_tw(tw, tab, lane);
+    uint32_t nxt = 0;
+    if (wave < n_polys) nxt = in[wave * 64 + lane];
+    for (size_t p = wave; p < n_polys; p += n_waves) {
+        const uint32_t d = nxt;
+        if (p + n_waves < n_polys) nxt = in[(p + n_waves) * 64 + lane];
+        int32_t r[4] = {(int8_t)(d & 0xFF), (int8_t)((d >> 8) & 0xFF), (int8_t)((d >> 16) & 0xFF), (int8_t)(d >> 24)};
+        ntt_fwd_wave(r, tw, lane);
+        store_packed(r, out + p * N, lane);
+    }
+}
+
 // -------------------------------------------------------- inverse NTT (ntt.rs:85-161)
 __global__ __launch_bounds__(BLOCK) void k_inv_ntt(const int32_t *__restrict__ in, int32_t *__restrict__ out,
                                                    size_t n_polys, const Twiddle *__restrict__ tab) {
@@ -385,6 +406,14 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
 int launch_ntt(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n, hipStream_t s, const uint32_t *n_dev) {
     if (n == 0 && !n_dev) return MLDSA_OK;
     hipLaunchKernelGGL(k_ntt, dim3(grid_for(ctx, n, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, in, out, n, ctx->d_fwd_tw, n_dev);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_ntt_c8(mldsa_ctx *ctx, const int32_t *c8, int32_t *out, size_t n, hipStream_t s, const uint32_t *n_dev) {
+    if (n == 0 && !n_dev) return MLDSA_OK;
+    hipLaunchKernelGGL(k_ntt_c8, dim3(grid_for(ctx, n, WAVES_PER_BLOCK, 8)), dim3(BLOCK), 0, s, reinterpret_cast<const uint32_t *>(c8), out, n,
+                       ctx->d_fwd_tw, n_dev);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

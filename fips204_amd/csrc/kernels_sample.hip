@@ -223,7 +223,9 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4))
 // sign bits h; for i = 256 - tau .. 255: draw bytes j until j <= i; c[i] = c[j];
 // c[j] = 1 - 2 * bit(i + tau - 256) of h.  The Fisher-Yates array and the squeezed block
 // live in lane-private LDS rows (dynamic indexing); output c[op] as int32[256].
-template <int CT>  // c_tilde bytes: 32, 48 or 64
+// C8 (the op-level pipelines): c as 256 bytes per op, the four coefficients 64 k + lane (each -1, 0 or 1) in lane's dword -- what a
+// wave's forward transform loads; the seam-level mldsa_sample_in_ball keeps int32[256].
+template <int CT, bool C8 = false>  // c_tilde bytes: 32, 48 or 64
 __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict__ c_tilde, size_t ct_stride,
                                                        int tau, int32_t* __restrict__ c_out, size_t n_ops,
                                                        const uint32_t* __restrict__ n_dev) {
@@ -246,6 +248,12 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
         wave_lds_sync();
         for (int row = 0; row < 64; row++) {
             if (wave_base + row >= n_ops) break;
+            if constexpr (C8) {
+                const uint8_t* cb = reinterpret_cast<const uint8_t*>(c_lds + row * SIB_C_STRIDE);
+                reinterpret_cast<uint32_t*>(c_out)[(wave_base + row) * 64 + lane] =
+                    (uint32_t)cb[lane] | ((uint32_t)cb[64 + lane] << 8) | ((uint32_t)cb[128 + lane] << 16) | ((uint32_t)cb[192 + lane] << 24);
+                continue;
+            }
             const uint32_t packed = c_lds[row * SIB_C_STRIDE + lane];
             int4 v = make_int4((int8_t)(packed & 0xFF), (int8_t)((packed >> 8) & 0xFF), (int8_t)((packed >> 16) & 0xFF),
                                (int8_t)(packed >> 24));
@@ -309,11 +317,18 @@ int launch_expand_mask(mldsa_ctx*, int set, const uint8_t* rho_pp, size_t rho_st
 }
 
 int launch_sample_in_ball(mldsa_ctx*, int set, const uint8_t* c_tilde, size_t ct_stride, int32_t* c, size_t n_ops, hipStream_t s,
-                          const uint32_t* n_dev) {
+                          const uint32_t* n_dev, bool c8) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sample_in_ball: unknown parameter set");
     dim3 grid((unsigned)(((n_ops ? n_ops : 1) + 63) / 64)), block(64);
+    if (c8) {
+        if (p->ctilde_len == 32) hipLaunchKernelGGL((k_sample_in_ball<32, true>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+        else if (p->ctilde_len == 48) hipLaunchKernelGGL((k_sample_in_ball<48, true>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+        else hipLaunchKernelGGL((k_sample_in_ball<64, true>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+        MLDSA_HIP_CHECK(hipGetLastError());
+        return MLDSA_OK;
+    }
     if (p->ctilde_len == 32) hipLaunchKernelGGL((k_sample_in_ball<32>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
     else if (p->ctilde_len == 48) hipLaunchKernelGGL((k_sample_in_ball<48>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
     else hipLaunchKernelGGL((k_sample_in_ball<64>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);

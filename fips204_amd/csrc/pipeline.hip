@@ -83,7 +83,7 @@ struct VerifyWs {
     VerifyWs(void *base, const mldsa_params *p, size_t n, bool own_a_hat) {
         Carver cv(base);
         a_hat = cv.take<int32_t>(own_a_hat ? n * p->k * p->l * N : 0);
-        c = cv.take<int32_t>(n * N);
+        c = cv.take<int32_t>(n * (N / 4));  // one byte per coefficient (k_sample_in_ball<.., C8>)
         znorm = cv.take<int32_t>(n);
         hvalid = cv.take<int32_t>(n);
         ctx_bad = cv.take<int32_t>(n);
@@ -143,7 +143,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         {
             // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
             ProfScope ps(ctx, aux, "sample_in_ball");
-            TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, aux));
+            TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, aux, nullptr, true));
         }
         MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, aux));
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
@@ -355,7 +355,7 @@ namespace {
 struct SignWs {
     // y / w / w1 / wrisk / yrisk / c / ctilde are ROWS (one per generated candidate: `rows` = ns, or 2 n when two candidates per op
     // may be generated at once); accept is per TESTED candidate (slot)
-    int32_t *a_hat, *y, *w, *c, *done, *bad_op, *key_bad, *accept;
+    int32_t *a_hat, *y, *w, *c, *c8, *done, *bad_op, *key_bad, *accept;
     uint8_t *rnd_mu, *rho_pp, *w1, *ctilde, *wrisk, *yrisk, *key_oor;
     uint16_t *kappa, *slot_kappa, *gen_kappa;
     uint32_t *act[2], *ypos[2], *slot_op, *gen_op, *gen_key, *slot_y, *kidx, *exp_list;
@@ -374,7 +374,8 @@ struct SignWs {
         // ExpandMask's squeezed bytes, 32 c per polynomial (k_expand_mask<.., RAW>); first secret-dependent carve: everything from here on is zeroised
         y = cv.take<int32_t>(rows * (size_t)p->l * (size_t)(8 * (p->gamma1 == (1 << 17) ? 18 : 20)));
         w = cv.take<int32_t>(rows * (size_t)p->k * PACKED_POLY_DWORDS);  // 24-bit fields (sign_w)
-        c = cv.take<int32_t>(rows * (size_t)N);
+        c = cv.take<int32_t>(rows * (size_t)N);       // c_hat
+        c8 = cv.take<int32_t>(rows * (size_t)(N / 4));  // c as SampleInBall leaves it: one byte per coefficient
         done = cv.take<int32_t>(n);
         bad_op = cv.take<int32_t>(n);
         accept = cv.take<int32_t>(ns);
@@ -560,9 +561,9 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     int32_t *y = w.y;
     uint8_t *yrisk = w.yrisk;
     // 16: c <- SampleInBall(c_tilde)                                  :237
-    STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c, gen_hint, s, ns_gen_dev));
-    // 17: c_hat <- NTT(c), in place                                   :240
-    STAGE("ntt_c", launch_ntt(ctx, w.c, w.c, gen_hint, s, ns_gen_dev));
+    STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c8, gen_hint, s, ns_gen_dev, true));
+    // 17: c_hat <- NTT(c)                                             :240
+    STAGE("ntt_c", launch_ntt_c8(ctx, w.c8, w.c, gen_hint, s, ns_gen_dev));
     // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
     // (in a speculative round: only the tests that can reject, one verdict per candidate)
     STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
