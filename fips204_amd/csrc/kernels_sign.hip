@@ -394,14 +394,17 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
 // position each surviving op had (ypos), its slot s tests row 2 ypos[s] + 1 (use_pre) and its ExpandMask / sign_w launches find
 // ns_gen = 0.  A fifth of the second candidates belong to ops that finished and are never read.  Decided here, on the device:
 // the host only says what its plan allows (may_gen2 / may_use_pre); gen_par[] carries what the previous round really did.
-__global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, int parity, SpecRule rule, uint32_t spec_max,
+__global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, int parity, SpecRule rule, uint32_t spec_max, uint32_t ns_cap,
                                                     const uint32_t* __restrict__ act, const uint16_t* __restrict__ kappa, int l,
                                                     uint32_t* __restrict__ slot_op, uint16_t* __restrict__ slot_kappa,
                                                     const uint32_t* __restrict__ key_idx, uint32_t* __restrict__ gen_op,
                                                     uint16_t* __restrict__ gen_kappa, uint32_t* __restrict__ gen_key, int may_use_pre,
                                                     int may_gen2, const uint32_t* __restrict__ ypos, uint32_t* __restrict__ slot_y) {
     const uint32_t m = ctl->cnt[parity];
-    const uint32_t spec = m ? rule.spec(m, spec_max) : 1u;
+    uint32_t spec = m ? rule.spec(m, spec_max) : 1u;
+    // ns_cap = the slots the workspace was carved for (plan_sign: the rule's maximum over every m, >= the batch): never exceeded,
+    // whatever rule and count arrive here
+    if (m && (unsigned long long)m * spec > ns_cap) spec = ns_cap / m ? ns_cap / m : 1u;
     const uint32_t ns = m * spec;
     const bool use_pre = may_use_pre && spec == 1u && ctl->gen_par[parity ^ 1] == 2u;  // gen_par[parity ^ 1]: not written here
     const uint32_t gen = use_pre ? 0u : (may_gen2 && spec == 1u) ? 2u : 1u;
@@ -784,11 +787,11 @@ int launch_key_range(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s2, c
     return MLDSA_OK;
 }
 
-int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, const SpecRule& rule, uint32_t spec_max, const uint32_t* act,
+int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, const SpecRule& rule, uint32_t spec_max, uint32_t ns_cap, const uint32_t* act,
                       const uint16_t* kappa, int l, uint32_t* slot_op, uint16_t* slot_kappa, const uint32_t* key_idx,
                       uint32_t* gen_op, uint16_t* gen_kappa, uint32_t* gen_key, size_t slots_hint, hipStream_t s, int may_use_pre,
                       int may_gen2, const uint32_t* ypos, uint32_t* slot_y) {
-    hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, rule, spec_max, act, kappa, l,
+    hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, rule, spec_max, ns_cap, act, kappa, l,
                        slot_op, slot_kappa, key_idx, gen_op, gen_kappa, gen_key, may_use_pre, may_gen2, ypos, slot_y);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;

@@ -452,6 +452,18 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
             pl.rule.thr[s] = lo;
         }
     }
+    // the most slots a round can have = max over m <= n of m * spec(m): with the rounded rule a count just below a threshold has
+    // MORE slots than `rows` (22 300 ops x 3 = 66 900 for rows = 65 536); spec is non-increasing in m, so the maximum sits at n or
+    // at one of the thresholds.  Every slot / row array of the workspace is sized from this (k_make_slots clamps to it as well).
+    {
+        auto slots_at = [&](uint32_t mm) { return (size_t)mm * pl.rule.spec(mm, pl.spec_max); };
+        size_t top = slots_at((uint32_t)std::min<size_t>(n, 0xFFFFFFFFu));
+        for (uint32_t sidx = 1; sidx < 64; sidx++) {
+            const uint32_t t = pl.rule.thr[sidx];
+            if (t >= 1 && t <= n) top = std::max(top, slots_at(t));
+        }
+        pl.ns_max = std::max(pl.ns_max, top);
+    }
     const double q = 1.0 - accept_prob(set);
     double m = (double)n;
     // a synchronous call looks at the device once anyway and adds rounds if an op is left, so its plan stops when that is
@@ -539,7 +551,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     const bool own_a = a_hat_keys == nullptr;
     const uint32_t *ns_gen_dev = &w.ctl->ns_gen;  // rows generated this round (the tail kernels read ctl->ns themselves)
     const size_t gen_hint = gen2 ? 2 * ns_hint : ns_hint;  // grids of the generating kernels (a round that tests ready rows finds ns_gen = 0)
-    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.rule, pl.spec_max, w.act[par], w.kappa, p->l, w.slot_op,
+    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.rule, pl.spec_max, (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu), w.act[par], w.kappa, p->l, w.slot_op,
                                           w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
                                           pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
     // 11: y <- ExpandMask(rho'', kappa)                               :215

@@ -474,6 +474,40 @@ def test_sign_host_direct_with_one_key_per_op(sets):
         h2.close()
 
 
+# ------------------------------------------------------------------------------ slot capacity at the speculation rule's thresholds
+@pytest.mark.parametrize("n,env", [(22300, {}), (22200, {}), (65536, {"MLDSA_SPEC_ROWS": "81920"}), (50800, {"MLDSA_SPEC_ROWS": "81920", "MLDSA_SPEC_TARGET": "131072"})])
+def test_rounds_just_below_a_speculation_threshold_fit_the_workspace(n, env):
+    """Candidates per op = round((rows / m) ^ 0.85): a count just below a threshold of that rule has more slots than `rows`
+    (22 300 ops x 3 = 66 900 for rows = 65 536).  The workspace is carved for the rule's true maximum and k_make_slots never makes
+    more: every signature of such a batch verifies and a sample equals the oracle's (ml_dsa.rs:212-330: the FIRST accepted
+    candidate, whatever the speculation)."""
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        h2 = HotPath(0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    try:
+        m = MlDsa(65, hotpath=h2)
+        nk = 16
+        pk, sk = m.keygen_from_seed([shake(b"cap-key", i) for i in range(nk)])
+        sks, pks = m.private_keys_from_bytes(sk), m.public_keys_from_bytes(pk)
+        msgs = [shake(b"cap-msg", i, 32) for i in range(n)]
+        rnd = [shake(b"cap-rnd", i) for i in range(n)]
+        kidx = (np.arange(n) % nk).astype(np.uint32)
+        sig = m.try_sign_with_seed(sks, msgs, rnd, key_idx=kidx)          # ONE device-resident call of n ops
+        assert np.asarray(m.verify(pks, msgs, sig, key_idx=kidx)).all()
+        sigb, skb = host(sig), host(sk)
+        sk_o = [orc.sk_try_from_bytes(65, skb[i].tobytes()) for i in range(nk)]
+        for i in list(range(8)) + [n // 2, n - 1]:
+            assert sigb[i].tobytes() == orc.sign_internal(65, sk_o[kidx[i]], msgs[i], rnd[i], ctx=b"", mode=0)
+    finally:
+        h2.close()
+
+
 # ------------------------------------------------------------------------------ two candidates per op generated at once
 @pytest.mark.parametrize("pset", [44, 65, 87])
 def test_two_candidate_generation_and_the_speculation_table_do_not_change_a_signature(hp, sets, pset):
