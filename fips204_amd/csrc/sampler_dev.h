@@ -46,17 +46,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 // iteration stores 8 rows x 32 coefficients with one dwordx4 store per lane: 8 iterations per
 // flush instead of 32.  Rows keep up to 3 left-over coefficients for the next flush (the caller
 // moves them to the front of its row).
-// PACK24: the stream's coefficients (all < 2^23) are stored as 24-bit little-endian fields, 768 bytes per
-// polynomial instead of 1024: four coefficients = three dwords, so a flush piece is one dwordx3 store.
-// The A_hat the op-level pipelines keep for themselves uses this form (a quarter less HBM traffic in
-// the kernels that stream it); the seam-level mldsa_expand_a keeps the reference's int32 layout.
-
-template <bool PACK24 = false>
+// (int32 rows: the seam-level mldsa_expand_a / mldsa_expand_s; the pipelines' own 24-bit A_hat is written without staging,
+// rej_ntt_poly_lane_direct below.)
 __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int32_t* __restrict__ out, size_t wave_base,
                                             int fc, int n, int lane) {
-    constexpr uint32_t POLY_BYTES = PACK24 ? PACKED_POLY_DWORDS * 4 : N * 4;
+    constexpr uint32_t POLY_BYTES = N * 4;
     // per row: fc << 16 | byte offset of coefficient n inside the stream's polynomial
-    meta[lane] = ((uint32_t)fc << 16) | (uint32_t)(PACK24 ? (n >> 2) * 12 : n * 4);
+    meta[lane] = ((uint32_t)fc << 16) | (uint32_t)(n * 4);
     wave_lds_sync();
     const int grp = lane >> 3, j4 = (lane & 7) * 4;
     // The wave's 64 polynomials are contiguous and start at a wave-uniform address: scalar base + 32-bit byte offset per
@@ -64,7 +60,7 @@ __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int
     const size_t wb = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_base >> 32)) << 32) |
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
     char* base = reinterpret_cast<char*>(out) + wb * POLY_BYTES;
-    const uint32_t lane_b = (uint32_t)grp * POLY_BYTES + (uint32_t)(lane & 7) * (PACK24 ? 12u : 16u);
+    const uint32_t lane_b = (uint32_t)grp * POLY_BYTES + (uint32_t)(lane & 7) * 16u;
     uint32_t m[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) m[i] = meta[8 * i + grp];
@@ -74,15 +70,7 @@ __device__ __forceinline__ void flush_rows4(uint32_t* stage, uint32_t* meta, int
         if (j4 < (int)(m[i] >> 16)) {
             const uint32_t* src = stage + row * STAGE_STRIDE + j4;
             const uint32_t off = lane_b + (uint32_t)i * (8u * POLY_BYTES) + (m[i] & 0xFFFFu);
-            if constexpr (PACK24) {
-                const uint32_t c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];  // < 2^23: the top bytes are zero
-                // c0 | c1 << 24,  c1 >> 8 | c2 << 16,  c2 >> 16 | c3 << 8  as byte selections
-                Packed3 v{__builtin_amdgcn_perm(c1, c0, 0x04020100u), __builtin_amdgcn_perm(c2, c1, 0x05040201u),
-                          __builtin_amdgcn_perm(c3, c2, 0x06050402u)};
-                *reinterpret_cast<Packed3*>(base + off) = v;
-            } else {
-                *reinterpret_cast<int4*>(base + off) = make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
-            }
+            *reinterpret_cast<int4*>(base + off) = make_int4((int)src[0], (int)src[1], (int)src[2], (int)src[3]);
         }
     }
     wave_lds_sync();
@@ -100,7 +88,6 @@ __device__ __forceinline__ void keep_leftover(uint32_t* my, int fc) {
 // Squeezes SHAKE128 blocks until the lane has its 256 coefficients (wave-uniform loop: every lane
 // keeps permuting until the whole wave is done, extra output is dropped) and flushes 28-candidate
 // half blocks through the staging rows to out[(wave_base + lane) * 256 + ...].
-template <bool PACK24 = false>
 __device__ __forceinline__ void rej_ntt_poly_lane(KeccakState& st, uint32_t* stage, uint32_t* meta, uint32_t* my,
                                                   int32_t* __restrict__ out, size_t wave_base, int lane, bool valid) {
     int n = valid ? 0 : N;  // coefficients already in `out` (a multiple of 4)
@@ -118,10 +105,50 @@ __device__ __forceinline__ void rej_ntt_poly_lane(KeccakState& st, uint32_t* sta
             });
             const int have = min(cnt, N - n);
             const int fc = (n + have == N) ? have : (have & ~3);  // N and n are multiples of 4, so fc is too
-            flush_rows4<PACK24>(stage, meta, out, wave_base, fc, n, lane);
+            flush_rows4(stage, meta, out, wave_base, fc, n, lane);
             keep_leftover(my, fc);
             carry = have - fc;
             n += fc;
+        });
+    }
+}
+
+// The PACK24 form of the same sampler, WITHOUT staging: the packed polynomial is the squeezed byte stream itself with bit 23 of every
+// 3-byte candidate cleared and the rejected candidates (1 in 1 024) left out.  A lane walks its block in groups of four candidates =
+// three state words: if all four are below q (and four are still wanted) the three masked words go to its row with one 12-byte
+// store at byte 3 x count -- the lane's own row, any alignment -- else the accepted ones are stored byte by byte.  A rejection in
+// some lane of the wave happens in about a fifth of the groups; only those groups run the byte path.  No LDS, no flush, and a row's
+// lines fill from consecutive stores a few cycles apart instead of from two flushes ~10 us apart.
+struct __attribute__((packed, aligned(1))) Packed3Unaligned { uint32_t a, b, c; };
+
+__device__ __forceinline__ void rej_ntt_poly_lane_direct(KeccakState& st, int32_t* __restrict__ out, size_t stream, bool valid) {
+    uint8_t* row = reinterpret_cast<uint8_t*>(out) + stream * (size_t)(PACKED_POLY_DWORDS * 4);
+    int cnt = valid ? 0 : N;  // coefficients stored so far
+    while (__any(cnt < N)) {
+        keccak_f1600(st);
+        static_for<0, 14>([&](auto gc) {  // group G: bytes 12 G .. 12 G + 11 of the 168-byte block
+            constexpr int G = decltype(gc)::value;
+            const uint32_t d0 = state_word<3 * G>(st), d1 = state_word<3 * G + 1>(st), d2 = state_word<3 * G + 2>(st);
+            // coeff_from_three_bytes (conversion.rs:40-61) x 4
+            const uint32_t c0 = d0 & 0x7FFFFFu, c1 = __builtin_amdgcn_alignbit(d1, d0, 24) & 0x7FFFFFu,
+                           c2 = __builtin_amdgcn_alignbit(d2, d1, 16) & 0x7FFFFFu, c3 = (d2 >> 8) & 0x7FFFFFu;
+            const uint32_t top = max(max(c0, c1), max(c2, c3));
+            if (top < (uint32_t)Q && cnt <= N - 4) {
+                *reinterpret_cast<Packed3Unaligned*>(row + 3 * cnt) = Packed3Unaligned{d0 & 0xFF7FFFFFu, d1 & 0xFFFF7FFFu, d2 & 0x7FFFFF7Fu};
+                cnt += 4;
+            } else if (cnt < N) {
+                const uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (c[k] < (uint32_t)Q && cnt < N) {
+                        uint8_t* dst = row + 3 * cnt;
+                        dst[0] = (uint8_t)c[k];
+                        dst[1] = (uint8_t)(c[k] >> 8);
+                        dst[2] = (uint8_t)(c[k] >> 16);
+                        cnt++;
+                    }
+                }
+            }
         });
     }
 }
