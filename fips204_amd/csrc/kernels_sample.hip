@@ -37,8 +37,8 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restr
     KeccakState st;
     expand_a_seed(st, rho + (key_idx ? key_idx[op] : op) * rho_stride, sidx, r);
     if constexpr (PACK24) {
-        (void)stage; (void)meta; (void)my; (void)wave_base;
-        rej_ntt_poly_lane_direct(st, a_hat, g, valid);
+        (void)stage; (void)meta; (void)my;
+        rej_ntt_poly_lane_direct(st, a_hat, wave_base, lane, valid);
     } else {
         rej_ntt_poly_lane(st, stage, meta, my, a_hat, wave_base, lane, valid);
     }

@@ -121,31 +121,40 @@ __device__ __forceinline__ void rej_ntt_poly_lane(KeccakState& st, uint32_t* sta
 // lines fill from consecutive stores a few cycles apart instead of from two flushes ~10 us apart.
 struct __attribute__((packed, aligned(1))) Packed3Unaligned { uint32_t a, b, c; };
 
-__device__ __forceinline__ void rej_ntt_poly_lane_direct(KeccakState& st, int32_t* __restrict__ out, size_t stream, bool valid) {
-    uint8_t* row = reinterpret_cast<uint8_t*>(out) + stream * (size_t)(PACKED_POLY_DWORDS * 4);
-    int cnt = valid ? 0 : N;  // coefficients stored so far
-    while (__any(cnt < N)) {
+__device__ __forceinline__ void rej_ntt_poly_lane_direct(KeccakState& st, int32_t* __restrict__ out, size_t wave_base, int lane, bool valid) {
+    constexpr uint32_t ROW = PACKED_POLY_DWORDS * 4;
+    // wave-uniform base + a 32-bit byte offset per lane (global_store ... v_off, s[base]): `off` = lane's row + bytes stored so far
+    const size_t wb = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_base >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
+    uint8_t* base = reinterpret_cast<uint8_t*>(out) + wb * ROW;
+    const uint32_t end = (uint32_t)(lane + 1) * ROW;   // the row is full when off reaches this
+    uint32_t off = valid ? (uint32_t)lane * ROW : end;
+    while (__any(off < end)) {
         keccak_f1600(st);
-        static_for<0, 14>([&](auto gc) {  // group G: bytes 12 G .. 12 G + 11 of the 168-byte block
+        static_for<0, 14>([&](auto gc) {  // group G: bytes 12 G .. 12 G + 11 of the 168-byte block = four candidates
             constexpr int G = decltype(gc)::value;
-            const uint32_t d0 = state_word<3 * G>(st), d1 = state_word<3 * G + 1>(st), d2 = state_word<3 * G + 2>(st);
-            // coeff_from_three_bytes (conversion.rs:40-61) x 4
-            const uint32_t c0 = d0 & 0x7FFFFFu, c1 = __builtin_amdgcn_alignbit(d1, d0, 24) & 0x7FFFFFu,
-                           c2 = __builtin_amdgcn_alignbit(d2, d1, 16) & 0x7FFFFFu, c3 = (d2 >> 8) & 0x7FFFFFu;
-            const uint32_t top = max(max(c0, c1), max(c2, c3));
-            if (top < (uint32_t)Q && cnt <= N - 4) {
-                *reinterpret_cast<Packed3Unaligned*>(row + 3 * cnt) = Packed3Unaligned{d0 & 0xFF7FFFFFu, d1 & 0xFFFF7FFFu, d2 & 0x7FFFFF7Fu};
-                cnt += 4;
-            } else if (cnt < N) {
-                const uint32_t c[4] = {c0, c1, c2, c3};
+            // coeff_from_three_bytes (conversion.rs:40-61) x 4, in place: bit 23 of every 3-byte field cleared ...
+            const uint32_t m0 = state_word<3 * G>(st) & 0xFF7FFFFFu, m1 = state_word<3 * G + 1>(st) & 0xFFFF7FFFu,
+                           m2 = state_word<3 * G + 2>(st) & 0x7FFFFF7Fu;
+            // ... and z >= q  <=>  z + (2^23 - q) carries into the cleared bit: one 96-bit addition of 0x001FFF per field (no field
+            // carries into its neighbour: z + 8191 < 2^24) and a test of the four bits 23
+            const uint64_t lo = (((uint64_t)m1 << 32) | m0) + 0x1FFF001FFF001FFFull;
+            const uint32_t hi = m2 + 0x001FFF00u + (uint32_t)(lo < 0x1FFF001FFF001FFFull ? 1u : 0u);
+            const uint32_t over = ((uint32_t)lo & 0x00800000u) | ((uint32_t)(lo >> 32) & 0x00008000u) | (hi & 0x80000080u);
+            if (over == 0u && off + 12u <= end) {
+                *reinterpret_cast<Packed3Unaligned*>(base + off) = Packed3Unaligned{m0, m1, m2};
+                off += 12u;
+            } else if (off < end) {
+                const uint32_t c[4] = {m0 & 0x7FFFFFu, __builtin_amdgcn_alignbit(m1, m0, 24) & 0x7FFFFFu,
+                                       __builtin_amdgcn_alignbit(m2, m1, 16) & 0x7FFFFFu, m2 >> 8};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (c[k] < (uint32_t)Q && cnt < N) {
-                        uint8_t* dst = row + 3 * cnt;
+                    if (c[k] < (uint32_t)Q && off < end) {
+                        uint8_t* dst = base + off;
                         dst[0] = (uint8_t)c[k];
                         dst[1] = (uint8_t)(c[k] >> 8);
                         dst[2] = (uint8_t)(c[k] >> 16);
-                        cnt++;
+                        off += 3u;
                     }
                 }
             }
