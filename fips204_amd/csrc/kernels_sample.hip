@@ -16,8 +16,12 @@ namespace mldsa {
 // ExpandA (hashing.rs:225-239) = K*L x RejNTTPoly (hashing.rs:111-146):
 // stream (op, r, s): SHAKE128(rho || s || r); 3 bytes -> 23-bit candidate, keep if < q
 // (coeff_from_three_bytes, conversion.rs:40-61).  Output A_hat[op][r][s], canonical [0, q).
+// At most FOUR waves per SIMD (the packed form needs no LDS and 72 VGPRs and would fit seven): the kernel is issue-bound from four
+// on, and the verifier's mu and SampleInBall run on a second stream underneath it -- with seven ExpandA waves on every SIMD those
+// one-wave-per-SIMD kernels got an eighth of the issue slots, took as long as ExpandA itself (1.2 ms instead of 0.2) and delayed
+// k_verify_main by 75 us.
 template <int K, int L, bool PACK24>
-__global__ __launch_bounds__(64 * SWAVES) void k_expand_a(const uint8_t* __restrict__ rho, size_t rho_stride,
+__global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_expand_a(const uint8_t* __restrict__ rho, size_t rho_stride,
                                                           const uint32_t* __restrict__ key_idx,
                                                           int32_t* __restrict__ a_hat, size_t n_ops) {
     __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
