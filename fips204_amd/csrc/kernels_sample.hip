@@ -6,6 +6,7 @@
 // squeezed block into a small lane-private LDS staging row; the wave then flushes the rows
 // cooperatively so that HBM only sees contiguous runs (one coalesced store instruction per
 // stream and flush) instead of 64 lanes scattering single dwords 1 KiB apart.
+#include <algorithm>
 #include "ctx.h"
 #include "challenge_dev.h"
 #include "sampler_dev.h"
@@ -23,7 +24,7 @@ namespace mldsa {
 template <int K, int L, bool PACK24>
 __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_expand_a(const uint8_t* __restrict__ rho, size_t rho_stride,
                                                           const uint32_t* __restrict__ key_idx,
-                                                          int32_t* __restrict__ a_hat, size_t n_ops) {
+                                                          int32_t* __restrict__ a_hat, size_t n_ops, uint32_t n_keys) {
     __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
     __shared__ uint32_t meta_lds[SWAVES * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -39,7 +40,11 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4, 
     const int r = rs / L, sidx = rs % L;
 
     KeccakState st;
-    expand_a_seed(st, rho + (key_idx ? key_idx[op] : op) * rho_stride, sidx, r);
+    // n_keys != 0: key_idx comes unchecked from the caller (verify_batch checks it beside this kernel, k_sanitize_keys on the
+    // second stream): an out-of-range index reads key 0 here, its op is refused there
+    size_t key = key_idx ? key_idx[op] : op;
+    if (n_keys && key >= n_keys) key = 0;
+    expand_a_seed(st, rho + key * rho_stride, sidx, r);
     if constexpr (PACK24) {
         (void)stage; (void)meta; (void)my;
         rej_ntt_poly_lane_direct(st, a_hat, wave_base, lane, valid);
@@ -294,15 +299,16 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
 static inline unsigned stream_blocks(size_t n_streams) { return (unsigned)((n_streams + 64 * SWAVES - 1) / (64 * SWAVES)); }
 
 int launch_expand_a(mldsa_ctx*, int set, const uint8_t* rho, size_t rho_stride, const uint32_t* key_idx, int32_t* a_hat,
-                    size_t n_ops, hipStream_t s, bool pack24) {
+                    size_t n_ops, hipStream_t s, bool pack24, size_t n_keys_unchecked) {
+    const uint32_t n_keys = (uint32_t)std::min<size_t>(n_keys_unchecked, 0xFFFFFFFFu);
     if (n_ops == 0) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_a: unknown parameter set");
     dim3 grid(stream_blocks(n_ops * (size_t)(p->k * p->l))), block(64 * SWAVES);
 #define MLDSA_EA(KK, LL)                                                                                                          \
     do {                                                                                                                          \
-        if (pack24) hipLaunchKernelGGL((k_expand_a<KK, LL, true>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);     \
-        else hipLaunchKernelGGL((k_expand_a<KK, LL, false>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops);          \
+        if (pack24) hipLaunchKernelGGL((k_expand_a<KK, LL, true>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops, n_keys);     \
+        else hipLaunchKernelGGL((k_expand_a<KK, LL, false>), grid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops, n_keys);          \
     } while (0)
     if (set == MLDSA_44) MLDSA_EA(4, 4);
     else if (set == MLDSA_65) MLDSA_EA(6, 5);

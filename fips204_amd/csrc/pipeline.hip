@@ -123,17 +123,17 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         // with a bad index are flagged (ok = 0).  Identity mapping (key_idx == NULL) was checked by the caller.
         const uint32_t *kidx = nullptr;
         const int32_t *key_bad = nullptr;
-        if (key_idx) {
-            TRY(launch_sanitize_keys(ctx, key_idx + o, n_keys, n, w.kidx, w.key_bad, s));
-            kidx = w.kidx;
-            key_bad = w.key_bad;
-        }
         const size_t key_base = key_idx ? 0 : o;  // identity mapping: op i uses key i
         // fork: the small lane-per-op kernels are latency-bound (1-2 Keccak-f per op, <= 1 wave per SIMD) and
         // independent of ExpandA, so they run on the context's second stream underneath it
         hipStream_t aux = parallel_stream(ctx, s);
         MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(aux, ctx->fork_ev, 0));
+        if (key_idx) {  // (on the second stream too: ExpandA starts at once and clamps the raw indices itself)
+            TRY(launch_sanitize_keys(ctx, key_idx + o, n_keys, n, w.kidx, w.key_bad, aux));
+            kidx = w.kidx;
+            key_bad = w.key_bad;
+        }
         {
             // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
             ProfScope ps(ctx, aux, "mu");
@@ -149,7 +149,8 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
         // (skipped when the caller keeps A_hat with its keys: the optimisation the reference's benches/README.md
         //  names as missing; the rows are then looked up by key instead of by op)
-        if (!a_hat_keys) STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, kidx, w.a_hat, n, s, true));
+        if (!a_hat_keys) STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, key_idx ? key_idx + o : nullptr, w.a_hat, n, s, true,
+                                                           key_idx ? n_keys : 0));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
         // 2: (c_tilde, z, h) <- sigDecode(sigma), inside k_verify_main                      ml_dsa.rs:368-376
         // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
