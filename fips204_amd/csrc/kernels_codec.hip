@@ -153,8 +153,9 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
                 int32_t mx = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t v = load_field_aligned(src, (int)(64 * k + ul) * CB, CB);  // hints follow z: over-read is in-buffer
-                    r[k] = (1 << GB) - (int32_t)v;
+                    // one byte-granular dword load per field (field.h; the same encoding as the signer's raw y); hints follow z:
+                    // the over-read is in-buffer
+                    r[k] = y_from_raw<CB>(y_raw_dword<CB>(src, k, (int)ul), (int)ul);
                     const int32_t a = r[k] < 0 ? -r[k] : r[k];
                     mx = a > mx ? a : mx;
                 }
