@@ -253,7 +253,11 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
         int32_t nr[4];
         const size_t zrow = (z_idx ? (size_t)z_idx[op] : op) * z_polys_per_op;  // first polynomial of the op's z / y vector
         auto load_z = [&](size_t poly) {
-            if constexpr (YRAW) {
+            if constexpr (KG) {  // ExpandS's byte rows (k_expand_s<.., S8>): coefficient i = byte i
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(z) + poly * (size_t)(N / 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) nr[k] = (int32_t)src[16 * k + (lane >> 2)];  // the dword that holds coefficient 64 k + lane
+            } else if constexpr (YRAW) {
                 const uint8_t *src = reinterpret_cast<const uint8_t *>(z) + poly * (size_t)(32 * YCB);
 #pragma unroll
                 for (int k = 0; k < 4; k++) nr[k] = (int32_t)y_raw_dword<YCB>(src, k, lane);
@@ -275,20 +279,19 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
                 }
                 const bool any_near = __ballot(near) != 0ull;
                 if (yr.flags && lane == 0) yr.flags[zrow + j] = any_near ? 1 : 0;
+            } else if constexpr (KG) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[k] = (int32_t)(int8_t)((uint32_t)nr[k] >> (8 * (lane & 3)));
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) r[k] = reduce32(nr[k]);
             }
-            if constexpr (KG) {  // s1_j passes through here: its section of sk (encodings.rs:118-134) is packed on the way
-#pragma unroll
-                for (int k = 0; k < 4; k++) xp_kg[wave][64 * k + lane] = r[k];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int4 s4 = reinterpret_cast<const int4 *>(&xp_kg[wave][0])[lane];
-                const uint32_t f[4] = {(uint32_t)(kg.eta - s4.x), (uint32_t)(kg.eta - s4.y), (uint32_t)(kg.eta - s4.z), (uint32_t)(kg.eta - s4.w)};
+            if constexpr (KG) {  // s1_j passes through here: its section of sk (encodings.rs:118-134) is packed on the way,
+                                 // from the lane's four CONSECUTIVE coefficients = dword `lane` of the byte row
+                const uint32_t d = reinterpret_cast<const uint32_t *>(z)[(zrow + j) * (size_t)(N / 4) + lane];
+                const uint32_t f[4] = {(uint32_t)(kg.eta - (int8_t)(d & 0xFF)), (uint32_t)(kg.eta - (int8_t)((d >> 8) & 0xFF)),
+                                       (uint32_t)(kg.eta - (int8_t)((d >> 16) & 0xFF)), (uint32_t)(kg.eta - (int8_t)(d >> 24))};
                 store_fields(kg.sk + op * kg.sk_len + 128 + (size_t)j * (32 * kg.ebits), f, kg.ebits, lane);
-                __builtin_amdgcn_wave_barrier();
             }
             if (j + 1 < L) load_z(zrow + j + 1);
             else if (HAS_C && j + 1 == L) load_strided(nr, c + op * (size_t)N, lane);
@@ -334,17 +337,14 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
             ntt_inv_wave(acc, itw, lane, F_MONT2);
             if constexpr (KG) {
                 int32_t s2v[4];
-                load_strided(s2v, z + (zrow + L + i) * (size_t)N, lane);  // s2_i: centred coefficients in [-eta, eta]
-                {   // ... and its section of sk
+                const uint32_t *s2row = reinterpret_cast<const uint32_t *>(z) + (zrow + L + i) * (size_t)(N / 4);  // s2_i: bytes in [-eta, eta]
 #pragma unroll
-                    for (int k = 0; k < 4; k++) xp_kg[wave][64 * k + lane] = s2v[k];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int4 s4 = reinterpret_cast<const int4 *>(&xp_kg[wave][0])[lane];
-                    const uint32_t f[4] = {(uint32_t)(kg.eta - s4.x), (uint32_t)(kg.eta - s4.y), (uint32_t)(kg.eta - s4.z), (uint32_t)(kg.eta - s4.w)};
+                for (int k = 0; k < 4; k++) s2v[k] = (int32_t)(int8_t)(s2row[16 * k + (lane >> 2)] >> (8 * (lane & 3)));
+                {   // ... and its section of sk
+                    const uint32_t d = s2row[lane];
+                    const uint32_t f[4] = {(uint32_t)(kg.eta - (int8_t)(d & 0xFF)), (uint32_t)(kg.eta - (int8_t)((d >> 8) & 0xFF)),
+                                           (uint32_t)(kg.eta - (int8_t)((d >> 16) & 0xFF)), (uint32_t)(kg.eta - (int8_t)(d >> 24))};
                     store_fields(kg.sk + op * kg.sk_len + 128 + (size_t)(L + i) * (32 * kg.ebits), f, kg.ebits, lane);
-                    __builtin_amdgcn_wave_barrier();
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) xp_kg[wave][64 * k + lane] = freeze(acc[k] + s2v[k]);  // t = A s1 + s2 (ml_dsa.rs:88-91)

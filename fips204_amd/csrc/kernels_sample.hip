@@ -69,7 +69,10 @@ __device__ __forceinline__ bool half_byte(uint32_t b, int32_t& out) {
     }
 }
 
-template <int ETA>
+// S8 (key generation's own s1 / s2): one BYTE per coefficient, 256 bytes per polynomial in coefficient order -- the staging
+// row holds bytes too (132 of them), so a 136-byte block is flushed in three groups of up to 96 candidates instead of twelve of 24,
+// in 16-byte pieces; the seam-level mldsa_expand_s keeps int32[256].
+template <int ETA, bool S8 = false>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restrict__ rho_prime, size_t rho_stride,
                                                           int32_t* __restrict__ s12, int polys_per_op, size_t n_ops) {
     __shared__ uint32_t lds[SWAVES * 64 * STAGE_STRIDE + 4];  // + keep_leftover's read-ahead past the last row
@@ -92,8 +95,61 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s(const uint8_t* __restr
         st.lo[8] = r | (0x1Fu << 16);  // hashing.rs:260/266: rho' || r || 0  (then pad)
         st.hi[SHAKE256_RATE / 8 - 1] = 0x80000000u;
     }
-    int n = valid ? 0 : N;  // coefficients already in s12 (a multiple of 4)
-    int carry = 0;          // accepted coefficients waiting in my[0 .. carry), < 4
+    int n = valid ? 0 : N;  // coefficients already in s12 (a multiple of 4; S8: of 16)
+    int carry = 0;          // accepted coefficients waiting in my[0 .. carry), < 4 (S8: < 16)
+    if constexpr (S8) {
+        uint8_t* myb = reinterpret_cast<uint8_t*>(my);
+        uint8_t* out8 = reinterpret_cast<uint8_t*>(s12);
+        while (__any(n < N)) {
+            keccak_f1600(st);
+            static_for<0, 3>([&](auto gc) {  // words 0..11, 12..23, 24..33 of the block: at most 15 + 96 bytes in the row
+                constexpr int G = decltype(gc)::value;
+                constexpr int NW = (G == 2) ? 10 : 12;
+                int cnt = carry;
+                static_for<0, NW>([&](auto wc) {
+                    constexpr int W = 12 * G + decltype(wc)::value;
+                    const uint32_t w = state_word<W>(st);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {  // low nibble of each byte first (hashing.rs:177-180)
+                        int32_t v;
+                        const bool ok = half_byte<ETA>((w >> (4 * k)) & 15u, v);
+                        myb[cnt] = (uint8_t)v;
+                        cnt += ok ? 1 : 0;
+                    }
+                });
+                const int have = min(cnt, N - n);
+                const int fc = (n + have == N) ? have : (have & ~15);  // bytes to flush: a multiple of 16 (N and n are)
+                meta[lane] = ((uint32_t)fc << 16) | (uint32_t)n;
+                wave_lds_sync();
+                {
+                    const int grp = lane >> 3, j16 = (lane & 7) * 16;
+                    const size_t wb = ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_base >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
+                    uint8_t* base = out8 + wb * N;
+                    uint32_t m[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) m[i] = meta[8 * i + grp];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int row = 8 * i + grp;
+                        if (j16 < (int)(m[i] >> 16)) {
+                            const uint32_t* src = stage + row * STAGE_STRIDE + (lane & 7) * 4;
+                            *reinterpret_cast<uint4*>(base + (uint32_t)row * N + (m[i] & 0xFFFFu) + j16) = make_uint4(src[0], src[1], src[2], src[3]);
+                        }
+                    }
+                }
+                wave_lds_sync();
+                {  // the (at most 15) unflushed bytes to the row front
+                    const uint32_t* q = my + (fc >> 2);
+                    const uint32_t a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+                    my[0] = a0; my[1] = a1; my[2] = a2; my[3] = a3;
+                }
+                carry = have - fc;
+                n += fc;
+            });
+        }
+        return;
+    }
     while (__any(n < N)) {
         keccak_f1600(st);
         // 136 bytes = 34 words; 3 words (24 half-bytes) per flush so that carry + candidates fit a row
@@ -318,12 +374,18 @@ int launch_expand_a(mldsa_ctx*, int set, const uint8_t* rho, size_t rho_stride, 
     return MLDSA_OK;
 }
 
-int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_stride, int32_t* s12, size_t n_ops, hipStream_t s) {
+int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_stride, int32_t* s12, size_t n_ops, hipStream_t s, bool s8) {
     if (n_ops == 0) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_s: unknown parameter set");
     const int ppo = p->k + p->l;
     dim3 grid(stream_blocks(n_ops * (size_t)ppo)), block(64 * SWAVES);
+    if (s8) {
+        if (p->eta == 2) hipLaunchKernelGGL((k_expand_s<2, true>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
+        else hipLaunchKernelGGL((k_expand_s<4, true>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
+        MLDSA_HIP_CHECK(hipGetLastError());
+        return MLDSA_OK;
+    }
     if (p->eta == 2) hipLaunchKernelGGL((k_expand_s<2>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
     else hipLaunchKernelGGL((k_expand_s<4>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
     MLDSA_HIP_CHECK(hipGetLastError());

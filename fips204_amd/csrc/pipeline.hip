@@ -227,13 +227,15 @@ struct KeygenWs {
     uint8_t *hbuf;
     int32_t *s1s2, *a_hat, *as1;
     size_t bytes, secret_bytes;  // secret_bytes: hbuf .. end of as1 (rho' / K, s1, s2, A s1)
-    KeygenWs(void *base, const mldsa_params *p, size_t n) {
+    // byte_rows: key generation's own carve (s1 / s2 as one byte per coefficient from k_expand_s<.., S8>, A s1 never stored);
+    // otherwise get_public_key's (int32 rows from k_key_intt, A s1 stored).  Reservations use the larger, default form.
+    KeygenWs(void *base, const mldsa_params *p, size_t n, bool byte_rows = false) {
         Carver cv(base);
         a_hat = cv.take<int32_t>(n * (size_t)(p->k * p->l) * N);  // public (ExpandA(rho)): first, outside the zeroised span
         hbuf = cv.take<uint8_t>(n * 128);
         const size_t secret_off = cv.off - n * 128;
-        s1s2 = cv.take<int32_t>(n * (size_t)(p->l + p->k) * N);
-        as1 = cv.take<int32_t>(n * (size_t)p->k * N);
+        s1s2 = cv.take<int32_t>(n * (size_t)(p->l + p->k) * (byte_rows ? N / 4 : N));
+        as1 = cv.take<int32_t>(byte_rows ? 0 : n * (size_t)p->k * N);
         secret_bytes = cv.off - secret_off;
         bytes = cv.off + 256;
     }
@@ -251,7 +253,7 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     const size_t chunk = std::min(n_keys, ctx->pass_ops);
     if (ctx->ws_bytes < KeygenWs(nullptr, p, chunk).bytes) return set_error(MLDSA_ERR_NOMEM, "keygen: workspace not reserved");
     const size_t pkl = (size_t)p->pk_len, skl = (size_t)p->sk_len;
-    KeygenWs w(ctx->ws, p, chunk);
+    KeygenWs w(ctx->ws, p, chunk, true);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     const bool capturing = s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     // what this call will clear at its end: rho' / K (hbuf), s1, s2 -- A s1 is no longer stored
@@ -281,7 +283,7 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
                 wait_rest = false;
                 ctx->zero_pending = false;
             }
-            STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s));                     // :79
+            STAGE("expand_s", launch_expand_s(ctx, set, w.hbuf + 32, 128, w.s1s2, n, s, true));               // :79 (byte rows)
             // :86-92 t = inv_ntt(A * ntt(s1)) + s2, Power2Round and the whole encoding of the polynomials: the matrix-vector kernel
             // packs s1 and s2 into sk as it reads them (in place, from the rows ExpandS wrote) and t1 -> pk, t0 -> sk in its
             // epilogue; A s1 and t never exist in HBM
