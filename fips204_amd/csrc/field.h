@@ -29,6 +29,8 @@ __device__ __forceinline__ int4 unpack24(const Packed3& p) {
 // fields (conversion.rs:227-262), 32 c bytes per polynomial.  Field i starts at bit c i: ONE dword load at its byte (no alignment
 // needed on gfx950) holds it, shifted by (c i) & 7 -- which for i = 64 k + lane depends on the lane only.
 typedef uint32_t __attribute__((aligned(1))) u32_any;
+typedef uint64_t __attribute__((aligned(1))) u64_any;
+typedef uint16_t __attribute__((aligned(1))) u16_any;
 template <int CB>
 __device__ __forceinline__ uint32_t y_raw_dword(const uint8_t* poly, int k, int lane) {
     return *reinterpret_cast<const u32_any*>(poly + 8 * CB * k + ((lane * CB) >> 3));

@@ -196,10 +196,13 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
                         lo |= f << sh;
                         if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
                     }
-                    const int nbytes = cb / 2;
-                    uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * cb) + (size_t)lane * nbytes;
-                    for (int t = 0; t < 8; t++) dst[t] = (uint8_t)(lo >> (8 * t));
-                    for (int t = 8; t < nbytes; t++) dst[t] = (uint8_t)(hi >> (8 * (t - 8)));
+                    // the lane's 4 c bits = 9 or 10 bytes: one 8-byte store at whatever alignment the signature row has (SIG_LEN is
+                    // odd) and one 1- or 2-byte store, instead of 9 / 10 byte stores
+                    constexpr int NBYTES = YCB / 2;
+                    uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * YCB) + (size_t)lane * NBYTES;
+                    *reinterpret_cast<u64_any*>(dst) = lo;
+                    if constexpr (NBYTES == 10) *reinterpret_cast<u16_any*>(dst + 8) = (uint16_t)hi;
+                    else dst[8] = (uint8_t)hi;
                     __builtin_amdgcn_wave_barrier();
                 }
             }

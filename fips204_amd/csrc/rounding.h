@@ -95,12 +95,17 @@ __device__ __forceinline__ void store_fields(uint8_t* dst, const uint32_t f[4], 
             uint8_t* d = dst + (lane >> 1) * 13;
             const uint64_t lo = v | (other << 52);
             const uint64_t hi = other >> 12;
-            for (int i = 0; i < 8; i++) d[i] = (uint8_t)(lo >> (8 * i));
-            for (int i = 0; i < 5; i++) d[8 + i] = (uint8_t)(hi >> (8 * i));
+            // 8 + 4 + 1 bytes at whatever alignment the key row has (byte-granular stores of gfx950) instead of 13 byte stores
+            *reinterpret_cast<u64_any*>(d) = lo;
+            *reinterpret_cast<u32_any*>(d + 8) = (uint32_t)hi;
+            d[12] = (uint8_t)(hi >> 32);
         }
-    } else {
-        uint8_t* d = dst + lane * nbytes;
-        for (int i = 0; i < nbytes; i++) d[i] = (uint8_t)(v >> (8 * i));
+    } else if (bits == 10) {  // 5 bytes per lane
+        uint8_t* d = dst + lane * 5;
+        *reinterpret_cast<u32_any*>(d) = (uint32_t)v;
+        d[4] = (uint8_t)(v >> 32);
+    } else {              // bits == 4: 2 bytes per lane
+        *reinterpret_cast<u16_any*>(dst + lane * nbytes) = (uint16_t)v;
     }
 }
 
