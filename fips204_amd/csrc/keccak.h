@@ -128,7 +128,8 @@ __device__ __forceinline__ void keccak_f1600(KeccakState& s) {
 // little-endian 32-bit load with no alignment requirement (signature / key byte strings
 // start at arbitrary byte offsets: SIG_LEN = 3309 and 4627 are odd)
 __device__ __forceinline__ uint32_t load_le32(const uint8_t* p) {
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;  // one byte-granular dword load (gfx950), not four byte loads
+    return *reinterpret_cast<const u32_unaligned*>(p);
 }
 
 // `bits`-wide little-endian field at bit offset `bo` of an arbitrarily aligned byte string, fetched

@@ -359,11 +359,9 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
             uint8_t* po = out + op * so;
             static_for_c<0, OUT / 8>([&](auto wc) {
                 constexpr int W = decltype(wc)::value;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    po[8 * W + i] = (uint8_t)(st.lo[W] >> (8 * i));
-                    po[8 * W + 4 + i] = (uint8_t)(st.hi[W] >> (8 * i));
-                }
+                typedef uint32_t __attribute__((aligned(1))) u32_unaligned;  // (any alignment: pk / sk rows are odd-sized)
+                *reinterpret_cast<u32_unaligned*>(po + 8 * W) = st.lo[W];
+                *reinterpret_cast<u32_unaligned*>(po + 8 * W + 4) = st.hi[W];
             });
         }
     }
