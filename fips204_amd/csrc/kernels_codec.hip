@@ -272,17 +272,27 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
     for (size_t b = 0; b < max_blocks; b++) {
         if (valid && b < my_blocks) {
             const size_t base = b * SHAKE256_RATE;
-            for (int i = 0; i < SHAKE256_RATE; i++) {
-                const size_t pos = base + i;
-                uint8_t v = 0;
+            auto byte_at = [&](size_t pos) -> uint8_t {
                 if (pos < total) {
-                    if (pos < 64) v = trp[pos];
-                    else if (pos < 64 + pre) {
+                    if (pos < 64) return trp[pos];
+                    if (pos < 64 + pre) {
                         const size_t q = pos - 64;
-                        v = q == 0 ? (uint8_t)(mode == MLDSA_MODE_PREHASH ? 1 : 0) : q == 1 ? (uint8_t)clen : cp[q - 2];
-                    } else v = mp[pos - 64 - pre];
-                } else if (pos == total) v = 0x1F;
-                rowb[i] = v;
+                        return q == 0 ? (uint8_t)(mode == MLDSA_MODE_PREHASH ? 1 : 0) : q == 1 ? (uint8_t)clen : cp[q - 2];
+                    }
+                    return mp[pos - 64 - pre];
+                }
+                return pos == total ? (uint8_t)0x1F : (uint8_t)0;
+            };
+            // dword by dword: whole dwords of tr and of the message come from one (byte-granular) load each, only the dwords
+            // that straddle a boundary (prefix, message end, pad) are assembled from bytes
+            for (int i = 0; i < SHAKE256_RATE / 4; i++) {
+                const size_t pos = base + 4 * (size_t)i;
+                uint32_t v;
+                if (pos + 4 <= 64) v = load_le32(trp + pos);
+                else if (pos >= 64 + pre && pos + 4 <= total) v = load_le32(mp + (pos - 64 - pre));
+                else if (pos > total) v = 0;
+                else v = (uint32_t)byte_at(pos) | ((uint32_t)byte_at(pos + 1) << 8) | ((uint32_t)byte_at(pos + 2) << 16) | ((uint32_t)byte_at(pos + 3) << 24);
+                row[i] = v;
             }
             if (b == my_blocks - 1) rowb[SHAKE256_RATE - 1] |= 0x80;
             static_for_c<0, 17>([&](auto wc) {
