@@ -29,6 +29,24 @@ class Params(C.Structure):
 _P, _SZ, _I = C.c_void_p, C.c_size_t, C.c_int
 
 
+class VerifySlice(C.Structure):
+    """mldsa_verify_slice: the arguments of mldsa_verify for one device's slice (device pointers of THAT device)"""
+    _fields_ = [("rho", _P), ("tr", _P), ("t1_d2_hat_mont", _P), ("n_keys", _SZ), ("key_idx", _P), ("msgs", _P), ("msg_off", _P),
+                ("ctxs", _P), ("ctx_off", _P), ("sigs", _P), ("ok", _P), ("n_ops", _SZ), ("stream", _P)]
+
+
+class SignSlice(C.Structure):
+    """mldsa_sign_slice"""
+    _fields_ = [("rho", _P), ("cap_k", _P), ("tr", _P), ("s_1_hat_mont", _P), ("s_2_hat_mont", _P), ("t_0_hat_mont", _P), ("n_keys", _SZ),
+                ("key_idx", _P), ("msgs", _P), ("msg_off", _P), ("ctxs", _P), ("ctx_off", _P), ("rnd", _P), ("sigs", _P), ("status", _P),
+                ("n_ops", _SZ), ("stream", _P)]
+
+
+class KeygenSlice(C.Structure):
+    """mldsa_keygen_slice"""
+    _fields_ = [("xi", _P), ("pk", _P), ("sk", _P), ("n_keys", _SZ), ("stream", _P)]
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in (
         "graphs_captured", "graph_replays", "direct_calls", "workspace_growths", "sign_extra_rounds", "workspace_shrinks")]
@@ -36,7 +54,8 @@ class Stats(C.Structure):
 
 OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
 OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE, OPT_SIGN_ROUNDS = 1, 2, 3, 4, 5, 6
-OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD = 7, 8, 9, 10
+OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD, OPT_WORKSPACE_CAP_MB = 7, 8, 9, 10, 11
+ABI_VERSION = 4
 ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
@@ -46,8 +65,18 @@ _SIGNATURES = {
     "mldsa_last_error": [],
     "mldsa_get_params": [_I, C.POINTER(Params)],
     "mldsa_device_count": [],
+    "mldsa_abi_version": [],
+    "mldsa_check_offsets": [_P, _SZ],
+    "mldsa_get_stats_sized": [_P, _P, _SZ],
+    "mldsa_debug_secret_residue": [_P, C.POINTER(_SZ), C.POINTER(_SZ)],
+    "mldsa_debug_count_nonzero": [_P, _SZ, C.POINTER(_SZ)],
+    "mldsa_verify_group": [_P, _I, _I, _P, _I],
+    "mldsa_sign_group": [_P, _I, _I, _P, _I],
+    "mldsa_keygen_group": [_P, _I, _P, _I],
+    "mldsa_group_sync": [_P],
     "mldsa_ctx_device": [_P],
     "mldsa_reserve": [_P, _I, _I, _SZ],
+    "mldsa_ctx_set_workspace": [_P, _P, _SZ],
     "mldsa_set_option": [_P, _I, C.c_long],
     "mldsa_get_option": [_P, _I],
     "mldsa_get_stats": [_P, C.POINTER(Stats)],

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -67,6 +68,23 @@ int mldsa_get_params(int set, mldsa_params *out) {
     return MLDSA_OK;
 }
 
+int mldsa_abi_version(void) { return MLDSA_ABI_VERSION; }
+
+// One O(n) pass over a caller's offset table: non-decreasing, so that every op's length is off[i + 1] - off[i] without
+// wrapping and every op's bytes lie inside [off[0], off[n_ops]).  No device, no context: hosts call it on their own tables
+// before the device-resident entry points if they want a call-level error instead of per-op refusals.
+int mldsa_check_offsets(const uint64_t *off, size_t n_ops) {
+    REQUIRE(off || n_ops == 0, "mldsa_check_offsets: NULL table");
+    for (size_t i = 0; i < n_ops; i++)
+        if (off[i + 1] < off[i]) {
+            char msg[96];
+            snprintf(msg, sizeof(msg), "offset table decreases at entry %zu (%llu after %llu)", i + 1, (unsigned long long)off[i + 1],
+                     (unsigned long long)off[i]);
+            return set_error(MLDSA_ERR_PARAM, msg);
+        }
+    return MLDSA_OK;
+}
+
 int mldsa_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -98,6 +116,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_host_sub_sign = env_long("MLDSA_HOST_SUB_SIGN", 64, 65536, ctx->opt_host_sub_sign);
     ctx->opt_host_direct = env_long("MLDSA_HOST_DIRECT", 0, 1, ctx->opt_host_direct);
     ctx->opt_side_prologue = env_long("MLDSA_SIDE_PROLOGUE", 0, 1, ctx->opt_side_prologue);
+    ctx->opt_ws_cap_bytes = (size_t)env_long("MLDSA_WORKSPACE_CAP_MB", 0, 1L << 20, 0) << 20;
     ctx->pass_ops = (size_t)env_long("MLDSA_PASS_OPS", 256, 1 << 20, (long)ctx->pass_ops);
     ctx->pass_ops_sign = (size_t)env_long("MLDSA_PASS_OPS_SIGN", 256, 1 << 20, (long)ctx->pass_ops_sign);
     hipDeviceProp_t prop;
@@ -145,8 +164,8 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     drop_graphs(ctx);
     host_stage_destroy(ctx);
     if (ctx->ws) {
-        (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // secrets (y, rho'', s1..) live here: types.rs:19
-        (void)hipFree(ctx->ws);
+        MLDSA_WIPE(hipMemset(ctx->ws, 0, ctx->ws_bytes));  // secrets (y, rho'', s1..) live here: types.rs:19
+        if (!ctx->ws_external) (void)hipFree(ctx->ws);
     }
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -219,6 +238,10 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             }
             ctx->opt_ct0_exact = value;
             return MLDSA_OK;
+        case MLDSA_OPT_WORKSPACE_CAP_MB:
+            REQUIRE(value >= 0 && value <= (1L << 20), "mldsa_set_option: MLDSA_OPT_WORKSPACE_CAP_MB out of range");
+            ctx->opt_ws_cap_bytes = (size_t)value << 20;
+            return MLDSA_OK;
         default: return set_error(MLDSA_ERR_PARAM, "mldsa_set_option: unknown option");
     }
 }
@@ -236,14 +259,39 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option) {
         case MLDSA_OPT_SIGN_CT0_EXACT: return ctx->opt_ct0_exact;
         case MLDSA_OPT_SIGN_LOOKAHEAD: return ctx->opt_lookahead;
         case MLDSA_OPT_SIGN_ASYNC_EXP: return std::lround(-std::log10(ctx->async_stop));
+        case MLDSA_OPT_WORKSPACE_CAP_MB: return (long)(ctx->opt_ws_cap_bytes >> 20);
         default: return MLDSA_ERR_PARAM;
     }
 }
 
-int mldsa_get_stats(mldsa_ctx *ctx, mldsa_stats *out) {
+int mldsa_get_stats(mldsa_ctx *ctx, mldsa_stats *out) { return mldsa_get_stats_sized(ctx, out, sizeof(mldsa_stats)); }
+
+// a client built against an older (shorter) or newer (longer) mldsa_stats names the size of ITS struct: only that much is written,
+// fields this build does not know read as zero
+int mldsa_get_stats_sized(mldsa_ctx *ctx, void *out, size_t out_bytes) {
     REQUIRE(ctx && out, "mldsa_get_stats: NULL pointer");
     std::lock_guard<std::mutex> lk(ctx->op_mutex);
-    *out = ctx->stats;
+    memset(out, 0, out_bytes);
+    memcpy(out, &ctx->stats, std::min(out_bytes, sizeof(mldsa_stats)));
+    return MLDSA_OK;
+}
+
+int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes) {
+    ENTER(ctx, "mldsa_ctx_set_workspace");
+    REQUIRE((dev_buf != nullptr) == (bytes != 0), "mldsa_ctx_set_workspace: a buffer and its size, or NULL and 0");
+    REQUIRE(((uintptr_t)dev_buf & 255) == 0, "mldsa_ctx_set_workspace: the buffer must be 256-byte aligned");
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
+    MLDSA_HIP_CHECK(hipDeviceSynchronize());  // nothing of the context still runs in the old buffer
+    ctx->zero_pending = ctx->zero_head_valid = ctx->zero_wait_after_ea = false;
+    drop_graphs(ctx);                         // captured launches point into it
+    if (ctx->ws) {
+        MLDSA_WIPE(hipMemset(ctx->ws, 0, ctx->ws_bytes));
+        if (!ctx->ws_external) MLDSA_HIP_CHECK(hipFree(ctx->ws));
+    }
+    ctx->secret_spans.clear();
+    ctx->ws = dev_buf;
+    ctx->ws_bytes = bytes;
+    ctx->ws_external = dev_buf != nullptr;
     return MLDSA_OK;
 }
 
@@ -254,6 +302,35 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops) {
     REQUIRE(op == MLDSA_OP_KEYGEN || op == MLDSA_OP_SIGN || op == MLDSA_OP_VERIFY, "mldsa_reserve: unknown operation");
     std::lock_guard<std::mutex> lk(ctx->op_mutex);
     return n_ops ? reserve_workspace(ctx, p, op, n_ops, true) : MLDSA_OK;
+}
+
+// ---- test support: is anything secret left behind? --------------------------------------------------------------------
+int mldsa_debug_count_nonzero(const void *dev_ptr, size_t bytes, size_t *nonzero) {
+    REQUIRE(nonzero && (dev_ptr || bytes == 0), "mldsa_debug_count_nonzero: NULL pointer");
+    return count_nonzero_dev(dev_ptr, bytes, nonzero);
+}
+
+int mldsa_debug_secret_residue(mldsa_ctx *ctx, size_t *scanned_bytes, size_t *nonzero_bytes) {
+    REQUIRE(scanned_bytes && nonzero_bytes, "mldsa_debug_secret_residue: NULL pointer");
+    ENTER(ctx, "mldsa_debug_secret_residue");
+    std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
+    // everything the context enqueued has run, the background clearing of the last call included; nothing is cleared HERE
+    MLDSA_HIP_CHECK(hipDeviceSynchronize());
+    size_t scanned = 0, nonzero = 0;
+    for (const auto &sp : ctx->secret_spans) {
+        if (!ctx->ws || sp.first + sp.second > ctx->ws_bytes) continue;  // the workspace was replaced since (cleared before it was freed)
+        size_t nz = 0;
+        const int rc = count_nonzero_dev(static_cast<const uint8_t *>(ctx->ws) + sp.first, sp.second, &nz);
+        if (rc != MLDSA_OK) return rc;
+        scanned += sp.second;
+        nonzero += nz;
+    }
+    const int rc = host_stage_residue(ctx, &scanned, &nonzero);
+    if (rc != MLDSA_OK) return rc;
+    *scanned_bytes = scanned;
+    *nonzero_bytes = nonzero;
+    return MLDSA_OK;
 }
 
 int mldsa_malloc(void **dev_ptr, size_t bytes) {

@@ -35,6 +35,8 @@ struct mldsa_group {
     std::vector<void *> comms;
     bool rccl_tried = false;
     std::vector<hipStream_t> gather_streams;
+    std::vector<hipStream_t> last_streams;  // stream of slice i in the last device-resident group call (mldsa_group_sync)
+    std::vector<char> last_used;
 };
 
 namespace mldsa {
@@ -91,6 +93,28 @@ inline void slice(size_t n_ops, int n_parts, int part, size_t &first, size_t &co
     count = std::min(n_ops, first + per) - first;
 }
 
+}  // namespace
+}  // namespace mldsa
+
+namespace mldsa {
+namespace {
+template <class Slice, class Call>
+int run_slices(mldsa_group *g, const Slice *slices, int wait, const Call &call) {
+    const int n = (int)g->w.size();
+    g->last_streams.assign((size_t)n, nullptr);
+    g->last_used.assign((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        g->last_streams[(size_t)i] = (hipStream_t)slices[i].stream;
+        g->last_used[(size_t)i] = 1;
+    }
+    return run_on_all(g, [&](int i) -> int {
+        const int rc = call(g->w[i]->ctx, slices[i]);
+        if (rc != MLDSA_OK || !wait) return rc;
+        DeviceGuard dg(g->w[i]->ctx->device);
+        MLDSA_HIP_CHECK(hipStreamSynchronize((hipStream_t)slices[i].stream));
+        return MLDSA_OK;
+    });
+}
 }  // namespace
 }  // namespace mldsa
 
@@ -166,6 +190,7 @@ int mldsa_verify_host_group(mldsa_group *g, int set, int mode, const uint8_t *pk
     if (n_ops == 0) return MLDSA_OK;
     REQUIRE(pk && msg_off && sigs && ok, "mldsa_verify_host_group: NULL pointer");
     REQUIRE(key_idx ? n_keys > 0 : n_keys >= n_ops, "mldsa_verify_host_group: n_keys does not cover the batch");
+    { const int rc = check_tables("mldsa_verify_host_group", msgs, msg_off, ctxs, ctx_off, n_ops); if (rc != MLDSA_OK) return rc; }
     std::lock_guard<std::mutex> lk(g->call_mu);
     const int n = (int)g->w.size();
     return run_on_all(g, [&](int i) -> int {
@@ -189,6 +214,7 @@ int mldsa_sign_host_group(mldsa_group *g, int set, int mode, const uint8_t *sk, 
     if (n_ops == 0) return MLDSA_OK;
     REQUIRE(sk && msg_off && rnd && sigs, "mldsa_sign_host_group: NULL pointer");
     REQUIRE(key_idx ? n_keys > 0 : n_keys >= n_ops, "mldsa_sign_host_group: n_keys does not cover the batch");
+    { const int rc = check_tables("mldsa_sign_host_group", msgs, msg_off, ctxs, ctx_off, n_ops); if (rc != MLDSA_OK) return rc; }
     std::lock_guard<std::mutex> lk(g->call_mu);
     const int n = (int)g->w.size();
     return run_on_all(g, [&](int i) -> int {
@@ -218,6 +244,53 @@ int mldsa_keygen_host_group(mldsa_group *g, int set, const uint8_t *xi, uint8_t 
     });
 }
 
+// ---- device-resident slices ------------------------------------------------------------------------------------------
+// Slice i of the caller's batch already lives on device i of the group (keys expanded there, inputs uploaded there): worker i
+// makes the ordinary device-resident call of its context on the slice's own stream.  wait != 0: every worker also waits for its
+// stream, so the results are complete when the call returns; wait == 0: the call returns once everything is enqueued
+// (mldsa_sign_group then signs with mldsa_sign_async) and mldsa_group_sync waits later.
+
+int mldsa_verify_group(mldsa_group *g, int set, int mode, const mldsa_verify_slice *slices, int wait) {
+    REQUIRE(g && slices, "mldsa_verify_group: NULL pointer");
+    REQUIRE(params_of(set), "mldsa_verify_group: unknown parameter set");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return run_slices(g, slices, wait, [&](mldsa_ctx *c, const mldsa_verify_slice &s) {
+        return mldsa_verify(c, set, mode, s.rho, s.tr, s.t1_d2_hat_mont, s.n_keys, s.key_idx, s.msgs, s.msg_off, s.ctxs, s.ctx_off, s.sigs, s.ok,
+                            s.n_ops, s.stream);
+    });
+}
+
+int mldsa_sign_group(mldsa_group *g, int set, int mode, const mldsa_sign_slice *slices, int wait) {
+    REQUIRE(g && slices, "mldsa_sign_group: NULL pointer");
+    REQUIRE(params_of(set), "mldsa_sign_group: unknown parameter set");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return run_slices(g, slices, wait, [&](mldsa_ctx *c, const mldsa_sign_slice &s) {
+        return (wait ? mldsa_sign : mldsa_sign_async)(c, set, mode, s.rho, s.cap_k, s.tr, s.s_1_hat_mont, s.s_2_hat_mont, s.t_0_hat_mont, s.n_keys,
+                                                      s.key_idx, s.msgs, s.msg_off, s.ctxs, s.ctx_off, s.rnd, s.sigs, s.status, s.n_ops, s.stream);
+    });
+}
+
+int mldsa_keygen_group(mldsa_group *g, int set, const mldsa_keygen_slice *slices, int wait) {
+    REQUIRE(g && slices, "mldsa_keygen_group: NULL pointer");
+    REQUIRE(params_of(set), "mldsa_keygen_group: unknown parameter set");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    return run_slices(g, slices, wait, [&](mldsa_ctx *c, const mldsa_keygen_slice &s) {
+        return mldsa_keygen(c, set, s.xi, s.pk, s.sk, s.n_keys, s.stream);
+    });
+}
+
+int mldsa_group_sync(mldsa_group *g) {
+    REQUIRE(g, "mldsa_group_sync: NULL group");
+    std::lock_guard<std::mutex> lk(g->call_mu);
+    if (g->last_used.empty()) return MLDSA_OK;
+    return run_on_all(g, [&](int i) -> int {
+        if (!g->last_used[(size_t)i]) return MLDSA_OK;
+        DeviceGuard dg(g->w[i]->ctx->device);
+        MLDSA_HIP_CHECK(hipStreamSynchronize(g->last_streams[(size_t)i]));
+        return MLDSA_OK;
+    });
+}
+
 // ---- device-resident verdicts: all-gather ----------------------------------------------------------------------------
 // bufs[i]: device pointer ON DEVICE i of the group, N * ceil(n_ops / N) bytes; slice i (mldsa_group_shard) of it holds what
 // device i computed.  Afterwards every buffer holds all n_ops bytes.  use_rccl: 1 = ncclAllGather (distinct devices only),
@@ -235,10 +308,30 @@ int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, in
         for (int j = 0; j < i; j++) distinct &= g->w[i]->ctx->device != g->w[j]->ctx->device;
     if (use_rccl == 1 && !distinct) return set_error(MLDSA_ERR_PARAM, "mldsa_group_allgather: RCCL needs distinct devices");
     if (g->gather_streams.empty()) {
-        g->gather_streams.assign((size_t)n, nullptr);
+        std::vector<hipStream_t> made((size_t)n, nullptr);
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < n && e == hipSuccess; i++) {
+            DeviceGuard dg(g->w[i]->ctx->device);
+            e = hipStreamCreateWithFlags(&made[(size_t)i], hipStreamNonBlocking);
+        }
+        if (e != hipSuccess) {  // all or nothing: a later call must not find a half-filled table and use the NULL stream
+            for (int i = 0; i < n; i++)
+                if (made[(size_t)i]) { DeviceGuard dg(g->w[i]->ctx->device); (void)hipStreamDestroy(made[(size_t)i]); }
+            return set_error(MLDSA_ERR_DEVICE, "mldsa_group_allgather: stream creation", e);
+        }
+        g->gather_streams = std::move(made);
+    }
+    // Ordering: the verdicts were produced by op-level calls of the group's contexts, on streams of the caller's choosing.  Every
+    // context records an event behind its last op-level call (OpGuard); each gather stream waits for the events of ALL contexts
+    // (with peer copies device i reads the other devices' buffers), so a gather enqueued right after mldsa_verify /
+    // mldsa_verify_group needs no synchronisation by the caller.  Data written by other means is the caller's to order.
+    for (int j = 0; j < n; j++) {
+        mldsa_ctx *c = g->w[j]->ctx;
+        std::lock_guard<std::mutex> clk(c->op_mutex);
+        if (!c->ws_busy) continue;
         for (int i = 0; i < n; i++) {
             DeviceGuard dg(g->w[i]->ctx->device);
-            MLDSA_HIP_CHECK(hipStreamCreateWithFlags(&g->gather_streams[i], hipStreamNonBlocking));
+            MLDSA_HIP_CHECK(hipStreamWaitEvent(g->gather_streams[(size_t)i], c->ws_ev, 0));
         }
     }
     bool rccl = use_rccl != 0 && distinct;

@@ -11,6 +11,7 @@
 // wants a slot back.  The device pointers of a slot never change, so the kernel sequence of a sub-batch is a
 // repeated call shape and replays as a hipGraph (pipeline.hip run_op).
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -56,6 +57,7 @@ struct HostStage {
     Buf key_bytes;                          // wire-format keys of the call
     Buf k_rho, k_capk, k_tr, k_a, k_b, k_c;  // expanded key fields (pk: rho, tr, t1; sk: rho, K, tr, s1, s2, t0)
     hipEvent_t keys_ready = nullptr;
+    int secret_last = 0;  // which buffers held secrets during the last *_host call: 0 none (verify), MLDSA_OP_SIGN, MLDSA_OP_KEYGEN
 };
 
 namespace {
@@ -66,19 +68,38 @@ namespace {
     } while (0)
 #define TRY(expr) do { int _rc = (expr); if (_rc != MLDSA_OK) return _rc; } while (0)
 
-bool is_pinned(const void *p) {
+// Is [p, p + bytes) page-locked memory the runtime knows, over its WHOLE extent?  The first byte alone does not say so: a caller may
+// have registered (hipHostRegister) only the head of an array, or handed a slice that runs off the end of a page-locked slab -- a
+// kernel storing through the device view of such a buffer faults, and the process with it.  Both ends must be host memory of one
+// mapping, and where the runtime can name the allocation the extent must lie inside it.  Anything else is treated as pageable
+// (bounce copies / the sub-batch path): slower, never wrong.
+bool is_pinned(const void *p, size_t bytes) {
     if (!p) return true;
-    hipPointerAttribute_t a;
+    hipPointerAttribute_t a, b;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
         (void)hipGetLastError();  // pageable memory is "invalid value" to the runtime: clear the sticky error
         return false;
     }
-    return a.type == hipMemoryTypeHost;
+    if (a.type != hipMemoryTypeHost) return false;
+    if (bytes <= 1) return true;
+    const char *last = static_cast<const char *>(p) + (bytes - 1);
+    if (hipPointerGetAttributes(&b, last) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (b.type != hipMemoryTypeHost) return false;
+    if (static_cast<const char *>(b.devicePointer) - static_cast<const char *>(a.devicePointer) != (ptrdiff_t)(bytes - 1)) return false;
+    void *base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, const_cast<void *>(p)) == hipSuccess && base && size)
+        return static_cast<const char *>(p) >= static_cast<const char *>(base) && last < static_cast<const char *>(base) + size;
+    (void)hipGetLastError();
+    return true;  // the runtime cannot name the allocation: both ends are mapped host memory of one device view
 }
 
 int grow_dev(Buf &b, size_t bytes) {
     if (b.cap >= bytes) return MLDSA_OK;
-    if (b.dev) { HCHECK(hipDeviceSynchronize()); (void)hipMemset(b.dev, 0, b.cap); HCHECK(hipFree(b.dev)); b.dev = nullptr; b.cap = 0; }
+    if (b.dev) { HCHECK(hipDeviceSynchronize()); MLDSA_WIPE(hipMemset(b.dev, 0, b.cap)); HCHECK(hipFree(b.dev)); b.dev = nullptr; b.cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
     if (hipMalloc((void **)&b.dev, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: device staging allocation");
     b.cap = want;
@@ -87,7 +108,7 @@ int grow_dev(Buf &b, size_t bytes) {
 
 int grow_pin(Buf &b, size_t bytes) {
     if (b.pin_cap >= bytes) return MLDSA_OK;
-    if (b.pin) { HCHECK(hipDeviceSynchronize()); memset(b.pin, 0, b.pin_cap); HCHECK(hipHostFree(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
+    if (b.pin) { HCHECK(hipDeviceSynchronize()); MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); HCHECK(hipHostFree(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
     if (hipHostMalloc((void **)&b.pin, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: page-locked staging allocation");
     b.pin_cap = want;
@@ -171,19 +192,37 @@ int stage_get(mldsa_ctx *ctx, HostStage **out) {
 
 // secrets must not outlive the call in the staging buffers (the reference zeroizes on drop, types.rs:19)
 void wipe_buf(Buf &b, hipStream_t st) {
-    if (b.dev) (void)hipMemsetAsync(b.dev, 0, b.cap, st);
-    if (b.pin) memset(b.pin, 0, b.pin_cap);
+    if (b.dev) MLDSA_WIPE(hipMemsetAsync(b.dev, 0, b.cap, st));
+    if (b.pin) MLDSA_WIPE(memset(b.pin, 0, b.pin_cap));
 }
 
 void free_buf(Buf &b) {
-    if (b.dev) { (void)hipMemset(b.dev, 0, b.cap); (void)hipFree(b.dev); }
-    if (b.pin) { memset(b.pin, 0, b.pin_cap); (void)hipHostFree(b.pin); }
+    if (b.dev) { MLDSA_WIPE(hipMemset(b.dev, 0, b.cap)); (void)hipFree(b.dev); }
+    if (b.pin) { MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); (void)hipHostFree(b.pin); }
     b = Buf();
 }
 
-// bytes of the [a, b) slice of a concatenated byte-string array
+// bytes of the [a, b) slice of a concatenated byte-string array (the tables were validated: check_tables)
 inline size_t span(const uint64_t *off, size_t a, size_t b) { return (size_t)(off[b] - off[a]); }
 }  // namespace
+
+// The host paths memcpy by the caller's offsets: one O(n) pass makes sure they are non-decreasing before anything is copied or
+// uploaded (a decreasing pair would be a ~2^64-byte copy); a table that names bytes of a NULL array is refused as well.
+int check_tables(const char *who, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, size_t n_ops) {
+    int rc = mldsa_check_offsets(msg_off, n_ops);
+    if (rc == MLDSA_OK && ctx_off) rc = mldsa_check_offsets(ctx_off, n_ops);
+    if (rc != MLDSA_OK) {
+        char msg[200];
+        snprintf(msg, sizeof(msg), "%s: %s", who, mldsa_last_error());
+        return set_error(rc, msg);
+    }
+    if ((!msgs && msg_off[n_ops] != msg_off[0]) || (ctx_off && !ctxs && ctx_off[n_ops] != ctx_off[0])) {
+        char msg[200];
+        snprintf(msg, sizeof(msg), "%s: the offsets name bytes of a NULL array", who);
+        return set_error(MLDSA_ERR_PARAM, msg);
+    }
+    return MLDSA_OK;
+}
 
 void host_stage_destroy(mldsa_ctx *ctx) {
     HostStage *hs = ctx->host_stage;
@@ -203,6 +242,33 @@ void host_stage_destroy(mldsa_ctx *ctx) {
     if (hs->down) (void)hipStreamDestroy(hs->down);
     delete hs;
     ctx->host_stage = nullptr;
+}
+
+// mldsa_debug_secret_residue: the staging buffers that held secrets during the last *_host call -- private keys (wire bytes and
+// expanded fields) and rnd of a signing call, seeds and private keys of a key-generation call; device and page-locked twins
+int host_stage_residue(mldsa_ctx *ctx, size_t *scanned, size_t *nonzero) {
+    HostStage *hs = ctx->host_stage;
+    if (!hs || hs->secret_last == 0) return MLDSA_OK;
+    std::vector<Buf *> bufs;
+    if (hs->secret_last == MLDSA_OP_SIGN) {
+        for (Buf *b : {&hs->key_bytes, &hs->k_capk, &hs->k_a, &hs->k_b, &hs->k_c}) bufs.push_back(b);
+        for (auto &sl : hs->slot) bufs.push_back(&sl.rnd);
+    } else {
+        for (auto &sl : hs->slot) { bufs.push_back(&sl.xi); bufs.push_back(&sl.sk); }
+    }
+    for (Buf *b : bufs) {
+        if (b->dev) {
+            size_t nz = 0;
+            TRY(count_nonzero_dev(b->dev, b->cap, &nz));
+            *scanned += b->cap;
+            *nonzero += nz;
+        }
+        if (b->pin) {
+            for (size_t i = 0; i < b->pin_cap; i++) *nonzero += b->pin[i] != 0;
+            *scanned += b->pin_cap;
+        }
+    }
+    return MLDSA_OK;
 }
 
 // shared by verify_host and sign_host: upload the per-op inputs of ops [a, b) into slot `sl` on the up stream
@@ -280,13 +346,15 @@ int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size
     if (n_ops == 0) return MLDSA_OK;
     REQUIRE(pk && msg_off && sigs && ok, "mldsa_verify_host: NULL pointer");
     REQUIRE(key_idx ? n_keys > 0 : n_keys >= n_ops, "mldsa_verify_host: n_keys does not cover the batch");
+    TRY(check_tables("mldsa_verify_host", msgs, msg_off, ctxs, ctx_off, n_ops));
     DeviceGuard dg(ctx->device);
     std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
     HostStage *hs;
     TRY(stage_get(ctx, &hs));
+    hs->secret_last = 0;
     const size_t pkl = (size_t)p->pk_len, sgl = (size_t)p->sig_len, k = (size_t)p->k;
     // keys: upload once, expand once (PublicKey::try_from_bytes, ml_dsa.rs:477-498)
-    TRY(upload(hs->key_bytes, pk, n_keys * pkl, is_pinned(pk), hs->up));
+    TRY(upload(hs->key_bytes, pk, n_keys * pkl, is_pinned(pk, n_keys * pkl), hs->up));
     TRY(grow_dev(hs->k_rho, n_keys * 32));
     TRY(grow_dev(hs->k_tr, n_keys * 64));
     TRY(grow_dev(hs->k_a, n_keys * k * 1024));
@@ -295,8 +363,9 @@ int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size
     TRY(mldsa_pk_expand(ctx, set, hs->key_bytes.dev, hs->k_rho.dev, hs->k_tr.dev, reinterpret_cast<int32_t *>(hs->k_a.dev), n_keys, hs->comp));
     const size_t sub = std::min(n_ops, (size_t)ctx->opt_host_sub_verify);
     TRY(mldsa_reserve(ctx, set, MLDSA_OP_VERIFY, sub));
-    OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
-    const bool pin_sigs = is_pinned(sigs), pin_ok = is_pinned(ok);
+    OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx, n_ops * 4), is_pinned(msgs ? msgs + msg_off[0] : nullptr, span(msg_off, 0, n_ops)), is_pinned(msg_off, (n_ops + 1) * 8),
+                is_pinned(ctxs && ctx_off ? ctxs + ctx_off[0] : nullptr, ctx_off ? span(ctx_off, 0, n_ops) : 0), is_pinned(ctx_off, (n_ops + 1) * 8)};
+    const bool pin_sigs = is_pinned(sigs, n_ops * sgl), pin_ok = is_pinned(ok, n_ops);
     int rc = MLDSA_OK;
     // Side inputs (key indices, offsets, messages, ctxs): when the whole call's fit one pack they go up ONCE, right after
     // the first sub-batch's signatures (the host-side gather then overlaps that DMA); a separate small DMA per
@@ -364,10 +433,14 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     if (n_ops == 0) return MLDSA_OK;
     REQUIRE(sk && msg_off && rnd && sigs, "mldsa_sign_host: NULL pointer");
     REQUIRE(key_idx ? n_keys > 0 : n_keys >= n_ops, "mldsa_sign_host: n_keys does not cover the batch");
+    TRY(check_tables("mldsa_sign_host", msgs, msg_off, ctxs, ctx_off, n_ops));
     DeviceGuard dg(ctx->device);
     std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
     HostStage *hs;
     TRY(stage_get(ctx, &hs));
+    hs->secret_last = MLDSA_OP_SIGN;
+    // the body runs in a lambda so that EVERY way out -- early error returns included -- passes the clearing below
+    const int rc_all = [&]() -> int {
     const size_t skl = (size_t)p->sk_len, sgl = (size_t)p->sig_len, k = (size_t)p->k, l = (size_t)p->l;
     // Page-locked signature buffer: the signing rounds write finished signatures straight into it (k_export_done after every
     // round, pipeline.hip) -- the 3.3 KB per signature cross PCIe while later rounds still run, so the whole batch is ONE signing
@@ -376,7 +449,7 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     // Used for calls of 16 385 ... 98 304 ops (measured, ML-DSA-65: 5.7 instead of 7.3 ms at 32 768, 10.3 instead of 11.1 ms at 65 536, 20.5 instead of 19.6 ms at 131 072; smaller calls replay as
     // hipGraphs on the sub-batch path, larger ones amortise their rounds anyway and lose more to the export's interference).
     // (One lane only: the export hangs off lane 0's rounds.)
-    const bool pin_sigs = is_pinned(sigs);
+    const bool pin_sigs = is_pinned(sigs, n_ops * sgl);  // the WHOLE array: k_export_done stores across all of it
     uint8_t *sigs_dev_view = nullptr;
     const bool direct_size = n_ops > HOST_DIRECT_MIN_OPS && n_ops <= HOST_DIRECT_MAX_OPS;
     if (pin_sigs && direct_size && ctx->opt_host_direct && ctx->opt_sign_lanes < 2) {
@@ -391,11 +464,11 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     if (sigs_dev_view && key_idx) {
         Slot &sl = hs->slot[0];
         TRY(reclaim(sl));
-        TRY(upload(sl.key_idx, key_idx, n_ops * 4, is_pinned(key_idx), hs->up));
+        TRY(upload(sl.key_idx, key_idx, n_ops * 4, is_pinned(key_idx, n_ops * 4), hs->up));
         d_kidx_early = reinterpret_cast<const uint32_t *>(sl.key_idx.dev);
     }
     // keys: upload once, expand once (PrivateKey::try_from_bytes, ml_dsa.rs:445-469)
-    TRY(upload(hs->key_bytes, sk, n_keys * skl, is_pinned(sk), hs->up));
+    TRY(upload(hs->key_bytes, sk, n_keys * skl, is_pinned(sk, n_keys * skl), hs->up));
     TRY(grow_dev(hs->k_rho, n_keys * 32));
     TRY(grow_dev(hs->k_capk, n_keys * 32));
     TRY(grow_dev(hs->k_tr, n_keys * 64));
@@ -425,13 +498,14 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
         if (sigs_dev_view) largest = n_ops;  // one signing call for the whole batch (see above)
         TRY(mldsa_reserve(ctx, set, MLDSA_OP_SIGN, largest));
     }
-    OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx), is_pinned(msgs), is_pinned(msg_off), is_pinned(ctxs), is_pinned(ctx_off)};
-    const bool pin_rnd = is_pinned(rnd);
+    OpInputs in{key_idx, msgs, msg_off, ctxs, ctx_off, is_pinned(key_idx, n_ops * 4), is_pinned(msgs ? msgs + msg_off[0] : nullptr, span(msg_off, 0, n_ops)), is_pinned(msg_off, (n_ops + 1) * 8),
+                is_pinned(ctxs && ctx_off ? ctxs + ctx_off[0] : nullptr, ctx_off ? span(ctx_off, 0, n_ops) : 0), is_pinned(ctx_off, (n_ops + 1) * 8)};
+    const bool pin_rnd = is_pinned(rnd, n_ops * 32);
     // per-op status always comes back: MLDSA_ERR_AGAIN marks the (practically never) ops that need another pass
     std::vector<int32_t> st_local;
     int32_t *st = status;
     if (!st) { st_local.resize(n_ops); st = st_local.data(); }
-    const bool pin_st = status && is_pinned(status);
+    const bool pin_st = status && is_pinned(status, n_ops * 4);
     int rc = MLDSA_OK;
     // the calls below cannot wait for the device, but an op they leave unfinished is signed again further down: plan the
     // rounds like a synchronous call (three or four empty ~0.2 ms rounds less per sub-batch than the 1e-9 plan).  Passed per
@@ -504,13 +578,7 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
         const int r2 = reclaim(sl);
         if (rc == MLDSA_OK) rc = r2;
     }
-    if (rc != MLDSA_OK) {
-        (void)hipDeviceSynchronize();
-        for (Buf *b : {&hs->key_bytes, &hs->k_capk, &hs->k_a, &hs->k_b, &hs->k_c}) wipe_buf(*b, hs->comp);
-        for (auto &sl : hs->slot) wipe_buf(sl.rnd, hs->comp);
-        (void)hipStreamSynchronize(hs->comp);
-        return rc;
-    }
+    if (rc != MLDSA_OK) return rc;
     // ops the enqueued rounds left unfinished (probability < 1e-9 per call): sign them again, waiting this time
     for (size_t op = 0; op < n_ops && rc == MLDSA_OK; op++) {
         if (st[op] != MLDSA_ERR_AGAIN) continue;
@@ -534,11 +602,15 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
             return MLDSA_OK;
         }();
     }
+    return rc;
+    }();
     // the private keys (wire bytes and expanded fields) and the per-signature randomness leave the staging buffers
+    // (the reference zeroizes on drop, types.rs:19)
+    if (rc_all != MLDSA_OK) (void)hipDeviceSynchronize();  // copies of a failed call may still be in flight
     for (Buf *b : {&hs->key_bytes, &hs->k_capk, &hs->k_a, &hs->k_b, &hs->k_c}) wipe_buf(*b, hs->comp);
     for (auto &sl : hs->slot) wipe_buf(sl.rnd, hs->comp);
     (void)hipStreamSynchronize(hs->comp);
-    return rc;
+    return rc_all;
 }
 
 int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys) {
@@ -551,10 +623,12 @@ int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, u
     std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
     HostStage *hs;
     TRY(stage_get(ctx, &hs));
+    hs->secret_last = MLDSA_OP_KEYGEN;
+    const int rc_all = [&]() -> int {
     const size_t pkl = (size_t)p->pk_len, skl = (size_t)p->sk_len;
     const size_t sub = std::min(n_keys, (size_t)ctx->opt_host_sub_verify);
     TRY(mldsa_reserve(ctx, set, MLDSA_OP_KEYGEN, sub));
-    const bool pin_xi = is_pinned(xi), pin_pk = is_pinned(pk), pin_sk = is_pinned(sk);
+    const bool pin_xi = is_pinned(xi, n_keys * 32), pin_pk = is_pinned(pk, n_keys * pkl), pin_sk = is_pinned(sk, n_keys * skl);
     int rc = MLDSA_OK;
     // seeds of sub-batch i + 1 go up before the keys of sub-batch i come down (copies are served in submission order)
     const size_t n_sub = (n_keys + sub - 1) / sub;
@@ -590,10 +664,12 @@ int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, u
         const int r2 = reclaim(sl);
         if (rc == MLDSA_OK) rc = r2;
     }
-    if (rc != MLDSA_OK) (void)hipDeviceSynchronize();
+    return rc;
+    }();
+    if (rc_all != MLDSA_OK) (void)hipDeviceSynchronize();
     for (auto &sl : hs->slot) { wipe_buf(sl.xi, hs->comp); wipe_buf(sl.sk, hs->comp); }  // seeds and private keys
     (void)hipStreamSynchronize(hs->comp);
-    return rc;
+    return rc_all;
 }
 
 }  // extern "C"

@@ -232,12 +232,19 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
 // its 136-byte rate block in a lane-private LDS row, then absorbs it.
 constexpr int MU_BLK_STRIDE = 35;  // dwords per lane row (136 bytes + pad, odd stride)
 
+// Offsets are the caller's and are never trusted: the call vouches for the bytes [off[0], off[n_call]) of msgs / ctxs, and an op
+// is hashed only if its pair lies inside that range in order (off[0] <= off[i] <= off[i + 1] <= off[n_call]).  Any other pair
+// -- decreasing, wrapping, pointing past the end -- refuses the op (flag 2: ok = 0 / MLDSA_ERR_PARAM) without reading a byte of
+// it; a monotonic table never trips this.  An op whose ctx is longer than 255 bytes is refused before anything of it is read,
+// like the reference's early return (lib.rs:274, 368): a 100 MB ctx costs what an empty one costs.
+// msg_off / ctx_off: the CALL's tables (n_call + 1 entries); this launch covers ops [op0, op0 + n_ops) of it, and the per-op
+// arrays (tr without key_idx, mu, ctx_bad, key_bad, key_idx) are the launch's own (index op - op0).
 __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_t tr_stride,
                                            const uint32_t* __restrict__ key_idx, int mode,
                                            const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ msg_off,
                                            const uint8_t* __restrict__ ctxs, const uint64_t* __restrict__ ctx_off,
                                            uint8_t* __restrict__ mu, size_t mu_stride, int32_t* __restrict__ ctx_bad,
-                                           const int32_t* __restrict__ key_bad, size_t n_ops) {
+                                           const int32_t* __restrict__ key_bad, size_t n_ops, size_t op0, size_t n_call) {
     __shared__ uint32_t blk[64 * MU_BLK_STRIDE];
     const int lane = threadIdx.x;
     const size_t op = (size_t)blockIdx.x * 64 + lane;
@@ -247,20 +254,28 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
 
     const uint8_t *trp = nullptr, *mp = nullptr, *cp = nullptr;
     size_t mlen = 0, clen = 0;
+    bool live = false;  // the op is hashed
     if (valid) {
         trp = tr + (key_idx ? key_idx[op] : op) * tr_stride;
-        mp = msgs + msg_off[op];
-        mlen = (size_t)(msg_off[op + 1] - msg_off[op]);
+        const uint64_t m0 = msg_off[op0 + op], m1 = msg_off[op0 + op + 1];
+        bool bad_off = !(msg_off[0] <= m0 && m0 <= m1 && m1 <= msg_off[n_call]);
+        mp = msgs + m0;
+        mlen = (size_t)(m1 - m0);
         if (ctx_off) {
-            cp = ctxs + ctx_off[op];
-            clen = (size_t)(ctx_off[op + 1] - ctx_off[op]);
+            const uint64_t c0 = ctx_off[op0 + op], c1 = ctx_off[op0 + op + 1];
+            bad_off |= !(ctx_off[0] <= c0 && c0 <= c1 && c1 <= ctx_off[n_call]);
+            cp = ctxs + c0;
+            clen = (size_t)(c1 - c0);
         }
-        // 1: ctx too long (lib.rs:274, 368, 589, 605: every entry point); 2: key index out of range
-        if (ctx_bad) ctx_bad[op] = clen > 255 ? 1 : (key_bad ? key_bad[op] : 0);
+        // 2: malformed offsets or key index out of range; 1: ctx too long (lib.rs:274, 368, 589, 605: every entry point)
+        const int flag = bad_off ? 2 : clen > 255 ? 1 : (key_bad ? key_bad[op] : 0);
+        if (ctx_bad) ctx_bad[op] = flag;
+        live = !bad_off && clen <= 255;
+        if (!live) mlen = clen = 0;
     }
     const size_t pre = (mode == MLDSA_MODE_INTERNAL) ? 0 : 2 + clen;
-    const size_t total = valid ? 64 + pre + mlen : 0;
-    const size_t my_blocks = total / SHAKE256_RATE + 1;  // the pad always fits in the last block
+    const size_t total = live ? 64 + pre + mlen : 0;
+    const size_t my_blocks = live ? total / SHAKE256_RATE + 1 : 0;  // the pad always fits in the last block
     size_t max_blocks = my_blocks;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
     KeccakState st;
     keccak_zero(st);
     for (size_t b = 0; b < max_blocks; b++) {
-        if (valid && b < my_blocks) {
+        if (b < my_blocks) {
             const size_t base = b * SHAKE256_RATE;
             auto byte_at = [&](size_t pos) -> uint8_t {
                 if (pos < total) {
@@ -404,9 +419,9 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
 
 int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* key_idx, int mode, const uint8_t* msgs,
               const uint64_t* msg_off, const uint8_t* ctxs, const uint64_t* ctx_off, uint8_t* mu, size_t mu_stride,
-              int32_t* ctx_bad, size_t n_ops, hipStream_t s, const int32_t* key_bad) {
+              int32_t* ctx_bad, size_t n_ops, hipStream_t s, const int32_t* key_bad, size_t op0, size_t n_call) {
     hipLaunchKernelGGL(k_mu, dim3((unsigned)((n_ops + 63) / 64)), dim3(64), 0, s, tr, tr_stride, key_idx, mode, msgs, msg_off,
-                       ctxs, ctx_off, mu, mu_stride, ctx_bad, key_bad, n_ops);
+                       ctxs, ctx_off, mu, mu_stride, ctx_bad, key_bad, n_ops, op0, n_call);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

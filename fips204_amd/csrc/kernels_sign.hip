@@ -604,6 +604,25 @@ __global__ __launch_bounds__(256) void k_zero(uint8_t* __restrict__ dst, size_t 
     if (tid < bytes - tail0) dst[tail0 + tid] = 0;
 }
 
+// number of non-zero bytes of a device range (mldsa_debug_secret_residue: test support, any alignment)
+__global__ __launch_bounds__(256) void k_count_nonzero(const uint8_t* __restrict__ src, size_t bytes, unsigned long long* __restrict__ out) {
+    const size_t head = (size_t)((16 - (reinterpret_cast<uintptr_t>(src) & 15)) & 15);
+    const size_t h = head < bytes ? head : bytes;
+    const size_t n16 = (bytes - h) / 16;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const uint4* mid = reinterpret_cast<const uint4*>(src + h);
+    unsigned long long cnt = 0;
+    auto nz = [](uint32_t v) { return (unsigned)((v & 0xFFu) != 0) + (unsigned)((v & 0xFF00u) != 0) + (unsigned)((v & 0xFF0000u) != 0) + (unsigned)((v >> 24) != 0); };
+    for (size_t i = tid; i < n16; i += stride) {
+        const uint4 v = mid[i];
+        if (v.x | v.y | v.z | v.w) cnt += nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
+    }
+    const size_t tail0 = h + n16 * 16;
+    if (tid < h) cnt += src[tid] != 0;
+    if (tid < bytes - tail0) cnt += src[tail0 + tid] != 0;
+    if (cnt) atomicAdd(out, cnt);
+}
+
 // dst[i][0 .. row_bytes) = src[i][0 .. row_bytes) for rows of different strides (row_bytes % 4 == 0; kernels
 // instead of hipMemcpy2DAsync so that the pipelines consist of kernel and memset nodes only when captured)
 __global__ __launch_bounds__(256) void k_copy_rows(uint8_t* __restrict__ dst, size_t dst_stride, const uint8_t* __restrict__ src,
@@ -871,6 +890,25 @@ int launch_zero(mldsa_ctx* ctx, void* dst, size_t bytes, hipStream_t s) {
     if (bytes == 0) return MLDSA_OK;
     hipLaunchKernelGGL(k_zero, dim3(grid_for(ctx, bytes / 16 + 1, 256, 8)), dim3(256), 0, s, static_cast<uint8_t*>(dst), bytes);
     MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int count_nonzero_dev(const void* dev, size_t bytes, size_t* nonzero) {
+    *nonzero = 0;
+    if (bytes == 0) return MLDSA_OK;
+    unsigned long long* d_cnt = nullptr;
+    if (hipMalloc((void**)&d_cnt, sizeof(*d_cnt)) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "count_nonzero: counter allocation");
+    unsigned long long h_cnt = 0;
+    hipError_t e = hipMemset(d_cnt, 0, sizeof(*d_cnt));
+    if (e == hipSuccess) {
+        const size_t blocks = std::min<size_t>((bytes / 16 + 256) / 256, 8192);
+        hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)blocks), dim3(256), 0, nullptr, static_cast<const uint8_t*>(dev), bytes, d_cnt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+    (void)hipFree(d_cnt);
+    if (e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "count_nonzero", e);
+    *nonzero = (size_t)h_cnt;
     return MLDSA_OK;
 }
 

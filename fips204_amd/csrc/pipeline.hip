@@ -26,6 +26,8 @@ namespace mldsa {
 // (the default of mldsa_ctx::pass_ops: a context whose device cannot hold that workspace halves it, reserve_workspace)
 // MLDSA_OPT_GRAPHS = 1 replays signing calls of up to this many ops (run_op)
 constexpr size_t GRAPH_AUTO_MAX_OPS = 16384;
+// a context never shrinks its passes below this (reserve_workspace)
+constexpr size_t MIN_PASS_OPS = 1024, MIN_SPEC_ROWS = 1024;
 
 // Workspace for `n_ops` ops of operation `op`.  The pass sizes above are tuned for a whole MI355X (a 262 144-op ML-DSA-87 signing
 // pass takes 15 GB of the 288); on a device that cannot give that much -- smaller, partitioned, or shared with other work --
@@ -37,28 +39,75 @@ int reserve_workspace(mldsa_ctx *ctx, const mldsa_params *p, int op, size_t n_op
                                                      : keygen_workspace_bytes(ctx, p, n_ops);
         const int rc = ensure_workspace(ctx, bytes);
         size_t &pass = op == MLDSA_OP_SIGN ? ctx->pass_ops_sign : ctx->pass_ops;
-        if (rc != MLDSA_ERR_NOMEM || pass <= 1024 || n_ops <= pass / 2) return rc;
-        pass /= 2;
+        if (rc != MLDSA_ERR_NOMEM) return rc;
+        // A signing pass holds one row set (y, w, c ...) per candidate of a speculative round -- up to MLDSA_OPT_SPEC_TARGET rows
+        // whatever the batch size: those come down first, to the size of the pass.  (Speculation only trades rounds for width:
+        // the signatures do not depend on it.)
+        const size_t resident = std::min(pass, n_ops);
+        if (op == MLDSA_OP_SIGN && (size_t)ctx->opt_spec_rows > std::max(resident, MIN_SPEC_ROWS)) {
+            ctx->opt_spec_rows = (long)std::max<size_t>((size_t)ctx->opt_spec_rows / 2, MIN_SPEC_ROWS);
+            ctx->opt_spec_target = std::min(ctx->opt_spec_target, ctx->opt_spec_rows);
+        } else {
+            if (pass <= MIN_PASS_OPS) return rc;
+            // The workspace follows min(n_ops, pass): the pass size is halved until it is BELOW the call's size (halving a pass
+            // that is still larger than the call would ask for the same bytes again); the call then runs in two or more passes.
+            do pass /= 2; while (pass > MIN_PASS_OPS && pass >= n_ops);
+        }
         ctx->stats.workspace_shrinks++;
     }
 }
 
 int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return MLDSA_OK;
+    if (ctx->ws_external) return set_error(MLDSA_ERR_NOMEM, "workspace: the caller's buffer (mldsa_ctx_set_workspace) is too small for a pass");
+    // MLDSA_OPT_WORKSPACE_CAP_MB: a host that shares the device bounds what the context may take
+    if (ctx->opt_ws_cap_bytes && bytes > ctx->opt_ws_cap_bytes) return set_error(MLDSA_ERR_NOMEM, "workspace: above MLDSA_OPT_WORKSPACE_CAP_MB");
     // growing replaces the buffer every captured graph points into: wait for whatever still runs, then drop them
     MLDSA_HIP_CHECK(hipDeviceSynchronize());
+    // (a background clearing of the previous call's secrets has finished with the device: nothing is pending on the old buffer)
+    ctx->zero_pending = ctx->zero_head_valid = ctx->zero_wait_after_ea = false;
     drop_graphs(ctx);
     if (ctx->ws) {
-        (void)hipMemset(ctx->ws, 0, ctx->ws_bytes);  // may hold secrets of a previous sign / keygen call
+        MLDSA_WIPE(hipMemset(ctx->ws, 0, ctx->ws_bytes));  // may hold secrets of a previous sign / keygen call
         MLDSA_HIP_CHECK(hipFree(ctx->ws));
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
     }
+    ctx->secret_spans.clear();
     hipError_t e = hipMalloc(&ctx->ws, bytes);
-    if (e != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "workspace allocation", e);
+    if (e != hipSuccess) {
+        ctx->ws = nullptr;
+        (void)hipGetLastError();
+        return set_error(MLDSA_ERR_NOMEM, "workspace allocation", e);
+    }
     ctx->ws_bytes = bytes;
     ctx->stats.workspace_growths++;
     return MLDSA_OK;
+}
+
+// Secrets are cleared on every path out of a call (the reference zeroizes on drop, types.rs:19).  On the successful path the
+// clearing runs on a helper stream, off the caller's critical path: `head` (optional, small) first with its own event, then `rest`;
+// the next op-level call of the context waits for the events on the device.  If any step of that plumbing fails, the spans are
+// cleared on the call's own stream and waited for instead -- a failure never leaves secrets behind.
+struct ZeroSpan { void *p; size_t bytes; };
+static bool clear_in_background(mldsa_ctx *ctx, hipStream_t s, const ZeroSpan *head, const ZeroSpan *rest, int n_rest) {
+    hipStream_t z = parallel_stream(ctx, s);
+    bool ok = hipEventRecord(ctx->zero_fork_ev, s) == hipSuccess && hipStreamWaitEvent(z, ctx->zero_fork_ev, 0) == hipSuccess;
+    if (ok && head) {
+        MLDSA_WIPE(launch_zero(ctx, head->p, head->bytes, z));
+        ok = hipEventRecord(ctx->zero_head_ev, z) == hipSuccess;
+    }
+    if (ok) {
+        for (int i = 0; i < n_rest; i++) MLDSA_WIPE(launch_zero(ctx, rest[i].p, rest[i].bytes, z));
+        ok = hipEventRecord(ctx->zero_ev, z) == hipSuccess;
+    }
+    if (ok) return true;
+    (void)hipGetLastError();
+    if (head) MLDSA_WIPE(launch_zero(ctx, head->p, head->bytes, s));
+    for (int i = 0; i < n_rest; i++) MLDSA_WIPE(launch_zero(ctx, rest[i].p, rest[i].bytes, s));
+    (void)hipStreamSynchronize(z);  // whatever part of the background clearing did start
+    (void)hipStreamSynchronize(s);
+    return false;
 }
 
 namespace {
@@ -137,8 +186,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         {
             // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
             ProfScope ps(ctx, aux, "mu");
-            TRY(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off + o, ctxs, ctx_off ? ctx_off + o : nullptr,
-                          w.mu_w1, mw, w.ctx_bad, n, aux, key_bad));
+            TRY(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off, ctxs, ctx_off, w.mu_w1, mw, w.ctx_bad, n, aux, key_bad, o, n_ops));
         }
         {
             // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
@@ -297,19 +345,16 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     // rho' / K, s1 and s2 are secret: cleared on every path out, like the reference's zeroize-on-drop (types.rs:19).  Off the
     // caller's critical path: on a helper stream, the seed block first; the next op-level call of the context waits for it on
     // the device (OpGuard / above), destroy and regrow wait for the whole device.
+    ctx->secret_spans.push_back({z_lo, z_hi - z_lo});
     if (capturing || rc != MLDSA_OK) {
-        (void)launch_zero(ctx, w.hbuf, z_hi - z_lo, s);
+        MLDSA_WIPE(launch_zero(ctx, w.hbuf, z_hi - z_lo, s));
     } else {
-        hipStream_t z = parallel_stream(ctx, s);
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_fork_ev, s));
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(z, ctx->zero_fork_ev, 0));
-        (void)launch_zero(ctx, w.hbuf, z_mid - z_lo, z);
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_head_ev, z));
-        (void)launch_zero(ctx, w.s1s2, z_hi - z_mid, z);
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_ev, z));
-        ctx->zero_pending = true;
-        ctx->zero_head_valid = true;
-        ctx->zero_lo = z_lo; ctx->zero_mid = z_mid; ctx->zero_hi = z_hi;
+        const ZeroSpan head{w.hbuf, z_mid - z_lo}, rest{w.s1s2, z_hi - z_mid};
+        if (clear_in_background(ctx, s, &head, &rest, 1)) {
+            ctx->zero_pending = true;
+            ctx->zero_head_valid = true;
+            ctx->zero_lo = z_lo; ctx->zero_mid = z_mid; ctx->zero_hi = z_hi;
+        }
     }
     return rc;
 }
@@ -340,7 +385,8 @@ int get_public_key_batch(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint
             return MLDSA_OK;
         }();
     }
-    (void)launch_zero(ctx, w.hbuf, w.secret_bytes, s);
+    ctx->secret_spans.push_back({(size_t)(w.hbuf - static_cast<uint8_t *>(ctx->ws)), w.secret_bytes});
+    MLDSA_WIPE(launch_zero(ctx, w.hbuf, w.secret_bytes, s));
     return rc;
 }
 
@@ -611,6 +657,7 @@ struct SignArgs {
     hipEvent_t inputs_ev;  // optional (mldsa_sign_host): msgs / ctxs / rnd are on the device once this event has fired; waited for after ExpandA
     uint8_t *export_sigs;  // optional: the caller's page-locked host array (device-visible), finished signatures are copied there round by round
     size_t offset, n;   // this chunk: first op and number of ops
+    size_t n_total;     // ops of the whole call (the offset tables have n_total + 1 entries)
     size_t chunk;       // ops the workspace / plan is laid out for
     int async_mode;
 };
@@ -641,7 +688,7 @@ void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
     // y, rho'', cs1 / cs2, staged signatures are secret-dependent (the reference zeroizes on drop, types.rs:19);
     // A_hat = ExpandA(rho) is public and is the first and largest carve: skipped.
     uint8_t *secrets = reinterpret_cast<uint8_t *>(w.y);
-    (void)launch_zero(ctx, secrets, (size_t)(w.base + w.bytes - secrets), s);
+    MLDSA_WIPE(launch_zero(ctx, secrets, (size_t)(w.base + w.bytes - secrets), s));
 }
 
 // steps 1-8 of Algorithm 7 for one lane's slice of a chunk: enqueue only (capturable)
@@ -685,8 +732,8 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     // one an asynchronous call leaves unfinished (k_mark_unfinished) gets its zeros there
     TRY(launch_zero(ctx, w.ctl, sizeof(RoundCtl), s));
     // 6: mu <- H(tr || M', 64)                                            ml_dsa.rs:185-196
-    STAGE("mu", launch_mu(ctx, a.tr + key_base * 64, 64, c.kidx, a.mode, a.msgs, a.msg_off + o, a.ctxs, a.ctx_off ? a.ctx_off + o : nullptr,
-                          w.rnd_mu + 32, 96, w.bad_op, n, s, key_bad));
+    STAGE("mu", launch_mu(ctx, a.tr + key_base * 64, 64, c.kidx, a.mode, a.msgs, a.msg_off, a.ctxs, a.ctx_off, w.rnd_mu + 32, 96, w.bad_op, n, s,
+                          key_bad, o, a.n_total));
     TRY(launch_copy_rows(ctx, w.rnd_mu, 96, a.rnd + o * 32, 32, 32, n, s));
     // 7: rho'' <- H(K || rnd || mu, 64)                                   ml_dsa.rs:199-201
     STAGE("rho_pp_hash", launch_shake256_2(ctx, 64, a.cap_k + key_base * 32, 32, 32, c.kidx, w.rnd_mu, 96, 96, 0, 0, w.rho_pp, 64, n, s));
@@ -857,6 +904,10 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         ws_off += lanes[i].w.bytes;
     }
     if (ctx->ws_bytes < ws_off) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
+    for (int i = 0; i < n_lanes; i++) {  // where this call's secrets will live (mldsa_debug_secret_residue)
+        const uint8_t *secrets = reinterpret_cast<const uint8_t *>(lanes[i].w.y);
+        ctx->secret_spans.push_back({(size_t)(secrets - static_cast<uint8_t *>(ctx->ws)), (size_t)(lanes[i].w.base + lanes[i].w.bytes - secrets)});
+    }
     if (ctx->zero_pending) {
         // The previous synchronous call is (perhaps) still clearing its secrets on a helper stream.  This call's ExpandA may run
         // beside that -- one is integer-issue-bound, the other a stream of stores -- when it is launched directly on one lane
@@ -882,7 +933,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
             SignArgs &a = key.a[live];
             a.set = set; a.mode = mode; a.rho = rho; a.cap_k = cap_k; a.tr = tr; a.s1 = s1; a.s2 = s2; a.t0 = t0; a.n_keys = n_keys;
             a.key_idx = key_idx; a.msgs = msgs; a.msg_off = msg_off; a.ctxs = ctxs; a.ctx_off = ctx_off; a.rnd = rnd; a.sigs = sigs;
-            a.status = status; a.a_hat_keys = a_hat_keys; a.export_sigs = export_sigs; a.inputs_ev = inputs_ev; a.offset = o + lo; a.n = hi - lo; a.chunk = per_lane;
+            a.status = status; a.a_hat_keys = a_hat_keys; a.export_sigs = export_sigs; a.inputs_ev = inputs_ev; a.offset = o + lo; a.n = hi - lo; a.n_total = n_ops; a.chunk = per_lane;
             a.async_mode = async_mode ? 1 : 0;
             lanes[live].a = a;
             live++;
@@ -906,15 +957,17 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         // stream, off the caller's critical path (1.1 GB for a 65 536-op ML-DSA-65 call: ~0.2 ms of an 8 ms call): the next
         // op-level call on this context waits for zero_ev on the device before it touches the workspace, destroy / regrow
         // wait for the whole device.
-        hipStream_t z = parallel_stream(ctx, s);
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_fork_ev, s));
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(z, ctx->zero_fork_ev, 0));
-        for (int i = 0; i < n_lanes; i++) zeroise_sign_ws(ctx, lanes[i].w, z);
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->zero_ev, z));
-        ctx->zero_pending = true;
-        ctx->zero_head_valid = false;
-        ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
-        ctx->zero_hi = ws_off;
+        ZeroSpan spans[2];
+        for (int i = 0; i < n_lanes; i++) {
+            uint8_t *secrets = reinterpret_cast<uint8_t *>(lanes[i].w.y);
+            spans[i] = {secrets, (size_t)(lanes[i].w.base + lanes[i].w.bytes - secrets)};
+        }
+        if (clear_in_background(ctx, s, nullptr, spans, n_lanes)) {
+            ctx->zero_pending = true;
+            ctx->zero_head_valid = false;
+            ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
+            ctx->zero_hi = ws_off;
+        }
     }
     return rc;
 }

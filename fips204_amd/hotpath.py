@@ -52,9 +52,20 @@ class HotPath:
         _lib.check(self.lib.mldsa_ctx_create(device, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def from_handle(cls, handle, device):
+        """A non-owning view of an existing mldsa_ctx (e.g. mldsa_group_ctx(g, i)): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device)
+        self._h = handle
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self.lib.mldsa_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.mldsa_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -74,6 +85,23 @@ class HotPath:
         st = _lib.Stats()
         _lib.check(self.lib.mldsa_get_stats(self._h, C.byref(st)))
         return {n: int(getattr(st, n)) for n, _ in _lib.Stats._fields_}
+
+    def set_workspace(self, buf):
+        """mldsa_ctx_set_workspace: a uint8 CUDA tensor of the caller's as the context's workspace (None: context-owned again).
+        The caller keeps the tensor alive for as long as the context uses it."""
+        if buf is None:
+            _lib.check(self.lib.mldsa_ctx_set_workspace(self._h, None, 0))
+        else:
+            _bytes(buf, "workspace", 0)
+            _lib.check(self.lib.mldsa_ctx_set_workspace(self._h, _ptr(buf), buf.numel()))
+        self._ws_keepalive = buf
+
+    def secret_residue(self):
+        """mldsa_debug_secret_residue: (bytes scanned, non-zero bytes) of the last call's secret-dependent workspace span and
+        of the staging buffers that held secrets -- test support for the mirror of ZeroizeOnDrop (src/types.rs:19, 45)"""
+        scanned, nonzero = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.mldsa_debug_secret_residue(self._h, C.byref(scanned), C.byref(nonzero)))
+        return scanned.value, nonzero.value
 
     def reserve(self, pset, op, n_ops):
         """Size the workspace ahead of time (mldsa_reserve): later calls of that size never wait for the device."""

@@ -496,6 +496,63 @@ class MlDsaGroup(MlDsa):
         for i in range(len(self)):
             _lib.check(self.lib.mldsa_set_option(self.ctx(i), option, value))
 
+    # ---- device-resident slices: one process, one thread, N devices (mldsa_*_group) --------------------------
+    def on_device(self, i):
+        """an MlDsa bound to the i-th context of the group (its device, its workspace): expand keys and stage a slice's
+        inputs there, then hand the slices to verify_group / sign_group / keygen_group"""
+        h = HotPath.from_handle(self.ctx(i), self.device_ids[i])
+        return MlDsa(self.pset, hotpath=h)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    @staticmethod
+    def _slice_stream(t, stream):
+        if stream is not None:
+            return C.c_void_p(stream)
+        with torch.cuda.device(t.device):
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def verify_group(self, slices, mode=MODE_PURE, wait=True):
+        """mldsa_verify_group.  slices[i]: dict(pks=PublicKeys on device i, msg_buf, msg_off, sigs, ok, n_ops and optionally
+        ctx_buf, ctx_off, key_idx, stream) -- the arguments of MlDsa.verify_device for slice i, tensors on device i."""
+        arr = (_lib.VerifySlice * len(self))()
+        for i, sl in enumerate(slices):
+            pks = sl["pks"]
+            arr[i] = _lib.VerifySlice(self._p(pks.rho), self._p(pks.tr), self._p(pks.t1_d2_hat_mont), len(pks), self._p(sl.get("key_idx")),
+                                      self._p(sl["msg_buf"]), self._p(sl["msg_off"]), self._p(sl.get("ctx_buf")), self._p(sl.get("ctx_off")),
+                                      self._p(sl["sigs"]), self._p(sl["ok"]), sl["n_ops"], self._slice_stream(sl["ok"], sl.get("stream")))
+        _lib.check(self.lib.mldsa_verify_group(self._g, self.pset, mode, arr, 1 if wait else 0))
+
+    def sign_group(self, slices, mode=MODE_PURE, wait=True):
+        """mldsa_sign_group.  slices[i]: dict(sks=PrivateKeys on device i, msg_buf, msg_off, rnd, sigs, status, n_ops and
+        optionally ctx_buf, ctx_off, key_idx, stream); wait=False signs with mldsa_sign_async semantics."""
+        arr = (_lib.SignSlice * len(self))()
+        for i, sl in enumerate(slices):
+            sks = sl["sks"]
+            arr[i] = _lib.SignSlice(self._p(sks.rho), self._p(sks.cap_k), self._p(sks.tr), self._p(sks.s_1_hat_mont), self._p(sks.s_2_hat_mont),
+                                    self._p(sks.t_0_hat_mont), len(sks), self._p(sl.get("key_idx")), self._p(sl["msg_buf"]), self._p(sl["msg_off"]),
+                                    self._p(sl.get("ctx_buf")), self._p(sl.get("ctx_off")), self._p(sl["rnd"]), self._p(sl["sigs"]),
+                                    self._p(sl.get("status")), sl["n_ops"], self._slice_stream(sl["sigs"], sl.get("stream")))
+        _lib.check(self.lib.mldsa_sign_group(self._g, self.pset, mode, arr, 1 if wait else 0))
+
+    def keygen_group(self, slices, wait=True):
+        """mldsa_keygen_group.  slices[i]: dict(xi, pk, sk, n_keys[, stream]), tensors on device i."""
+        arr = (_lib.KeygenSlice * len(self))()
+        for i, sl in enumerate(slices):
+            arr[i] = _lib.KeygenSlice(self._p(sl["xi"]), self._p(sl["pk"]), self._p(sl["sk"]), sl["n_keys"], self._slice_stream(sl["pk"], sl.get("stream")))
+        _lib.check(self.lib.mldsa_keygen_group(self._g, self.pset, arr, 1 if wait else 0))
+
+    def sync(self):
+        """mldsa_group_sync: waits for the streams of the last device-resident group call"""
+        _lib.check(self.lib.mldsa_group_sync(self._g))
+
+    def allgather(self, bufs, n_ops, use_rccl=-1):
+        """mldsa_group_allgather over one uint8 tensor per device (N * ceil(n_ops / N) bytes each, slice i of bufs[i] filled)"""
+        arr = (C.c_void_p * len(self))(*[b.data_ptr() for b in bufs])
+        _lib.check(self.lib.mldsa_group_allgather(self._g, arr, n_ops, use_rccl))
+
     def shard(self, n_ops, part):
         """(first, count) of the slice part `part` owns: mldsa_group_shard (= multi_gpu.shard)"""
         a, c = C.c_size_t(), C.c_size_t()

@@ -73,6 +73,11 @@ extern "C" {
 #define MLDSA_MODE_INTERNAL 1  /* mu = H(tr | M)   (`nist = true`, the ACVP "internal" interface)   */
 #define MLDSA_MODE_PREHASH 2   /* mu = H(tr | 0x01 | len(ctx) | ctx | OID | PH(M)); msg = OID|PH(M) */
 
+/* Bumped whenever a struct of this header grows or an entry point changes its meaning (4: mldsa_stats has 6 fields, the group
+ * calls take device-resident slices, offset tables are validated).  mldsa_abi_version() reports the library's. */
+#define MLDSA_ABI_VERSION 4
+int mldsa_abi_version(void);
+
 typedef struct mldsa_ctx mldsa_ctx;
 
 typedef struct {
@@ -95,6 +100,15 @@ int mldsa_ctx_device(const mldsa_ctx *ctx); /* device id the context is bound to
 #define MLDSA_OP_VERIFY 3
 int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
 
+/* Caller-owned workspace.  The reference allocates nothing (`#![no_std]`, no alloc: README.md:15-16); a host that manages device
+ * memory itself -- a pool, a fixed budget next to other work -- hands the context its workspace instead of letting it hipMalloc
+ * one: dev_buf (256-byte aligned, on the context's device, `bytes` long) is used for every op-level call from now on, is never
+ * freed or regrown by the context, and is still cleared of secrets at the end of every call and (entirely) on mldsa_ctx_destroy /
+ * when it is replaced.  A call whose full pass does not fit runs in smaller passes, like under MLDSA_OPT_WORKSPACE_CAP_MB; a
+ * buffer too small for a 1024-op pass fails the call with MLDSA_ERR_NOMEM.  (NULL, 0) returns to a context-owned workspace.
+ * Waits for the device. */
+int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
+
 /* Tuning knobs (per context).  Defaults are the measured best; none changes any result. */
 #define MLDSA_OPT_GRAPHS 1          /* hipGraph replay of repeated call shapes: 0 never, 1 (default) signing calls of <= 16384 ops, 2 every call */
 #define MLDSA_OPT_SPEC_TARGET 2     /* sign: candidate slots per speculative round (1 ... 524288, default 65536)       */
@@ -115,6 +129,9 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
                                        by re-reading A_hat from HBM there --, and the next round tests the second one without generating
                                        anything.  0 = never, 1 (default) = for the parameter sets where it measured faster (ML-DSA-65: +2.7 %),
                                        2 = for every set.  Signatures are identical */
+#define MLDSA_OPT_WORKSPACE_CAP_MB 11 /* most MiB of device memory the context's workspace may take (0 = default: whatever the device gives).  A call
+                                       whose full pass does not fit runs in smaller passes (see workspace_shrinks); results are identical.  For hosts
+                                       that share the GPU with other work; a cap too small even for a 1024-op pass fails the call with MLDSA_ERR_NOMEM */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,
@@ -124,6 +141,9 @@ typedef struct {
     unsigned long long graphs_captured, graph_replays, direct_calls, workspace_growths, sign_extra_rounds, workspace_shrinks;
 } mldsa_stats;
 int mldsa_get_stats(mldsa_ctx *ctx, mldsa_stats *out);
+/* the same with the size of the CALLER's struct: at most out_bytes are written (a client built against a header whose mldsa_stats
+ * was shorter is not overrun; fields the library does not know read as zero) */
+int mldsa_get_stats_sized(mldsa_ctx *ctx, void *out, size_t out_bytes);
 
 /* Per-stage timing of the op-level calls (bench.py's roofline figure): while enabled, every
  * kernel launch of mldsa_verify / mldsa_sign is bracketed by a HIP event pair on the launch
@@ -131,6 +151,16 @@ int mldsa_get_stats(mldsa_ctx *ctx, mldsa_stats *out);
  * {"stage": {"ms": total, "calls": n}, ...} into buf and resets the counters. */
 int mldsa_profile_enable(mldsa_ctx *ctx, int on);
 int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len);
+
+/* Test support for the mirror of the reference's `Zeroize, ZeroizeOnDrop` key structs (src/types.rs:19, 45): secret-dependent
+ * intermediates (y, w, c s1, rho'', rho', s1, s2, K ...) and staged private keys / seeds / rnd must not outlive the call that used
+ * them.  mldsa_debug_secret_residue waits for the device (and with it for the call's background clearing), then counts the non-zero
+ * bytes of (a) the part of the workspace the LAST op-level call used for secret-dependent data and (b) the staging buffers that
+ * held secrets during the last *_host call.  scanned_bytes says how much was looked at (0 after a verify-only history);
+ * nonzero_bytes must be 0.  Nothing is cleared by the probe itself.  mldsa_debug_count_nonzero: the same count over any device
+ * range (synchronous). */
+int mldsa_debug_secret_residue(mldsa_ctx *ctx, size_t *scanned_bytes, size_t *nonzero_bytes);
+int mldsa_debug_count_nonzero(const void *dev_ptr, size_t bytes, size_t *nonzero);
 
 /* ---- device memory helpers for hosts without their own HIP binding ------------------ */
 int mldsa_malloc(void **dev_ptr, size_t bytes);
@@ -223,11 +253,22 @@ int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_
  *   msgs/msg_off: concatenated messages and n_ops + 1 byte offsets; ctxs/ctx_off likewise
  *   (ctx_off NULL = every ctx empty).  mode: MLDSA_MODE_*.  sigs: n_ops * SIG_LEN bytes.
  *   ok[op] = 1 iff the reference returns true; malformed hints, |ctx| > 255, z too large and
- *   c_tilde mismatch all give 0 (ml_dsa.rs:368-376, 434-436; lib.rs:368-370). */
+ *   c_tilde mismatch all give 0 (ml_dsa.rs:368-376, 434-436; lib.rs:368-370).
+ *   Offsets are untrusted input like everything else (the reference never panics on it, fuzz_all.rs:25-37): the call vouches
+ *   for the bytes [off[0], off[n_ops]) of msgs / ctxs and nothing outside them is read; an op whose pair is not in order inside
+ *   that range (off[0] <= off[i] <= off[i + 1] <= off[n_ops]: a decreasing, wrapping or overshooting entry) is refused on its own
+ *   -- ok = 0 here, status MLDSA_ERR_PARAM and an all-zero signature in mldsa_sign -- and the other ops are unaffected; an op
+ *   whose ctx is longer than 255 bytes is refused before a byte of its ctx or message is read (lib.rs:274, 368).  The *_host
+ *   entry points, which copy by these offsets on the host, check the tables first (mldsa_check_offsets) and fail the whole call
+ *   with MLDSA_ERR_PARAM. */
 int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr,
                  const int32_t *t1_d2_hat_mont, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
                  const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                  const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream);
+
+/* n_ops + 1 byte offsets, non-decreasing?  MLDSA_OK or MLDSA_ERR_PARAM (mldsa_last_error names the entry).  Pure host code:
+ * needs no context and no device. */
+int mldsa_check_offsets(const uint64_t *off, size_t n_ops);
 
 /* SerDes::try_from_bytes for PublicKey (src/lib.rs:471-475) -> expand_public
  * (src/ml_dsa.rs:477-498): pk[n][PK_LEN] -> rho[n][32], tr[n][64] = H(pk),
@@ -356,10 +397,61 @@ int mldsa_sign_host_group(mldsa_group *g, int set, int mode, const uint8_t *sk, 
                           const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                           const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops);
 int mldsa_keygen_host_group(mldsa_group *g, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n_keys);
+/* Device-resident slices: the batch is already sharded, slice i lives in the memory of device i of the group (keys expanded there
+ * with mldsa_pk_expand / mldsa_sk_expand on mldsa_group_ctx(g, i), inputs uploaded there) -- the HBM-resident form of the calls
+ * above, driven from ONE host thread of ONE process.  slices[i] holds exactly the arguments of mldsa_verify / mldsa_sign /
+ * mldsa_keygen for slice i (offset tables are the slice's own: n_ops + 1 entries; n_ops may be 0); worker i makes that call on
+ * its context.  wait != 0: the call returns when every slice's results are complete (mldsa_sign semantics for signing);
+ * wait == 0: it returns when everything is enqueued on the slices' streams (mldsa_sign_async semantics: status is required and
+ * may carry MLDSA_ERR_AGAIN) and mldsa_group_sync waits for those streams later.  Results are byte-identical to the
+ * single-context calls on the same ops. */
+typedef struct {
+    const uint8_t *rho, *tr;               /* expanded public keys on the slice's device (mldsa_pk_expand) */
+    const int32_t *t1_d2_hat_mont;
+    size_t n_keys;
+    const uint32_t *key_idx;
+    const uint8_t *msgs;
+    const uint64_t *msg_off;
+    const uint8_t *ctxs;
+    const uint64_t *ctx_off;
+    const uint8_t *sigs;
+    uint8_t *ok;
+    size_t n_ops;
+    void *stream;                          /* hipStream_t of the slice's device (NULL = its default stream) */
+} mldsa_verify_slice;
+typedef struct {
+    const uint8_t *rho, *cap_k, *tr;       /* expanded private keys on the slice's device (mldsa_sk_expand) */
+    const int32_t *s_1_hat_mont, *s_2_hat_mont, *t_0_hat_mont;
+    size_t n_keys;
+    const uint32_t *key_idx;
+    const uint8_t *msgs;
+    const uint64_t *msg_off;
+    const uint8_t *ctxs;
+    const uint64_t *ctx_off;
+    const uint8_t *rnd;
+    uint8_t *sigs;
+    int32_t *status;
+    size_t n_ops;
+    void *stream;
+} mldsa_sign_slice;
+typedef struct {
+    const uint8_t *xi;
+    uint8_t *pk, *sk;
+    size_t n_keys;
+    void *stream;
+} mldsa_keygen_slice;
+int mldsa_verify_group(mldsa_group *g, int set, int mode, const mldsa_verify_slice *slices /* [mldsa_group_size] */, int wait);
+int mldsa_sign_group(mldsa_group *g, int set, int mode, const mldsa_sign_slice *slices, int wait);
+int mldsa_keygen_group(mldsa_group *g, int set, const mldsa_keygen_slice *slices, int wait);
+int mldsa_group_sync(mldsa_group *g); /* waits for the streams of the last device-resident group call */
+
 /* Device-resident verdicts (each device ran mldsa_verify on its slice): the one exchange SURVEY 8e names.
  * bufs[i] = device pointer on device i of the group, N * ceil(n_ops / N) bytes, slice i of it filled; afterwards
  * every buffer holds all n_ops bytes.  use_rccl: 1 = ncclAllGather over xGMI (librccl.so is loaded on first
- * use; the devices must be distinct), 0 = device-to-device copies, -1 = RCCL if possible, copies otherwise. */
+ * use; the devices must be distinct), 0 = device-to-device copies, -1 = RCCL if possible, copies otherwise.
+ * Ordering: the gather runs after the last op-level call of every context of the group (a device-side wait on the event each
+ * context records behind its calls -- no host synchronisation is needed between mldsa_verify / mldsa_verify_group and this
+ * call); buffers filled by anything else must be complete before the call.  Returns when every buffer is gathered. */
 int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, int use_rccl);
 
 #ifdef __cplusplus

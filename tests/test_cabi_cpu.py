@@ -116,3 +116,36 @@ int main() {
             assert got[i] == want[ph].hex(), (n, ph)
             assert hash_message(m, ph) == want[ph]  # the Python mirror's front-end
             i += 1
+
+
+def test_offset_tables_are_checked_without_a_device():
+    """mldsa_check_offsets (the O(n) pass every *_host entry point makes before it copies by the caller's offsets): pure host
+    code of the REAL library, so it runs here.  A decreasing pair -- which would be a ~2^64-byte length -- is MLDSA_ERR_PARAM and
+    the message names the entry (the reference's slices carry their own lengths and cannot be malformed, src/traits.rs:330-362)."""
+    import numpy as np
+    lib = _lib.load()
+    def chk(values, n=None):
+        a = np.array(values, dtype=np.uint64)
+        return lib.mldsa_check_offsets(C.c_void_p(a.ctypes.data), len(values) - 1 if n is None else n)
+    assert chk([0]) == 0 and chk([7, 7, 7, 9]) == 0 and chk([0, 5, 5, 2 ** 63, 2 ** 64 - 1]) == 0
+    assert lib.mldsa_check_offsets(None, 0) == 0
+    assert lib.mldsa_check_offsets(None, 3) == _lib.ERR_PARAM
+    assert chk([0, 4, 3, 9]) == _lib.ERR_PARAM and b"entry 2" in lib.mldsa_last_error()
+    assert chk([5, 4]) == _lib.ERR_PARAM
+    assert chk([0, 2 ** 64 - 8, 16]) == _lib.ERR_PARAM         # a wrapping pair
+    assert chk([0, 10, 2 ** 40, 20, 30]) == _lib.ERR_PARAM     # an overshooting entry is caught where the table comes back down
+    big = np.arange(1 << 20, dtype=np.uint64)
+    big[777_777] = 5
+    assert lib.mldsa_check_offsets(C.c_void_p(big.ctypes.data), big.size - 1) == _lib.ERR_PARAM
+
+
+def test_abi_version_and_sized_stats():
+    """mldsa_stats grew by a field; a client built against the shorter struct must not be overrun.
+    mldsa_get_stats_sized writes at most the caller's size (checked here with a NULL context: argument errors come first)."""
+    lib = _lib.load()
+    assert lib.mldsa_abi_version() == _lib.ABI_VERSION
+    text = open(_lib.HEADER_PATH).read()
+    assert f"#define MLDSA_ABI_VERSION {_lib.ABI_VERSION}" in text
+    buf = (C.c_ubyte * 16)()
+    assert lib.mldsa_get_stats_sized(None, buf, 16) == _lib.ERR_PARAM
+    assert C.sizeof(_lib.Stats) == 48

@@ -1,0 +1,437 @@
+"""Boundary hardening (round 4): untrusted offset tables, workspace shrinking, page-locked extents, device-resident group calls.
+
+The reference never panics on untrusted input (fuzz/fuzz_targets/fuzz_all.rs:25-37) and returns a plain error / `false`
+(src/lib.rs:274, 368-370).  Its slices carry their own lengths; the C ABI's offset tables are the caller's and can be wrong:
+an op with a malformed pair is refused on its own, every other op of the batch still equals the oracle's result."""
+import ctypes as C
+import hashlib
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from fips204_amd.hotpath import HotPath
+    h = HotPath(0)
+    yield h
+    h.close()
+
+
+@pytest.fixture(scope="module")
+def sets(hp):
+    from fips204_amd.ml_dsa import MlDsa
+    return {s: MlDsa(s, hotpath=hp) for s in (44, 65, 87)}
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def shake(tag, i, n=32):
+    return hashlib.shake_256(tag + int(i).to_bytes(8, "little")).digest(n)
+
+
+def dev(a):
+    return torch.from_numpy(np.array(a, copy=True)).cuda()
+
+
+def dev_off(off):
+    return torch.from_numpy(np.ascontiguousarray(off, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def table(items):
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    np.cumsum([len(b) for b in items], out=off[1:])
+    return np.frombuffer(b"".join(items) + bytes(16), dtype=np.uint8), off
+
+
+def pairs_ok(off):
+    """per op: the pair lies in order inside [off[0], off[n]] (the rule of k_mu / include/mldsa_hip.h)"""
+    off = [int(x) for x in off]
+    lo, hi = off[0], off[-1]
+    return np.array([lo <= a <= b <= hi for a, b in zip(off[:-1], off[1:])], dtype=bool)
+
+
+def corruptions(off, rng):
+    """name -> corrupted copy of a monotonic table (n + 1 entries), the damage in the middle of the batch"""
+    n = off.size - 1
+    k = n // 2
+    out = {}
+    assert off[k] > 0
+    t = off.copy(); t[k + 1] = t[k] - np.uint64(1)
+    out["decreasing"] = t
+    t = off.copy(); t[k:k + 5] = t[k]
+    out["equal_run"] = t                                    # legal: four empty byte strings
+    t = off.copy(); t[k + 1] = np.uint64(1) << np.uint64(63)
+    out["overshoot"] = t                                    # far past the end: two ops refused
+    t = off.copy(); t[k] = np.uint64(2 ** 64 - 8); t[k + 1] = np.uint64(2 ** 64 - 1)
+    out["near_2_64"] = t
+    t = off.copy(); t[k + 1] = t[0]
+    out["back_to_start"] = t
+    t = off.copy(); t[-1] = t[n // 4]
+    out["short_last_entry"] = t                             # the call vouches for fewer bytes than the table names
+    t = off.copy(); idx = rng.choice(np.arange(1, n), 40, replace=False); t[idx] = rng.integers(0, 2 ** 63, 40, dtype=np.uint64)
+    out["forty_random_entries"] = t
+    return out
+
+
+@pytest.mark.parametrize("pset,mode", [(44, 0), (65, 1), (87, 2)])
+def test_malformed_offset_tables_refuse_only_their_ops(sets, pset, mode):
+    """a decreasing / overshooting / wrapping msg_off or ctx_off pair used to be a ~2^64-byte length inside
+    k_mu (endless loop, out-of-bounds reads).  Now: the op is refused (verify: ok = 0; sign and sign_async: status
+    MLDSA_ERR_PARAM, all-zero signature), the call returns in the usual time, and every op whose pair is in order gets exactly the
+    oracle's result for the bytes its pair names.  4 096 ops, damage in the middle, all three modes."""
+    m = sets[pset]
+    n, nk = 4096, 16
+    rng = np.random.default_rng(4000 + pset)
+    xi = [shake(b"off-key%d" % pset, i) for i in range(nk)]
+    pk, sk = m.keygen_from_seed(xi)
+    pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+    sk_o = [orc.sk_try_from_bytes(pset, bytes(r)) for r in host(sk)]
+    if mode == 2:   # pre-hash mode: the message is OID || PH(M), a fixed 43 / 75 bytes
+        from fips204_amd.ml_dsa import hash_message
+        msgs = [hash_message(shake(b"off-msg", i, 50), "SHA256" if i % 2 else "SHA512") for i in range(n)]
+    else:
+        msgs = [shake(b"off-msg", i, int(rng.integers(0, 300))) for i in range(n)]
+    ctxs = [shake(b"off-ctx", i, i % 7) for i in range(n)]
+    rnd = np.frombuffer(b"".join(shake(b"off-rnd", i) for i in range(n)), dtype=np.uint8).reshape(n, 32)
+    kidx_h = (np.arange(n) * 3 % nk).astype(np.uint32)
+    kidx = dev(kidx_h.view(np.int32))
+    mflat, moff = table(msgs)
+    cflat, coff = table(ctxs)
+    d_m, d_c, d_rnd = dev(mflat), dev(cflat), dev(rnd)
+
+    def sign(mo, co, wait):
+        sig = torch.full((n, m.SIG_LEN), 0xAB, dtype=torch.uint8, device="cuda")
+        st = torch.full((n,), 77, dtype=torch.int32, device="cuda")
+        t0 = time.perf_counter()
+        m.sign_device(sks, d_m, dev_off(mo), d_rnd, sig, n, d_c, dev_off(co), kidx, mode, st, wait=wait)
+        torch.cuda.synchronize()
+        return host(sig), host(st), time.perf_counter() - t0
+
+    def verify(mo, co, sig):
+        ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        t0 = time.perf_counter()
+        m.verify_device(pks, d_m, dev_off(mo), dev(sig), ok, n, d_c, dev_off(co), kidx, mode)
+        torch.cuda.synchronize()
+        return host(ok).astype(bool), time.perf_counter() - t0
+
+    sign(moff, coff, True)  # warm-up (workspace growth, stream probing)
+    good, st0, t_sign = sign(moff, coff, True)
+    assert (st0 == 0).all()
+    v0, t_ver = verify(moff, coff, good)
+    assert v0.all()
+    for i in rng.choice(n, 24, replace=False):   # the clean batch against the oracle
+        assert good[i].tobytes() == orc.sign_internal(pset, sk_o[kidx_h[i]], msgs[i], rnd[i].tobytes(), ctx=ctxs[i], mode=mode), int(i)
+
+    def named(flat, off, i):  # the bytes a (valid) pair names
+        return flat[int(off[i]):int(off[i + 1])].tobytes()
+
+    for which in ("msg", "ctx"):
+        base = moff if which == "msg" else coff
+        for name, bad in corruptions(base, rng).items():
+            mo, co = (bad, coff) if which == "msg" else (moff, bad)
+            valid = pairs_ok(mo) & pairs_ok(co)
+            clen_ok = np.array([(int(co[i + 1]) - int(co[i])) <= 255 if valid[i] else True for i in range(n)])
+            same = valid & (mo[:-1] == moff[:-1]) & (mo[1:] == moff[1:]) & (co[:-1] == coff[:-1]) & (co[1:] == coff[1:])
+            for wait in (True, False):
+                sig, st, dt = sign(mo, co, wait)
+                assert dt < 20 * t_sign + 0.5, (which, name, wait, dt, t_sign)     # no endless loop
+                assert ((st == -1) == ~valid).all(), (which, name, wait, np.nonzero((st == -1) != ~valid)[0][:5])
+                assert ((st == -2) == (valid & ~clen_ok)).all(), (which, name)
+                assert (st[valid & clen_ok] == 0).all()
+                assert not sig[st != 0].any(), (which, name, "refused ops get all-zero signatures")
+                assert np.array_equal(sig[same], good[same]), (which, name, wait)  # untouched ops: byte-identical
+                shifted = np.nonzero(valid & clen_ok & ~same)[0]                   # in order, but naming other bytes: the oracle on THOSE bytes
+                for i in shifted[:12]:
+                    want = orc.sign_internal(pset, sk_o[kidx_h[i]], named(mflat, mo, i), rnd[i].tobytes(), ctx=named(cflat, co, i), mode=mode)
+                    assert sig[i].tobytes() == want, (which, name, int(i))
+            ok, dt = verify(mo, co, good)
+            assert dt < 20 * t_ver + 0.5, (which, name, dt, t_ver)
+            # valid exactly where the pair still names the bytes that were signed (an op shifted onto other bytes fails its c~ check)
+            # (the internal interface hashes no ctx, ml_dsa.rs:386-388: there only its length matters)
+            same_bytes = np.array([bool(valid[i] and clen_ok[i]) and named(mflat, mo, i) == msgs[i] and (mode == 1 or named(cflat, co, i) == ctxs[i])
+                                   for i in range(n)])
+            assert np.array_equal(ok, same_bytes), (which, name, np.nonzero(ok != same_bytes)[0][:5])
+            assert ok.sum() >= n - 100 or name == "short_last_entry", (which, name, int(ok.sum()))
+
+
+def test_over_long_ctx_is_refused_before_it_is_read(sets):
+    """lib.rs:274 / 368 return before touching the message: an op whose ctx is 100 MB costs what an op with an empty ctx costs
+    (the lane used to hash all of it: ~0.7 M serial permutations), and the other ops of the batch are unaffected."""
+    m = sets[44]
+    n = 256
+    xi = [shake(b"ctx-key", 0)]
+    pk, sk = m.keygen_from_seed(xi)
+    pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+    msgs = [shake(b"ctx-msg", i) for i in range(n)]
+    mflat, moff = table(msgs)
+    big = 100 * 1000 * 1000
+    ctx_bytes = torch.randint(0, 256, (big + 4096,), dtype=torch.uint8, device="cuda")
+    lens = np.array([i % 4 for i in range(n)], dtype=np.uint64)
+    lens[100] = big
+    lens[200] = 256
+    coff = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=coff[1:])
+    small = np.zeros(n + 1, dtype=np.uint64)  # the same batch with the two long ctxs emptied
+    lens2 = lens.copy(); lens2[[100, 200]] = 0
+    np.cumsum(lens2, out=small[1:])
+    kidx = dev(np.zeros(n, dtype=np.int32))
+    rnd = dev(np.zeros((n, 32), dtype=np.uint8))
+    d_m = dev(mflat)
+
+    def run(co):
+        sig = torch.zeros((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+        st = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        t0 = time.perf_counter()
+        m.sign_device(sks, d_m, dev_off(moff), rnd, sig, n, ctx_bytes, dev_off(co), kidx, 0, st)
+        m.verify_device(pks, d_m, dev_off(moff), sig, ok, n, ctx_bytes, dev_off(co), kidx, 0)
+        torch.cuda.synchronize()
+        return host(sig), host(st), host(ok), time.perf_counter() - t0
+
+    run(small)
+    _, st_s, ok_s, t_small = run(small)
+    sig, st, ok, t_big = run(coff)
+    assert (st_s == 0).all() and ok_s.all()
+    assert st[100] == -2 and st[200] == -2 and (np.delete(st, [100, 200]) == 0).all()
+    assert not ok[100] and not ok[200] and np.delete(ok, [100, 200]).all()
+    assert not sig[100].any() and not sig[200].any()
+    assert t_big < 3 * t_small + 0.05, (t_big, t_small)
+    cb = host(ctx_bytes[:int(coff[99]) + 8])
+    sk_o = orc.sk_try_from_bytes(44, bytes(host(sk)[0]))
+    for i in (0, 1, 2, 3, 99):
+        assert sig[i].tobytes() == orc.sign_internal(44, sk_o, msgs[i], bytes(32), ctx=cb[int(coff[i]):int(coff[i + 1])].tobytes(), mode=0)
+
+
+@pytest.mark.parametrize("group", [False, True])
+def test_host_entry_points_refuse_malformed_tables(sets, group):
+    """mldsa_verify_host / mldsa_sign_host (and the group forms) memcpy by the caller's offsets: a decreasing pair fails the whole
+    call with MLDSA_ERR_PARAM before anything is copied or uploaded; a table naming bytes of a NULL array likewise."""
+    from fips204_amd import _lib
+    from fips204_amd.ml_dsa import MlDsaGroup
+    m = sets[44]
+    lib = m.lib
+    n = 300
+    xi = np.frombuffer(b"".join(shake(b"hoff-key", i) for i in range(4)), dtype=np.uint8)
+    pk, sk = m.keygen_host(xi)
+    msgs = [shake(b"hoff-msg", i, i % 90) for i in range(n)]
+    rnd = np.zeros(n * 32, dtype=np.uint8)
+    kidx = (np.arange(n) % 4).astype(np.uint32)
+    sig = m.sign_host(sk, msgs, rnd, key_idx=kidx)
+    mflat, moff = table(msgs)
+    g = MlDsaGroup(44, [0, 0]) if group else None
+    handle = g._g if group else m.hp._h
+    vfn = lib.mldsa_verify_host_group if group else lib.mldsa_verify_host
+    sfn = lib.mldsa_sign_host_group if group else lib.mldsa_sign_host
+    vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+    try:
+        ok = np.zeros(n, dtype=np.uint8)
+        out = np.zeros((n, m.SIG_LEN), dtype=np.uint8)
+        st = np.zeros(n, dtype=np.int32)
+        assert vfn(handle, 44, 0, vp(pk), 4, vp(kidx), vp(mflat), vp(moff), None, None, vp(sig), vp(ok), n) == 0 and ok.all()
+        for k, val in ((150, None), (1, 2 ** 64 - 1), (299, 0)):
+            bad = moff.copy()
+            bad[k] = np.uint64(val) if val is not None else bad[k - 1] - np.uint64(1) if bad[k - 1] else np.uint64(0)
+            if (bad[1:] >= bad[:-1]).all():
+                continue
+            t0 = time.perf_counter()
+            assert vfn(handle, 44, 0, vp(pk), 4, vp(kidx), vp(mflat), vp(bad), None, None, vp(sig), vp(ok), n) == _lib.ERR_PARAM
+            assert b"decreases at entry" in lib.mldsa_last_error()
+            assert sfn(handle, 44, 0, vp(sk), 4, vp(kidx), vp(mflat), vp(bad), None, None, vp(rnd), vp(out), vp(st), n) == _lib.ERR_PARAM
+            # the ctx table is checked the same way
+            assert vfn(handle, 44, 0, vp(pk), 4, vp(kidx), vp(mflat), vp(moff), vp(mflat), vp(bad), vp(sig), vp(ok), n) == _lib.ERR_PARAM
+            assert time.perf_counter() - t0 < 0.5
+        # offsets that name bytes of a NULL array
+        assert vfn(handle, 44, 0, vp(pk), 4, vp(kidx), None, vp(moff), None, None, vp(sig), vp(ok), n) == _lib.ERR_PARAM
+        assert sfn(handle, 44, 0, vp(sk), 4, vp(kidx), vp(mflat), vp(moff), None, vp(moff), vp(rnd), vp(out), vp(st), n) == _lib.ERR_PARAM
+        # and the context still works afterwards
+        assert vfn(handle, 44, 0, vp(pk), 4, vp(kidx), vp(mflat), vp(moff), None, None, vp(sig), vp(ok), n) == 0 and ok.all()
+    finally:
+        if g:
+            g.close()
+
+
+# ------------------------------------------------------------------------------ workspace that does not fit (pipeline.hip:40)
+@pytest.mark.parametrize("pset", [44, 87])
+def test_workspace_cap_shrinks_the_passes_and_changes_nothing(sets, pset):
+    """A device that cannot hold the workspace of a full pass: reserve_workspace used to give up whenever the call was smaller
+    than half a pass (every signing call up to 131 072 ops).  With MLDSA_OPT_WORKSPACE_CAP_MB standing in for the allocation
+    failure the context halves its pass size until the workspace fits, runs the call in several passes, and keygen / sign /
+    verify output is byte-identical to an uncapped context's."""
+    from fips204_amd import _lib
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    m = sets[pset]
+    n, nk = 6000, 40
+    xi = [shake(b"cap-key%d" % pset, i) for i in range(n)]
+    msgs = [shake(b"cap-msg", i, i % 50) for i in range(n)]
+    rnd = [shake(b"cap-rnd", i) for i in range(n)]
+    kidx = (np.arange(n) * 7 % nk).astype(np.uint32)
+    pk0, sk0 = m.keygen_from_seed(xi)
+    sks0 = m.private_keys_from_bytes(sk0[:nk])
+    pks0 = m.public_keys_from_bytes(pk0[:nk])
+    sig0 = m.try_sign_with_seed(sks0, msgs, rnd, key_idx=kidx)
+    bad = host(sig0).copy()
+    bad[::9, 40] ^= 1
+    v0 = m.verify(pks0, msgs, dev(bad), key_idx=kidx)
+    hp2 = HotPath(0)
+    try:
+        cap = {44: 100, 87: 200}[pset]   # MiB: below what a 6 000-op pass of keygen / sign / verify needs
+        hp2.set_option(_lib.OPT_WORKSPACE_CAP_MB, cap)
+        assert hp2.get_option(_lib.OPT_WORKSPACE_CAP_MB) == cap
+        m2 = MlDsa(pset, hotpath=hp2)
+        pk1, sk1 = m2.keygen_from_seed(xi)
+        s_keygen = hp2.stats()["workspace_shrinks"]
+        assert torch.equal(pk1, pk0) and torch.equal(sk1, sk0)
+        sks1, pks1 = m2.private_keys_from_bytes(sk1[:nk]), m2.public_keys_from_bytes(pk1[:nk])
+        sig1 = m2.try_sign_with_seed(sks1, msgs, rnd, key_idx=kidx)
+        s_sign = hp2.stats()["workspace_shrinks"]
+        assert torch.equal(sig1, sig0)
+        v1 = m2.verify(pks1, msgs, dev(bad), key_idx=kidx)
+        assert np.array_equal(v1, v0) and not v1[::9].any() and v1[1::9].all()
+        st = hp2.stats()
+        assert s_keygen > 0 and s_sign > s_keygen, st          # both pass sizes had to come down below the call's size
+        # a cap too small even for the smallest pass is an error, not a crash -- and the context recovers when it is lifted
+        hp3 = HotPath(0)
+        try:
+            hp3.set_option(_lib.OPT_WORKSPACE_CAP_MB, 1)
+            with pytest.raises(_lib.MldsaError) as e:
+                MlDsa(pset, hotpath=hp3).keygen_from_seed(xi)
+            assert e.value.code == _lib.ERR_NOMEM
+            hp3.set_option(_lib.OPT_WORKSPACE_CAP_MB, 0)
+            pk3, _ = MlDsa(pset, hotpath=hp3).keygen_from_seed(xi[:100])
+            assert torch.equal(pk3, pk0[:100])
+        finally:
+            hp3.close()
+    finally:
+        hp2.close()
+
+
+# ------------------------------------------------------------------------------ page-locked extents (host_api.hip:382)
+def test_partially_registered_signature_buffer_takes_the_safe_path(sets):
+    """mldsa_sign_host writes finished signatures straight into a page-locked caller buffer (k_export_done).  The decision used to
+    look at the FIRST byte only: a buffer whose head alone is registered (hipHostRegister of a sub-range) would make the GPU store
+    into unmapped host memory -- a fault that aborts the process.  The whole extent is checked now; such a buffer goes through
+    the sub-batch path and the signatures are the same."""
+    m = sets[44]
+    hip = C.CDLL("libamdhip64.so")
+    n, nk = 20000, 8        # > 16 384 ops: the size range of the direct export
+    xi = np.frombuffer(b"".join(shake(b"pin-key", i) for i in range(nk)), dtype=np.uint8)
+    pk, sk = m.keygen_host(xi)
+    msgs = [shake(b"pin-msg", i) for i in range(n)]
+    rnd = np.frombuffer(b"".join(shake(b"pin-rnd", i) for i in range(n)), dtype=np.uint8)
+    kidx = (np.arange(n) % nk).astype(np.uint32)
+    want = m.sign_host(sk, msgs, rnd, key_idx=kidx)          # pageable output
+    # fully page-locked output: the direct path
+    pinned = C.c_void_p()
+    assert m.lib.mldsa_host_alloc(C.byref(pinned), n * m.SIG_LEN) == 0
+    try:
+        full = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8)), shape=(n * m.SIG_LEN,)).reshape(n, m.SIG_LEN)
+        full[:] = 0
+        st = np.zeros(n, dtype=np.int32)
+        got = m.sign_host(sk, msgs, rnd, key_idx=kidx, out=(full, st))
+        assert np.array_equal(got, want)
+    finally:
+        m.lib.mldsa_host_free(pinned)
+    # head registered, tail pageable
+    raw = np.zeros(n * m.SIG_LEN + 8192, dtype=np.uint8)
+    base = (raw.ctypes.data + 4095) & ~4095
+    view = raw[base - raw.ctypes.data:][:n * m.SIG_LEN].reshape(n, m.SIG_LEN)
+    reg_bytes = (n * m.SIG_LEN // 3) & ~4095
+    assert hip.hipHostRegister(C.c_void_p(base), C.c_size_t(reg_bytes), C.c_uint(0)) == 0
+    try:
+        st = np.zeros(n, dtype=np.int32)
+        got = m.sign_host(sk, msgs, rnd, key_idx=kidx, out=(view, st))
+        assert np.array_equal(got, want) and (st == 0).all()
+        assert m.verify_host(pk, msgs, got, key_idx=kidx).all()
+    finally:
+        hip.hipHostUnregister(C.c_void_p(base))
+
+
+# ------------------------------------------------------------------------------ device-resident group calls
+@pytest.mark.parametrize("devices", [[0, 0, 0], [0]])
+def test_device_resident_group_calls_match_the_single_context(sets, devices):
+    """mldsa_keygen_group / mldsa_sign_group / mldsa_verify_group: slice i of the batch already lives on device
+    i; one host thread drives all of them.  Byte-identical to the single-context calls on the same ops, ragged split and an empty
+    slice included; wait=0 + mldsa_group_sync; and the verdicts gathered with mldsa_group_allgather WITHOUT a host
+    synchronisation in between (the gather waits for each context's last call on the device).  src/traits.rs:118-308, 330-362."""
+    from fips204_amd.ml_dsa import MlDsaGroup
+    pset = 65
+    m = sets[pset]
+    g = MlDsaGroup(pset, devices)
+    N = len(devices)
+    try:
+        for n, nk in ((1001, 37), (2, 2), (4099, 64)):
+            rng = np.random.default_rng(n)
+            xi = np.frombuffer(b"".join(shake(b"dg-key", i) for i in range(nk)), dtype=np.uint8).reshape(nk, 32)
+            msgs = [shake(b"dg-msg", i, int(rng.integers(0, 120))) for i in range(n)]
+            ctxs = [shake(b"dg-ctx", i, i % 5) for i in range(n)]
+            rnd = np.frombuffer(b"".join(shake(b"dg-rnd", i) for i in range(n)), dtype=np.uint8).reshape(n, 32)
+            kidx = rng.integers(0, nk, n).astype(np.uint32)
+            # single context
+            pk0, sk0 = m.keygen_from_seed(dev(xi))
+            sks0, pks0 = m.private_keys_from_bytes(sk0), m.public_keys_from_bytes(pk0)
+            sig0 = host(m.try_sign_with_seed(sks0, msgs, [bytes(r) for r in rnd], ctxs=ctxs, key_idx=kidx)).copy()
+            bad = sig0.copy()
+            bad[::4, 9] ^= 0x10
+            v0 = m.verify(pks0, msgs, dev(bad), ctxs=ctxs, key_idx=kidx)
+            # keygen: the seeds sharded
+            ks = []
+            for i in range(N):
+                a, c = g.shard(nk, i)
+                ks.append(dict(xi=dev(xi[a:a + c]) if c else torch.zeros(32, dtype=torch.uint8, device="cuda"),
+                               pk=torch.zeros((max(c, 1), m.PK_LEN), dtype=torch.uint8, device="cuda"),
+                               sk=torch.zeros((max(c, 1), m.SK_LEN), dtype=torch.uint8, device="cuda"), n_keys=c))
+            g.keygen_group(ks, wait=False)
+            g.sync()
+            pk1 = np.concatenate([host(s["pk"])[:s["n_keys"]] for s in ks])
+            sk1 = np.concatenate([host(s["sk"])[:s["n_keys"]] for s in ks])
+            assert np.array_equal(pk1, host(pk0)) and np.array_equal(sk1, host(sk0))
+            # sign + verify: every device holds the whole (small) key table, the ops are sharded
+            per = -(-n // N)
+            oks = [torch.full((per * N,), 7, dtype=torch.uint8, device="cuda") for _ in range(N)]
+            ss, vs = [], []
+            for i in range(N):
+                a, c = g.shard(n, i)
+                mi = g.on_device(i)
+                sks_i, pks_i = mi.private_keys_from_bytes(sk0), mi.public_keys_from_bytes(pk0)
+                mf, mo = table(msgs[a:a + c])
+                cf, co = table(ctxs[a:a + c])
+                common = dict(msg_buf=dev(mf), msg_off=dev_off(mo), ctx_buf=dev(cf), ctx_off=dev_off(co),
+                              key_idx=dev(kidx[a:a + c].view(np.int32)) if c else None, n_ops=c)
+                ss.append(dict(common, sks=sks_i, rnd=dev(rnd[a:a + c]) if c else torch.zeros(32, dtype=torch.uint8, device="cuda"),
+                               sigs=torch.zeros((max(c, 1), m.SIG_LEN), dtype=torch.uint8, device="cuda"),
+                               status=torch.full((max(c, 1),), 5, dtype=torch.int32, device="cuda")))
+                vs.append(dict(common, pks=pks_i, sigs=dev(bad[a:a + c]) if c else torch.zeros(m.SIG_LEN, dtype=torch.uint8, device="cuda"),
+                               ok=oks[i][a:a + c] if c else oks[i][:0]))
+            torch.cuda.synchronize()
+            for wait in (True, False):
+                for s in ss:
+                    s["sigs"].zero_()
+                g.sign_group(ss, wait=wait)
+                if not wait:
+                    g.sync()
+                sig1 = np.concatenate([host(s["sigs"])[:s["n_ops"]] for s in ss])
+                assert np.array_equal(sig1, sig0), (n, wait)
+                assert all((host(s["status"])[:s["n_ops"]] == 0).all() for s in ss)
+            # verify without waiting, then gather: no host synchronisation between the two
+            for i in range(N):   # (an empty slice's view cannot carry a device pointer: give the call a dummy)
+                if vs[i]["n_ops"] == 0:
+                    vs[i]["ok"] = torch.zeros(1, dtype=torch.uint8, device="cuda")
+            g.verify_group(vs, wait=False)
+            g.allgather(oks, n, use_rccl=0)
+            for b in oks:
+                assert np.array_equal(host(b)[:n].astype(bool), v0), n
+            g.verify_group(vs, wait=True)
+            assert np.array_equal(np.concatenate([host(oks[i])[g.shard(n, i)[0]:sum(g.shard(n, i))] for i in range(N)]).astype(bool), v0)
+    finally:
+        g.close()
