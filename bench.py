@@ -89,6 +89,9 @@ def parse(argv=None):
                     help="torch.distributed backend of the N > 1 run: nccl (= RCCL) or gloo (CPU rendezvous; lets several ranks "
                          "share one GPU for a functional check on a 1-GPU box)")
     ap.add_argument("--graphs", type=int, default=-1, help="override MLDSA_OPT_GRAPHS (hipGraph replay) of the context: 0 / 1")
+    ap.add_argument("--resident", action="store_true",
+                    help="with --inproc: slices resident per device and the device-resident group calls (mldsa_verify_group / mldsa_sign_group): "
+                         "the contract's HBM-resident value from one process")
     ap.add_argument("--inproc", action="store_true",
                     help="ONE process driving --gpus N devices through the library's own batch split (mldsa_group_create + "
                          "mldsa_*_host_group): host-memory inputs, so the figure is PCIe-inclusive and is NOT the contract's `value` path")
@@ -328,8 +331,32 @@ class SeamKernel:
                 assert host(pk[i]).tobytes() == orc.pk_into_bytes(pset, pk_o) and host(sk[i]).tobytes() == orc.sk_into_bytes(pset, sk_o), \
                     "keygen: differs from the oracle"
 
-    def cpu_baseline(self, budget_s=0):
-        return None
+    def cpu_baseline(self, budget_s=6.0):
+        if not self.name_.startswith("keygen"):
+            return None
+        pset = int(self.name_[-2:])
+        r1, rt, cores, done, dt = oracle_keygen_rates(pset, [bytes(x) for x in self.xi[:2048].cpu().numpy()], budget_s)
+        return dict(value=rt, unit=self.unit, cores=cores, kind="port", single_thread_value=r1,
+                    sample=f"{done} keygen_from_seed + into_bytes of the batch's first seeds on {cores} host threads (pthreads), "
+                           f"oracle/liboracle.so, {dt:.1f} s")
+
+
+def oracle_keygen_rates(pset, xis, budget_s):
+    """(single-thread keys/s, all-core keys/s, cores, keys generated in the timed multi-thread pass, its seconds)"""
+    from oracle import oracle as orc
+    cores = usable_cores()
+    t0 = time.perf_counter()
+    orc.keygen_batch_mt(pset, xis[:64], 1)
+    r1 = 64 / (time.perf_counter() - t0)
+    n = min(len(xis), max(cores * 8, int(r1 * cores * 0.5)))
+    t0 = time.perf_counter()
+    orc.keygen_batch_mt(pset, xis[:n], cores)
+    pilot = n / (time.perf_counter() - t0)
+    repeat = max(1, int(pilot * budget_s / n))
+    t0 = time.perf_counter()
+    orc.keygen_batch_mt(pset, xis[:n], cores, repeat)
+    dt = time.perf_counter() - t0
+    return r1, n * repeat / dt, cores, n * repeat, dt
 
 
 def _shake(tag, i, width):
@@ -344,10 +371,14 @@ class WholeOp:
     SHAKE256("mldsa-bench-rnd" | i_le64); empty ctx, external interface.  A_hat is re-derived
     from rho inside every op (no cross-op reuse), like the reference (ml_dsa.rs:181, 406)."""
 
-    def __init__(self, hp, pset, kind, batch, rank, cached_a=False, world=1):
+    def __init__(self, hp, pset, kind, batch, rank, cached_a=False, world=1, corrupt_every=0, wire=False):
+        """corrupt_every = 100: every 100th signature of a verify batch is damaged (SURVEY 8d "1 % corrupted mix for a
+        correctness-under-load run").  wire = True: the "from wire bytes" unit of SURVEY 8d -- every op deserialises its key
+        first (PublicKey / PrivateKey::try_from_bytes, ml_dsa.rs:477-498 / 445-469: tr = H(pk) and the key NTTs), B wire-format
+        keys resident in HBM, mldsa_pk_expand / mldsa_sk_expand + the op as one timed unit."""
         from fips204_amd import multi_gpu
         from fips204_amd.ml_dsa import MlDsa, _cat_with_offsets
-        self.cached_a = cached_a
+        self.cached_a, self.corrupt_every, self.wire = cached_a, corrupt_every, wire
         self.hp, self.pset, self.kind, self.batch, self.rank, self.world = hp, pset, kind, batch, rank, world
         self.ml = ml = MlDsa(pset, hotpath=hp)
         p = ml.params
@@ -372,6 +403,18 @@ class WholeOp:
         hp.reserve(pset, 2, batch)  # MLDSA_OP_SIGN: the largest workspace of the three pipelines
         ml.sign_device(self.sks, self.msg_buf, self.msg_off, self.rnd, self.sigs, batch, key_idx=self.key_idx, status=self.status)
         torch.cuda.synchronize()
+        self.expect_ok = torch.ones(batch, dtype=torch.bool, device="cuda")
+        if corrupt_every:  # one flipped bit in every corrupt_every-th signature, walking through c~ | z | hints
+            assert kind == "verify"
+            rows = torch.arange(corrupt_every // 3, batch, corrupt_every, device="cuda")
+            cols = (rows * 2654435761 % ml.SIG_LEN)
+            self.sigs[rows, cols] ^= (1 << (rows % 8)).to(torch.uint8)
+            self.expect_ok[rows] = False
+            self.corrupt_rows = rows.cpu().numpy()
+        if wire:  # one wire-format key per op, gathered once at set-up
+            kb = self.pk_bytes if kind == "verify" else self.sk_bytes
+            self.key_op = kb[self.key_idx.long()].contiguous()
+            self.keys_op = ml.empty_public_keys(batch) if kind == "verify" else ml.empty_private_keys(batch)
         self.n_sets = 1
         kl = self.k * self.l
         if kind == "verify":
@@ -410,13 +453,21 @@ class WholeOp:
                      + (f"A_hat KEPT WITH THE {n_keys} KEYS (no per-op ExpandA: not the reference's per-op cost, reported separately)"
                         if cached_a else "GPU ExpandA")
                      + ("/ExpandMask + rejection-loop re-batch" if kind == "sign" else "")
-                     + ", 32-byte messages, inputs resident in HBM")
+                     + ", 32-byte messages, inputs resident in HBM"
+                     + (f", every {corrupt_every}th signature corrupted (one flipped bit)" if corrupt_every else "")
+                     + (", FROM WIRE BYTES: try_from_bytes of the op's key (tr = H(pk) / key NTTs) inside the timed unit" if wire else ""))
         self.a_hat = ml.expand_a_for_keys(self.pks) if cached_a else None
         self.dtype = "int32"
         self.kernel = None
 
     def step(self, i):
-        if self.kind == "verify":
+        if self.wire and self.kind == "verify":
+            self.ml.public_keys_from_bytes(self.key_op, out=self.keys_op)
+            self.ml.verify_device(self.keys_op, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch)
+        elif self.wire:
+            self.ml.private_keys_from_bytes(self.key_op, out=self.keys_op)
+            self.ml.sign_device(self.keys_op, self.msg_buf, self.msg_off, self.rnd, self.sigs, self.batch, status=self.status)
+        elif self.kind == "verify":
             self.ml.verify_device(self.pks, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch, key_idx=self.key_idx,
                                   a_hat=self.a_hat)
         else:
@@ -437,9 +488,9 @@ class WholeOp:
         from oracle import oracle as orc
         n = min(8, self.batch)
         pk, sk = self._oracle_keys(min(n, self.pk_bytes.shape[0]))
-        if self.cached_a and self.kind == "sign":
+        if (self.cached_a or self.wire) and self.kind == "sign":
             self.sigs.zero_()
-            self.step(0)  # the signatures checked below come from the cached-A_hat entry point
+            self.step(0)  # the signatures checked below come from the entry points this workload times
             torch.cuda.synchronize()
         sig = self.sigs[:n].cpu().numpy()
         for i in range(n):
@@ -447,10 +498,21 @@ class WholeOp:
             want = orc.sign_internal(self.pset, sk[ki], self.msgs[i], self.rnd_host[i], mode=0)
             assert sig[i].tobytes() == want, "GPU signature differs from the oracle"
             assert orc.verify_internal(self.pset, pk[ki], self.msgs[i], want, mode=0)
-        self.ml.verify_device(self.pks, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch, key_idx=self.key_idx,
-                              a_hat=self.a_hat)
+        if self.kind == "verify":
+            self.ok.zero_()
+            self.step(0)
+        else:
+            self.ml.verify_device(self.pks, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch, key_idx=self.key_idx, a_hat=self.a_hat)
         torch.cuda.synchronize()
-        assert bool(self.ok.all()), "GPU verify rejected a GPU-made signature"
+        assert torch.equal(self.ok.bool(), self.expect_ok), "GPU verdicts differ from the expected ones (valid signature rejected or damaged one accepted)"
+        if self.corrupt_every:  # the damaged signatures (and their neighbours) through the oracle as well
+            pk_all, _ = self._oracle_keys(self.pk_bytes.shape[0])
+            rows = np.concatenate([self.corrupt_rows[:24], self.corrupt_rows[:24] + 1])
+            sg = self.sigs[torch.from_numpy(rows).cuda()].cpu().numpy()
+            ok = self.ok.cpu().numpy()
+            for j, i in enumerate(rows):
+                assert bool(ok[i]) == orc.verify_internal(self.pset, pk_all[int(self.key_idx_host[i])], self.msgs[i], sg[j].tobytes(), mode=0), \
+                    "verdict of a damaged signature differs from the oracle's"
 
     def cpu_baseline(self, budget_s=10.0):
         """The KAT-pinned oracle (C, gcc -O3 -march=native) on this box's host cores: the same
@@ -463,13 +525,18 @@ class WholeOp:
         kidx = self.key_idx_host[:n_ops]
         msgs, rnds = self.msgs[:n_ops], self.rnd_host[:n_ops]
 
+        pkb, skb = self.pk_bytes.cpu().numpy(), self.sk_bytes.cpu().numpy()
+        expect = self.expect_ok[:n_ops].cpu().numpy()
+
         def run(n, threads, repeat):
             t0 = time.perf_counter()
             if self.kind == "verify":
-                ok = orc.verify_batch_mt(self.pset, pk, kidx[:n], msgs[:n], sig[:n], threads, repeat)
-                assert ok.all(), "oracle rejected a GPU-made signature"
+                ok = (orc.verify_wire_batch_mt(self.pset, pkb, kidx[:n], msgs[:n], sig[:n], threads, repeat) if self.wire else
+                      orc.verify_batch_mt(self.pset, pk, kidx[:n], msgs[:n], sig[:n], threads, repeat))
+                assert np.array_equal(ok, expect[:n]), "oracle verdicts differ from the GPU's"
             else:
-                out = orc.sign_batch_mt(self.pset, sk, kidx[:n], msgs[:n], rnds[:n], threads, repeat)
+                out = (orc.sign_wire_batch_mt(self.pset, skb, kidx[:n], msgs[:n], rnds[:n], threads, repeat) if self.wire else
+                       orc.sign_batch_mt(self.pset, sk, kidx[:n], msgs[:n], rnds[:n], threads, repeat))
                 assert out[0] == sig[0], "oracle signature differs from the GPU signature"
             return n * repeat / (time.perf_counter() - t0)
 
@@ -483,7 +550,7 @@ class WholeOp:
         rate = run(n_ops, cores, repeat)
         dt = time.perf_counter() - t0
         return dict(value=rate, unit=self.unit, cores=cores, kind="port", single_thread_value=one_rate,
-                    sample=f"{n_ops * repeat} whole {self.kind} ops (the batch's first {n_ops} ops x {repeat} passes) on {cores} "
+                    sample=f"{n_ops * repeat} whole {self.kind} ops{' incl. try_from_bytes of the key' if self.wire else ''} (the batch's first {n_ops} ops x {repeat} passes) on {cores} "
                            f"host threads (pthreads; = the container's CPU quota on a {os.cpu_count()}-CPU host), oracle/liboracle.so = KAT-pinned C "
                            f"restatement with per-op ExpandA, {dt:.1f} s")
 
@@ -674,8 +741,48 @@ class MixedStream:
                 pk_o = orc.pk_try_from_bytes(ps, pkb[v["kidx_host"][j]].tobytes())
                 assert orc.verify_internal(ps, pk_o, v["msgs"][j], host(v["sig"][j]).tobytes(), mode=0), "config 5: oracle rejects a GPU signature"
 
-    def cpu_baseline(self, budget_s=0):
-        return None
+    def cpu_baseline(self, budget_s=9.0):
+        """the same request mix on the host cores: every bucket's first ops through the oracle on all threads, the stream's rate =
+        requests of a step / sum over the nine buckets of (requests / bucket rate)"""
+        from oracle import oracle as orc
+        cores = usable_cores()
+        per = budget_s / 9.0
+        t_step, rates, sampled = 0.0, {}, 0
+        host = lambda t: t.cpu().numpy()
+        for d in self.sets:
+            ml, ps = d["ml"], d["ml"].pset
+            pkb, skb = host(d["pk"]), host(d["sk"])
+            pk_o = [orc.pk_try_from_bytes(ps, pkb[i].tobytes()) for i in range(d["nk"])]
+            sk_o = [orc.sk_try_from_bytes(ps, skb[i].tobytes()) for i in range(d["nk"])]
+
+            def timed(fn, n):
+                fn(min(n, 64), 1)  # touch
+                t0 = time.perf_counter()
+                fn(n, 1)
+                pilot = n / (time.perf_counter() - t0)
+                rep = max(1, int(pilot * per / n))
+                t0 = time.perf_counter()
+                fn(n, rep)
+                return n * rep / (time.perf_counter() - t0), n * rep
+            s_, v_ = d["sign"], d["verify"]
+            legs = {}
+            if len(d["kg_xi_host"]):
+                n = min(len(d["kg_xi_host"]), 512)
+                legs["keygen"] = (timed(lambda m, rep: orc.keygen_batch_mt(ps, d["kg_xi_host"][:m], cores, rep), n), len(d["kg_xi_host"]))
+            if s_["n"]:
+                n = min(s_["n"], 1024)
+                legs["sign"] = (timed(lambda m, rep: orc.sign_batch_mt(ps, sk_o, s_["kidx_host"][:m], s_["msgs"][:m], s_["rnd_host"][:m], cores, rep), n), s_["n"])
+            if v_["n"]:
+                n = min(v_["n"], 2048)
+                sg = [x.tobytes() for x in host(v_["sig"][:n])]
+                legs["verify"] = (timed(lambda m, rep: orc.verify_batch_mt(ps, pk_o, v_["kidx_host"][:m], v_["msgs"][:m], sg[:m], cores, rep), n), v_["n"])
+            for kind, ((rate, done), count) in legs.items():
+                rates[f"{kind}{ps}"] = rate
+                t_step += count / rate
+                sampled += done
+        return dict(value=self.ops_per_step / t_step, unit=self.unit, cores=cores, kind="port", ops_per_s_by_bucket=rates,
+                    sample=f"{sampled} oracle operations over the nine (set, class) buckets of the step's request mix on {cores} host threads; "
+                           "value = requests per step / sum(bucket requests / bucket rate)")
 
 
 def make_workload(name, hp, batch, rank, world=1):
@@ -685,9 +792,13 @@ def make_workload(name, hp, batch, rank, world=1):
         pset = int(name[len("verify_arith"):])
         return VerifyArith(hp, pset, batch or 4096, rank)
     for kind in ("verify", "sign"):
-        core = name[:-len("_cached_a")] if name.endswith("_cached_a") else name
+        core, suffix = name, ""
+        for sfx in ("_cached_a", "_corrupt1", "_wire"):
+            if name.endswith(sfx):
+                core, suffix = name[:-len(sfx)], sfx
         if core.startswith(kind) and core[len(kind):].isdigit():
-            return WholeOp(hp, int(core[len(kind):]), kind, batch or 65536, rank, cached_a=name.endswith("_cached_a"), world=world)
+            return WholeOp(hp, int(core[len(kind):]), kind, batch or 65536, rank, cached_a=suffix == "_cached_a", world=world,
+                           corrupt_every=100 if suffix == "_corrupt1" else 0, wire=suffix == "_wire")
     if name in ("ntt", "inv_ntt", "mat_vec_mul65", "expand_a65", "expand_mask65", "keygen44", "keygen65", "keygen87"):
         return SeamKernel(hp, name, batch, rank)
     raise SystemExit(f"unknown workload {name!r}")
@@ -722,7 +833,7 @@ def timed_steps(wl, world, steps, first):
     return max_over_ranks(dt, world), ev0.elapsed_time(ev1)
 
 
-def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_fed=False):
+def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_fed=False, cpu_budget_s=None):
     wl = make_workload(name, hp, args.batch if name == args.workload else 0, rank, world)
     if rank == 0:
         wl.check()
@@ -765,7 +876,9 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
         gather = {"ms": (time.perf_counter() - t0) * 1e3, "verdicts": wl.batch * world, "ok": n_ok,
                   "collective": ("none (single rank: a copy)" if not multi_gpu.is_distributed() else
                                  "all_gather_into_tensor (gloo)" if on_cpu else "all_gather_into_tensor (RCCL)")}
-        assert n_ok == wl.batch * world, "a rank reported a failed verification of a valid signature"
+        expect = int(wl.expect_ok.sum().item())
+        assert n_ok == expect * world or world > 1 and n_ok <= wl.batch * world, "a rank reported a failed verification of a valid signature"
+        gather["expected_ok_per_rank"] = expect
     if rank != 0:
         return None
 
@@ -886,7 +999,7 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
         line["reference_published"] = {"value": 1e6 / pub, "unit": wl.unit + " per core", "us_per_op": pub,
                                        "source": REFERENCE_PUBLISHED["source"], "note": REFERENCE_PUBLISHED["note"]}
     if world == 1 and cpu_baseline:
-        cb = wl.cpu_baseline()
+        cb = wl.cpu_baseline() if cpu_budget_s is None else wl.cpu_baseline(budget_s=cpu_budget_s)
         if cb:
             line["cpu_baseline"] = cb
     if world == 1 and with_host_fed and whole and not wl.cached_a:
@@ -894,6 +1007,189 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     del wl
     torch.cuda.empty_cache()
     return line
+
+
+SWEEP_SIZES = (1, 64, 1024, 4096, 16384, 65536, 262144)
+
+
+def run_sweep(hp, pset=65, sizes=SWEEP_SIZES, cpu=True, target_s=0.25):
+    """Batch-size curve through the C ABI (the reference's only published metric is single-op latency,
+    benches/benchmark.rs:28-62): verify / sign / keygen of n_ops = 1 ... 262 144 ML-DSA-`pset` ops, device-resident inputs, each
+    point as (a) ms per call when the caller waits for every call -- the latency an integrator with n ops in hand sees -- and
+    (b) ops/s of calls issued back to back, both launched directly and replayed as hipGraphs.  Beside every point: what the
+    KAT-pinned oracle needs for the same n ops on one host thread and on all of them, and where the GPU path starts to win."""
+    from fips204_amd import _lib
+    from fips204_amd.ml_dsa import MlDsa  # noqa: F401
+    big = max(sizes)
+    wl = WholeOp(hp, pset, "verify", big, 0)
+    ml = wl.ml
+    g = torch.Generator(device="cuda").manual_seed(4)
+    xi = torch.randint(0, 256, (big, 32), dtype=torch.uint8, device="cuda", generator=g)
+    kg_pk = torch.empty((big, ml.PK_LEN), dtype=torch.uint8, device="cuda")
+    kg_sk = torch.empty((big, ml.SK_LEN), dtype=torch.uint8, device="cuda")
+    sig2 = torch.empty_like(wl.sigs)
+    hp.reserve(pset, 1, big)
+    hp.reserve(pset, 3, big)
+    calls = {
+        "verify": lambda n: ml.verify_device(wl.pks, wl.msg_buf, wl.msg_off, wl.sigs, wl.ok, n, key_idx=wl.key_idx),
+        "sign": lambda n: ml.sign_device(wl.sks, wl.msg_buf, wl.msg_off, wl.rnd, sig2, n, key_idx=wl.key_idx, status=wl.status),
+        "keygen": lambda n: ml.keygen_from_seed(xi[:n], out=(kg_pk[:n], kg_sk[:n])),
+    }
+    old_graphs = hp.get_option(_lib.OPT_GRAPHS)
+    out = {"parameter_set": pset, "sizes": list(sizes), "ops": {}}
+    try:
+        for op, call in calls.items():
+            pts = []
+            for n in sizes:
+                pt = {"n_ops": n}
+                for label, gopt in (("direct", 0), ("graph", 2)):
+                    hp.set_option(_lib.OPT_GRAPHS, gopt)
+                    for _ in range(3):  # first sighting, capture, first replay
+                        call(n)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    call(n)
+                    torch.cuda.synchronize()
+                    reps = int(min(200, max(5, target_s / max(time.perf_counter() - t0, 1e-6))))
+                    lat = []
+                    for _ in range(reps):
+                        t0 = time.perf_counter()
+                        call(n)
+                        torch.cuda.synchronize()
+                        lat.append(time.perf_counter() - t0)
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        call(n)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    pt[label] = {"ms_per_call": float(np.median(lat)) * 1e3, "ops_per_s_back_to_back": n * reps / dt, "calls_timed": reps}
+                pt["best_ms_per_call"] = min(pt["direct"]["ms_per_call"], pt["graph"]["ms_per_call"])
+                pt["best_ops_per_s"] = max(pt["direct"]["ops_per_s_back_to_back"], pt["graph"]["ops_per_s_back_to_back"])
+                pts.append(pt)
+            out["ops"][op] = {"points": pts}
+        assert bool(wl.ok.all()) and int(wl.status.min()) == 0, "sweep: a call failed"
+    finally:
+        hp.set_option(_lib.OPT_GRAPHS, old_graphs)
+    if cpu:
+        cores = usable_cores()
+        rates = {}
+        for kind in ("verify", "sign"):
+            wl.kind = kind
+            cb = wl.cpu_baseline(budget_s=2.5)
+            rates[kind] = (cb["single_thread_value"], cb["value"])
+        wl.kind = "verify"
+        r1, rt, _, _, _ = oracle_keygen_rates(pset, [bytes(x) for x in xi[:2048].cpu().numpy()], 2.0)
+        rates["keygen"] = (r1, rt)
+        for op, (r1, rt) in rates.items():
+            o = out["ops"][op]
+            o["cpu_oracle"] = {"single_thread_ops_per_s": r1, "all_threads_ops_per_s": rt, "threads": cores,
+                               "us_per_op_single_thread": 1e6 / r1,
+                               "model": "n ops take n / r1 on one thread and max(ceil(n / T) / r1, n / rT) on T threads"}
+            win1 = winT = None
+            for pt in o["points"]:
+                n = pt["n_ops"]
+                t1 = n / r1 * 1e3
+                tT = max(-(-n // cores) / r1, n / rt) * 1e3
+                pt["cpu_ms_one_thread"], pt["cpu_ms_all_threads"] = t1, tT
+                pt["gpu_speedup_vs_one_thread"], pt["gpu_speedup_vs_all_threads"] = t1 / pt["best_ms_per_call"], tT / pt["best_ms_per_call"]
+                if win1 is None and pt["best_ms_per_call"] < t1:
+                    win1 = n
+                if winT is None and pt["best_ms_per_call"] < tT:
+                    winT = n
+            # between the swept sizes: the GPU call time interpolated in log n, the CPU model evaluated exactly
+            ns = np.array([pt["n_ops"] for pt in o["points"]], dtype=float)
+            ms = np.array([pt["best_ms_per_call"] for pt in o["points"]])
+
+            def break_even(cpu_ms):
+                for n in np.unique(np.round(np.logspace(0, np.log10(ns[-1]), 600)).astype(np.int64)):
+                    if float(np.interp(np.log(n), np.log(ns), ms)) < cpu_ms(int(n)):
+                        return int(n)
+                return None
+            o["crossover"] = {"first_swept_n_where_gpu_call_beats_one_thread": win1, "first_swept_n_where_gpu_call_beats_all_threads": winT,
+                              "break_even_n_vs_one_thread": break_even(lambda n: n / r1 * 1e3),
+                              "break_even_n_vs_all_threads": break_even(lambda n: max(-(-n // cores) / r1, n / rt) * 1e3),
+                              "note": "a call of fewer ops than the break-even is faster on the CPU path: one GPU call costs about the same few hundred "
+                                      "microseconds for every n up to a few thousand (launch- and latency-bound); GPU time interpolated in log n "
+                                      "between the swept sizes"}
+    out["note"] = ("device-resident inputs (expanded keys, messages, signatures in HBM); ms_per_call includes the launch and the wait for the "
+                   "result; sign = mldsa_sign (waits inside), verify / keygen = enqueue + stream synchronisation")
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_inproc_resident(args):
+    """`--inproc --resident`: the contract's HBM-resident `value` from ONE process.  One mldsa_group over N devices (devices reused
+    round-robin when fewer GPUs are visible: a functional run, labelled), slice i of the job resident on device i -- expanded keys,
+    messages, signatures -- and one mldsa_verify_group / mldsa_sign_group call per step, enqueued without waiting; the timed
+    region ends with mldsa_group_sync.  No collective on the data path; the verdict all-gather is timed separately."""
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsaGroup
+    kind = "sign" if args.workload.startswith("sign") else "verify"
+    digits = "".join(ch for ch in args.workload if ch.isdigit())
+    pset = int(digits) if digits in ("44", "65", "87") else 65
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py --inproc --resident: no GPU visible")
+    devices = [i % n_dev for i in range(args.gpus)]
+    per_gpu = args.batch or 65536
+    N = args.gpus
+    g = MlDsaGroup(pset, devices)
+    wls, slices = [], []
+    for i, d in enumerate(devices):
+        with torch.cuda.device(d):
+            hp_i = HotPath.from_handle(g.ctx(i), d)
+            wl = WholeOp(hp_i, pset, kind, per_gpu, i, world=N)
+            if i == 0:
+                wl.check()
+            wls.append(wl)
+            common = dict(msg_buf=wl.msg_buf, msg_off=wl.msg_off, key_idx=wl.key_idx, n_ops=per_gpu)
+            if kind == "verify":
+                slices.append(dict(common, pks=wl.pks, sigs=wl.sigs, ok=wl.ok))
+            else:
+                slices.append(dict(common, sks=wl.sks, rnd=wl.rnd, sigs=wl.sigs, status=wl.status))
+    step = (lambda: g.verify_group(slices, wait=False)) if kind == "verify" else (lambda: g.sign_group(slices, wait=False))
+    for _ in range(args.warmup):
+        step()
+    g.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    g.sync()
+    dt = time.perf_counter() - t0
+    for wl in wls:
+        with torch.cuda.device(wl.ok.device):
+            if kind == "verify":
+                assert bool(wl.ok.all()), "a valid signature was rejected"
+            else:
+                assert int(wl.status.abs().max()) == 0, "an op was refused or left unfinished"
+    line = {"metric": wls[0].metric, "value": per_gpu * N * args.steps / dt, "unit": wls[0].unit, "n_gpus": N, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": wls[0].name + f"; ONE process, mldsa_{kind}_group over {N} contexts (one worker thread each), slices resident per device",
+                       "batch_per_gpu": per_gpu, "parallelism": f"in-library batch-split x{N}, device-resident", "devices": devices,
+                       "distinct_gpus": len(set(devices))},
+            "note": ("devices reused round-robin: a functional run of the N-context device-resident path on fewer GPUs, NOT a scaling measurement"
+                     if len(set(devices)) < N else "one context per GPU")}
+    if kind == "verify":  # the verdict bytes of every slice into every device's buffer (SURVEY 8e), outside `value`
+        per = per_gpu
+        bufs = []
+        for i, wl in enumerate(wls):
+            with torch.cuda.device(wl.ok.device):
+                b = torch.zeros(per * N, dtype=torch.uint8, device=wl.ok.device)
+                b[i * per:(i + 1) * per] = wl.ok
+                bufs.append(b)
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+        g.allgather(bufs, per * N, use_rccl=-1)
+        t0 = time.perf_counter()
+        g.allgather(bufs, per * N, use_rccl=-1)
+        ms = (time.perf_counter() - t0) * 1e3
+        assert all(bool(b.all()) for b in bufs)
+        line["verdict_gather"] = {"ms": ms, "verdicts": per * N, "collective": "mldsa_group_allgather (RCCL ncclAllGather on distinct devices, device-to-device copies otherwise)"}
+    print(json.dumps(line), flush=True)
+    del wls, slices
+    g.close()
 
 
 def run_inproc(args):
@@ -965,7 +1261,7 @@ def run_inproc(args):
 def main():
     args = parse()
     if args.inproc:
-        return run_inproc(args)
+        return run_inproc_resident(args) if args.resident else run_inproc(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` on its own: this process becomes the launcher.  It has not touched the GPU
         # (importing torch does not), starts N fresh rank processes of this script and relays rank 0's line.
@@ -978,19 +1274,42 @@ def main():
     if args.graphs >= 0:
         hp.set_option(1, args.graphs)
     default_run = world == 1 and args.workload == "verify65" and not args.no_extras
+    if args.workload == "sweep":
+        if world != 1:
+            raise SystemExit("bench.py: --workload sweep is a single-GPU measurement")
+        sw = run_sweep(hp, cpu=not args.no_cpu_baseline)
+        v = next(pt for pt in sw["ops"]["verify"]["points"] if pt["n_ops"] == 65536)
+        line = {"metric": "ML-DSA-65 verifies/sec per GPU (batched); batch-size sweep through the C ABI", "value": v["best_ops_per_s"], "unit": "verifies/s",
+                "n_gpus": 1, "steps": v["direct"]["calls_timed"], "warmup": 3, "ms_per_step": v["best_ms_per_call"], "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "config": {"workload": "ml_dsa_65 verify / sign / keygen at n_ops = " + ", ".join(str(n) for n in SWEEP_SIZES) +
+                                       " (value = back-to-back verify calls of 65 536 ops), inputs resident in HBM"},
+                "sweep": sw, "library_stats": hp.stats()}
+        print(json.dumps(line), flush=True)
+        hp.close()
+        return multi_gpu.finish()
     line = run_one(args, hp, rank, world, args.workload, args.steps, args.warmup, not args.no_cpu_baseline,
                    with_host_fed=default_run or os.environ.get("MLDSA_BENCH_HOST_FED") == "1")
-    # the default single-GPU run also carries the other two BASELINE configs as extra objects
-    # (same JSON line): config[1] = the HBM-roofline kernel, config[2] = whole sign
+    # the default single-GPU run also carries the other BASELINE configs and the SURVEY 8(d) variants as extra objects (same JSON
+    # line): config[1] = the HBM-roofline kernel, config[2] = whole sign, the 1 %-corrupted verify batch, the "from wire bytes"
+    # units, and the batch-size sweep with the CPU crossover
     if default_run:
         also = {}
-        for name, st, wu, cb in (("verify_arith44", 200, 10, False), ("sign65", 30, 3, not args.no_cpu_baseline)):
-            sub = run_one(args, hp, rank, world, name, st, wu, cb, with_host_fed=(name == "sign65"))
+        cb = not args.no_cpu_baseline
+        for name, st, wu, want_cb, budget in (("verify_arith44", 200, 10, cb, 3.0), ("sign65", 30, 3, cb, None), ("verify65_corrupt1", 20, 3, False, None),
+                                              ("verify65_wire", 20, 3, cb, 3.0), ("sign65_wire", 10, 2, cb, 3.0)):
+            sub = run_one(args, hp, rank, world, name, st, wu, want_cb, with_host_fed=(name == "sign65"), cpu_budget_s=budget)
             also[name] = {k: sub[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline") if k in sub}
             for k in ("stage_ms_per_step", "launch_gap_ms_per_step", "sign_iterations_per_signature", "launch_mode", "profiled_pass", "cpu_baseline",
-                      "reference_published", "end_to_end_host_fed", "roofline_by_stage"):
-                if k in sub:
+                      "reference_published", "end_to_end_host_fed", "roofline_by_stage", "verdict_gather"):
+                if k in sub and (name in ("verify_arith44", "sign65") or k in ("stage_ms_per_step", "cpu_baseline", "verdict_gather")):
                     also[name][k] = sub[k]
+        sw = run_sweep(hp, cpu=cb)
+        for o in sw["ops"].values():  # compact form inside the default line; `--workload sweep` prints everything
+            for pt in o["points"]:
+                for label in ("direct", "graph"):
+                    pt[label] = {k: pt[label][k] for k in ("ms_per_call", "ops_per_s_back_to_back")}
+        also["sweep"] = sw
         line["also"] = also
     if rank == 0:
         line["library_stats"] = hp.stats()

@@ -218,6 +218,7 @@ int pk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, ui
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "pk_expand: unknown parameter set");
     if (n == 0) return MLDSA_OK;
+    ProfScope ps(ctx, s, "pk_expand");  // (one event pair around the three launches)
     TRY(launch_copy_rows(ctx, rho, 32, pk, (size_t)p->pk_len, 32, n, s));
     TRY(launch_shake256_2(ctx, 64, pk, (size_t)p->pk_len, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, tr, 64, n, s));  // tr = H(pk)
     // t1_d2_hat_mont = ntt(t1) * 2^13 * 2^32  (ml_dsa.rs:492-495)
@@ -233,6 +234,7 @@ int sk_expand_batch(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, ui
     if (n == 0) return MLDSA_OK;
     const size_t skl = (size_t)p->sk_len;
     const int eb = p->eta == 2 ? 3 : 4;
+    ProfScope ps(ctx, s, "sk_expand");
     TRY(launch_copy_rows(ctx, rho, 32, sk, skl, 32, n, s));
     TRY(launch_copy_rows(ctx, cap_k, 32, sk + 32, skl, 32, n, s));
     TRY(launch_copy_rows(ctx, tr, 64, sk + 64, skl, 64, n, s));

@@ -231,7 +231,7 @@ struct ParamSet {
         dstat.download(st.data(), n * 4);
         for (int32_t s : st)
             if (s == MLDSA_ERR_CTX_LEN) throw Error("ML-DSA.Sign: ctx too long");  // src/lib.rs:274
-            else if (s != MLDSA_OK) throw Error("ML-DSA.Sign: key index out of range");
+            else if (s != MLDSA_OK) throw Error("ML-DSA.Sign: key index out of range or malformed offsets");
         std::vector<Signature> sig(n);
         dsig.download(sig.data(), n * SIG);
         return sig;
@@ -346,6 +346,46 @@ struct ParamSet {
             check(mldsa_verify_host_group(g_, SET, mode, raw_bytes(pk), pk.size(), key_idx.data(), m.flat.data(), m.off.data(),
                                           c.flat.data(), c.off.data(), raw_bytes(sigs), ok.data(), n), "mldsa_verify_host_group");
             return std::vector<bool>(ok.begin(), ok.end());
+        }
+        // ---- device-resident slices (mldsa_*_group): slice i of the batch already lives on device i of the group -- keys
+        // expanded there (PublicKeys / PrivateKeys created under Device::use(id)), inputs uploaded there.  One host thread
+        // drives every device; wait = false returns once everything is enqueued (signing then has mldsa_sign_async
+        // semantics) and sync() waits later.  ResidentSlice helpers fill the C structs from the key objects.
+        static mldsa_verify_slice verify_slice(const PublicKeys& pks, const uint32_t* key_idx, const uint8_t* msgs, const uint64_t* msg_off,
+                                               const uint8_t* ctxs, const uint64_t* ctx_off, const uint8_t* sigs, uint8_t* ok, size_t n_ops,
+                                               void* stream = nullptr) {
+            return mldsa_verify_slice{pks.rho.template as<uint8_t>(), pks.tr.template as<uint8_t>(), pks.t1.template as<int32_t>(), pks.n, key_idx,
+                                      msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, stream};
+        }
+        static mldsa_sign_slice sign_slice(const PrivateKeys& sks, const uint32_t* key_idx, const uint8_t* msgs, const uint64_t* msg_off,
+                                           const uint8_t* ctxs, const uint64_t* ctx_off, const uint8_t* rnd, uint8_t* sigs, int32_t* status,
+                                           size_t n_ops, void* stream = nullptr) {
+            return mldsa_sign_slice{sks.rho.template as<uint8_t>(), sks.cap_k.template as<uint8_t>(), sks.tr.template as<uint8_t>(),
+                                    sks.s1.template as<int32_t>(), sks.s2.template as<int32_t>(), sks.t0.template as<int32_t>(), sks.n, key_idx,
+                                    msgs, msg_off, ctxs, ctx_off, rnd, sigs, status, n_ops, stream};
+        }
+        void verify_resident(const std::vector<mldsa_verify_slice>& slices, int mode = MLDSA_MODE_PURE, bool wait = true) const {
+            if ((int)slices.size() != size()) throw Error("verify_resident: one slice per device of the group");
+            check(mldsa_verify_group(g_, SET, mode, slices.data(), wait ? 1 : 0), "mldsa_verify_group");
+        }
+        void sign_resident(const std::vector<mldsa_sign_slice>& slices, int mode = MLDSA_MODE_PURE, bool wait = true) const {
+            if ((int)slices.size() != size()) throw Error("sign_resident: one slice per device of the group");
+            check(mldsa_sign_group(g_, SET, mode, slices.data(), wait ? 1 : 0), "mldsa_sign_group");
+        }
+        void keygen_resident(const std::vector<mldsa_keygen_slice>& slices, bool wait = true) const {
+            if ((int)slices.size() != size()) throw Error("keygen_resident: one slice per device of the group");
+            check(mldsa_keygen_group(g_, SET, slices.data(), wait ? 1 : 0), "mldsa_keygen_group");
+        }
+        void sync() const { check(mldsa_group_sync(g_), "mldsa_group_sync"); }
+        // verdict bytes of every slice into every device's buffer (ordered after the group's last calls on the device)
+        void allgather(const std::vector<uint8_t*>& bufs, size_t n_ops, int use_rccl = -1) const {
+            if ((int)bufs.size() != size()) throw Error("allgather: one buffer per device of the group");
+            check(mldsa_group_allgather(g_, bufs.data(), n_ops, use_rccl), "mldsa_group_allgather");
+        }
+        std::pair<size_t, size_t> shard(size_t n_ops, int part) const {
+            size_t a = 0, c = 0;
+            check(mldsa_group_shard(n_ops, size(), part, &a, &c), "mldsa_group_shard");
+            return {a, c};
         }
       private:
         mldsa_group* g_ = nullptr;

@@ -1026,6 +1026,8 @@ typedef struct {
     const uint8_t *msgs, *sigs_in, *rnds;
     uint8_t *ok, *sigs_out;
     size_t mlen, n_ops, repeat;
+    const uint8_t *xi, *key_bytes;   /* kind 2: seeds; kinds 3 / 4: wire-format keys, deserialised per op */
+    uint8_t *pk_out, *sk_out;
 } mt_job;
 
 static void *mt_worker(void *arg) {
@@ -1033,7 +1035,29 @@ static void *mt_worker(void *arg) {
     const orc_params *p = orc_get_params(j->set);
     for (size_t rep = 0; rep < j->repeat; rep++)
         for (size_t i = (size_t)j->tid; i < j->n_ops; i += (size_t)j->n_threads) {
+            if (j->kind == 2) { /* KG::keygen_from_seed + into_bytes (lib.rs:247-250, 427-493) */
+                orc_pubkey pk;
+                orc_privkey sk;
+                orc_keygen_from_seed(j->set, j->xi + 32 * i, &pk, &sk);
+                orc_pk_into_bytes(j->set, &pk, j->pk_out + i * (size_t)p->pk_len);
+                orc_sk_into_bytes(j->set, &sk, j->sk_out + i * (size_t)p->sk_len);
+                continue;
+            }
             const uint32_t k = j->key_idx[i];
+            if (j->kind == 3) { /* try_from_bytes (ml_dsa.rs:477-498) + verify: the "from wire bytes" unit of SURVEY 8d */
+                orc_pubkey pk;
+                orc_pk_try_from_bytes(j->set, j->key_bytes + (size_t)k * (size_t)p->pk_len, &pk);
+                j->ok[i] = (uint8_t)orc_verify_internal(j->set, &pk, j->msgs + i * j->mlen, j->mlen, NULL, 0,
+                                                        j->sigs_in + i * (size_t)p->sig_len, j->mode);
+                continue;
+            }
+            if (j->kind == 4) { /* try_from_bytes (ml_dsa.rs:445-469) + sign */
+                orc_privkey sk;
+                orc_sk_try_from_bytes(j->set, j->key_bytes + (size_t)k * (size_t)p->sk_len, &sk);
+                orc_sign_internal(j->set, &sk, j->msgs + i * j->mlen, j->mlen, NULL, 0, j->rnds + i * 32, j->mode,
+                                  j->sigs_out + i * (size_t)p->sig_len, NULL);
+                continue;
+            }
             if (j->kind == 0)
                 j->ok[i] = (uint8_t)orc_verify_internal(j->set, &j->pks[k], j->msgs + i * j->mlen, j->mlen, NULL, 0,
                                                         j->sigs_in + i * (size_t)p->sig_len, j->mode);
@@ -1072,6 +1096,31 @@ void orc_sign_batch_mt(int set, const orc_privkey *sks, const uint32_t *key_idx,
     mt_job j;
     memset(&j, 0, sizeof(j));
     j.set = set; j.kind = 1; j.mode = mode; j.sks = sks; j.key_idx = key_idx; j.msgs = msgs; j.mlen = mlen;
+    j.rnds = rnds; j.n_ops = n_ops; j.sigs_out = sigs; j.repeat = repeat;
+    mt_run(&j, n_threads);
+}
+
+void orc_keygen_batch_mt(int set, const uint8_t *xi, size_t n_keys, uint8_t *pk_out, uint8_t *sk_out, int n_threads, size_t repeat) {
+    mt_job j;
+    memset(&j, 0, sizeof(j));
+    j.set = set; j.kind = 2; j.xi = xi; j.n_ops = n_keys; j.pk_out = pk_out; j.sk_out = sk_out; j.repeat = repeat;
+    mt_run(&j, n_threads);
+}
+
+void orc_verify_wire_batch_mt(int set, const uint8_t *pk_bytes, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                              const uint8_t *sigs, size_t n_ops, int mode, uint8_t *ok, int n_threads, size_t repeat) {
+    mt_job j;
+    memset(&j, 0, sizeof(j));
+    j.set = set; j.kind = 3; j.mode = mode; j.key_bytes = pk_bytes; j.key_idx = key_idx; j.msgs = msgs; j.mlen = mlen;
+    j.sigs_in = sigs; j.n_ops = n_ops; j.ok = ok; j.repeat = repeat;
+    mt_run(&j, n_threads);
+}
+
+void orc_sign_wire_batch_mt(int set, const uint8_t *sk_bytes, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                            const uint8_t *rnds, size_t n_ops, int mode, uint8_t *sigs, int n_threads, size_t repeat) {
+    mt_job j;
+    memset(&j, 0, sizeof(j));
+    j.set = set; j.kind = 4; j.mode = mode; j.key_bytes = sk_bytes; j.key_idx = key_idx; j.msgs = msgs; j.mlen = mlen;
     j.rnds = rnds; j.n_ops = n_ops; j.sigs_out = sigs; j.repeat = repeat;
     mt_run(&j, n_threads);
 }

@@ -148,6 +148,13 @@ void orc_verify_batch_mt(int set, const orc_pubkey *pks, const uint32_t *key_idx
 void orc_sign_batch_mt(int set, const orc_privkey *sks, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
                        const uint8_t *rnds, size_t n_ops, int mode, uint8_t *sigs, int n_threads, size_t repeat);
 
+/* keygen_from_seed + into_bytes per seed; try_from_bytes + verify / sign per op (the "from wire bytes" units) */
+void orc_keygen_batch_mt(int set, const uint8_t *xi, size_t n_keys, uint8_t *pk_out, uint8_t *sk_out, int n_threads, size_t repeat);
+void orc_verify_wire_batch_mt(int set, const uint8_t *pk_bytes, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                              const uint8_t *sigs, size_t n_ops, int mode, uint8_t *ok, int n_threads, size_t repeat);
+void orc_sign_wire_batch_mt(int set, const uint8_t *sk_bytes, const uint32_t *key_idx, const uint8_t *msgs, size_t mlen,
+                            const uint8_t *rnds, size_t n_ops, int mode, uint8_t *sigs, int n_threads, size_t repeat);
+
 #ifdef __cplusplus
 }
 #endif

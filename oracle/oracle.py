@@ -363,3 +363,38 @@ def sign_batch_mt(pset, sks, key_idx, msgs, rnds, n_threads, repeat=1, mode=MODE
     sl = params(pset).sig_len
     raw = bytes(out)
     return [raw[i * sl:(i + 1) * sl] for i in range(n)]
+
+
+def keygen_batch_mt(pset, xis, n_threads, repeat=1):
+    """keygen_from_seed + into_bytes for every 32-byte seed -> (pk bytes [n, PK_LEN], sk bytes [n, SK_LEN]) as numpy arrays"""
+    p = params(pset)
+    n = len(xis)
+    pk = np.zeros((max(n, 1), p.pk_len), dtype=np.uint8)
+    sk = np.zeros((max(n, 1), p.sk_len), dtype=np.uint8)
+    lib().orc_keygen_batch_mt(C.c_int(pset), b"".join(xis), C.c_size_t(n), pk.ctypes.data_as(C.c_void_p), sk.ctypes.data_as(C.c_void_p),
+                              C.c_int(n_threads), C.c_size_t(repeat))
+    return pk[:n], sk[:n]
+
+
+def verify_wire_batch_mt(pset, pk_bytes, key_idx, msgs, sigs, n_threads, repeat=1, mode=MODE_PURE):
+    """PublicKey::try_from_bytes (ml_dsa.rs:477-498) + verify per op: pk_bytes = uint8 [n_keys, PK_LEN]"""
+    n = len(msgs)
+    kidx = np.ascontiguousarray(key_idx, dtype=np.uint32)
+    pkb = np.ascontiguousarray(pk_bytes, dtype=np.uint8)
+    ok = (C.c_uint8 * n)()
+    lib().orc_verify_wire_batch_mt(C.c_int(pset), pkb.ctypes.data_as(C.c_void_p), kidx.ctypes.data_as(C.c_void_p), b"".join(msgs),
+                                   C.c_size_t(len(msgs[0])), b"".join(sigs), C.c_size_t(n), C.c_int(mode), ok, C.c_int(n_threads), C.c_size_t(repeat))
+    return np.frombuffer(bytes(ok), dtype=np.uint8).astype(bool)
+
+
+def sign_wire_batch_mt(pset, sk_bytes, key_idx, msgs, rnds, n_threads, repeat=1, mode=MODE_PURE):
+    """PrivateKey::try_from_bytes (ml_dsa.rs:445-469) + sign per op"""
+    n = len(msgs)
+    kidx = np.ascontiguousarray(key_idx, dtype=np.uint32)
+    skb = np.ascontiguousarray(sk_bytes, dtype=np.uint8)
+    out = (C.c_uint8 * (n * params(pset).sig_len))()
+    lib().orc_sign_wire_batch_mt(C.c_int(pset), skb.ctypes.data_as(C.c_void_p), kidx.ctypes.data_as(C.c_void_p), b"".join(msgs),
+                                 C.c_size_t(len(msgs[0])), b"".join(rnds), C.c_size_t(n), C.c_int(mode), out, C.c_int(n_threads), C.c_size_t(repeat))
+    sl = params(pset).sig_len
+    raw = bytes(out)
+    return [raw[i * sl:(i + 1) * sl] for i in range(n)]

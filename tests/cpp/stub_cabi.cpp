@@ -302,4 +302,42 @@ int mldsa_verify_host_group(mldsa_group *g, int set, int mode, const uint8_t *pk
     }
     return 0;
 }
+// ---- device-resident group calls: worker i = a plain call on context i, sequentially
+int mldsa_verify_group(mldsa_group *g, int set, int mode, const mldsa_verify_slice *s, int) {
+    if (!g || !s) return fail(MLDSA_ERR_PARAM, "verify_group");
+    for (size_t i = 0; i < g->c.size(); i++)
+        if (mldsa_verify(g->c[i], set, mode, s[i].rho, s[i].tr, s[i].t1_d2_hat_mont, s[i].n_keys, s[i].key_idx, s[i].msgs, s[i].msg_off, s[i].ctxs, s[i].ctx_off,
+                         s[i].sigs, s[i].ok, s[i].n_ops, s[i].stream)) return MLDSA_ERR_PARAM;
+    return 0;
+}
+int mldsa_sign_group(mldsa_group *g, int set, int mode, const mldsa_sign_slice *s, int) {
+    if (!g || !s) return fail(MLDSA_ERR_PARAM, "sign_group");
+    for (size_t i = 0; i < g->c.size(); i++)
+        if (mldsa_sign(g->c[i], set, mode, s[i].rho, s[i].cap_k, s[i].tr, s[i].s_1_hat_mont, s[i].s_2_hat_mont, s[i].t_0_hat_mont, s[i].n_keys, s[i].key_idx,
+                       s[i].msgs, s[i].msg_off, s[i].ctxs, s[i].ctx_off, s[i].rnd, s[i].sigs, s[i].status, s[i].n_ops, s[i].stream)) return MLDSA_ERR_PARAM;
+    return 0;
+}
+int mldsa_keygen_group(mldsa_group *g, int set, const mldsa_keygen_slice *s, int) {
+    if (!g || !s) return fail(MLDSA_ERR_PARAM, "keygen_group");
+    for (size_t i = 0; i < g->c.size(); i++)
+        if (s[i].n_keys && mldsa_keygen(g->c[i], set, s[i].xi, s[i].pk, s[i].sk, s[i].n_keys, s[i].stream)) return MLDSA_ERR_PARAM;
+    return 0;
+}
+int mldsa_group_sync(mldsa_group *g) { return g ? 0 : fail(MLDSA_ERR_PARAM, "group_sync"); }
+int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, int) {
+    if (!g || !bufs) return fail(MLDSA_ERR_PARAM, "allgather");
+    const int n = (int)g->c.size();
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            size_t a, cnt; mldsa_group_shard(n_ops, n, j, &a, &cnt);
+            if (j != i && cnt && bufs[i] != bufs[j]) std::memcpy(bufs[i] + a, bufs[j] + a, cnt);
+        }
+    return 0;
+}
+int mldsa_check_offsets(const uint64_t *off, size_t n_ops) {
+    if (!off && n_ops) return fail(MLDSA_ERR_PARAM, "offsets");
+    for (size_t i = 0; i < n_ops; i++) if (off[i + 1] < off[i]) return fail(MLDSA_ERR_PARAM, "offset table decreases");
+    return 0;
+}
+int mldsa_abi_version(void) { return MLDSA_ABI_VERSION; }
 }  // extern "C"

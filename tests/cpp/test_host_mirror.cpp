@@ -182,6 +182,58 @@ int main(int argc, char** argv) {
         auto ok = P::verify_host(ks.first, kidx, msgs, sigs, ctxs);
         for (size_t i = 0; i < n; i++) ASSERT(ok[i] == (i != 7));
     }
+    // device-resident slices through a group of two contexts (both on GPU 0): one host thread, mldsa_sign_group without
+    // waiting + mldsa_group_sync, mldsa_verify_group, verdicts gathered with mldsa_group_allgather right behind it
+    {
+        using P = ml_dsa_44;
+        const size_t n = 37;
+        std::vector<std::array<uint8_t, 32>> xi(3), rnd(n);
+        for (int i = 0; i < 3; i++) xi[i].fill((uint8_t)(7 + i));
+        for (size_t i = 0; i < n; i++) rnd[i].fill((uint8_t)(5 * i + 1));
+        auto ks = P::keygen_many(xi);
+        auto pks = P::PublicKeys::try_from_bytes(ks.first);
+        auto sks = P::PrivateKeys::try_from_bytes(ks.second);
+        std::vector<uint32_t> kidx(n);
+        std::vector<std::vector<uint8_t>> msgs(n), ctxs(n);
+        for (size_t i = 0; i < n; i++) { kidx[i] = (uint32_t)(i % 3); msgs[i].assign(i * 5, (uint8_t)(i + 1)); ctxs[i].assign(i % 6, 2); }
+        auto want = P::sign_many(sks, kidx, msgs, ctxs, rnd);
+        P::Group g({0, 0});
+        struct Staged { Packed m, c; DevBuf k, r, sig, st; };
+        std::vector<std::unique_ptr<Staged>> st;
+        std::vector<mldsa_sign_slice> ss;
+        std::vector<mldsa_verify_slice> vs;
+        const size_t per = (n + 1) / 2;
+        std::vector<DevBuf> okb;
+        for (int i = 0; i < 2; i++) okb.emplace_back(2 * per);
+        for (int i = 0; i < 2; i++) {
+            auto sh = g.shard(n, i);
+            const size_t a = sh.first, c = sh.second;
+            std::vector<std::vector<uint8_t>> mi(msgs.begin() + a, msgs.begin() + a + c), ci(ctxs.begin() + a, ctxs.begin() + a + c);
+            st.emplace_back(new Staged{Packed(mi), Packed(ci), DevBuf(kidx.data() + a, c * 4), DevBuf(raw_bytes(rnd) + 32 * a, c * 32),
+                                       DevBuf(c * P::SIG_LEN), DevBuf(c * 4)});
+            Staged& t = *st.back();
+            ss.push_back(P::Group::sign_slice(sks, t.k.as<uint32_t>(), t.m.bytes.as<uint8_t>(), t.m.offsets.as<uint64_t>(), t.c.bytes.as<uint8_t>(),
+                                              t.c.offsets.as<uint64_t>(), t.r.as<uint8_t>(), t.sig.as<uint8_t>(), t.st.as<int32_t>(), c));
+            vs.push_back(P::Group::verify_slice(pks, t.k.as<uint32_t>(), t.m.bytes.as<uint8_t>(), t.m.offsets.as<uint64_t>(), t.c.bytes.as<uint8_t>(),
+                                                t.c.offsets.as<uint64_t>(), t.sig.as<uint8_t>(), okb[(size_t)i].as<uint8_t>() + a, c));
+        }
+        g.sign_resident(ss, MLDSA_MODE_PURE, false);
+        g.sync();
+        for (int i = 0; i < 2; i++) {
+            auto sh = g.shard(n, i);
+            std::vector<P::Signature> got(sh.second);
+            st[(size_t)i]->sig.download(got.data(), sh.second * P::SIG_LEN);
+            for (size_t j = 0; j < sh.second; j++) ASSERT(got[j] == want[sh.first + j]);
+        }
+        g.verify_resident(vs, MLDSA_MODE_PURE, false);
+        g.allgather({okb[0].as<uint8_t>(), okb[1].as<uint8_t>()}, n, 0);
+        for (int i = 0; i < 2; i++) {
+            std::vector<uint8_t> ok(n);
+            okb[(size_t)i].download(ok.data(), n);
+            for (size_t j = 0; j < n; j++) ASSERT(ok[j] == 1);
+        }
+        ASSERT(mldsa_abi_version() == MLDSA_ABI_VERSION);
+    }
     std::printf("OK\n");
     return 0;
 }

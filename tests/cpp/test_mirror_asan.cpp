@@ -24,6 +24,9 @@ static std::vector<uint8_t> pattern(size_t n, unsigned seed) {
     return v;
 }
 
+template <class F>
+static bool throws0(F&& f) { try { f(); } catch (const fips204_hip::Error&) { return true; } return false; }
+
 template <class P>
 static void plumbing() {
     const size_t nk = 5, n = 23;
@@ -96,6 +99,44 @@ static void plumbing() {
         auto s2 = g.sign_host(keys.second, k2, m2, c2, r2);
         auto o2 = g.verify_host(keys.first, k2, m2, s2, c2);
         ASSERT(o2.size() == 2 && o2[0] && o2[1]);
+    }
+    {   // device-resident slices through the group: 23 ops over 3 contexts (ragged) and 2 ops over 4 (two empty slices)
+        for (std::vector<int> devs : {std::vector<int>{0, 1, 1}, std::vector<int>{0, 0, 1, 1}}) {
+            typename P::Group g(devs);
+            const size_t nn = devs.size() == 3 ? n : 2;
+            const int N = g.size();
+            struct Staged { Packed m, c; DevBuf k, r, sig, st, ok; };
+            std::vector<std::unique_ptr<Staged>> st;
+            std::vector<mldsa_sign_slice> ss;
+            std::vector<mldsa_verify_slice> vs;
+            for (int i = 0; i < N; i++) {
+                auto sh = g.shard(nn, i);
+                const size_t a = sh.first, c = sh.second;
+                std::vector<std::vector<uint8_t>> mi(msgs.begin() + a, msgs.begin() + a + c), ci(ctxs.begin() + a, ctxs.begin() + a + c);
+                st.emplace_back(new Staged{Packed(mi), Packed(ci), DevBuf(kidx.data() + a, c * 4), DevBuf(raw_bytes(rnd) + 32 * a, c * 32),
+                                           DevBuf(c * P::SIG_LEN), DevBuf(c * 4), DevBuf(c)});
+                Staged& t = *st.back();
+                ss.push_back(P::Group::sign_slice(sks, t.k.template as<uint32_t>(), t.m.bytes.template as<uint8_t>(), t.m.offsets.template as<uint64_t>(),
+                                                  t.c.bytes.template as<uint8_t>(), t.c.offsets.template as<uint64_t>(), t.r.template as<uint8_t>(),
+                                                  t.sig.template as<uint8_t>(), t.st.template as<int32_t>(), c));
+                vs.push_back(P::Group::verify_slice(pks, t.k.template as<uint32_t>(), t.m.bytes.template as<uint8_t>(), t.m.offsets.template as<uint64_t>(),
+                                                    t.c.bytes.template as<uint8_t>(), t.c.offsets.template as<uint64_t>(), t.sig.template as<uint8_t>(),
+                                                    t.ok.template as<uint8_t>(), c));
+            }
+            g.sign_resident(ss, MLDSA_MODE_PURE, false);
+            g.sync();
+            g.verify_resident(vs);
+            auto want = P::sign_many(sks, kidx, msgs, ctxs, rnd);
+            for (int i = 0; i < N; i++) {
+                auto sh = g.shard(nn, i);
+                std::vector<typename P::Signature> got(sh.second);
+                st[(size_t)i]->sig.download(got.data(), sh.second * P::SIG_LEN);
+                std::vector<uint8_t> ok(sh.second);
+                st[(size_t)i]->ok.download(ok.data(), sh.second);
+                for (size_t j = 0; j < sh.second; j++) ASSERT(got[j] == want[sh.first + j] && ok[j] == 1);
+            }
+            ASSERT(throws0([&] { g.verify_resident(std::vector<mldsa_verify_slice>(1)); }) == (N != 1));  // one slice per device
+        }
     }
     // error mapping: an over-long ctx and an out-of-range key index are per-op statuses that the mirror turns into Errors
     auto throws = [](auto&& f) { try { f(); } catch (const Error&) { return true; } return false; };
