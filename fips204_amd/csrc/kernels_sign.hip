@@ -94,20 +94,58 @@ struct TailPtrs {
     const int32_t *s1, *s2, *t0;
 };
 
+// The parameter set's scalars as compile-time constants (src/lib.rs:639-656, 681-698, 723-740): (K, L) names the set, so the tail
+// kernels take none of them as arguments -- shifts and bounds become immediates, and the kernels fit their scalar registers
+// (with gamma1's bit count, beta, omega, the c~ length and the signature length as kernel arguments k_sign_tail / k_resolve
+// spilled 32-63 SGPRs into VGPR lanes).
+template <int K, int L> struct TailConst;
+template <> struct TailConst<4, 4> { static constexpr int GB = 17, BETA = 78, OMEGA = 80, CTILDE = 32; static constexpr size_t SIG_LEN = 2420; };
+template <> struct TailConst<6, 5> { static constexpr int GB = 19, BETA = 196, OMEGA = 55, CTILDE = 48; static constexpr size_t SIG_LEN = 3309; };
+template <> struct TailConst<8, 7> { static constexpr int GB = 19, BETA = 120, OMEGA = 75, CTILDE = 64; static constexpr size_t SIG_LEN = 4627; };
+
+// Kernel arguments that are needed once per slot (the prefetch of the next slot, the verdict at the end) are NOT held in scalar
+// registers across the slot: the kernels take one struct by value -- it sits at offset 0 of the kernarg segment -- and read
+// those fields from the segment where they are used (an s_load that hits the scalar cache).  The empty asm makes the segment
+// pointer opaque at that point, so the load can neither be hoisted to the kernel's entry nor kept live through the inverse
+// transforms; with all ~20 pointers live the two kernels needed 32-63 more scalar registers than the 102 there are.
+template <class T>
+__device__ __forceinline__ T late_arg(unsigned byte_offset) {
+    typedef const char __attribute__((address_space(4))) * kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *(const T __attribute__((address_space(4)))*)(ka + byte_offset);
+}
+#define LATE(ARGS, field) late_arg<decltype(ARGS::field)>((unsigned)offsetof(ARGS, field))
+
+struct SignTailArgs {
+    TailPtrs a;          // used throughout a slot
+    uint8_t* sigs;
+    int ct0_exact, oor_by_op;
+    const RoundCtl* ctl;  // prologue
+    const Twiddle* inv_tab;
+    // read where they are used (LATE):
+    const uint32_t *slot_op, *slot_y, *key_idx;
+    const uint8_t *wrisk, *yrisk, *key_oor;
+    uint16_t* kappa;
+    int32_t *done, *accept;
+};
+
 template <int K, int L, bool G2HI, bool FULL>
 __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, size_t yrow, size_t key, uint32_t r_risky, uint32_t z_risky,
-                                             bool s2_oor, uint8_t* sig, int32_t* xp, const LdsTw& itw, int lane, int gb, int beta,
-                                             int omega, int ctilde_len, int ct0_exact) {
+                                             bool s2_oor, uint8_t* sig, int32_t* xp, const LdsTw& itw, int lane) {
+    constexpr int gb = TailConst<K, L>::GB, beta = TailConst<K, L>::BETA, omega = TailConst<K, L>::OMEGA, ctilde_len = TailConst<K, L>::CTILDE;
     constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
     // ||c t0||inf <= tau * 2^12: below gamma2 = (q-1)/32 for ML-DSA-65 / 87 (200 704, 245 760 < 261 888), not for ML-DSA-44
     constexpr bool CT0_CAN_FAIL = !G2HI;
-    const int32_t gamma1 = 1 << gb;
-    const int cb = gb + 1;
+    constexpr int32_t gamma1 = 1 << gb;
+    constexpr int cb = gb + 1;
     constexpr int YCB = G2HI ? 20 : 18;  // = cb: gamma2 = (q - 1) / 32 goes with gamma1 = 2^19, (q - 1) / 88 with 2^17
     // everything a candidate owns -- y, w, c_hat, c~ and the risk flags -- lives in its ROW (k_make_slots)
     (void)slot;
-    const int4 cv = reinterpret_cast<const int4*>(a.c_hat + yrow * N)[lane];
-    if (FULL && lane < ctilde_len) sig[lane] = a.ctilde[yrow * 64 + lane];
+    // (c_hat and c~ are read once, here: their pointers come from the kernarg segment -- TailPtrs opens both argument structs --
+    //  and are not held in scalar registers through the transforms)
+    const int4 cv = reinterpret_cast<const int4*>(late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, c_hat)) + yrow * N)[lane];
+    if (FULL && lane < ctilde_len) sig[lane] = late_arg<const uint8_t*>((unsigned)offsetof(TailPtrs, ctilde))[yrow * 64 + lane];
     // ---- stage 1.  ||c s1||inf and ||c s2||inf are at most beta = tau * eta, so a polynomial of w whose
     // LowBits all stay below gamma2 - 2 beta cannot fail ||LowBits(w - c s2)||inf < gamma2 - beta, and a
     // polynomial of y below gamma1 - 2 beta cannot fail ||y + c s1||inf < gamma1 - beta (ml_dsa.rs:280; with
@@ -123,12 +161,14 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
     const uint32_t risky = (r_risky & ((1u << K) - 1u)) | (z_risky << K);
     auto issue_loads = [&](int idx, int32_t(&v)[4], int32_t(&x)[4]) {
         const bool is_r = idx < K;
-        const int32_t* sp = is_r ? a.s2 + (key * K + idx) * (size_t)N : a.s1 + (key * L + (idx - K)) * (size_t)N;
+        // (the key and row tables' pointers come from the kernarg segment at this point, like c_hat above)
+        const int32_t* sp = is_r ? late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, s2)) + (key * K + idx) * (size_t)N
+                                 : late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, s1)) + (key * L + (idx - K)) * (size_t)N;
         // One load shape for both: w_i (sign_w's 24-bit form) is three planes of 64 dwords, y_j (ExpandMask's squeezed bytes, field.h)
         // four dwords at byte granularity; both are decoded where they are used.  (The fourth dword of a w_i is the next
         // polynomial's first plane -- the carve after w follows the last one -- and is not used.)
-        const uint8_t* xb = is_r ? reinterpret_cast<const uint8_t*>(a.w) + (yrow * K + idx) * (size_t)(PACKED_POLY_DWORDS * 4)
-                                 : reinterpret_cast<const uint8_t*>(a.y) + (yrow * L + (idx - K)) * (size_t)(32 * YCB);
+        const uint8_t* xb = is_r ? reinterpret_cast<const uint8_t*>(late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, w))) + (yrow * K + idx) * (size_t)(PACKED_POLY_DWORDS * 4)
+                                 : reinterpret_cast<const uint8_t*>(late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, y))) + (yrow * L + (idx - K)) * (size_t)(32 * YCB);
         const int kstride = is_r ? 256 : 8 * YCB, lane_off = is_r ? 4 * lane : (lane * YCB) >> 3;
         load_packed(v, sp, lane);
 #pragma unroll
@@ -222,7 +262,7 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
             // w1), and  h = [HighBits(w - cs2 + ct0) != HighBits(w)],  w - cs2 + ct0 = w + invNTT(c_hat o (t0_hat - s2_hat)):
             // ONE inverse transform per row instead of the reference's two (cs2 and ct0).
             int32_t v[4], v2[4], r[4], base[4];
-            load_packed(v, a.t0 + (key * K + i) * (size_t)N, lane);
+            load_packed(v, late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, t0)) + (key * K + i) * (size_t)N, lane);  // (t0: stage 2 only)
             load_packed(v2, a.s2 + (key * K + i) * (size_t)N, lane);
             // w_i stays in its three packed dwords across the transform
             const uint32_t* wq = reinterpret_cast<const uint32_t*>(a.w) + (yrow * K + i) * (size_t)PACKED_POLY_DWORDS;
@@ -281,12 +321,12 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
             };
             dmax = wave_max(dmax);
             bool ct0_ok = dmax + (s2_oor ? 0 : beta) < GAMMA2;
-            if (!s2_oor && (!ct0_ok || ct0_exact)) {
+            if (!s2_oor && (!ct0_ok || LATE(SignTailArgs, ct0_exact))) {  // (the test knob MLDSA_OPT_SIGN_CT0_EXACT: read here, once per accepted attempt)
                 int32_t tmax = 0;
 #pragma unroll 1
                 for (int i = 0; i < K; i++) {
                     int32_t v[4], r[4];
-                    load_packed(v, a.t0 + (key * K + i) * (size_t)N, lane);
+                    load_packed(v, late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, t0)) + (key * K + i) * (size_t)N, lane);  // (t0: stage 2 only)
                     r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
                     ntt_inv_wave(r, itw, lane, F_MONT);
 #pragma unroll
@@ -306,21 +346,18 @@ __device__ __forceinline__ bool tail_attempt(const TailPtrs& a, size_t slot, siz
 
 template <int K, int L, bool G2HI>
 __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_sign_tail(
-    TailPtrs a, const uint32_t* __restrict__ slot_op, const uint32_t* __restrict__ key_idx,
-    uint16_t* __restrict__ kappa, int32_t* __restrict__ done, uint8_t* __restrict__ sigs,
-    const RoundCtl* __restrict__ ctl, int32_t* __restrict__ accept, int gb, int beta, int omega,
-    int ctilde_len, size_t sig_len, const Twiddle* __restrict__ inv_tab,
-    const uint8_t* __restrict__ wrisk, const uint8_t* __restrict__ yrisk, const uint8_t* __restrict__ key_oor, int oor_by_op,
-    int ct0_exact, const uint32_t* __restrict__ slot_y) {
+    SignTailArgs args) {
+    typedef SignTailArgs A;
+    constexpr size_t sig_len = TailConst<K, L>::SIG_LEN;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: slot indices and row pointers stay scalar
     // slots and candidates per op of this round: written by k_make_slots (the host never sees them)
-    const uint32_t n_slots32 = ctl->ns;
-    const int spec = (int)ctl->spec;
+    const uint32_t n_slots32 = args.ctl->ns;
+    const int spec = (int)args.ctl->spec;
     if (n_slots32 == 0) return;
-    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = inv_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = args.inv_tab[i];
     __syncthreads();
     const LdsTw itw{tw_lds, lane};
     const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES;
@@ -329,48 +366,39 @@ __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))
     // ... and so are its risk flags (which polynomials stage 1 has to transform)
     // (y, w and their flags are addressed by the slot's ROW: the slot itself, or where a round that generated two candidates
     //  per op put this one)
-    auto risk_flags = [&](uint32_t sl, uint32_t yr, uint32_t& rr, uint32_t& zr) {
-        (void)sl;
-        rr = wrisk ? (uint32_t)wrisk[yr] : (1u << K) - 1u;
-        zr = (1u << L) - 1u;
-        if (yrisk) {
-            zr = 0;
+    // one word per slot: bits 0 .. K-1 = which w_i can reject (wrisk), bits 8 .. 8+L-1 = which y_j (yrisk), bit 16 = the key's s2 is
+    // out of range (one scalar register instead of three, for the current slot and for the prefetched one)
+    uint32_t op_next = 0, key_next = 0, flags_next = 0, yrow_next = 0;
+    auto fetch_slot = [&](uint32_t sl) {
+        op_next = LATE(A, slot_op)[sl];
+        yrow_next = LATE(A, slot_y)[sl];
+        const uint32_t* kidx = LATE(A, key_idx);
+        key_next = kidx ? kidx[op_next] : op_next;
+        uint32_t f = (uint32_t)LATE(A, wrisk)[yrow_next];
+        const uint8_t* yr = LATE(A, yrisk) + (size_t)yrow_next * L;
 #pragma unroll
-            for (int j = 0; j < L; j++) zr |= (yrisk[(size_t)yr * L + j] ? 1u : 0u) << j;
-        }
+        for (int j = 0; j < L; j++) f |= (yr[j] ? 1u : 0u) << (8 + j);
+        flags_next = f | (LATE(A, key_oor)[LATE(A, oor_by_op) ? op_next : key_next] ? 1u << 16 : 0u);
     };
-    uint32_t op_next = 0, key_next = 0, rrisk_next = 0, zrisk_next = 0, oor_next = 0, yrow_next = 0;
-    if (wid < n_slots32) {
-        op_next = slot_op[wid];
-        yrow_next = slot_y ? slot_y[wid] : wid;
-        key_next = key_idx ? key_idx[op_next] : op_next;
-        risk_flags(wid, yrow_next, rrisk_next, zrisk_next);
-        oor_next = key_oor ? key_oor[oor_by_op ? op_next : key_next] : 0u;
-    }
+    if (wid < n_slots32) fetch_slot(wid);
     for (uint32_t slot32 = wid; slot32 < n_slots32; slot32 += n_waves) {
         const size_t slot = slot32, op = op_next, key = key_next, yrow = yrow_next;
         // a key whose s2 leaves [-eta, eta] (k_key_range) voids ||c s2||inf <= beta: every polynomial can reject and the
         // hint stage takes the reference's two-transform form
-        const bool s2_oor = oor_next != 0;  // wave-uniform
-        const uint32_t r_risky = s2_oor ? (1u << K) - 1u : rrisk_next, z_risky = zrisk_next;
-        if (slot32 + n_waves < n_slots32) {
-            op_next = slot_op[slot32 + n_waves];
-            yrow_next = slot_y ? slot_y[slot32 + n_waves] : slot32 + n_waves;
-            key_next = key_idx ? key_idx[op_next] : op_next;
-            risk_flags(slot32 + n_waves, yrow_next, rrisk_next, zrisk_next);
-            oor_next = key_oor ? key_oor[oor_by_op ? op_next : key_next] : 0u;
-        }
+        const uint32_t flags = flags_next;
+        const bool s2_oor = (flags >> 16) != 0;  // wave-uniform
+        const uint32_t r_risky = s2_oor ? (1u << K) - 1u : (flags & 0xFFu), z_risky = (flags >> 8) & 0xFFu;
+        if (slot32 + n_waves < n_slots32) fetch_slot(slot32 + n_waves);
         if (spec == 1) {
-            const bool ok = tail_attempt<K, L, G2HI, true>(a, slot, yrow, key, r_risky, z_risky, s2_oor, sigs + op * sig_len, xpose[wave], itw,
-                                                           lane, gb, beta, omega, ctilde_len, ct0_exact);
+            const bool ok = tail_attempt<K, L, G2HI, true>(args.a, slot, yrow, key, r_risky, z_risky, s2_oor, LATE(A, sigs) + op * sig_len, xpose[wave], itw,
+                                                           lane);
             if (lane == 0) {
-                if (ok) done[op] = 1;
-                else kappa[op] = (uint16_t)(kappa[op] + L);  // ml_dsa.rs:281 / 316
+                if (ok) LATE(A, done)[op] = 1;
+                else { uint16_t* kp = LATE(A, kappa) + op; *kp = (uint16_t)(*kp + L); }  // ml_dsa.rs:281 / 316
             }
         } else {
-            const bool ok = tail_attempt<K, L, G2HI, false>(a, slot, yrow, key, r_risky, z_risky, s2_oor, nullptr, xpose[wave], itw, lane, gb,
-                                                            beta, omega, ctilde_len, ct0_exact);
-            if (lane == 0) accept[slot] = ok ? 1 : 0;
+            const bool ok = tail_attempt<K, L, G2HI, false>(args.a, slot, yrow, key, r_risky, z_risky, s2_oor, nullptr, xpose[wave], itw, lane);
+            if (lane == 0) LATE(A, accept)[slot] = ok ? 1 : 0;
         }
     }
 }
@@ -447,30 +475,44 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
 // candidates; the wave takes the FIRST survivor -- the candidate the sequential loop of ml_dsa.rs:212-330 would have reached --
 // and runs the whole iteration for it with the bytes going straight to the op's signature (tail_attempt<FULL>: all z_j, the
 // hint stage).  Should the hint stage reject it (weight(h) > omega, about 1 %), the next survivor is tried, as the loop would.
+struct ResolveArgs {
+    TailPtrs a;
+    uint8_t* sigs;
+    int ct0_exact, oor_by_op;
+    const RoundCtl* ctl;
+    const Twiddle* inv_tab;
+    // LATE:
+    const uint32_t *act, *slot_y, *key_idx;
+    const int32_t* accept;
+    const uint8_t* key_oor;
+    uint16_t* kappa;
+    int32_t* done;
+};
+
+static_assert(offsetof(ResolveArgs, ct0_exact) == offsetof(SignTailArgs, ct0_exact) && offsetof(ResolveArgs, a) == 0 && offsetof(SignTailArgs, a) == 0,
+              "tail_attempt reads ct0_exact, c_hat and c~ at the same kernarg offsets for both kernels");
+
 template <int K, int L, bool G2HI>
-__global__ __launch_bounds__(64 * GWAVES) void k_resolve(const RoundCtl* __restrict__ ctl, const uint32_t* __restrict__ act,
-                                                         const int32_t* __restrict__ accept, TailPtrs a,
-                                                         const uint32_t* __restrict__ key_idx, uint8_t* __restrict__ sigs, size_t sig_len,
-                                                         int32_t* __restrict__ done, uint16_t* __restrict__ kappa, int gb, int beta,
-                                                         int omega, int ctilde_len, const Twiddle* __restrict__ inv_tab,
-                                                         const uint8_t* __restrict__ key_oor, int oor_by_op, int ct0_exact,
-                                                         const uint32_t* __restrict__ slot_y) {
+__global__ __launch_bounds__(64 * GWAVES) void k_resolve(ResolveArgs args) {
+    typedef ResolveArgs A;
+    constexpr size_t sig_len = TailConst<K, L>::SIG_LEN;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];
-    const int spec = (int)ctl->spec;
+    const int spec = (int)args.ctl->spec;
     if (spec == 1) return;  // k_sign_tail wrote done[] / kappa[] / the signature itself
-    const uint32_t m = ctl->m;
+    const uint32_t m = args.ctl->m;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = inv_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * GWAVES) tw_lds[i] = args.inv_tab[i];
     __syncthreads();
     const LdsTw itw{tw_lds, lane};
     const uint32_t wid = blockIdx.x * GWAVES + wave, n_waves = gridDim.x * GWAVES;
     for (uint32_t i = wid; i < m; i += n_waves) {
-        const uint32_t op = act[i];
-        const size_t key = key_idx ? key_idx[op] : op;
-        const bool s2_oor = key_oor ? key_oor[oor_by_op ? op : key] != 0 : false;
-        const int mine = lane < spec ? accept[(size_t)i * spec + lane] : 0;
+        const uint32_t op = LATE(A, act)[i];
+        const uint32_t* kidx = LATE(A, key_idx);
+        const size_t key = kidx ? kidx[op] : op;
+        const bool s2_oor = LATE(A, key_oor)[LATE(A, oor_by_op) ? op : key] != 0;
+        const int mine = lane < spec ? LATE(A, accept)[(size_t)i * spec + lane] : 0;
         unsigned long long mask = __ballot(mine != 0);
         bool fin = false;
         while (mask && !fin) {
@@ -478,12 +520,12 @@ __global__ __launch_bounds__(64 * GWAVES) void k_resolve(const RoundCtl* __restr
             mask &= mask - 1ull;
             // every z_j is wanted (bytes); the r_i were tested by k_sign_tail and are not needed on their own
             const size_t slot = (size_t)i * spec + j;
-            fin = tail_attempt<K, L, G2HI, true>(a, slot, slot_y ? (size_t)slot_y[slot] : slot, key, 0u, (1u << L) - 1u, s2_oor,
-                                                 sigs + (size_t)op * sig_len, xpose[wave], itw, lane, gb, beta, omega, ctilde_len, ct0_exact);
+            fin = tail_attempt<K, L, G2HI, true>(args.a, slot, (size_t)LATE(A, slot_y)[slot], key, 0u, (1u << L) - 1u, s2_oor,
+                                                 LATE(A, sigs) + (size_t)op * sig_len, xpose[wave], itw, lane);
         }
         if (lane == 0) {
-            if (fin) done[op] = 1;
-            else kappa[op] = (uint16_t)(kappa[op] + spec * L);
+            if (fin) LATE(A, done)[op] = 1;
+            else { uint16_t* kp = LATE(A, kappa) + op; *kp = (uint16_t)(*kp + spec * L); }
         }
     }
 }
@@ -783,13 +825,14 @@ int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, co
                      uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, int32_t* accept, size_t slots_hint,
                      hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk, const uint8_t* key_oor, int oor_by_op,
                      const uint32_t* slot_y) {
-    const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
-    const TailPtrs a{c, y, w, ctilde, s1, s2, t0};
+    if (!wrisk || !yrisk || !key_oor || !slot_y) return set_error(MLDSA_ERR_PARAM, "sign_tail: wrisk, yrisk, key_oor and slot_y are required");
+    SignTailArgs args;
+    args.a = TailPtrs{c, y, w, ctilde, s1, s2, t0};
+    args.sigs = sigs; args.ct0_exact = (int)ctx->opt_ct0_exact; args.oor_by_op = oor_by_op; args.ctl = ctl; args.inv_tab = ctx->d_inv_tw;
+    args.slot_op = slot_op; args.slot_y = slot_y; args.key_idx = key_idx; args.wrisk = wrisk; args.yrisk = yrisk; args.key_oor = key_oor;
+    args.kappa = kappa; args.done = done; args.accept = accept;
     dim3 grid(grid_for(ctx, slots_hint, GWAVES, 16));  // more, shorter blocks than fit at once: the dispatcher evens out the early exits
-#define MLDSA_TAIL(KK, LL, G2)                                                                                                    \
-    hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, a, slot_op, key_idx, kappa, done, sigs, ctl, accept, \
-                       gb, p->beta, p->omega, p->ctilde_len, (size_t)p->sig_len, ctx->d_inv_tw, wrisk, yrisk, key_oor, oor_by_op,  \
-                       (int)ctx->opt_ct0_exact, slot_y)
+#define MLDSA_TAIL(KK, LL, G2) hipLaunchKernelGGL((k_sign_tail<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, args)
     if (p->set == MLDSA_44) MLDSA_TAIL(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_TAIL(6, 5, true);
     else MLDSA_TAIL(8, 7, true);
@@ -823,12 +866,13 @@ int launch_resolve(mldsa_ctx* ctx, const mldsa_params* p, const RoundCtl* ctl, c
                    const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde, const uint32_t* key_idx,
                    const int32_t* s1, const int32_t* s2, const int32_t* t0, uint8_t* sigs, int32_t* done, uint16_t* kappa,
                    size_t ops_hint, hipStream_t s, const uint8_t* key_oor, int oor_by_op, const uint32_t* slot_y) {
-    const int gb = p->gamma1 == (1 << 17) ? 17 : 19;
-    const TailPtrs a{c, y, w, ctilde, s1, s2, t0};
+    if (!key_oor || !slot_y) return set_error(MLDSA_ERR_PARAM, "resolve: key_oor and slot_y are required");
+    ResolveArgs args;
+    args.a = TailPtrs{c, y, w, ctilde, s1, s2, t0};
+    args.sigs = sigs; args.ct0_exact = (int)ctx->opt_ct0_exact; args.oor_by_op = oor_by_op; args.ctl = ctl; args.inv_tab = ctx->d_inv_tw;
+    args.act = act; args.slot_y = slot_y; args.key_idx = key_idx; args.accept = accept; args.key_oor = key_oor; args.kappa = kappa; args.done = done;
     dim3 grid(grid_for(ctx, ops_hint, GWAVES, 8));
-#define MLDSA_RES(KK, LL, G2)                                                                                                      \
-    hipLaunchKernelGGL((k_resolve<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, ctl, act, accept, a, key_idx, sigs, (size_t)p->sig_len, \
-                       done, kappa, gb, p->beta, p->omega, p->ctilde_len, ctx->d_inv_tw, key_oor, oor_by_op, (int)ctx->opt_ct0_exact, slot_y)
+#define MLDSA_RES(KK, LL, G2) hipLaunchKernelGGL((k_resolve<KK, LL, G2>), grid, dim3(64 * GWAVES), 0, s, args)
     if (p->set == MLDSA_44) MLDSA_RES(4, 4, false);
     else if (p->set == MLDSA_65) MLDSA_RES(6, 5, true);
     else MLDSA_RES(8, 7, true);
