@@ -261,11 +261,13 @@ __global__ __launch_bounds__(64) void k_mu(const uint8_t* __restrict__ tr, size_
         bool bad_off = !(msg_off[0] <= m0 && m0 <= m1 && m1 <= msg_off[n_call]);
         mp = msgs + m0;
         mlen = (size_t)(m1 - m0);
+        bad_off |= mlen != 0 && msgs == nullptr;  // offsets that name bytes of a NULL array
         if (ctx_off) {
             const uint64_t c0 = ctx_off[op0 + op], c1 = ctx_off[op0 + op + 1];
             bad_off |= !(ctx_off[0] <= c0 && c0 <= c1 && c1 <= ctx_off[n_call]);
             cp = ctxs + c0;
             clen = (size_t)(c1 - c0);
+            bad_off |= clen != 0 && ctxs == nullptr;
         }
         // 2: malformed offsets or key index out of range; 1: ctx too long (lib.rs:274, 368, 589, 605: every entry point)
         const int flag = bad_off ? 2 : clen > 255 ? 1 : (key_bad ? key_bad[op] : 0);

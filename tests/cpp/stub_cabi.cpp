@@ -229,6 +229,7 @@ int mldsa_sign_host(mldsa_ctx *c, int set, int mode, const uint8_t *sk, size_t n
     const mldsa_params *p = pp(set);
     if (!c || !p) return fail(MLDSA_ERR_PARAM, "sign_host");
     if (!(key_idx ? n_keys > 0 : n_keys >= n_ops)) return fail(MLDSA_ERR_PARAM, "mldsa_sign_host: n_keys does not cover the batch");
+    if (mldsa_check_offsets(moff, n_ops) || (coff && mldsa_check_offsets(coff, n_ops))) return MLDSA_ERR_PARAM;  // before anything is copied
     std::vector<uint8_t> rho(n_keys * 32), tr(n_keys * 64);
     Fnv touch; touch.add(sk, n_keys * (size_t)p->sk_len); touch.add(rnd, n_ops * 32);
     for (size_t i = 0; i < n_keys; i++) { std::memcpy(&rho[32 * i], sk + i * (size_t)p->sk_len, 32); std::memcpy(&tr[64 * i], sk + i * (size_t)p->sk_len + 64, 64); }
@@ -239,6 +240,7 @@ int mldsa_verify_host(mldsa_ctx *c, int set, int mode, const uint8_t *pk, size_t
     const mldsa_params *p = pp(set);
     if (!c || !p) return fail(MLDSA_ERR_PARAM, "verify_host");
     if (!(key_idx ? n_keys > 0 : n_keys >= n_ops)) return fail(MLDSA_ERR_PARAM, "mldsa_verify_host: n_keys does not cover the batch");
+    if (mldsa_check_offsets(moff, n_ops) || (coff && mldsa_check_offsets(coff, n_ops))) return MLDSA_ERR_PARAM;
     std::vector<uint8_t> rho(n_keys * 32), tr(n_keys * 64);
     for (size_t i = 0; i < n_keys; i++) {
         std::memcpy(&rho[32 * i], pk + i * (size_t)p->pk_len, 32);

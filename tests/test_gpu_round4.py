@@ -435,3 +435,36 @@ def test_device_resident_group_calls_match_the_single_context(sets, devices):
             assert np.array_equal(np.concatenate([host(oks[i])[g.shard(n, i)[0]:sum(g.shard(n, i))] for i in range(N)]).astype(bool), v0)
     finally:
         g.close()
+
+
+def test_offsets_that_name_bytes_of_a_null_array_refuse_the_op(sets):
+    """Device-resident calls cannot check the caller's tables on the host.  msgs = NULL is legal when every message is empty; an op
+    whose offsets name bytes of the NULL array is refused like any other malformed pair (no read through the NULL pointer)."""
+    from fips204_amd import _lib
+    m = sets[44]
+    lib, h = m.lib, m.hp._h
+    n = 64
+    pk, sk = m.keygen_from_seed([shake(b"null-key", 0)])
+    pks, sks = m.public_keys_from_bytes(pk), m.private_keys_from_bytes(sk)
+    lens = np.zeros(n, dtype=np.uint64)
+    lens[[5, 40]] = 9                       # two ops claim nine bytes of a message array that is not there
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    d_off = dev_off(off)
+    kidx = dev(np.zeros(n, dtype=np.int32))
+    rnd = dev(np.zeros((n, 32), dtype=np.uint8))
+    sig = torch.full((n, m.SIG_LEN), 7, dtype=torch.uint8, device="cuda")
+    st = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.mldsa_sign(h, 44, 0, P(sks.rho), P(sks.cap_k), P(sks.tr), P(sks.s_1_hat_mont), P(sks.s_2_hat_mont), P(sks.t_0_hat_mont), 1,
+                              P(kidx), None, P(d_off), None, None, P(rnd), P(sig), P(st), n, s))
+    st_h, sig_h = host(st), host(sig)
+    bad = np.zeros(n, dtype=bool)
+    bad[[5, 40]] = True
+    assert (st_h[bad] == _lib.ERR_PARAM).all() and (st_h[~bad] == 0).all() and not sig_h[bad].any()
+    ok = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.mldsa_verify(h, 44, 0, P(pks.rho), P(pks.tr), P(pks.t1_d2_hat_mont), 1, P(kidx), None, P(d_off), None, None, P(sig), P(ok), n, s))
+    assert np.array_equal(host(ok).astype(bool), ~bad)
+    sk_o = orc.sk_try_from_bytes(44, bytes(host(sk)[0]))
+    assert sig_h[0].tobytes() == orc.sign_internal(44, sk_o, b"", bytes(32), mode=0)
