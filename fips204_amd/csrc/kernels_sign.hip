@@ -820,12 +820,24 @@ int launch_unpack_ntt(mldsa_ctx* ctx, const uint8_t* src, size_t key_stride, siz
     return MLDSA_OK;
 }
 
+// the tail kernels' compile-time scalars (TailConst) against the parameter table the rest of the library uses (capi.hip PARAMS)
+template <int K, int L>
+static bool tail_consts_are(const mldsa_params* p) {
+    typedef TailConst<K, L> T;
+    return p->k == K && p->l == L && p->gamma1 == (1 << T::GB) && p->beta == T::BETA && p->omega == T::OMEGA && p->ctilde_len == T::CTILDE &&
+           (size_t)p->sig_len == T::SIG_LEN;
+}
+static bool tail_consts_match(const mldsa_params* p) {
+    return p->set == MLDSA_44 ? tail_consts_are<4, 4>(p) : p->set == MLDSA_65 ? tail_consts_are<6, 5>(p) : p->set == MLDSA_87 && tail_consts_are<8, 7>(p);
+}
+
 int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde,
                      const uint32_t* slot_op, const uint32_t* key_idx, const int32_t* s1, const int32_t* s2, const int32_t* t0,
                      uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, int32_t* accept, size_t slots_hint,
                      hipStream_t s, const uint8_t* wrisk, const uint8_t* yrisk, const uint8_t* key_oor, int oor_by_op,
                      const uint32_t* slot_y) {
     if (!wrisk || !yrisk || !key_oor || !slot_y) return set_error(MLDSA_ERR_PARAM, "sign_tail: wrisk, yrisk, key_oor and slot_y are required");
+    if (!tail_consts_match(p)) return set_error(MLDSA_ERR_PARAM, "sign_tail: parameter table and compiled constants disagree");
     SignTailArgs args;
     args.a = TailPtrs{c, y, w, ctilde, s1, s2, t0};
     args.sigs = sigs; args.ct0_exact = (int)ctx->opt_ct0_exact; args.oor_by_op = oor_by_op; args.ctl = ctl; args.inv_tab = ctx->d_inv_tw;
@@ -867,6 +879,7 @@ int launch_resolve(mldsa_ctx* ctx, const mldsa_params* p, const RoundCtl* ctl, c
                    const int32_t* s1, const int32_t* s2, const int32_t* t0, uint8_t* sigs, int32_t* done, uint16_t* kappa,
                    size_t ops_hint, hipStream_t s, const uint8_t* key_oor, int oor_by_op, const uint32_t* slot_y) {
     if (!key_oor || !slot_y) return set_error(MLDSA_ERR_PARAM, "resolve: key_oor and slot_y are required");
+    if (!tail_consts_match(p)) return set_error(MLDSA_ERR_PARAM, "resolve: parameter table and compiled constants disagree");
     ResolveArgs args;
     args.a = TailPtrs{c, y, w, ctilde, s1, s2, t0};
     args.sigs = sigs; args.ct0_exact = (int)ctx->opt_ct0_exact; args.oor_by_op = oor_by_op; args.ctl = ctl; args.inv_tab = ctx->d_inv_tw;

@@ -468,3 +468,52 @@ def test_offsets_that_name_bytes_of_a_null_array_refuse_the_op(sets):
     assert np.array_equal(host(ok).astype(bool), ~bad)
     sk_o = orc.sk_try_from_bytes(44, bytes(host(sk)[0]))
     assert sig_h[0].tobytes() == orc.sign_internal(44, sk_o, b"", bytes(32), mode=0)
+
+
+def test_caller_owned_workspace_and_sized_stats(sets):
+    """mldsa_ctx_set_workspace: the caller's buffer is the workspace (the reference allocates nothing, README.md:15-16).  A buffer too
+    small for a full pass makes the context run smaller passes -- same keys, signatures and verdicts --, one too small for any pass
+    is MLDSA_ERR_NOMEM, and the context never grows or frees it.  mldsa_get_stats_sized writes only what the caller's struct holds."""
+    from fips204_amd import _lib
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    m = sets[65]
+    n, nk = 5000, 8
+    xi = [shake(b"ws-key", i) for i in range(n)]
+    msgs = [shake(b"ws-msg", i, i % 40) for i in range(n)]
+    rnd = [shake(b"ws-rnd", i) for i in range(n)]
+    kidx = (np.arange(n) % nk).astype(np.uint32)
+    pk0, sk0 = m.keygen_from_seed(xi)
+    sig0 = m.try_sign_with_seed(m.private_keys_from_bytes(sk0[:nk]), msgs, rnd, key_idx=kidx)
+    hp2 = HotPath(0)
+    try:
+        ws = torch.full((192 << 20,), 0x5A, dtype=torch.uint8, device="cuda")   # 192 MiB: no 5 000-op ML-DSA-65 pass fits
+        guard = ws[-4096:].clone()
+        hp2.set_workspace(ws[:-4096])
+        m2 = MlDsa(65, hotpath=hp2)
+        pk1, sk1 = m2.keygen_from_seed(xi)
+        sig1 = m2.try_sign_with_seed(m2.private_keys_from_bytes(sk1[:nk]), msgs, rnd, key_idx=kidx)
+        ok1 = m2.verify(m2.public_keys_from_bytes(pk1[:nk]), msgs, sig1, key_idx=kidx)
+        assert torch.equal(pk1, pk0) and torch.equal(sk1, sk0) and torch.equal(sig1, sig0) and ok1.all()
+        st = hp2.stats()
+        assert st["workspace_shrinks"] > 0 and st["workspace_growths"] == 0, st     # smaller passes, and never a hipMalloc of its own
+        torch.cuda.synchronize()
+        assert torch.equal(ws[-4096:], guard), "the context wrote past the end of the caller's buffer"
+        # a client built against the five-field mldsa_stats of round 2: 40 bytes are written, the next 8 are left alone
+        buf = (C.c_ulonglong * 7)(*([0xDEADBEEF] * 7))
+        _lib.check(m.lib.mldsa_get_stats_sized(hp2._h, buf, 40))
+        assert buf[5] == 0xDEADBEEF and buf[6] == 0xDEADBEEF and buf[2] == st["direct_calls"]
+        # too small for the smallest pass
+        small = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+        hp2.set_workspace(small)
+        with pytest.raises(_lib.MldsaError) as e:
+            m2.keygen_from_seed(xi[:2000])
+        assert e.value.code == _lib.ERR_NOMEM
+        hp2.set_workspace(None)                                                      # back to a context-owned workspace
+        pk3, _ = m2.keygen_from_seed(xi[:300])
+        assert torch.equal(pk3, pk0[:300])
+        # misaligned or half-specified buffers are argument errors
+        assert m.lib.mldsa_ctx_set_workspace(hp2._h, C.c_void_p(ws.data_ptr() + 8), 1 << 20) == _lib.ERR_PARAM
+        assert m.lib.mldsa_ctx_set_workspace(hp2._h, C.c_void_p(ws.data_ptr()), 0) == _lib.ERR_PARAM
+    finally:
+        hp2.close()
