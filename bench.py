@@ -89,6 +89,9 @@ def parse(argv=None):
                     help="torch.distributed backend of the N > 1 run: nccl (= RCCL) or gloo (CPU rendezvous; lets several ranks "
                          "share one GPU for a functional check on a 1-GPU box)")
     ap.add_argument("--graphs", type=int, default=-1, help="override MLDSA_OPT_GRAPHS (hipGraph replay) of the context: 0 / 1")
+    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic live for --workload (two child rocprofv3 counter passes); "
+                                                       "the default run does this for verify65 unless --no-pmc")
+    ap.add_argument("--no-pmc", action="store_true", help="never start the profiler: roofline.traffic from the file kept under profiles/")
     ap.add_argument("--resident", action="store_true",
                     help="with --inproc: slices resident per device and the device-resident group calls (mldsa_verify_group / mldsa_sign_group): "
                          "the contract's HBM-resident value from one process")
@@ -807,12 +810,59 @@ def make_workload(name, hp, batch, rank, world=1):
 def pmc_traffic(name):
     """HBM bytes per launch from the PMC passes kept under profiles/ (tools/collect_profiles.sh): the dominant
     kernel's figure, and per stage where collected.  None when the file is absent."""
-    for fn in (f"r03_pmc_{name}.json", f"r02_pmc_{name}.json", f"pmc_{name}.json"):
+    for fn in (f"r04_pmc_{name}.json", f"r03_pmc_{name}.json", f"r02_pmc_{name}.json", f"pmc_{name}.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(path):
             d = json.load(open(path))
             return d.get("hbm_bytes_per_launch"), d.get("by_stage", {}), fn
     return None, {}, None
+
+
+def measure_pmc_traffic(workload, timeout_s=300):
+    """HBM traffic of `workload`'s kernels from the hardware counters, measured NOW on this box: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, the program itself after `--`, as
+    MI355X_MICROARCH.md prescribes), started before this process has touched the GPU.  Returns tools/pmc_summary.py's object
+    (bytes per launch per stage, FETCH_SIZE doubled for gfx950) or None when the profiler is not available / fails / times out --
+    the line then falls back to the figure kept under profiles/ and says so."""
+    import importlib.util
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None  # this process is itself being profiled: no nested profiler
+    dirs = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix=f"mldsa_pmc_{counter}_", dir="/tmp")
+            dirs[counter] = d
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", "python3", os.path.abspath(__file__),
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-pmc"]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)  # the exact process group this function started
+                return None
+            if rc != 0:
+                return None
+        spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out = mod.hbm_compute(workload, dirs["FETCH_SIZE"], dirs["WRITE_SIZE"])
+        return out if out.get("hbm_bytes_per_launch") else None
+    except Exception:
+        return None
+    finally:
+        for d in dirs.values():
+            shutil.rmtree(d, ignore_errors=True)
+
+
+LIVE_PMC = {}  # workload -> measure_pmc_traffic() object of this run
 
 
 def timed_steps(wl, world, steps, first):
@@ -884,6 +934,9 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
 
     alg_bytes = wl.bytes_per_op * units_per_step
     traffic, traffic_by_stage, traffic_file = pmc_traffic(name)
+    live = LIVE_PMC.get(name)
+    if live:
+        traffic, traffic_by_stage, traffic_file = live["hbm_bytes_per_launch"], live["by_stage"], None
     slots = op_rounds = None
     if whole:
         slots = stages.pop("_sign_slots", None)
@@ -917,8 +970,11 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     }
     # `traffic` is a PMC figure (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes) read from the file named beside it: it was
     # NOT measured by this process (counters need the profiler)
-    line["roofline"]["traffic_measured_in_this_run"] = False
-    if traffic_file:
+    line["roofline"]["traffic_measured_in_this_run"] = bool(live)
+    if live:
+        line["roofline"]["traffic_source"] = ("two child runs of this command under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate passes, "
+                                              "--kernel-trace only) on this box just before the timed region; FETCH_SIZE x 2 + WRITE_SIZE, KiB, mean per launch")
+    elif traffic_file:
         line["roofline"]["traffic_source"] = "profiles/" + traffic_file
     line["launch_mode"] = launch_mode
     if isinstance(wl, MixedStream):
@@ -1267,6 +1323,12 @@ def main():
         # (importing torch does not), starts N fresh rank processes of this script and relays rank 0's line.
         from fips204_amd import multi_gpu
         raise SystemExit(multi_gpu.launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    # live HBM-traffic counters (rocprofv3 child passes) BEFORE this process touches the GPU: single-GPU runs only
+    single = args.gpus == 1 and "RANK" not in os.environ
+    if single and not args.no_pmc and (args.pmc or (args.workload == "verify65" and not args.no_extras)):
+        got = measure_pmc_traffic(args.workload)
+        if got:
+            LIVE_PMC[args.workload] = got
     rank, local_rank, world = dist_setup(args)
     from fips204_amd import multi_gpu
     from fips204_amd.hotpath import HotPath

@@ -19,8 +19,10 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """torch's current stream ON `device` (None: the current device) as a hipStream_t.  Every call of a context must name a stream
+    of the context's own device: with several GPUs in one process the current device is not necessarily that one."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _bytes(t, name, row):
@@ -122,14 +124,14 @@ class HotPath:
         """ntt::<KL>(&[R; KL]) -> [T; KL]   (src/ntt.rs:14)"""
         w = _polys(w, "w")
         out = torch.empty_like(w) if out is None else out
-        _lib.check(self.lib.mldsa_ntt(self._h, _ptr(w), _ptr(out), w.numel() // N, _stream()))
+        _lib.check(self.lib.mldsa_ntt(self._h, _ptr(w), _ptr(out), w.numel() // N, _stream(self.device)))
         return out
 
     def inv_ntt(self, w_hat, out=None):
         """inv_ntt::<KL>(&[T; KL]) -> [R; KL]   (src/ntt.rs:85)"""
         w_hat = _polys(w_hat, "w_hat")
         out = torch.empty_like(w_hat) if out is None else out
-        _lib.check(self.lib.mldsa_inv_ntt(self._h, _ptr(w_hat), _ptr(out), w_hat.numel() // N, _stream()))
+        _lib.check(self.lib.mldsa_inv_ntt(self._h, _ptr(w_hat), _ptr(out), w_hat.numel() // N, _stream(self.device)))
         return out
 
     # ---- src/helpers.rs -----------------------------------------------------------
@@ -137,7 +139,7 @@ class HotPath:
         """to_mont(&[T; L]) -> [T; L]   (src/helpers.rs:131)"""
         v = _polys(v, "v")
         out = torch.empty_like(v)
-        _lib.check(self.lib.mldsa_to_mont(self._h, _ptr(v), _ptr(out), v.numel() // N, _stream()))
+        _lib.check(self.lib.mldsa_to_mont(self._h, _ptr(v), _ptr(out), v.numel() // N, _stream(self.device)))
         return out
 
     def mat_vec_mul(self, pset, a_hat, u_hat):
@@ -148,7 +150,7 @@ class HotPath:
         if u_hat.numel() != n_ops * p.l * N or a_hat.numel() != n_ops * p.k * p.l * N:
             raise ValueError("mat_vec_mul: shape mismatch")
         out = torch.empty((n_ops, p.k, N), dtype=torch.int32, device=a_hat.device)
-        _lib.check(self.lib.mldsa_mat_vec_mul(self._h, pset, _ptr(a_hat), _ptr(u_hat), _ptr(out), n_ops, _stream()))
+        _lib.check(self.lib.mldsa_mat_vec_mul(self._h, pset, _ptr(a_hat), _ptr(u_hat), _ptr(out), n_ops, _stream(self.device)))
         return out
 
     def pointwise_mont(self, c_hat, v_hat_mont):
@@ -159,7 +161,7 @@ class HotPath:
             raise ValueError("pointwise_mont: shape mismatch")
         ppo = v.numel() // (n_ops * N)
         out = torch.empty_like(v)
-        _lib.check(self.lib.mldsa_pointwise_mont(self._h, _ptr(c_hat), _ptr(v), _ptr(out), ppo, n_ops, _stream()))
+        _lib.check(self.lib.mldsa_pointwise_mont(self._h, _ptr(c_hat), _ptr(v), _ptr(out), ppo, n_ops, _stream(self.device)))
         return out
 
     def add_vector_ntt(self, a, b):
@@ -168,7 +170,7 @@ class HotPath:
         if a.numel() != b.numel():
             raise ValueError("add_vector_ntt: shape mismatch")
         out = torch.empty_like(a)
-        _lib.check(self.lib.mldsa_add_vector_ntt(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel() // N, _stream()))
+        _lib.check(self.lib.mldsa_add_vector_ntt(self._h, _ptr(a), _ptr(b), _ptr(out), a.numel() // N, _stream(self.device)))
         return out
 
     def infinity_norm(self, w, polys_per_op):
@@ -176,7 +178,7 @@ class HotPath:
         w = _polys(w, "w")
         n_ops = w.numel() // (polys_per_op * N)
         out = torch.empty(n_ops, dtype=torch.int32, device=w.device)
-        _lib.check(self.lib.mldsa_infinity_norm(self._h, _ptr(w), polys_per_op, n_ops, _ptr(out), _stream()))
+        _lib.check(self.lib.mldsa_infinity_norm(self._h, _ptr(w), polys_per_op, n_ops, _ptr(out), _stream(self.device)))
         return out
 
     def verify_arith(self, pset, a_hat, z, c, t1_d2_hat_mont, out=None):
@@ -191,7 +193,7 @@ class HotPath:
         if out is None:
             out = torch.empty((n_ops, p.k, N), dtype=torch.int32, device=c.device)
         _lib.check(self.lib.mldsa_verify_arith(self._h, pset, _ptr(a_hat), _ptr(z), _ptr(c),
-                                               _ptr(t1_d2_hat_mont), _ptr(out), n_ops, _stream()))
+                                               _ptr(t1_d2_hat_mont), _ptr(out), n_ops, _stream(self.device)))
         return out
 
     # ---- src/hashing.rs -----------------------------------------------------------
@@ -201,7 +203,7 @@ class HotPath:
         rho = _bytes(rho, "rho", 32)
         n_ops = rho.numel() // 32
         out = torch.empty((n_ops, p.k, p.l, N), dtype=torch.int32, device=rho.device)
-        _lib.check(self.lib.mldsa_expand_a(self._h, pset, _ptr(rho), _ptr(out), n_ops, _stream()))
+        _lib.check(self.lib.mldsa_expand_a(self._h, pset, _ptr(rho), _ptr(out), n_ops, _stream(self.device)))
         return out
 
     def expand_s(self, pset, rho_prime):
@@ -210,7 +212,7 @@ class HotPath:
         rho_prime = _bytes(rho_prime, "rho_prime", 64)
         n_ops = rho_prime.numel() // 64
         out = torch.empty((n_ops, p.l + p.k, N), dtype=torch.int32, device=rho_prime.device)
-        _lib.check(self.lib.mldsa_expand_s(self._h, pset, _ptr(rho_prime), _ptr(out), n_ops, _stream()))
+        _lib.check(self.lib.mldsa_expand_s(self._h, pset, _ptr(rho_prime), _ptr(out), n_ops, _stream(self.device)))
         return out[:, :p.l], out[:, p.l:]
 
     def expand_mask(self, pset, rho_pp, kappa):
@@ -221,7 +223,7 @@ class HotPath:
         if not (kappa.is_cuda and kappa.dtype == torch.int16 and kappa.numel() == n_ops):
             raise TypeError("kappa: expected an int16 CUDA tensor (u16 bit pattern) with one entry per op")
         out = torch.empty((n_ops, p.l, N), dtype=torch.int32, device=rho_pp.device)
-        _lib.check(self.lib.mldsa_expand_mask(self._h, pset, _ptr(rho_pp), _ptr(kappa), _ptr(out), n_ops, _stream()))
+        _lib.check(self.lib.mldsa_expand_mask(self._h, pset, _ptr(rho_pp), _ptr(kappa), _ptr(out), n_ops, _stream(self.device)))
         return out
 
     def sample_in_ball(self, pset, c_tilde):
@@ -230,5 +232,5 @@ class HotPath:
         c_tilde = _bytes(c_tilde, "c_tilde", p.ctilde_len)
         n_ops = c_tilde.numel() // p.ctilde_len
         out = torch.empty((n_ops, N), dtype=torch.int32, device=c_tilde.device)
-        _lib.check(self.lib.mldsa_sample_in_ball(self._h, pset, _ptr(c_tilde), _ptr(out), n_ops, _stream()))
+        _lib.check(self.lib.mldsa_sample_in_ball(self._h, pset, _ptr(c_tilde), _ptr(out), n_ops, _stream(self.device)))
         return out

@@ -143,7 +143,7 @@ class MlDsa:
             kidx = torch.as_tensor(key_idx.view(np.int32)).to(self.device)
         ok = torch.zeros(max(n_ops, 1), dtype=torch.uint8, device=self.device)
         self.verify_device(pks, msg_buf, msg_off, sigs, ok, n_ops, ctx_buf, ctx_off, kidx, mode)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         res = ok[:n_ops].cpu().numpy().astype(bool)
         if wrong_len is not None:
             res &= ~wrong_len
@@ -169,7 +169,7 @@ class MlDsa:
             self.hp._h, self.pset, mode, _ptr(first), _ptr(pks.tr), _ptr(pks.t1_d2_hat_mont), len(pks),
             _ptr(key_idx) if key_idx is not None else null, _ptr(msg_buf), _ptr(msg_off),
             _ptr(ctx_buf) if ctx_buf is not None else null, _ptr(ctx_off) if ctx_off is not None else null,
-            _ptr(sigs), _ptr(ok), n_ops, _stream()))
+            _ptr(sigs), _ptr(ok), n_ops, _stream(self.device)))
         return ok
 
     # ---- SerDes (src/traits.rs:372-424; src/lib.rs:421-424, 471-475) ------------------
@@ -201,7 +201,7 @@ class MlDsa:
         pk = self._key_bytes(pk_bytes, self.PK_LEN, "pk")
         n = pk.shape[0]
         o = out or self.empty_public_keys(n)
-        _lib.check(self.lib.mldsa_pk_expand(self.hp._h, self.pset, _ptr(pk), _ptr(o.rho), _ptr(o.tr), _ptr(o.t1_d2_hat_mont), n, _stream()))
+        _lib.check(self.lib.mldsa_pk_expand(self.hp._h, self.pset, _ptr(pk), _ptr(o.rho), _ptr(o.tr), _ptr(o.t1_d2_hat_mont), n, _stream(self.device)))
         return o
 
     def private_keys_from_bytes(self, sk_bytes, out=None):
@@ -210,14 +210,14 @@ class MlDsa:
         n = sk.shape[0]
         o = out or self.empty_private_keys(n)
         _lib.check(self.lib.mldsa_sk_expand(self.hp._h, self.pset, _ptr(sk), _ptr(o.rho), _ptr(o.cap_k), _ptr(o.tr), _ptr(o.s_1_hat_mont),
-                                            _ptr(o.s_2_hat_mont), _ptr(o.t_0_hat_mont), n, _stream()))
+                                            _ptr(o.s_2_hat_mont), _ptr(o.t_0_hat_mont), n, _stream(self.device)))
         return o
 
     def public_keys_into_bytes(self, pks):
         """PublicKey::into_bytes for a batch (src/lib.rs:478-493): uint8 tensor [n, PK_LEN]"""
         n = len(pks)
         pk = torch.empty((n, self.PK_LEN), dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.mldsa_pk_into_bytes(self.hp._h, self.pset, _ptr(pks.rho), _ptr(pks.t1_d2_hat_mont), _ptr(pk), n, _stream()))
+        _lib.check(self.lib.mldsa_pk_into_bytes(self.hp._h, self.pset, _ptr(pks.rho), _ptr(pks.t1_d2_hat_mont), _ptr(pk), n, _stream(self.device)))
         return pk
 
     def private_keys_into_bytes(self, sks):
@@ -226,7 +226,7 @@ class MlDsa:
         sk = torch.empty((n, self.SK_LEN), dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.mldsa_sk_into_bytes(self.hp._h, self.pset, _ptr(sks.rho), _ptr(sks.cap_k), _ptr(sks.tr),
                                                 _ptr(sks.s_1_hat_mont), _ptr(sks.s_2_hat_mont), _ptr(sks.t_0_hat_mont), _ptr(sk), n,
-                                                _stream()))
+                                                _stream(self.device)))
         return sk
 
     def get_public_key(self, sks):
@@ -236,7 +236,7 @@ class MlDsa:
         tr = torch.empty((n, 64), dtype=torch.uint8, device=self.device)
         t1 = torch.empty((n, k, N), dtype=torch.int32, device=self.device)
         _lib.check(self.lib.mldsa_get_public_key(self.hp._h, self.pset, _ptr(sks.rho), _ptr(sks.tr), _ptr(sks.s_1_hat_mont),
-                                                 _ptr(sks.s_2_hat_mont), _ptr(rho), _ptr(tr), _ptr(t1), n, _stream()))
+                                                 _ptr(sks.s_2_hat_mont), _ptr(rho), _ptr(tr), _ptr(t1), n, _stream(self.device)))
         return PublicKeys(self.pset, rho, tr, t1)
 
     # ---- host-memory entry points (numpy arrays in, numpy arrays out; staging inside the library) --------
@@ -365,7 +365,7 @@ class MlDsa:
         n = xi.shape[0]
         pk, sk = out or (torch.empty((n, self.PK_LEN), dtype=torch.uint8, device=self.device),
                          torch.empty((n, self.SK_LEN), dtype=torch.uint8, device=self.device))
-        _lib.check(self.lib.mldsa_keygen(self.hp._h, self.pset, _ptr(xi), _ptr(pk), _ptr(sk), n, _stream()))
+        _lib.check(self.lib.mldsa_keygen(self.hp._h, self.pset, _ptr(xi), _ptr(pk), _ptr(sk), n, _stream(self.device)))
         return pk, sk
 
     def try_keygen_with_rng(self, rng, n=1):
@@ -418,7 +418,7 @@ class MlDsa:
         sigs = torch.empty((max(n_ops, 1), self.SIG_LEN), dtype=torch.uint8, device=self.device)
         status = torch.zeros(max(n_ops, 1), dtype=torch.int32, device=self.device)
         self.sign_device(sks, msg_buf, msg_off, rnd, sigs, n_ops, ctx_buf, ctx_off, kidx, mode, status)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self.device)
         if n_ops and int(status[:n_ops].min()) < 0:
             raise ValueError("ML-DSA.Sign: ctx too long")
         return sigs[:n_ops]
@@ -444,7 +444,7 @@ class MlDsa:
             _ptr(sks.s_2_hat_mont), _ptr(sks.t_0_hat_mont), len(sks), _ptr(key_idx) if key_idx is not None else null,
             _ptr(msg_buf), _ptr(msg_off), _ptr(ctx_buf) if ctx_buf is not None else null,
             _ptr(ctx_off) if ctx_off is not None else null, _ptr(rnd), _ptr(sigs),
-            _ptr(status) if status is not None else null, n_ops, _stream()))
+            _ptr(status) if status is not None else null, n_ops, _stream(self.device)))
         return sigs
 
 

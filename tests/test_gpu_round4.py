@@ -517,3 +517,71 @@ def test_caller_owned_workspace_and_sized_stats(sets):
         assert m.lib.mldsa_ctx_set_workspace(hp2._h, C.c_void_p(ws.data_ptr()), 0) == _lib.ERR_PARAM
     finally:
         hp2.close()
+
+
+def test_argument_errors_never_abort(sets):
+    """include/mldsa_hip.h: "0 = MLDSA_OK, negative = error (never aborts)".  Every entry point with NULL pointers, unknown parameter
+    sets, unknown modes, n_keys that do not cover the batch and zero-sized batches: an error code (or MLDSA_OK for an empty batch)
+    and a message, never a fault -- and the context still signs and verifies afterwards (src/lib.rs:274, 368: the reference returns
+    Err / false on every malformed argument it can be handed)."""
+    from fips204_amd import _lib
+    m = sets[44]
+    lib, h = m.lib, m.hp._h
+    E, OK = _lib.ERR_PARAM, 0
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    off = dev_off(np.zeros(9, dtype=np.uint64))
+    p, z, o = C.c_void_p(buf.data_ptr()), None, C.c_void_p(off.data_ptr())
+    calls = [
+        # seam level: NULL pointers with n > 0, n = 0 with NULLs, unknown sets
+        (lib.mldsa_ntt, (h, z, p, 4, z), E), (lib.mldsa_ntt, (h, z, z, 0, z), OK), (lib.mldsa_ntt, (None, p, p, 4, z), E),
+        (lib.mldsa_inv_ntt, (h, p, z, 1, z), E), (lib.mldsa_to_mont, (h, z, z, 1, z), E),
+        (lib.mldsa_mat_vec_mul, (h, 45, p, p, p, 1, z), E), (lib.mldsa_mat_vec_mul, (h, 44, z, p, p, 1, z), E),
+        (lib.mldsa_pointwise_mont, (h, z, p, p, 4, 1, z), E), (lib.mldsa_add_vector_ntt, (h, p, z, p, 1, z), E),
+        (lib.mldsa_infinity_norm, (h, p, 0, 1, p, z), E), (lib.mldsa_infinity_norm, (h, z, 4, 1, p, z), E),
+        (lib.mldsa_verify_arith, (h, 44, p, p, z, p, p, 1, z), E), (lib.mldsa_verify_arith, (h, 0, p, p, p, p, p, 1, z), E),
+        (lib.mldsa_expand_a, (h, 66, p, p, 1, z), E), (lib.mldsa_expand_a, (h, 65, z, p, 1, z), E), (lib.mldsa_expand_s, (h, 44, p, z, 1, z), E),
+        (lib.mldsa_expand_mask, (h, 44, p, z, p, 1, z), E), (lib.mldsa_sample_in_ball, (h, 44, z, p, 1, z), E),
+        # op level
+        (lib.mldsa_verify, (h, 44, 0, p, p, p, 1, z, p, o, z, z, p, z, 1, z), E),                 # ok = NULL
+        (lib.mldsa_verify, (h, 44, 7, p, p, p, 1, z, p, o, z, z, p, p, 1, z), E),                 # mode 7
+        (lib.mldsa_verify, (h, 44, 0, p, p, p, 1, z, p, o, z, z, p, p, 8, z), E),                 # 1 key, 8 ops, no key_idx
+        (lib.mldsa_verify, (h, 44, 0, p, p, p, 0, p, p, o, z, z, p, p, 8, z), E),                 # key_idx with n_keys = 0
+        (lib.mldsa_verify, (h, 44, 0, z, z, z, 0, z, z, z, z, z, z, z, 0, z), OK),                # empty batch
+        (lib.mldsa_verify, (h, 44, 0, p, p, p, 1, z, p, z, z, z, p, p, 1, z), E),                 # msg_off = NULL
+        (lib.mldsa_verify_cached_a, (h, 44, 0, z, p, p, 1, z, p, o, z, z, p, p, 1, z), E),
+        (lib.mldsa_sign, (h, 44, 0, p, p, p, p, p, p, 1, z, p, o, z, z, z, p, p, 1, z), E),       # rnd = NULL
+        (lib.mldsa_sign, (h, 99, 0, p, p, p, p, p, p, 1, z, p, o, z, z, p, p, p, 1, z), E),
+        (lib.mldsa_sign, (h, 44, 0, z, z, z, z, z, z, 0, z, z, z, z, z, z, z, z, 0, z), OK),
+        (lib.mldsa_sign_async, (h, 44, 0, p, p, p, p, p, p, 1, z, p, o, z, z, p, p, z, 1, z), E),  # the asynchronous call needs `status`
+        (lib.mldsa_sign_cached_a, (h, 44, 3, p, p, p, p, p, p, 1, z, p, o, z, z, p, p, p, 1, z), E),
+        (lib.mldsa_keygen, (h, 44, z, p, p, 1, z), E), (lib.mldsa_keygen, (h, 45, p, p, p, 1, z), E), (lib.mldsa_keygen, (h, 44, z, z, z, 0, z), OK),
+        (lib.mldsa_pk_expand, (h, 44, p, p, z, p, 1, z), E), (lib.mldsa_sk_expand, (h, 44, p, p, p, p, p, z, p, 1, z), E),
+        (lib.mldsa_pk_into_bytes, (h, 44, p, z, p, 1, z), E), (lib.mldsa_sk_into_bytes, (h, 44, p, p, p, p, p, p, z, 1, z), E),
+        (lib.mldsa_get_public_key, (h, 44, p, p, p, p, p, p, z, 1, z), E),
+        # host-memory entry points and groups
+        (lib.mldsa_verify_host, (h, 44, 0, z, 1, z, z, z, z, z, z, z, 1), E), (lib.mldsa_verify_host, (None, 44, 0, z, 0, z, z, z, z, z, z, z, 0), E),
+        (lib.mldsa_sign_host, (h, 44, 0, z, 1, z, z, z, z, z, z, z, z, 1), E), (lib.mldsa_keygen_host, (h, 44, z, z, z, 3), E),
+        (lib.mldsa_keygen_host, (h, 44, z, z, z, 0), OK),
+        (lib.mldsa_verify_group, (None, 44, 0, z, 1), E), (lib.mldsa_group_sync, (None,), E), (lib.mldsa_group_allgather, (None, z, 1, 0), E),
+        # housekeeping
+        (lib.mldsa_reserve, (h, 44, 9, 100), E), (lib.mldsa_reserve, (h, 43, 2, 100), E), (lib.mldsa_set_option, (h, 99, 1), E),
+        (lib.mldsa_set_option, (h, _lib.OPT_SPEC_MAX, 65), E), (lib.mldsa_get_stats, (h, None), E),
+        (lib.mldsa_profile_report, (h, None, 0), E), (lib.mldsa_debug_secret_residue, (h, None, None), E),
+        (lib.mldsa_debug_count_nonzero, (None, 16, None), E),
+    ]
+    for fn, a, want in calls:
+        rc = fn(*a)
+        assert rc == want, (fn.__name__, a[1:4], rc, lib.mldsa_last_error())
+        if want != OK:
+            assert lib.mldsa_last_error(), fn.__name__
+    g = C.c_void_p()
+    assert lib.mldsa_group_create(None, 2, C.byref(g)) == E and lib.mldsa_group_create((C.c_int * 1)(0), 0, C.byref(g)) == E
+    assert lib.mldsa_group_create((C.c_int * 1)(77), 1, C.byref(g)) < 0 and not g.value
+    hh = C.c_void_p()
+    assert lib.mldsa_ctx_create(-1, C.byref(hh)) == E and lib.mldsa_ctx_create(0, None) == E
+    lib.mldsa_ctx_destroy(None)
+    lib.mldsa_group_destroy(None)
+    # the context is still in working order
+    pk, sk = m.keygen_from_seed([shake(b"err-key", 0)])
+    sig = m.try_sign_with_seed(m.private_keys_from_bytes(sk), [b"still works"], [bytes(32)])
+    assert m.verify(m.public_keys_from_bytes(pk), [b"still works"], sig).all()

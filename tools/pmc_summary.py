@@ -37,7 +37,8 @@ def stage_of(kernel):
     return None
 
 
-def hbm(workload, fdir, wdir, rnd):
+def hbm_compute(workload, fdir, wdir):
+    """the summary object of one FETCH_SIZE and one WRITE_SIZE pass (bench.py's live measurement uses it too)"""
     per = {}
     for d, counter in ((fdir, "FETCH_SIZE"), (wdir, "WRITE_SIZE")):
         for r in rows(d):
@@ -58,6 +59,12 @@ def hbm(workload, fdir, wdir, rnd):
            "fetch_correction": "x2 (gfx950 counts 128-B requests as 64 B for wide streaming reads; dwordx3 reads of the 24-bit A_hat "
                                "are booked like dwordx4, so read figures of kernels that stream it are upper bounds)",
            "dominant_stage": dom, "hbm_bytes_per_launch": by_stage.get(dom), "by_stage": by_stage, "detail": detail}
+    return out
+
+
+def hbm(workload, fdir, wdir, rnd):
+    out = hbm_compute(workload, fdir, wdir)
+    by_stage = out["by_stage"]
     path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{workload}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, json.dumps({k: round(v / 1e6, 2) for k, v in by_stage.items()}), "MB per launch")
