@@ -2,6 +2,7 @@
 include/mldsa_hip.h declares, agrees with the oracle on the parameter table, and fails
 loudly (no fallback) when no HIP device is present.  No compute calls here."""
 import ctypes as C
+import os
 
 import pytest
 
@@ -151,3 +152,36 @@ def test_abi_version_and_sized_stats():
     buf = (C.c_ubyte * 16)()
     assert lib.mldsa_get_stats_sized(None, buf, 16) == _lib.ERR_PARAM
     assert C.sizeof(_lib.Stats) == 48
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """The boundary is a C ABI (`extern "C"`, plain pointers and sizes): include/mldsa_hip.h compiles as strict C99 and
+    as C++11, and a C program that takes the address of EVERY declared entry point links against libmldsa_hip.so and runs the two
+    calls that need no device (mldsa_abi_version, mldsa_check_offsets)."""
+    import subprocess
+    names = _lib.declared_symbols()
+    src = tmp_path / "all_symbols.c"
+    body = "\n".join(f"    p[{i}] = (void (*)(void))&{n};" for i, n in enumerate(names))
+    src.write_text(f'''#include <stdio.h>
+#include "mldsa_hip.h"
+int main(void) {{
+    void (*p[{len(names)}])(void);
+{body}
+    for (int i = 0; i < {len(names)}; i++) if (!p[i]) return 2;
+    uint64_t good[3] = {{0, 5, 5}}, bad[3] = {{0, 5, 4}};
+    if (mldsa_abi_version() != MLDSA_ABI_VERSION) return 3;
+    if (mldsa_check_offsets(good, 2) != MLDSA_OK || mldsa_check_offsets(bad, 2) != MLDSA_ERR_PARAM) return 4;
+    mldsa_params pr;
+    if (mldsa_get_params(MLDSA_65, &pr) != MLDSA_OK || pr.sig_len != 3309 || mldsa_get_params(1, &pr) != MLDSA_ERR_PARAM) return 5;
+    printf("%d symbols\\n", {len(names)});
+    return 0;
+}}
+''')
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "all_symbols"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-Wno-pedantic", "-I", inc, str(src), "-o", str(exe), f"-L{libdir}", "-lmldsa_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == f"{len(names)} symbols", (out.returncode, out.stdout, out.stderr[-500:])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", os.path.join(inc, "mldsa_hip.h")])
