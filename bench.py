@@ -458,15 +458,19 @@ class WholeOp:
                      + ("/ExpandMask + rejection-loop re-batch" if kind == "sign" else "")
                      + ", 32-byte messages, inputs resident in HBM"
                      + (f", every {corrupt_every}th signature corrupted (one flipped bit)" if corrupt_every else "")
-                     + (", FROM WIRE BYTES: try_from_bytes of the op's key (tr = H(pk) / key NTTs) inside the timed unit" if wire else ""))
+                     + (", FROM WIRE BYTES: try_from_bytes of the op's key (tr = H(pk) / key NTTs) inside the timed unit"
+                        + (" (mldsa_verify_pk: one call)" if kind == "verify" else " (mldsa_sk_expand + mldsa_sign)") if wire else ""))
         self.a_hat = ml.expand_a_for_keys(self.pks) if cached_a else None
         self.dtype = "int32"
         self.kernel = None
 
     def step(self, i):
         if self.wire and self.kind == "verify":
-            self.ml.public_keys_from_bytes(self.key_op, out=self.keys_op)
-            self.ml.verify_device(self.keys_op, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch)
+            if os.environ.get("MLDSA_BENCH_WIRE_UNFUSED") == "1":   # the two calls a host without mldsa_verify_pk would make
+                self.ml.public_keys_from_bytes(self.key_op, out=self.keys_op)
+                self.ml.verify_device(self.keys_op, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch)
+            else:
+                self.ml.verify_pk_device(self.key_op, self.msg_buf, self.msg_off, self.sigs, self.ok, self.batch)
         elif self.wire:
             self.ml.private_keys_from_bytes(self.key_op, out=self.keys_op)
             self.ml.sign_device(self.keys_op, self.msg_buf, self.msg_off, self.rnd, self.sigs, self.batch, status=self.status)

@@ -106,6 +106,8 @@ _SIGNATURES = {
     # ctx, set, mode, rho | a_hat, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, stream
     "mldsa_verify": [_P, _I, _I, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mldsa_verify_cached_a": [_P, _I, _I, _P, _P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
+    # ctx, set, mode, pk (wire bytes), n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, stream
+    "mldsa_verify_pk": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mldsa_pk_expand": [_P, _I, _P, _P, _P, _P, _SZ, _P],
     "mldsa_sk_expand": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P],
     "mldsa_pk_into_bytes": [_P, _I, _P, _P, _P, _SZ, _P],

@@ -533,20 +533,21 @@ int mldsa_sample_in_ball(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, int32_
 // Shared by mldsa_verify and mldsa_verify_cached_a: reserve, then replay / capture / launch the pipeline.
 static int verify_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const int32_t *a_hat, const uint8_t *tr,
                        const int32_t *t1, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off,
-                       const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t s) {
+                       const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t s,
+                       const uint8_t *pk_wire = nullptr) {
     const mldsa_params *p = params_of(set);
     if (n_ops == 0) return MLDSA_OK;
     OpGuard guard(ctx, s);
-    int rc = reserve_workspace(ctx, p, MLDSA_OP_VERIFY, n_ops, a_hat == nullptr);
+    int rc = reserve_workspace(ctx, p, MLDSA_OP_VERIFY, n_ops, a_hat == nullptr, n_keys, pk_wire ? (key_idx ? 2 : 1) : 0);
     if (rc != MLDSA_OK) return rc;
-    struct { int op, set, mode; const void *rho, *a_hat, *tr, *t1; size_t n_keys; const void *key_idx, *msgs, *msg_off, *ctxs, *ctx_off, *sigs, *ok;
+    struct { int op, set, mode; const void *rho, *a_hat, *tr, *t1, *pk; size_t n_keys; const void *key_idx, *msgs, *msg_off, *ctxs, *ctx_off, *sigs, *ok;
              size_t n_ops; } key;
     memset(&key, 0, sizeof(key));
-    key.op = MLDSA_OP_VERIFY; key.set = set; key.mode = mode; key.rho = rho; key.a_hat = a_hat; key.tr = tr; key.t1 = t1; key.n_keys = n_keys;
+    key.op = MLDSA_OP_VERIFY; key.set = set; key.mode = mode; key.rho = rho; key.a_hat = a_hat; key.tr = tr; key.t1 = t1; key.pk = pk_wire; key.n_keys = n_keys;
     key.key_idx = key_idx; key.msgs = msgs; key.msg_off = msg_off; key.ctxs = ctxs; key.ctx_off = ctx_off; key.sigs = sigs; key.ok = ok;
     key.n_ops = n_ops;
     return run_op(ctx, s, MLDSA_OP_VERIFY, n_ops, &key, sizeof(key), [&](hipStream_t st) {
-        return verify_batch(ctx, set, mode, rho, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, st, a_hat);
+        return verify_batch(ctx, set, mode, rho, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops, st, a_hat, pk_wire);
     });
 }
 
@@ -561,6 +562,18 @@ int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
     REQUIRE(n_ops == 0 || (key_idx ? n_keys > 0 : n_keys >= n_ops), "mldsa_verify: n_keys does not cover the batch");
     return verify_call(ctx, set, mode, rho, nullptr, tr, t1_d2_hat_mont, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
                        (hipStream_t)stream);
+}
+
+int mldsa_verify_pk(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
+                    const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops,
+                    void *stream) {
+    ENTER(ctx, "mldsa_verify_pk");
+    REQUIRE(params_of(set), "mldsa_verify_pk: unknown parameter set");
+    REQUIRE(mode_ok(mode), "mldsa_verify_pk: bad mode");
+    REQUIRE(n_ops == 0 || (pk && msg_off && sigs && ok), "mldsa_verify_pk: NULL pointer");
+    REQUIRE(n_ops == 0 || (key_idx ? n_keys > 0 : n_keys >= n_ops), "mldsa_verify_pk: n_keys does not cover the batch");
+    return verify_call(ctx, set, mode, nullptr, nullptr, nullptr, nullptr, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok, n_ops,
+                       (hipStream_t)stream, pk);
 }
 
 int mldsa_verify_cached_a(mldsa_ctx *ctx, int set, int mode, const int32_t *a_hat, const uint8_t *tr,

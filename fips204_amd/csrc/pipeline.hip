@@ -32,10 +32,10 @@ constexpr size_t MIN_PASS_OPS = 1024, MIN_SPEC_ROWS = 1024;
 // Workspace for `n_ops` ops of operation `op`.  The pass sizes above are tuned for a whole MI355X (a 262 144-op ML-DSA-87 signing
 // pass takes 15 GB of the 288); on a device that cannot give that much -- smaller, partitioned, or shared with other work --
 // the context falls back to smaller passes (more of them per call, results identical) instead of failing the call.
-int reserve_workspace(mldsa_ctx *ctx, const mldsa_params *p, int op, size_t n_ops, bool own_a) {
+int reserve_workspace(mldsa_ctx *ctx, const mldsa_params *p, int op, size_t n_ops, bool own_a, size_t wire_table_keys, int wire_mode) {
     for (;;) {
         const size_t bytes = op == MLDSA_OP_SIGN ? sign_workspace_bytes(ctx, p, n_ops, own_a)
-                             : op == MLDSA_OP_VERIFY ? verify_workspace_bytes(ctx, p, n_ops, own_a)
+                             : op == MLDSA_OP_VERIFY ? verify_workspace_bytes(ctx, p, n_ops, own_a, wire_table_keys, wire_mode)
                                                      : keygen_workspace_bytes(ctx, p, n_ops);
         const int rc = ensure_workspace(ctx, bytes);
         size_t &pass = op == MLDSA_OP_SIGN ? ctx->pass_ops_sign : ctx->pass_ops;
@@ -128,10 +128,15 @@ struct VerifyWs {
     int32_t *a_hat, *c, *znorm, *hvalid, *ctx_bad, *key_bad;
     uint32_t *kidx;
     uint8_t *mu_w1;
+    // mldsa_verify_pk: the expanded fields of `wire_keys` wire-format public keys (tr = H(pk), t1_d2_hat_mont), expand_public's outputs
+    uint8_t *tr_w;
+    int32_t *t1_w;
     size_t bytes;
-    VerifyWs(void *base, const mldsa_params *p, size_t n, bool own_a_hat) {
+    VerifyWs(void *base, const mldsa_params *p, size_t n, bool own_a_hat, size_t wire_keys = 0) {
         Carver cv(base);
         a_hat = cv.take<int32_t>(own_a_hat ? n * p->k * p->l * N : 0);
+        tr_w = cv.take<uint8_t>(wire_keys * 64);
+        t1_w = cv.take<int32_t>(wire_keys * (size_t)p->k * N);
         c = cv.take<int32_t>(n * (N / 4));  // one byte per coefficient (k_sample_in_ball<.., C8>)
         znorm = cv.take<int32_t>(n);
         hvalid = cv.take<int32_t>(n);
@@ -147,26 +152,36 @@ struct VerifyWs {
 #define TRY(expr) do { int _rc = (expr); if (_rc != MLDSA_OK) return _rc; } while (0)
 #define STAGE(name, expr) do { ProfScope _ps(ctx, s, name); TRY(expr); } while (0)
 
-size_t verify_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a) {
-    return VerifyWs(nullptr, p, std::min(n_ops, ctx->pass_ops), own_a).bytes;
+// wire_keys: 0, or the key count of an mldsa_verify_pk call whose keys arrive in wire format (identity mapping: one per op of a pass)
+static size_t wire_keys_of_pass(const mldsa_ctx *ctx, size_t n_ops, size_t wire_table_keys, bool wire, bool by_table) {
+    return !wire ? 0 : by_table ? wire_table_keys : std::min(n_ops, ctx->pass_ops);
+}
+size_t verify_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a, size_t wire_table_keys, int wire_mode) {
+    return VerifyWs(nullptr, p, std::min(n_ops, ctx->pass_ops), own_a, wire_keys_of_pass(ctx, n_ops, wire_table_keys, wire_mode != 0, wire_mode == 2)).bytes;
 }
 
 // verify_internal (ml_dsa.rs:351-437) for n_ops independent (key, message, signature) triples
 int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint8_t *tr, const int32_t *t1, size_t n_keys,
                  const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *ctxs,
                  const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok, size_t n_ops, hipStream_t s,
-                 const int32_t *a_hat_keys) {
+                 const int32_t *a_hat_keys, const uint8_t *pk_wire) {
     const mldsa_params *p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "verify: unknown parameter set");
     if (n_ops == 0) return MLDSA_OK;
     const size_t chunk = std::min(n_ops, ctx->pass_ops);
-    if (ctx->ws_bytes < VerifyWs(nullptr, p, chunk, a_hat_keys == nullptr).bytes)
+    // mldsa_verify_pk: keys in wire format.  PublicKey::try_from_bytes (expand_public, ml_dsa.rs:477-498) becomes part of the call:
+    // rho is read where it lies in the key bytes, tr = H(pk) and t1_d2_hat_mont = NTT(t1) 2^13 are produced on the helper stream
+    // underneath ExpandA -- per pass for the identity mapping (key i belongs to op i), once for a key table
+    const bool wire = pk_wire != nullptr;
+    const size_t pkl = (size_t)p->pk_len;
+    const size_t wire_keys = wire_keys_of_pass(ctx, n_ops, n_keys, wire, key_idx != nullptr);
+    if (ctx->ws_bytes < VerifyWs(nullptr, p, chunk, a_hat_keys == nullptr, wire_keys).bytes)
         return set_error(MLDSA_ERR_NOMEM, "verify: workspace not reserved");
     const size_t mw = (size_t)(64 + p->w1_len);
     const size_t kl_coeffs = (size_t)(p->k * p->l) * N;
     for (size_t o = 0; o < n_ops; o += chunk) {
         const size_t n = (n_ops - o) < chunk ? (n_ops - o) : chunk;
-        VerifyWs w(ctx->ws, p, chunk, a_hat_keys == nullptr);
+        VerifyWs w(ctx->ws, p, chunk, a_hat_keys == nullptr, wire_keys);
         const uint8_t *sg = sigs + o * (size_t)p->sig_len;
         // key_idx is checked against n_keys on the device: the kernels below only see in-range indices, ops
         // with a bad index are flagged (ok = 0).  Identity mapping (key_idx == NULL) was checked by the caller.
@@ -183,10 +198,23 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
             kidx = w.kidx;
             key_bad = w.key_bad;
         }
+        const uint8_t *tr_keys = tr ? tr + key_base * 64 : nullptr;
+        const int32_t *t1_keys = t1 ? t1 + key_base * (size_t)p->k * N : nullptr;
+        if (wire) {
+            const size_t nk = key_idx ? n_keys : n;            // keys to deserialise now
+            const uint8_t *pkp = pk_wire + key_base * pkl;
+            if (!key_idx || o == 0) {
+                ProfScope ps(ctx, aux, "pk_expand");
+                TRY(launch_shake256_2(ctx, 64, pkp, pkl, p->pk_len, nullptr, nullptr, 0, 0, 0, 0, w.tr_w, 64, nk, aux));                 // tr = H(pk)
+                TRY(launch_unpack_ntt(ctx, pkp, pkl, 32, 10, -1, 6346488 /* 2^13 * 2^64 mod q */, w.t1_w, p->k, nk, aux));             // ml_dsa.rs:492-495
+            }
+            tr_keys = w.tr_w;   // rows of the keys just expanded: by op for the identity mapping, by key index for a table
+            t1_keys = w.t1_w;
+        }
         {
             // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
             ProfScope ps(ctx, aux, "mu");
-            TRY(launch_mu(ctx, tr + key_base * 64, 64, kidx, mode, msgs, msg_off, ctxs, ctx_off, w.mu_w1, mw, w.ctx_bad, n, aux, key_bad, o, n_ops));
+            TRY(launch_mu(ctx, tr_keys, 64, kidx, mode, msgs, msg_off, ctxs, ctx_off, w.mu_w1, mw, w.ctx_bad, n, aux, key_bad, o, n_ops));
         }
         {
             // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
@@ -197,13 +225,15 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
         // (skipped when the caller keeps A_hat with its keys: the optimisation the reference's benches/README.md
         //  names as missing; the rows are then looked up by key instead of by op)
-        if (!a_hat_keys) STAGE("expand_a", launch_expand_a(ctx, set, rho + key_base * 32, 32, key_idx ? key_idx + o : nullptr, w.a_hat, n, s, true,
-                                                           key_idx ? n_keys : 0));
+        if (!a_hat_keys) {
+            const uint8_t *rho_rows = wire ? pk_wire + key_base * pkl : rho + key_base * 32;  // pkEncode puts rho first (encodings.rs:29)
+            STAGE("expand_a", launch_expand_a(ctx, set, rho_rows, wire ? pkl : 32, key_idx ? key_idx + o : nullptr, w.a_hat, n, s, true, key_idx ? n_keys : 0));
+        }
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
         // 2: (c_tilde, z, h) <- sigDecode(sigma), inside k_verify_main                      ml_dsa.rs:368-376
         // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
         STAGE("verify_main", launch_verify_main(ctx, p, a_hat_keys ? a_hat_keys + key_base * kl_coeffs : w.a_hat, sg, w.c,
-                                                t1 + key_base * (size_t)p->k * N, kidx, w.hvalid, w.mu_w1 + 64, mw, w.znorm, n, s,
+                                                t1_keys, kidx, w.hvalid, w.mu_w1 + 64, mw, w.znorm, n, s,
                                                 a_hat_keys != nullptr, a_hat_keys == nullptr));
         // 12-13: c_tilde' <- H(mu || w1Encode(w1'), lambda/4); [[ ||z|| < gamma1 - beta ]] and [[ c_tilde = c_tilde' ]]   ml_dsa.rs:429-436
         STAGE("ctilde_hash", launch_ctilde_verdict(ctx, p, w.mu_w1, mw, sg, w.znorm, w.hvalid, w.ctx_bad, ok + o, n, s));

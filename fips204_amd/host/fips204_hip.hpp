@@ -253,6 +253,22 @@ struct ParamSet {
         return std::vector<bool>(ok.begin(), ok.end());
     }
 
+    // PublicKey::try_from_bytes + verify in one device call (mldsa_verify_pk): wire-format keys, one per op when key_idx is empty
+    static std::vector<bool> verify_pk_many(const std::vector<PkBytes>& pk, const std::vector<uint32_t>& key_idx,
+                                            const std::vector<std::vector<uint8_t>>& msgs, const std::vector<Signature>& sigs,
+                                            const std::vector<std::vector<uint8_t>>& ctxs, int mode = MLDSA_MODE_PURE) {
+        const size_t n = msgs.size();
+        if (ctxs.size() != n || sigs.size() != n || (!key_idx.empty() && key_idx.size() != n)) throw Error("verify_pk_many: argument lengths differ");
+        Packed m(msgs), c(ctxs);
+        DevBuf dpk(pk.data(), pk.size() * PK), dk(key_idx.data(), key_idx.size() * 4), dsig(sigs.data(), n * SIG), dok(n);
+        check(mldsa_verify_pk(Device::get().ctx(), SET, mode, dpk.as<uint8_t>(), pk.size(), key_idx.empty() ? nullptr : dk.as<uint32_t>(),
+                              m.bytes.as<uint8_t>(), m.offsets.as<uint64_t>(), c.bytes.as<uint8_t>(), c.offsets.as<uint64_t>(), dsig.as<uint8_t>(),
+                              dok.as<uint8_t>(), n, nullptr), "mldsa_verify_pk");
+        std::vector<uint8_t> ok(n);
+        dok.download(ok.data(), n);
+        return std::vector<bool>(ok.begin(), ok.end());
+    }
+
     // ---- the same three operations on host memory and wire-format keys (mldsa_*_host) --------------
     // Contiguous arrays in, contiguous arrays out; the library overlaps upload, kernels and download.
     struct HostBytes {  // concatenated byte strings + n + 1 offsets

@@ -172,6 +172,34 @@ class MlDsa:
             _ptr(sigs), _ptr(ok), n_ops, _stream(self.device)))
         return ok
 
+    def verify_pk_device(self, pk_bytes, msg_buf, msg_off, sigs, ok, n_ops, ctx_buf=None, ctx_off=None, key_idx=None, mode=MODE_PURE):
+        """mldsa_verify_pk: PublicKey::try_from_bytes + verify in one call -- pk_bytes = uint8 CUDA tensor [n_keys, PK_LEN] in wire format
+        (key_idx None: op i uses key i).  Same verdicts as public_keys_from_bytes + verify_device."""
+        null = C.c_void_p(0)
+        pk = self._key_bytes(pk_bytes, self.PK_LEN, "pk")
+        _lib.check(self.lib.mldsa_verify_pk(
+            self.hp._h, self.pset, mode, _ptr(pk), pk.shape[0], _ptr(key_idx) if key_idx is not None else null, _ptr(msg_buf), _ptr(msg_off),
+            _ptr(ctx_buf) if ctx_buf is not None else null, _ptr(ctx_off) if ctx_off is not None else null, _ptr(sigs), _ptr(ok), n_ops,
+            _stream(self.device)))
+        return ok
+
+    def verify_pk(self, pk_bytes, messages, sigs, ctxs=None, key_idx=None, mode=MODE_PURE):
+        """PublicKey::try_from_bytes(pk)?.verify(message, sig, ctx) for a batch of wire-format keys (src/lib.rs:471-475, 364-380)"""
+        n_ops = len(messages)
+        pk = self._key_bytes(pk_bytes, self.PK_LEN, "pk")
+        msg_buf, msg_off = _cat_with_offsets(messages, self.device)
+        ctx_buf = ctx_off = None
+        if ctxs is not None:
+            ctx_buf, ctx_off = _cat_with_offsets(ctxs, self.device)
+        kidx = _check_key_idx(key_idx, pk.shape[0], n_ops)
+        if kidx is not None:
+            kidx = torch.as_tensor(kidx.view(np.int32)).to(self.device)
+        sg = self._key_bytes(sigs, self.SIG_LEN, "sigs") if n_ops else torch.zeros((1, self.SIG_LEN), dtype=torch.uint8, device=self.device)
+        ok = torch.zeros(max(n_ops, 1), dtype=torch.uint8, device=self.device)
+        self.verify_pk_device(pk, msg_buf, msg_off, sg, ok, n_ops, ctx_buf, ctx_off, kidx, mode)
+        torch.cuda.synchronize(self.device)
+        return ok[:n_ops].cpu().numpy().astype(bool)
+
     # ---- SerDes (src/traits.rs:372-424; src/lib.rs:421-424, 471-475) ------------------
     def _key_bytes(self, keys, length, what):
         if isinstance(keys, torch.Tensor):

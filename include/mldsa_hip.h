@@ -266,6 +266,17 @@ int mldsa_verify(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
                  const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off,
                  const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *stream);
 
+/* PublicKey::try_from_bytes (src/lib.rs:471-475 -> expand_public, src/ml_dsa.rs:477-498) and Verifier::verify in ONE call: the public
+ * keys arrive in FIPS 204 wire format, pk[n_keys][PK_LEN] on the device, and are deserialised inside the call -- rho is read where it
+ * lies in the key bytes, tr = H(pk) and NTT(t1) 2^13 are produced on the context's helper stream underneath ExpandA -- so a batch in
+ * which every op carries its own key (key_idx NULL: op i uses key i, n_keys >= n_ops) costs little more than a batch on
+ * expanded keys; with key_idx the n_keys keys of the table are deserialised once per call.  Everything else -- arguments,
+ * verdicts, refusal rules -- is mldsa_verify's; the results are identical to mldsa_pk_expand followed by mldsa_verify.
+ * Workspace: 64 + 1024 K bytes per key of a pass (identity mapping) or of the table. */
+int mldsa_verify_pk(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs,
+                    const uint64_t *msg_off, const uint8_t *ctxs, const uint64_t *ctx_off, const uint8_t *sigs, uint8_t *ok,
+                    size_t n_ops, void *stream);
+
 /* n_ops + 1 byte offsets, non-decreasing?  MLDSA_OK or MLDSA_ERR_PARAM (mldsa_last_error names the entry).  Pure host code:
  * needs no context and no device. */
 int mldsa_check_offsets(const uint64_t *off, size_t n_ops);

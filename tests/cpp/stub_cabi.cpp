@@ -222,6 +222,11 @@ int mldsa_verify(mldsa_ctx *c, int set, int mode, const uint8_t *rho, const uint
     return verify_core(p, mode, rho, tr, n_keys, key_idx, msgs, moff, ctxs, coff, sigs, ok, n_ops);
 }
 
+int mldsa_verify_pk(mldsa_ctx *c, int set, int mode, const uint8_t *pk, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *moff,
+                    const uint8_t *ctxs, const uint64_t *coff, const uint8_t *sigs, uint8_t *ok, size_t n_ops, void *) {
+    return mldsa_verify_host(c, set, mode, pk, n_keys, key_idx, msgs, moff, ctxs, coff, sigs, ok, n_ops);  // same bytes, same verdicts
+}
+
 // ---- host-memory entry points: wire-format keys; expanded exactly like the device-side calls above
 int mldsa_keygen_host(mldsa_ctx *c, int set, const uint8_t *xi, uint8_t *pk, uint8_t *sk, size_t n) { return mldsa_keygen(c, set, xi, pk, sk, n, nullptr); }
 int mldsa_sign_host(mldsa_ctx *c, int set, int mode, const uint8_t *sk, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *moff,

@@ -62,6 +62,8 @@ static void plumbing() {
         ASSERT(sig_h == sig);
         auto ok_h = P::verify_host(keys.first, kidx, msgs, sig, ctxs, mode);
         for (size_t i = 0; i < n; i++) ASSERT(ok_h[i]);
+        auto ok_pk = P::verify_pk_many(keys.first, kidx, msgs, sig, ctxs, mode);   // try_from_bytes + verify in one call
+        for (size_t i = 0; i < n; i++) ASSERT(ok_pk[i]);
         // one flipped bit, a swapped message, a wrong key, a different ctx, a different mode: each op on its own
         auto bad = sig;
         bad[3][P::SIG_LEN - 1] ^= 1;

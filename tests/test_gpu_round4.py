@@ -585,3 +585,48 @@ def test_argument_errors_never_abort(sets):
     pk, sk = m.keygen_from_seed([shake(b"err-key", 0)])
     sig = m.try_sign_with_seed(m.private_keys_from_bytes(sk), [b"still works"], [bytes(32)])
     assert m.verify(m.public_keys_from_bytes(pk), [b"still works"], sig).all()
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_verify_pk_equals_try_from_bytes_plus_verify(sets, pset):
+    """mldsa_verify_pk = PublicKey::try_from_bytes (src/ml_dsa.rs:477-498) + Verifier::verify (351-437) in one call.  On a fuzzed batch
+    (good and damaged signatures, arbitrary public-key bytes: fuzz_all.rs:25-37, fuzz_verify.rs:17-31) its verdicts equal those of
+    mldsa_pk_expand + mldsa_verify AND the oracle's -- with a key table + key_idx, with one key per op (identity mapping), and
+    when the call runs in several passes (a capped workspace)."""
+    from test_gpu_round3 import fuzz_batch
+    from fips204_amd import _lib
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsa
+    m = sets[pset]
+    n, nk = 8192, 128
+    pk_all, kidx, msgs, sig, cls, changed = fuzz_batch(m, pset, n, nk, 9100 + pset)
+    d_pk, d_sig = dev(pk_all), dev(sig)
+    pks = m.public_keys_from_bytes(d_pk)
+    want = m.verify(pks, msgs, d_sig, key_idx=kidx, mode=0)
+    pk_o = [orc.pk_try_from_bytes(pset, pk_all[i].tobytes()) for i in range(2 * nk)]
+    want_o = np.asarray(orc.verify_batch_mt(pset, pk_o, kidx, msgs, [sig[i].tobytes() for i in range(n)], 16, 1, mode=0), dtype=bool)
+    assert np.array_equal(want, want_o) and np.array_equal(want, ~changed)
+    # a key table + key_idx
+    assert np.array_equal(m.verify_pk(d_pk, msgs, d_sig, key_idx=kidx, mode=0), want)
+    # one wire-format key per op
+    per_op = dev(pk_all[kidx])
+    assert np.array_equal(m.verify_pk(per_op, msgs, d_sig, mode=0), want)
+    # ragged tail, ctxs, internal mode on a prefix
+    ctxs = [shake(b"vpk-ctx", i, i % 9) for i in range(1001)]
+    got = m.verify_pk(per_op[:1001], msgs[:1001], d_sig[:1001], ctxs=ctxs, mode=1)
+    assert np.array_equal(got, m.verify(m.public_keys_from_bytes(per_op[:1001]), msgs[:1001], d_sig[:1001], ctxs=ctxs, mode=1))
+    # several passes: a workspace cap that does not hold 8 192 ops' A_hat and keys
+    hp2 = HotPath(0)
+    try:
+        hp2.set_option(_lib.OPT_WORKSPACE_CAP_MB, {44: 48, 65: 96, 87: 160}[pset])
+        m2 = MlDsa(pset, hotpath=hp2)
+        assert np.array_equal(m2.verify_pk(per_op, msgs, d_sig, mode=0), want)
+        assert np.array_equal(m2.verify_pk(d_pk, msgs, d_sig, key_idx=kidx, mode=0), want)
+        assert hp2.stats()["workspace_shrinks"] > 0
+    finally:
+        hp2.close()
+    # argument errors
+    lib, h = m.lib, m.hp._h
+    assert lib.mldsa_verify_pk(h, pset, 0, None, 1, None, None, None, None, None, None, None, 1, None) == _lib.ERR_PARAM
+    assert lib.mldsa_verify_pk(h, pset, 0, C.c_void_p(d_pk.data_ptr()), 4, None, None, C.c_void_p(d_pk.data_ptr()), None, None,
+                               C.c_void_p(d_sig.data_ptr()), C.c_void_p(d_sig.data_ptr()), 8, None) == _lib.ERR_PARAM   # 4 keys, 8 ops, no key_idx
