@@ -135,8 +135,9 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,
- * extra signing rounds, and workspace_shrinks = how often the context halved its pass size because the device could not hold
- * the workspace of a full pass (the call then runs in more passes; results are identical) */
+ * extra signing rounds, and workspace_shrinks = how often the context made its passes smaller (the speculative rows of a signing pass
+ * first, then the ops per pass) because the workspace of a full pass did not fit -- the device, MLDSA_OPT_WORKSPACE_CAP_MB or a caller-owned
+ * buffer; the call then runs in more passes, results are identical */
 typedef struct {
     unsigned long long graphs_captured, graph_replays, direct_calls, workspace_growths, sign_extra_rounds, workspace_shrinks;
 } mldsa_stats;

@@ -30,3 +30,16 @@ def test_cpp_host_mirror(tmp_path, ref_hex):
     sk_o = orc.sk_try_from_bytes(44, bytes.fromhex(lines["sk"]))
     for ph in ("SHA256", "SHA512", "SHAKE128"):
         assert lines["hsig_" + ph] == orc.hash_sign(44, sk_o, b"asdf", rnd, b"ctx", ph).hex(), ph
+
+
+def test_plain_c_host_example(tmp_path):
+    """tests/cpp/c_host.c: a C99 program over the C ABI alone (no C++, no Python) -- keygen, sign, verify through the host-memory entry
+    points, one damaged signature, a malformed offset table through both kinds of call, the residue probe."""
+    exe = tmp_path / "c_host"
+    libdir = os.path.join(ROOT, "fips204_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "c_host.c"), "-o", str(exe), f"-L{libdir}", "-lmldsa_hip", f"-Wl,-rpath,{libdir}",
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout[-800:], out.stderr[-800:])
+    assert "verified 99 of 100" in out.stdout and "secret residue: 0 non-zero bytes" in out.stdout
