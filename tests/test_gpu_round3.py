@@ -251,14 +251,39 @@ def test_soak_random_shapes_knobs_and_modes_against_the_oracle(hp, sets):
                     one = m.try_sign_with_seed(sks, [msgs[i]], [rnd[i]], ctxs=None if ctxs is None else [ctxs[i]],
                                                key_idx=kidx[i:i + 1], mode=mode)
                     sig[i] = one[0]
+            torch.cuda.synchronize()
+            assert hp.secret_residue()[1] == 0, what          # round 4: nothing secret outlives the signing call, whatever the knobs
             ok = m.verify(pks, msgs, sig, ctxs=ctxs, key_idx=kidx, mode=mode)
             assert ok.all(), what
+            if n >= 4 and rng.random() < 0.3:                  # round 4: a few damaged entries in the message offset table
+                from fips204_amd.ml_dsa import _cat_with_offsets
+                mb, mo = _cat_with_offsets(msgs, m.device)
+                cb = co = None
+                if ctxs is not None:
+                    cb, co = _cat_with_offsets(ctxs, m.device)
+                off = host(mo).view(np.uint64).copy()
+                for k in rng.choice(np.arange(1, n), min(3, n - 1), replace=False):
+                    cands = [0, int(off[k - 1]) - 1 if off[k - 1] else 0, 2 ** 63, 2 ** 64 - 1, int(off[-1]) + 1]
+                    off[k] = np.uint64(cands[int(rng.integers(len(cands)))])
+                lo, hi = int(off[0]), int(off[-1])
+                valid = np.array([lo <= int(a) <= int(b) <= hi for a, b in zip(off[:-1], off[1:])])
+                same = valid & (off[:-1] == host(mo).view(np.uint64)[:-1]) & (off[1:] == host(mo).view(np.uint64)[1:])
+                sg2 = torch.full((n, m.SIG_LEN), 0x33, dtype=torch.uint8, device="cuda")
+                st2 = torch.full((n,), 9, dtype=torch.int32, device="cuda")
+                m.sign_device(sks, mb, dev(off.view(np.int64)), dev(np.frombuffer(b"".join(rnd), dtype=np.uint8).reshape(n, 32)), sg2, n, cb, co,
+                              dev(kidx.view(np.int32)), mode, st2)
+                st2_h, sg2_h = host(st2), host(sg2)
+                clen_bad = np.array([ctxs is not None and len(ctxs[i]) > 255 for i in range(n)])
+                assert ((st2_h == -1) == ~valid).all() and (st2_h[valid & ~clen_bad] == 0).all(), what
+                assert not sg2_h[~valid].any() and np.array_equal(sg2_h[same & ~clen_bad], host(sig)[same & ~clen_bad]), what
             sig_h = host(sig).copy()
             flip = rng.random(n) < 0.3
             rows = np.nonzero(flip)[0]
             sig_h[rows, rng.integers(0, m.SIG_LEN, rows.size)] ^= (1 << rng.integers(0, 8, rows.size)).astype(np.uint8)
             ok2 = m.verify(pks, msgs, dev(sig_h), ctxs=ctxs, key_idx=kidx, mode=mode)
             assert np.array_equal(ok2, ~flip), what
+            if rng.random() < 0.5:                             # round 4: the same verdicts from wire-format keys in one call
+                assert np.array_equal(m.verify_pk(pk, msgs, dev(sig_h), ctxs=ctxs, key_idx=kidx, mode=mode), ok2), what
             # the oracle on a sample: keys, signatures (before the flips), verdicts (after)
             pkb, skb = host(pk), host(sk)
             sig_good = host(sig)

@@ -36,6 +36,7 @@ for w in verify65_wire sign65_wire verify65_corrupt1 verify44_wire verify87_wire
 done
 ./tools/ubench_graph 90 > "$OUT/ubench_graph.txt" 2>&1
 ./tools/ubench_d2h2 > "$OUT/ubench_d2h2.txt" 2>&1
+./tools/ubench_keccak_coop > "$OUT/ubench_keccak_coop.txt" 2>&1
 python tools/ubench_overlap2.py > "$OUT/ubench_overlap2.txt" 2>&1
 for n in 32768 65536 131072; do python tools/hostfed_sign.py $n 4 2>&1 | grep sign_host; MLDSA_HOST_DIRECT=0 python tools/hostfed_sign.py $n 4 2>&1 | grep sign_host; done > "$OUT/hostfed_sign.txt"
 # rocprofv3 per-kernel summaries of the commands whose kernel times bench.py reports: the headline workload on its own (every
