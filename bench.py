@@ -1178,6 +1178,42 @@ def run_sweep(hp, pset=65, sizes=SWEEP_SIZES, cpu=True, target_s=0.25):
     return out
 
 
+def run_small_calls(pset=65, sizes=(64, 1024), contexts=(1, 2, 4, 8, 16), calls=200, graphs=None):
+    """Many INDEPENDENT small calls that cannot be coalesced into one batch (a service with per-request latency bounds): C contexts on
+    one GPU, each with its own stream and worker thread (mldsa_group_create([0] * C)), every step = one n-op verify call per context,
+    enqueued without waiting (mldsa_verify_group, wait = 0), one mldsa_group_sync at the end.  A small call occupies a fraction of
+    the SIMDs for ~0.2 ms of latency chains, so calls of different contexts overlap on the device; what one context cannot do -- keep
+    the machine busy with 64-op calls -- several can.  Returns {n: {C: ops/s}}."""
+    from fips204_amd.hotpath import HotPath
+    from fips204_amd.ml_dsa import MlDsaGroup
+    out = {}
+    for n in sizes:
+        out[str(n)] = {}
+        for C_ in contexts:
+            g = MlDsaGroup(pset, [torch.cuda.current_device()] * C_)
+            if graphs is not None:
+                g.set_option(1, graphs)  # MLDSA_OPT_GRAPHS
+            wls, slices = [], []
+            for i in range(C_):
+                wl = WholeOp(HotPath.from_handle(g.ctx(i), torch.cuda.current_device()), pset, "verify", n, i, world=C_)
+                wls.append(wl)
+                slices.append(dict(pks=wl.pks, msg_buf=wl.msg_buf, msg_off=wl.msg_off, key_idx=wl.key_idx, n_ops=n, sigs=wl.sigs, ok=wl.ok,
+                                   stream=torch.cuda.Stream().cuda_stream))
+            for _ in range(10):
+                g.verify_group(slices, wait=False)
+            g.sync()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                g.verify_group(slices, wait=False)
+            g.sync()
+            dt = time.perf_counter() - t0
+            assert all(bool(wl.ok.all()) for wl in wls), "small calls: a valid signature was rejected"
+            out[str(n)][str(C_)] = {"ops_per_s": C_ * n * calls / dt, "calls_per_s": C_ * calls / dt, "us_per_step": dt / calls * 1e6}
+            del wls, slices
+            g.close()
+    return out
+
+
 def run_inproc_resident(args):
     """`--inproc --resident`: the contract's HBM-resident `value` from ONE process.  One mldsa_group over N devices (devices reused
     round-robin when fewer GPUs are visible: a functional run, labelled), slice i of the job resident on device i -- expanded keys,
@@ -1344,6 +1380,7 @@ def main():
         if world != 1:
             raise SystemExit("bench.py: --workload sweep is a single-GPU measurement")
         sw = run_sweep(hp, cpu=not args.no_cpu_baseline)
+        sw["concurrent_small_verify_calls"] = run_small_calls()
         v = next(pt for pt in sw["ops"]["verify"]["points"] if pt["n_ops"] == 65536)
         line = {"metric": "ML-DSA-65 verifies/sec per GPU (batched); batch-size sweep through the C ABI", "value": v["best_ops_per_s"], "unit": "verifies/s",
                 "n_gpus": 1, "steps": v["direct"]["calls_timed"], "warmup": 3, "ms_per_step": v["best_ms_per_call"], "higher_is_better": True,
