@@ -130,7 +130,9 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                        anything.  0 = never, 1 (default) = for the parameter sets where it measured faster (ML-DSA-65: +2.7 %),
                                        2 = for every set.  Signatures are identical */
 #define MLDSA_OPT_WORKSPACE_CAP_MB 11 /* most MiB of device memory the context's workspace may take (0 = default: whatever the device gives).  A call
-                                       whose full pass does not fit runs in smaller passes (see workspace_shrinks); results are identical.  For hosts
+                                       whose full pass does not fit runs in smaller passes (see workspace_shrinks: the context lowers its candidates
+                                       per speculative round -- MLDSA_OPT_SPEC_TARGET reads back smaller -- and then its ops per pass, and keeps
+                                       the smaller values); results are identical.  For hosts
                                        that share the GPU with other work; a cap too small even for a 1024-op pass fails the call with MLDSA_ERR_NOMEM */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
@@ -455,7 +457,7 @@ typedef struct {
 int mldsa_verify_group(mldsa_group *g, int set, int mode, const mldsa_verify_slice *slices /* [mldsa_group_size] */, int wait);
 int mldsa_sign_group(mldsa_group *g, int set, int mode, const mldsa_sign_slice *slices, int wait);
 int mldsa_keygen_group(mldsa_group *g, int set, const mldsa_keygen_slice *slices, int wait);
-int mldsa_group_sync(mldsa_group *g); /* waits for the streams of the last device-resident group call */
+int mldsa_group_sync(mldsa_group *g); /* waits for the streams of the last device-resident group call (they must still exist) */
 
 /* Device-resident verdicts (each device ran mldsa_verify on its slice): the one exchange SURVEY 8e names.
  * bufs[i] = device pointer on device i of the group, N * ceil(n_ops / N) bytes, slice i of it filled; afterwards
