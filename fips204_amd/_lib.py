@@ -94,6 +94,7 @@ _SIGNATURES = {
     "mldsa_ntt": [_P, _P, _P, _SZ, _P],
     "mldsa_inv_ntt": [_P, _P, _P, _SZ, _P],
     "mldsa_to_mont": [_P, _P, _P, _SZ, _P],
+    "mldsa_reduce": [_P, _I, _P, _P, _SZ, _P],
     "mldsa_mat_vec_mul": [_P, _I, _P, _P, _P, _SZ, _P],
     "mldsa_pointwise_mont": [_P, _P, _P, _P, _SZ, _SZ, _P],
     "mldsa_add_vector_ntt": [_P, _P, _P, _P, _SZ, _P],

@@ -459,6 +459,13 @@ int mldsa_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n_poly
     return launch_to_mont(ctx, in, out, n_polys, (hipStream_t)stream);
 }
 
+int mldsa_reduce(mldsa_ctx *ctx, int kind, const int32_t *in, int32_t *out, size_t n_polys, void *stream) {
+    ENTER(ctx, "mldsa_reduce");
+    REQUIRE(kind == MLDSA_REDUCE_PARTIAL || kind == MLDSA_REDUCE_FULL || kind == MLDSA_REDUCE_CENTER, "mldsa_reduce: unknown kind");
+    REQUIRE(n_polys == 0 || (in && out), "mldsa_reduce: NULL pointer");
+    return launch_reduce(ctx, kind, in, out, n_polys, (hipStream_t)stream);
+}
+
 int mldsa_mat_vec_mul(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *u_hat,
                       int32_t *w_hat, size_t n_ops, void *stream) {
     ENTER(ctx, "mldsa_mat_vec_mul");

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(BLOCK) void k_inv_ntt(const int32_t *__restrict__ i
 }
 
 // ------------------------------------------------------ element-wise helpers (16 B/lane)
-template <int OP>  // 0: to_mont (helpers.rs:131-135)   1: add (helpers.rs:125-127)
+template <int OP>  // 0: to_mont (helpers.rs:131-135)   1: add (helpers.rs:125-127)   2 / 3 / 4: partial_reduce32 / full_reduce32 / center_mod (61-95)
 __global__ __launch_bounds__(BLOCK) void k_elementwise(const int4 *__restrict__ a, const int4 *__restrict__ b,
                                                        int4 *__restrict__ out, size_t n_vec) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(BLOCK) void k_elementwise(const int4 *__restrict__ 
         int4 x = a[i];
         if constexpr (OP == 0) {
             out[i] = make_int4(to_mont(x.x), to_mont(x.y), to_mont(x.z), to_mont(x.w));
+        } else if constexpr (OP == 2) {
+            out[i] = make_int4(reduce32(x.x), reduce32(x.y), reduce32(x.z), reduce32(x.w));
+        } else if constexpr (OP == 3) {
+            out[i] = make_int4(freeze(x.x), freeze(x.y), freeze(x.z), freeze(x.w));
+        } else if constexpr (OP == 4) {
+            out[i] = make_int4(center(x.x), center(x.y), center(x.z), center(x.w));
         } else {
             int4 y = b[i];
             out[i] = make_int4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
@@ -430,6 +436,20 @@ int launch_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n, hi
     size_t n_vec = n * (N / 4);
     hipLaunchKernelGGL(k_elementwise<0>, dim3(grid_for(ctx, n_vec, BLOCK, 8)), dim3(BLOCK), 0, s,
                        reinterpret_cast<const int4 *>(in), (const int4 *)nullptr, reinterpret_cast<int4 *>(out), n_vec);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_reduce(mldsa_ctx *ctx, int kind, const int32_t *in, int32_t *out, size_t n, hipStream_t s) {
+    if (n == 0) return MLDSA_OK;
+    const size_t n_vec = n * (N / 4);
+    const dim3 grid(grid_for(ctx, n_vec, BLOCK, 8)), block(BLOCK);
+    const int4 *a = reinterpret_cast<const int4 *>(in);
+    int4 *o = reinterpret_cast<int4 *>(out);
+    if (kind == MLDSA_REDUCE_PARTIAL) hipLaunchKernelGGL(k_elementwise<2>, grid, block, 0, s, a, (const int4 *)nullptr, o, n_vec);
+    else if (kind == MLDSA_REDUCE_FULL) hipLaunchKernelGGL(k_elementwise<3>, grid, block, 0, s, a, (const int4 *)nullptr, o, n_vec);
+    else if (kind == MLDSA_REDUCE_CENTER) hipLaunchKernelGGL(k_elementwise<4>, grid, block, 0, s, a, (const int4 *)nullptr, o, n_vec);
+    else return set_error(MLDSA_ERR_PARAM, "reduce: unknown kind");
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

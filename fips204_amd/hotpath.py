@@ -142,6 +142,24 @@ class HotPath:
         _lib.check(self.lib.mldsa_to_mont(self._h, _ptr(v), _ptr(out), v.numel() // N, _stream(self.device)))
         return out
 
+    def _reduce(self, kind, w):
+        w = _polys(w, "w")
+        out = torch.empty_like(w)
+        _lib.check(self.lib.mldsa_reduce(self._h, kind, _ptr(w), _ptr(out), w.numel() // N, _stream(self.device)))
+        return out
+
+    def partial_reduce32(self, w):
+        """partial_reduce32, element-wise (src/helpers.rs:61-67): (-q, q)"""
+        return self._reduce(0, w)
+
+    def full_reduce32(self, w):
+        """full_reduce32, element-wise (src/helpers.rs:70-76): [0, q)"""
+        return self._reduce(1, w)
+
+    def center_mod(self, w):
+        """center_mod, element-wise (src/helpers.rs:88-95): (-q/2, q/2]"""
+        return self._reduce(2, w)
+
     def mat_vec_mul(self, pset, a_hat, u_hat):
         """mat_vec_mul::<K, L>(&[[T; L]; K], &[T; L]) -> [T; K], batched over ops (src/helpers.rs:100)"""
         p = _lib.get_params(pset)

@@ -191,6 +191,15 @@ int mldsa_inv_ntt(mldsa_ctx *ctx, const int32_t *w_hat, int32_t *w, size_t n_pol
 /* to_mont() src/helpers.rs:131-135: x * 2^32 mod q, output in (-q, q). */
 int mldsa_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n_polys, void *stream);
 
+/* partial_reduce32 / full_reduce32 / center_mod, src/helpers.rs:61-67, 70-76, 88-95, element-wise over n_polys polynomials (the
+ * reference applies them coefficient by coefficient at ml_dsa.rs:89-91, 263-272, 302-303, 334-335 and ntt.rs:153; inside the fused
+ * kernels they are single instructions of an epilogue -- these entry points exist so that the seam is testable on its own).
+ * Input: any representative with |a| < 2^31 - 2^22 (helpers.rs:62).  Output: PARTIAL (-q, q), FULL [0, q), CENTER (-q/2, q/2]. */
+#define MLDSA_REDUCE_PARTIAL 0
+#define MLDSA_REDUCE_FULL 1
+#define MLDSA_REDUCE_CENTER 2
+int mldsa_reduce(mldsa_ctx *ctx, int kind, const int32_t *in, int32_t *out, size_t n_polys, void *stream);
+
 /* mat_vec_mul::<K,L>() src/helpers.rs:100-114: w_hat[i] = sum_j a_hat[i][j] o u_hat[j]
  * for n_ops independent (a_hat, u_hat) pairs.  a_hat: n_ops*K*L polys, u_hat: n_ops*L,
  * w_hat: n_ops*K; output representative in (-L q, L q). */

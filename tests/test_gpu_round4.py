@@ -630,3 +630,24 @@ def test_verify_pk_equals_try_from_bytes_plus_verify(sets, pset):
     assert lib.mldsa_verify_pk(h, pset, 0, None, 1, None, None, None, None, None, None, None, 1, None) == _lib.ERR_PARAM
     assert lib.mldsa_verify_pk(h, pset, 0, C.c_void_p(d_pk.data_ptr()), 4, None, None, C.c_void_p(d_pk.data_ptr()), None, None,
                                C.c_void_p(d_sig.data_ptr()), C.c_void_p(d_sig.data_ptr()), 8, None) == _lib.ERR_PARAM   # 4 keys, 8 ops, no key_idx
+
+
+def test_scalar_reductions_as_a_seam(hp):
+    """partial_reduce32 / full_reduce32 / center_mod (src/helpers.rs:61-95) element-wise through mldsa_reduce, bit-exact
+    with the oracle's scalar functions over the whole input contract |a| < 2^31 - 2^22 (helpers.rs:62): edge values and 2^16 random ones."""
+    lib = orc.lib()
+    lim = 2 ** 31 - 2 ** 22
+    rng = np.random.default_rng(55)
+    edges = [0, 1, -1, orc.Q - 1, orc.Q, orc.Q + 1, -orc.Q, -orc.Q + 1, orc.Q // 2, orc.Q // 2 + 1, -(orc.Q // 2), -(orc.Q // 2) - 1, lim - 1, -lim + 1,
+             8 * orc.Q, -8 * orc.Q, 2 ** 23, -2 ** 23, 2 ** 22, 255 * orc.Q]
+    vals = np.concatenate([np.array(edges, dtype=np.int64), rng.integers(-lim + 1, lim, 65536 - len(edges))]).astype(np.int32)
+    d = dev(vals.reshape(-1, 256))
+    got = {"partial": host(hp.partial_reduce32(d)).ravel(), "full": host(hp.full_reduce32(d)).ravel(), "center": host(hp.center_mod(d)).ravel()}
+    for name, fn in (("partial", lib.orc_partial_reduce32), ("full", lib.orc_full_reduce32), ("center", lib.orc_center_mod)):
+        want = np.array([fn(int(v)) for v in vals], dtype=np.int32)
+        assert np.array_equal(got[name], want), (name, np.nonzero(got[name] != want)[0][:5])
+    assert (np.abs(got["partial"].astype(np.int64)) < orc.Q).all() and (got["full"] >= 0).all() and (got["full"] < orc.Q).all()
+    assert (got["center"] > -(orc.Q // 2) - 1).all() and (got["center"] <= orc.Q // 2).all()
+    assert (got["full"].astype(np.int64) - vals) .__mod__(orc.Q).max() == 0
+    from fips204_amd import _lib
+    assert hp.lib.mldsa_reduce(hp._h, 7, C.c_void_p(d.data_ptr()), C.c_void_p(d.data_ptr()), 1, None) == _lib.ERR_PARAM
