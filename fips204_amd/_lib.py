@@ -57,6 +57,7 @@ OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE
 OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD, OPT_WORKSPACE_CAP_MB = 7, 8, 9, 10, 11
 ABI_VERSION = 4
 ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
+ROUND_POWER2ROUND, ROUND_DECOMPOSE, ROUND_HIGH_BITS, ROUND_LOW_BITS, ROUND_MAKE_HINT, ROUND_USE_HINT = range(6)
 
 # name -> argtypes (all return int unless listed in _RESTYPES)
 _SIGNATURES = {
@@ -95,6 +96,14 @@ _SIGNATURES = {
     "mldsa_inv_ntt": [_P, _P, _P, _SZ, _P],
     "mldsa_to_mont": [_P, _P, _P, _SZ, _P],
     "mldsa_reduce": [_P, _I, _P, _P, _SZ, _P],
+    "mldsa_rounding": [_P, _I, _I, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_bit_pack": [_P, _P, _I, _I, _P, _SZ, _P],
+    "mldsa_bit_unpack": [_P, _P, _I, _I, _P, _P, _SZ, _P],
+    "mldsa_hint_bit_pack": [_P, _I, _P, _P, _P, _SZ, _P],
+    "mldsa_hint_bit_unpack": [_P, _I, _P, _P, _P, _SZ, _P],
+    "mldsa_sig_encode": [_P, _I, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_sig_decode": [_P, _I, _P, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_w1_encode": [_P, _I, _P, _P, _SZ, _P],
     "mldsa_mat_vec_mul": [_P, _I, _P, _P, _P, _SZ, _P],
     "mldsa_pointwise_mont": [_P, _P, _P, _P, _SZ, _SZ, _P],
     "mldsa_add_vector_ntt": [_P, _P, _P, _P, _SZ, _P],

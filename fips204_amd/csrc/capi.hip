@@ -466,6 +466,78 @@ int mldsa_reduce(mldsa_ctx *ctx, int kind, const int32_t *in, int32_t *out, size
     return launch_reduce(ctx, kind, in, out, n_polys, (hipStream_t)stream);
 }
 
+int mldsa_rounding(mldsa_ctx *ctx, int set, int op, const int32_t *a, const int32_t *b, int32_t *out1, int32_t *out2, size_t n_polys, void *stream) {
+    ENTER(ctx, "mldsa_rounding");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_rounding: unknown parameter set");
+    REQUIRE(op >= MLDSA_ROUND_POWER2ROUND && op <= MLDSA_ROUND_USE_HINT, "mldsa_rounding: unknown operation");
+    REQUIRE(n_polys == 0 || (a && out1), "mldsa_rounding: NULL pointer");
+    REQUIRE(n_polys == 0 || op < MLDSA_ROUND_MAKE_HINT || b, "mldsa_rounding: MakeHint / UseHint take two inputs");
+    REQUIRE(n_polys == 0 || op > MLDSA_ROUND_DECOMPOSE || out2, "mldsa_rounding: Power2Round / Decompose have two outputs");
+    return launch_rounding(ctx, p, op, a, b, out1, out2, n_polys, (hipStream_t)stream);
+}
+
+static int bit_length_of(int x) {  // helpers.rs bit_length: 32 - leading_zeros
+    int n = 0;
+    while (x > 0) { n++; x >>= 1; }
+    return n;
+}
+
+int mldsa_bit_pack(mldsa_ctx *ctx, const int32_t *w, int a, int b, uint8_t *out, size_t n_polys, void *stream) {
+    ENTER(ctx, "mldsa_bit_pack");
+    REQUIRE(a >= 0 && a < (1 << 20) && b >= 1 && b < (1 << 20), "mldsa_bit_pack: a in [0, 2^20), b in [1, 2^20) (conversion.rs:144-145)");
+    REQUIRE(n_polys == 0 || (w && out), "mldsa_bit_pack: NULL pointer");
+    return launch_bit_pack(ctx, w, a, b, bit_length_of(a + b), out, n_polys, (hipStream_t)stream);
+}
+
+int mldsa_bit_unpack(mldsa_ctx *ctx, const uint8_t *v, int a, int b, int32_t *w, uint8_t *ok, size_t n_polys, void *stream) {
+    ENTER(ctx, "mldsa_bit_unpack");
+    REQUIRE(a >= 0 && a < (1 << 20) && b >= 1 && b < (1 << 20), "mldsa_bit_unpack: a in [0, 2^20), b in [1, 2^20) (conversion.rs:228-229)");
+    REQUIRE(n_polys == 0 || (v && w), "mldsa_bit_unpack: NULL pointer");
+    return launch_bit_unpack(ctx, v, a, b, bit_length_of(a + b), w, ok, n_polys, (hipStream_t)stream);
+}
+
+int mldsa_hint_bit_pack(mldsa_ctx *ctx, int set, const int32_t *h, uint8_t *y, uint8_t *ok, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_hint_bit_pack");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_hint_bit_pack: unknown parameter set");
+    REQUIRE(n_ops == 0 || (h && y), "mldsa_hint_bit_pack: NULL pointer");
+    return launch_hint_pack(ctx, p, h, y, ok, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_hint_bit_unpack(mldsa_ctx *ctx, int set, const uint8_t *y, int32_t *h, uint8_t *ok, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_hint_bit_unpack");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_hint_bit_unpack: unknown parameter set");
+    REQUIRE(n_ops == 0 || (y && h && ok), "mldsa_hint_bit_unpack: NULL pointer");
+    return launch_hint_unpack(ctx, p, y, h, ok, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_sig_encode(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, const int32_t *z, const int32_t *h, uint8_t *sigs, uint8_t *ok, size_t n_ops,
+                     void *stream) {
+    ENTER(ctx, "mldsa_sig_encode");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_sig_encode: unknown parameter set");
+    REQUIRE(n_ops == 0 || (c_tilde && z && h && sigs), "mldsa_sig_encode: NULL pointer");
+    return launch_sig_encode(ctx, p, c_tilde, z, h, sigs, ok, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_sig_decode(mldsa_ctx *ctx, int set, const uint8_t *sigs, uint8_t *c_tilde, int32_t *z, int32_t *h, uint8_t *ok, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_sig_decode");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_sig_decode: unknown parameter set");
+    REQUIRE(n_ops == 0 || (sigs && c_tilde && z && h && ok), "mldsa_sig_decode: NULL pointer");
+    return launch_sig_decode(ctx, p, sigs, c_tilde, z, h, ok, n_ops, (hipStream_t)stream);
+}
+
+int mldsa_w1_encode(mldsa_ctx *ctx, int set, const int32_t *w1, uint8_t *out, size_t n_ops, void *stream) {
+    ENTER(ctx, "mldsa_w1_encode");
+    const mldsa_params *p = params_of(set);
+    REQUIRE(p, "mldsa_w1_encode: unknown parameter set");
+    REQUIRE(n_ops == 0 || (w1 && out), "mldsa_w1_encode: NULL pointer");
+    return launch_w1_encode(ctx, p, w1, out, n_ops, (hipStream_t)stream);
+}
+
 int mldsa_mat_vec_mul(mldsa_ctx *ctx, int set, const int32_t *a_hat, const int32_t *u_hat,
                       int32_t *w_hat, size_t n_ops, void *stream) {
     ENTER(ctx, "mldsa_mat_vec_mul");

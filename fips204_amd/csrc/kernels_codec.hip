@@ -470,4 +470,265 @@ static int launch_shake256_2v(int out_len, const uint8_t* a, size_t sa, int la, 
     return MLDSA_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// The codecs as seams of their own (SURVEY rows F1 w1Encode, F2 bit_pack / bit_unpack / hint_bit_pack / hint_bit_unpack /
+// sig_encode / sig_decode).  Inside the pipelines these are prologues and epilogues of k_verify_main, k_sign_tail and k_resolve;
+// the kernels below run the same device helpers (y_from_raw, hint_unpack_wave, pack_w1_strided) on int32 polynomials in HBM so
+// that parity tests reach the reference's seams directly.  Not on the timed path.
+
+// bit_pack (conversion.rs:143-186; simple_bit_pack 120-132 = a == 0): one thread per 8 coefficients = `bitlen` bytes
+__global__ __launch_bounds__(256) void k_bit_pack(const int32_t* __restrict__ w, int a, int b, int bitlen, uint8_t* __restrict__ out, size_t n_polys) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_polys * 32) return;
+    const int4 lo = reinterpret_cast<const int4*>(w)[2 * t], hi = reinterpret_cast<const int4*>(w)[2 * t + 1];
+    const int32_t c[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint8_t* dst = out + t * (size_t)bitlen;
+    uint64_t acc = 0;
+    int bits = 0, o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        // conversion.rs:166-171: b.abs_diff(coeff) for a > 0, coeff.unsigned_abs() otherwise; masked to the field (a coefficient
+        // outside [-a, b] is a debug_assert in the reference: here it cannot touch its neighbours)
+        const uint32_t f = a > 0 ? (uint32_t)(b > c[i] ? b - c[i] : c[i] - b) : (uint32_t)(c[i] < 0 ? -c[i] : c[i]);
+        acc |= (uint64_t)(f & ((1u << bitlen) - 1u)) << bits;
+        bits += bitlen;
+        while (bits >= 8) { dst[o++] = (uint8_t)acc; acc >>= 8; bits -= 8; }
+    }
+}
+
+// bit_unpack (conversion.rs:227-262; simple_bit_unpack 198-213 = a == 0); ok[poly] = the reference's Ok / Err (256-261)
+__global__ __launch_bounds__(256) void k_bit_unpack(const uint8_t* __restrict__ v, int a, int b, int bitlen, int32_t* __restrict__ w,
+                                                    uint8_t* __restrict__ ok, size_t n_polys) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = t < n_polys * 32;
+    bool bad = false;
+    if (live) {
+        const uint8_t* src = v + t * (size_t)bitlen;
+        const int32_t bot = b - (1 << bitlen) + 1;  // -|b - 2^c + 1|: never positive for the reference's (a, b) pairs
+        uint64_t acc = 0;
+        int bits = 0, o = 0;
+        int32_t c[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            while (bits < bitlen) { acc |= (uint64_t)src[o++] << bits; bits += 8; }
+            const int32_t f = (int32_t)(acc & ((1u << bitlen) - 1u));
+            acc >>= bitlen;
+            bits -= bitlen;
+            c[i] = a == 0 ? f : b - f;
+            bad |= c[i] < (bot < 0 ? bot : -bot) || c[i] > b;
+        }
+        reinterpret_cast<int4*>(w)[2 * t] = make_int4(c[0], c[1], c[2], c[3]);
+        reinterpret_cast<int4*>(w)[2 * t + 1] = make_int4(c[4], c[5], c[6], c[7]);
+    }
+    // 32 threads per polynomial = half a wave
+    const unsigned long long m = __ballot(bad);
+    const int lane = threadIdx.x & 63;
+    if (live && ok && (lane & 31) == 0) ok[t >> 5] = ((m >> (lane & 32)) & 0xFFFFFFFFull) == 0 ? 1 : 0;
+}
+
+// hint_bit_pack (conversion.rs:277-328) by one wave: positions in coefficient order through ballots.  ok = 0 when the weight
+// exceeds omega (the reference's debug_assert at 286-289; positions past omega are dropped, never written over the limits)
+template <int K>
+__device__ __forceinline__ bool hint_pack_wave(const int32_t* __restrict__ h, int omega, uint8_t* __restrict__ y, int lane) {
+    for (int i = lane; i < omega + K; i += 64) y[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int index = 0;
+#pragma unroll 1
+    for (int i = 0; i < K; i++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool bit = h[i * N + 64 * k + lane] != 0;
+            const unsigned long long mask = __ballot(bit);
+            if (bit) {
+                const int rank = index + __popcll(mask & ((1ull << lane) - 1ull));
+                if (rank < omega) y[rank] = (uint8_t)(64 * k + lane);
+            }
+            index += __popcll(mask);
+        }
+        if (lane == 0) y[omega + i] = (uint8_t)(index < omega ? index : omega);
+    }
+    return index <= omega;
+}
+
+// the masks hint_unpack_wave left in LDS -> K int32 polynomials of 0 / 1 (all zero for a refused hint section)
+template <int K>
+__device__ __forceinline__ void hint_masks_to_polys(const uint32_t* __restrict__ hl, bool valid, int32_t* __restrict__ h, int lane) {
+#pragma unroll 1
+    for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = 64 * k + lane;
+            h[i * N + j] = valid ? (int32_t)((hl[24 + i * 8 + (j >> 5)] >> (j & 31)) & 1u) : 0;
+        }
+}
+
+template <int K>
+__global__ __launch_bounds__(CBLOCK) void k_hint_pack(const int32_t* __restrict__ h, int omega, uint8_t* __restrict__ y, uint8_t* __restrict__ ok,
+                                                      size_t n_ops) {
+    const int lane = threadIdx.x & 63;
+    const size_t op = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6);
+    if (op >= n_ops) return;
+    const bool good = hint_pack_wave<K>(h + op * K * (size_t)N, omega, y + op * (size_t)(omega + K), lane);
+    if (ok && lane == 0) ok[op] = good ? 1 : 0;
+}
+
+template <int K>
+__global__ __launch_bounds__(CBLOCK) void k_hint_unpack(const uint8_t* __restrict__ y, int omega, int32_t* __restrict__ h, uint8_t* __restrict__ ok,
+                                                        size_t n_ops) {
+    __shared__ uint32_t hint_lds[CWAVES][HINT_LDS_DWORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t op = (size_t)blockIdx.x * CWAVES + wave;
+    if (op >= n_ops) return;
+    const HintBytes hb = hint_load(y + op * (size_t)(omega + K), omega, K, lane);
+    const bool good = hint_unpack_wave<K>(hb, omega, hint_lds[wave], lane);
+    hint_masks_to_polys<K>(hint_lds[wave], good, h + op * K * (size_t)N, lane);
+    if (ok && lane == 0) ok[op] = good ? 1 : 0;
+}
+
+// sig_decode (encodings.rs:290-328): c_tilde | z (bit_unpack with gamma1 - 1, gamma1: the forward loop of k_verify_main) | h
+template <int K, int L, int CB>
+__global__ __launch_bounds__(CBLOCK) void k_sig_decode(const uint8_t* __restrict__ sigs, size_t sig_len, int ctilde_len, int omega,
+                                                       uint8_t* __restrict__ c_tilde, int32_t* __restrict__ z, int32_t* __restrict__ h,
+                                                       uint8_t* __restrict__ ok, size_t n_ops) {
+    __shared__ uint32_t hint_lds[CWAVES][HINT_LDS_DWORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t op = (size_t)blockIdx.x * CWAVES + wave;
+    if (op >= n_ops) return;
+    const uint8_t* sig = sigs + op * sig_len;
+    if (lane < ctilde_len) c_tilde[op * (size_t)ctilde_len + lane] = sig[lane];
+    const uint8_t* zsrc = sig + ctilde_len;
+    const HintBytes hb = hint_load(zsrc + L * (32 * CB), omega, K, lane);
+#pragma unroll 1
+    for (int j = 0; j < L; j++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            z[(op * L + j) * (size_t)N + 64 * k + lane] = y_from_raw<CB>(y_raw_dword<CB>(zsrc + (size_t)j * (32 * CB), k, lane), lane);
+    const bool good = hint_unpack_wave<K>(hb, omega, hint_lds[wave], lane);
+    hint_masks_to_polys<K>(hint_lds[wave], good, h + op * K * (size_t)N, lane);
+    if (ok && lane == 0) ok[op] = good ? 1 : 0;
+}
+
+// sig_encode (encodings.rs:238-280): z as in the signer's tail (four consecutive coefficients = 9 / 10 bytes per lane)
+template <int K, int L, int CB>
+__global__ __launch_bounds__(CBLOCK) void k_sig_encode(const uint8_t* __restrict__ c_tilde, const int32_t* __restrict__ z, const int32_t* __restrict__ h,
+                                                       size_t sig_len, int ctilde_len, int omega, uint8_t* __restrict__ sigs,
+                                                       uint8_t* __restrict__ ok, size_t n_ops) {
+    const int lane = threadIdx.x & 63;
+    const size_t op = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6);
+    if (op >= n_ops) return;
+    uint8_t* sig = sigs + op * sig_len;
+    if (lane < ctilde_len) sig[lane] = c_tilde[op * (size_t)ctilde_len + lane];
+    constexpr int32_t GAMMA1 = 1 << (CB - 1);
+    bool bad = false;
+#pragma unroll 1
+    for (int j = 0; j < L; j++) {
+        const int4 z4 = reinterpret_cast<const int4*>(z + (op * L + j) * (size_t)N)[lane];
+        const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            bad |= zz[t] <= -GAMMA1 || zz[t] > GAMMA1;  // the reference's debug_assert (encodings.rs:249)
+            const uint64_t f = (uint64_t)((uint32_t)(GAMMA1 - zz[t]) & ((1u << CB) - 1u));
+            const int sh = t * CB;
+            lo |= f << sh;
+            if (sh + CB > 64) hi |= (uint32_t)(f >> (64 - sh));
+        }
+        constexpr int NBYTES = CB / 2;
+        uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * CB) + (size_t)lane * NBYTES;
+        *reinterpret_cast<u64_any*>(dst) = lo;
+        if constexpr (NBYTES == 10) *reinterpret_cast<u16_any*>(dst + 8) = (uint16_t)hi;
+        else dst[8] = (uint8_t)hi;
+    }
+    const bool hint_ok = hint_pack_wave<K>(h + op * K * (size_t)N, omega, sig + ctilde_len + (size_t)L * (32 * CB), lane);
+    const bool z_ok = __ballot(bad) == 0ull;
+    if (ok && lane == 0) ok[op] = hint_ok && z_ok ? 1 : 0;
+}
+
+// w1_encode (encodings.rs:338-360): one wave per polynomial, the packing k_verify_main and the signer's w kernel use
+template <bool G2HI>
+__global__ __launch_bounds__(CBLOCK) void k_w1_encode(const int32_t* __restrict__ w1, uint8_t* __restrict__ out, size_t n_polys) {
+    constexpr int BITS = G2HI ? 4 : 6;
+    const int lane = threadIdx.x & 63;
+    const size_t poly = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6);
+    if (poly >= n_polys) return;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (uint32_t)w1[poly * N + 64 * k + lane] & ((1u << BITS) - 1u);
+    pack_w1_strided<G2HI>(v, out + poly * (size_t)(32 * BITS), lane);
+}
+
+static inline unsigned wave_blocks(size_t n) { return (unsigned)((n + CWAVES - 1) / CWAVES); }
+
+int launch_bit_pack(mldsa_ctx*, const int32_t* w, int a, int b, int bitlen, uint8_t* out, size_t n_polys, hipStream_t s) {
+    if (n_polys == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_bit_pack, dim3((unsigned)((n_polys * 32 + 255) / 256)), dim3(256), 0, s, w, a, b, bitlen, out, n_polys);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_bit_unpack(mldsa_ctx*, const uint8_t* v, int a, int b, int bitlen, int32_t* w, uint8_t* ok, size_t n_polys, hipStream_t s) {
+    if (n_polys == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_bit_unpack, dim3((unsigned)((n_polys * 32 + 255) / 256)), dim3(256), 0, s, v, a, b, bitlen, w, ok, n_polys);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+#define MLDSA_BY_SET(p, KERNEL3, ...)                                                                               \
+    do {                                                                                                            \
+        if ((p)->set == MLDSA_44) hipLaunchKernelGGL((KERNEL3<4, 4, 18>), __VA_ARGS__);                             \
+        else if ((p)->set == MLDSA_65) hipLaunchKernelGGL((KERNEL3<6, 5, 20>), __VA_ARGS__);                        \
+        else hipLaunchKernelGGL((KERNEL3<8, 7, 20>), __VA_ARGS__);                                                  \
+    } while (0)
+#define MLDSA_BY_K(p, KERNEL1, ...)                                                                                 \
+    do {                                                                                                            \
+        if ((p)->k == 4) hipLaunchKernelGGL((KERNEL1<4>), __VA_ARGS__);                                             \
+        else if ((p)->k == 6) hipLaunchKernelGGL((KERNEL1<6>), __VA_ARGS__);                                        \
+        else hipLaunchKernelGGL((KERNEL1<8>), __VA_ARGS__);                                                         \
+    } while (0)
+
+int launch_hint_pack(mldsa_ctx*, const mldsa_params* p, const int32_t* h, uint8_t* y, uint8_t* ok, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    MLDSA_BY_K(p, k_hint_pack, dim3(wave_blocks(n_ops)), dim3(CBLOCK), 0, s, h, p->omega, y, ok, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_hint_unpack(mldsa_ctx*, const mldsa_params* p, const uint8_t* y, int32_t* h, uint8_t* ok, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    MLDSA_BY_K(p, k_hint_unpack, dim3(wave_blocks(n_ops)), dim3(CBLOCK), 0, s, y, p->omega, h, ok, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_sig_decode(mldsa_ctx*, const mldsa_params* p, const uint8_t* sigs, uint8_t* c_tilde, int32_t* z, int32_t* h, uint8_t* ok, size_t n_ops,
+                      hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    MLDSA_BY_SET(p, k_sig_decode, dim3(wave_blocks(n_ops)), dim3(CBLOCK), 0, s, sigs, (size_t)p->sig_len, p->ctilde_len, p->omega, c_tilde, z, h, ok,
+                 n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_sig_encode(mldsa_ctx*, const mldsa_params* p, const uint8_t* c_tilde, const int32_t* z, const int32_t* h, uint8_t* sigs, uint8_t* ok,
+                      size_t n_ops, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    MLDSA_BY_SET(p, k_sig_encode, dim3(wave_blocks(n_ops)), dim3(CBLOCK), 0, s, c_tilde, z, h, (size_t)p->sig_len, p->ctilde_len, p->omega, sigs, ok,
+                 n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_w1_encode(mldsa_ctx*, const mldsa_params* p, const int32_t* w1, uint8_t* out, size_t n_ops, hipStream_t s) {
+    const size_t n_polys = n_ops * p->k;
+    if (n_polys == 0) return MLDSA_OK;
+    if (p->gamma2 == (Q - 1) / 32) hipLaunchKernelGGL(k_w1_encode<true>, dim3(wave_blocks(n_polys)), dim3(CBLOCK), 0, s, w1, out, n_polys);
+    else hipLaunchKernelGGL(k_w1_encode<false>, dim3(wave_blocks(n_polys)), dim3(CBLOCK), 0, s, w1, out, n_polys);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+#undef MLDSA_BY_SET
+#undef MLDSA_BY_K
+
 }  // namespace mldsa

@@ -105,6 +105,46 @@ __global__ __launch_bounds__(BLOCK) void k_elementwise(const int4 *__restrict__ 
     }
 }
 
+// ------------------------------------------ rounding seams (high_low.rs), element-wise
+// OP: 0 power2round (15-48), 1 decompose (66-96), 2 high_bits (104-111), 3 low_bits (119-126), 4 make_hint (134-144), 5 use_hint (155-192)
+template <bool G2HI>
+__global__ __launch_bounds__(BLOCK) void k_rounding(int op, const int32_t *__restrict__ a, const int32_t *__restrict__ b,
+                                                    int32_t *__restrict__ out1, int32_t *__restrict__ out2, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (; i < n; i += stride) {
+        const int32_t x = a[i];
+        int32_t r1 = 0, r0 = 0;
+        if (op == 0) {                      // input in [0, q) (the reference's debug_assert, high_low.rs:21-24)
+            r1 = (x + (1 << 12) - 1) >> 13;
+            r0 = x - (r1 << 13);
+        } else if (op <= 3) {
+            decompose<G2HI>(freeze(x), r1, r0);   // decompose starts with full_reduce32 (high_low.rs:76)
+            if (op == 3) r1 = r0;
+        } else if (op == 4) {               // a = z, b = r
+            int32_t v1, t;
+            decompose<G2HI>(freeze(b[i]), r1, t);
+            decompose<G2HI>(freeze(b[i] + x), v1, t);
+            r1 = r1 != v1 ? 1 : 0;
+        } else {                            // a = h, b = r
+            r1 = use_hint<G2HI>(x, freeze(b[i]));
+        }
+        out1[i] = r1;
+        if (op <= 1 && out2) out2[i] = r0;
+    }
+}
+
+int launch_rounding(mldsa_ctx *ctx, const mldsa_params *p, int op, const int32_t *a, const int32_t *b, int32_t *out1, int32_t *out2, size_t n_polys,
+                    hipStream_t s) {
+    if (n_polys == 0) return MLDSA_OK;
+    const size_t n = n_polys * N;
+    const dim3 grid(grid_for(ctx, n, BLOCK, 8)), block(BLOCK);
+    if (p->gamma2 == (Q - 1) / 32) hipLaunchKernelGGL(k_rounding<true>, grid, block, 0, s, op, a, b, out1, out2, n);
+    else hipLaunchKernelGGL(k_rounding<false>, grid, block, 0, s, op, a, b, out1, out2, n);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
 // ------------------------------------------ mat_vec_mul (helpers.rs:100-114), one wave per row
 // w_hat[op][i] = sum_j a_hat[op][i][j] o u_hat[op][j];  u is converted with to_mont first,
 // exactly as the reference does, so each term is mont_reduce(a * u * 2^32) = a*u in (-q, q).

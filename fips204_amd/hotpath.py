@@ -160,6 +160,89 @@ class HotPath:
         """center_mod, element-wise (src/helpers.rs:88-95): (-q/2, q/2]"""
         return self._reduce(2, w)
 
+    def rounding(self, pset, op, a, b=None):
+        """high_low.rs element-wise: op 0 power2round -> (r1, r0), 1 decompose -> (r1, r0), 2 high_bits, 3 low_bits,
+        4 make_hint(z = a, r = b), 5 use_hint(h = a, r = b)"""
+        a = _polys(a, "a")
+        out1 = torch.empty_like(a)
+        out2 = torch.empty_like(a) if op <= 1 else None
+        _lib.check(self.lib.mldsa_rounding(self._h, pset, op, _ptr(a), _ptr(_polys(b, "b")) if b is not None else None, _ptr(out1),
+                                           _ptr(out2) if out2 is not None else None, a.numel() // N, _stream(self.device)))
+        return (out1, out2) if op <= 1 else out1
+
+    # ---- codecs as seams (conversion.rs, encodings.rs); every `ok` is a uint8 tensor, 1 = the reference returns Ok
+    def bit_pack(self, w, a, b):
+        """bit_pack(w, a, b) (src/conversion.rs:143-186; a = 0: simple_bit_pack) -> uint8 [n_polys, 32 * bitlen(a + b)]"""
+        w = _polys(w, "w")
+        n = w.numel() // N
+        out = torch.empty((n, 32 * int(a + b).bit_length()), dtype=torch.uint8, device=w.device)
+        _lib.check(self.lib.mldsa_bit_pack(self._h, _ptr(w), a, b, _ptr(out), n, _stream(self.device)))
+        return out
+
+    def bit_unpack(self, v, a, b):
+        """bit_unpack(v, a, b) (src/conversion.rs:227-262; a = 0: simple_bit_unpack) -> (w int32 [n_polys, 256], ok)"""
+        row = 32 * int(a + b).bit_length()
+        v = _bytes(v, "v", row)
+        n = v.numel() // row
+        w = torch.empty((n, N), dtype=torch.int32, device=v.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=v.device)
+        _lib.check(self.lib.mldsa_bit_unpack(self._h, _ptr(v), a, b, _ptr(w), _ptr(ok), n, _stream(self.device)))
+        return w, ok
+
+    def hint_bit_pack(self, pset, h):
+        """hint_bit_pack (src/conversion.rs:277-328): h int32 [n_ops, K, 256] -> (y uint8 [n_ops, omega + K], ok)"""
+        p = _lib.get_params(pset)
+        h = _polys(h, "h")
+        n = h.numel() // (p.k * N)
+        y = torch.empty((n, p.omega + p.k), dtype=torch.uint8, device=h.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=h.device)
+        _lib.check(self.lib.mldsa_hint_bit_pack(self._h, pset, _ptr(h), _ptr(y), _ptr(ok), n, _stream(self.device)))
+        return y, ok
+
+    def hint_bit_unpack(self, pset, y):
+        """hint_bit_unpack (src/conversion.rs:340-414): y uint8 [n_ops, omega + K] -> (h int32 [n_ops, K, 256], ok)"""
+        p = _lib.get_params(pset)
+        y = _bytes(y, "y", p.omega + p.k)
+        n = y.numel() // (p.omega + p.k)
+        h = torch.empty((n, p.k, N), dtype=torch.int32, device=y.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=y.device)
+        _lib.check(self.lib.mldsa_hint_bit_unpack(self._h, pset, _ptr(y), _ptr(h), _ptr(ok), n, _stream(self.device)))
+        return h, ok
+
+    def sig_encode(self, pset, c_tilde, z, h):
+        """sig_encode (src/encodings.rs:238-280) -> (sigs uint8 [n_ops, sig_len], ok)"""
+        p = _lib.get_params(pset)
+        c_tilde, z, h = _bytes(c_tilde, "c_tilde", p.ctilde_len), _polys(z, "z"), _polys(h, "h")
+        n = c_tilde.numel() // p.ctilde_len
+        if z.numel() != n * p.l * N or h.numel() != n * p.k * N:
+            raise ValueError("sig_encode: z / h do not match the number of c_tilde rows")
+        sigs = torch.empty((n, p.sig_len), dtype=torch.uint8, device=z.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=z.device)
+        _lib.check(self.lib.mldsa_sig_encode(self._h, pset, _ptr(c_tilde), _ptr(z), _ptr(h), _ptr(sigs), _ptr(ok), n, _stream(self.device)))
+        return sigs, ok
+
+    def sig_decode(self, pset, sigs):
+        """sig_decode (src/encodings.rs:290-328) -> (c_tilde, z int32 [n_ops, L, 256], h int32 [n_ops, K, 256], ok)"""
+        p = _lib.get_params(pset)
+        sigs = _bytes(sigs, "sigs", p.sig_len)
+        n = sigs.numel() // p.sig_len
+        dev = sigs.device
+        c_tilde = torch.empty((n, p.ctilde_len), dtype=torch.uint8, device=dev)
+        z = torch.empty((n, p.l, N), dtype=torch.int32, device=dev)
+        h = torch.empty((n, p.k, N), dtype=torch.int32, device=dev)
+        ok = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.mldsa_sig_decode(self._h, pset, _ptr(sigs), _ptr(c_tilde), _ptr(z), _ptr(h), _ptr(ok), n, _stream(self.device)))
+        return c_tilde, z, h, ok
+
+    def w1_encode(self, pset, w1):
+        """w1_encode (src/encodings.rs:338-360): w1 int32 [n_ops, K, 256] -> uint8 [n_ops, w1_len]"""
+        p = _lib.get_params(pset)
+        w1 = _polys(w1, "w1")
+        n = w1.numel() // (p.k * N)
+        out = torch.empty((n, p.w1_len), dtype=torch.uint8, device=w1.device)
+        _lib.check(self.lib.mldsa_w1_encode(self._h, pset, _ptr(w1), _ptr(out), n, _stream(self.device)))
+        return out
+
     def mat_vec_mul(self, pset, a_hat, u_hat):
         """mat_vec_mul::<K, L>(&[[T; L]; K], &[T; L]) -> [T; K], batched over ops (src/helpers.rs:100)"""
         p = _lib.get_params(pset)

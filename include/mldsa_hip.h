@@ -200,6 +200,45 @@ int mldsa_to_mont(mldsa_ctx *ctx, const int32_t *in, int32_t *out, size_t n_poly
 #define MLDSA_REDUCE_CENTER 2
 int mldsa_reduce(mldsa_ctx *ctx, int kind, const int32_t *in, int32_t *out, size_t n_polys, void *stream);
 
+/* The rounding functions of src/high_low.rs, element-wise over n_polys polynomials (inside the pipelines they are epilogues
+ * of k_verify_main / sign_w / k_sign_tail -- these entry points make the seam testable on its own).  gamma2 comes from `set`.
+ *   POWER2ROUND (high_low.rs:15-48)  a in [0, q)                 -> out1 = r1, out2 = r0
+ *   DECOMPOSE   (66-96)              a any representative         -> out1 = r1, out2 = r0
+ *   HIGH_BITS / LOW_BITS (104-126)   a                            -> out1
+ *   MAKE_HINT   (134-144)            a = z, b = r                 -> out1 = 0 / 1
+ *   USE_HINT    (155-192)            a = h (0 / 1), b = r         -> out1 */
+#define MLDSA_ROUND_POWER2ROUND 0
+#define MLDSA_ROUND_DECOMPOSE 1
+#define MLDSA_ROUND_HIGH_BITS 2
+#define MLDSA_ROUND_LOW_BITS 3
+#define MLDSA_ROUND_MAKE_HINT 4
+#define MLDSA_ROUND_USE_HINT 5
+int mldsa_rounding(mldsa_ctx *ctx, int set, int op, const int32_t *a, const int32_t *b, int32_t *out1, int32_t *out2, size_t n_polys,
+                   void *stream);
+
+/* The wire-format codecs as seams.  Inside mldsa_verify / mldsa_sign / mldsa_keygen they are fused
+ * into the arithmetic kernels (no int32 z, h or w1 ever reaches HBM); these entry points run the same device code on int32
+ * polynomials (16-byte aligned) so that every codec of src/conversion.rs and src/encodings.rs can be checked on its own.  `ok`
+ * arrays hold one byte per polynomial / operation: 1 = the reference returns Ok, 0 = it returns Err (or, for the encoders,
+ * trips a debug_assert: the output is then well-formed but lossy).  `ok` may be NULL for the encoders.
+ *   mldsa_bit_pack         bit_pack (conversion.rs:143-186); a = 0 is simple_bit_pack (120-132).  out: 32 * bitlen(a + b) bytes / poly
+ *   mldsa_bit_unpack       bit_unpack (227-262); a = 0 is simple_bit_unpack (198-213)
+ *   mldsa_hint_bit_pack    hint_bit_pack (277-328): h [n_ops][K][256] of 0 / 1 -> y [n_ops][omega + K]; ok = 0 if weight(h) > omega
+ *   mldsa_hint_bit_unpack  hint_bit_unpack (340-414): ok = 0 for a malformed section (h is then all zero)
+ *   mldsa_sig_encode       sig_encode (encodings.rs:238-280): c_tilde [n_ops][lambda/4], z [n_ops][L][256] in (-gamma1, gamma1],
+ *                          h [n_ops][K][256] -> sigs [n_ops][sig_len]
+ *   mldsa_sig_decode       sig_decode (290-328): the reverse; ok = 0 where the reference returns Err
+ *   mldsa_w1_encode        w1_encode (338-360): w1 [n_ops][K][256] in [0, (q-1)/(2 gamma2)) -> [n_ops][w1_len] */
+int mldsa_bit_pack(mldsa_ctx *ctx, const int32_t *w, int a, int b, uint8_t *out, size_t n_polys, void *stream);
+int mldsa_bit_unpack(mldsa_ctx *ctx, const uint8_t *v, int a, int b, int32_t *w, uint8_t *ok, size_t n_polys, void *stream);
+int mldsa_hint_bit_pack(mldsa_ctx *ctx, int set, const int32_t *h, uint8_t *y, uint8_t *ok, size_t n_ops, void *stream);
+int mldsa_hint_bit_unpack(mldsa_ctx *ctx, int set, const uint8_t *y, int32_t *h, uint8_t *ok, size_t n_ops, void *stream);
+int mldsa_sig_encode(mldsa_ctx *ctx, int set, const uint8_t *c_tilde, const int32_t *z, const int32_t *h, uint8_t *sigs, uint8_t *ok,
+                     size_t n_ops, void *stream);
+int mldsa_sig_decode(mldsa_ctx *ctx, int set, const uint8_t *sigs, uint8_t *c_tilde, int32_t *z, int32_t *h, uint8_t *ok, size_t n_ops,
+                     void *stream);
+int mldsa_w1_encode(mldsa_ctx *ctx, int set, const int32_t *w1, uint8_t *out, size_t n_ops, void *stream);
+
 /* mat_vec_mul::<K,L>() src/helpers.rs:100-114: w_hat[i] = sum_j a_hat[i][j] o u_hat[j]
  * for n_ops independent (a_hat, u_hat) pairs.  a_hat: n_ops*K*L polys, u_hat: n_ops*L,
  * w_hat: n_ops*K; output representative in (-L q, L q). */

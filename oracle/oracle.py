@@ -73,6 +73,10 @@ def lib():
             getattr(_lib, f).argtypes = [C.c_int, C.c_int32]
         _lib.orc_use_hint.restype = C.c_int32
         _lib.orc_use_hint.argtypes = [C.c_int, C.c_int32, C.c_int32]
+        _lib.orc_decompose.restype = None
+        _lib.orc_decompose.argtypes = [C.c_int, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        _lib.orc_power2round.restype = None
+        _lib.orc_power2round.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib.orc_make_hint.restype = C.c_int
         _lib.orc_make_hint.argtypes = [C.c_int, C.c_int32, C.c_int32]
     return _lib
