@@ -97,6 +97,7 @@ _SIGNATURES = {
     "mldsa_to_mont": [_P, _P, _P, _SZ, _P],
     "mldsa_reduce": [_P, _I, _P, _P, _SZ, _P],
     "mldsa_rounding": [_P, _I, _I, _P, _P, _P, _P, _SZ, _P],
+    "mldsa_xof": [_P, _I, _P, _P, _P, _SZ, _P, _SZ, _P],
     "mldsa_bit_pack": [_P, _P, _I, _I, _P, _SZ, _P],
     "mldsa_bit_unpack": [_P, _P, _I, _I, _P, _P, _SZ, _P],
     "mldsa_hint_bit_pack": [_P, _I, _P, _P, _P, _SZ, _P],

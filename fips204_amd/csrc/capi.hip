@@ -477,6 +477,14 @@ int mldsa_rounding(mldsa_ctx *ctx, int set, int op, const int32_t *a, const int3
     return launch_rounding(ctx, p, op, a, b, out1, out2, n_polys, (hipStream_t)stream);
 }
 
+int mldsa_xof(mldsa_ctx *ctx, int bits, const uint8_t *data, const uint64_t *off, uint8_t *out, size_t out_len, uint8_t *bad, size_t n_ops,
+              void *stream) {
+    ENTER(ctx, "mldsa_xof");
+    REQUIRE(bits == 128 || bits == 256, "mldsa_xof: bits must be 128 (g128_xof) or 256 (h256_xof)");
+    REQUIRE(n_ops == 0 || out_len == 0 || (off && out), "mldsa_xof: NULL pointer");
+    return launch_xof(ctx, bits, data, off, out, out_len, bad, n_ops, (hipStream_t)stream);
+}
+
 static int bit_length_of(int x) {  // helpers.rs bit_length: 32 - leading_zeros
     int n = 0;
     while (x > 0) { n++; x >>= 1; }

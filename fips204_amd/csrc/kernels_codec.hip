@@ -731,4 +731,83 @@ int launch_w1_encode(mldsa_ctx*, const mldsa_params* p, const int32_t* w1, uint8
 #undef MLDSA_BY_SET
 #undef MLDSA_BY_K
 
+// h256_xof / g128_xof (hashing.rs:13-27) as a seam: SHAKE256 / SHAKE128 of one byte string per op (the reference's list of slices,
+// concatenated by the caller), any input length, the first out_len bytes of the output.  One op per lane like every sponge of the
+// pipelines (keccak.h); the rate block is assembled in a lane-private LDS row.  Offsets are validated like k_mu's: an op whose
+// pair is malformed is not read, gets a zero output and bad[op] = 1.  Not on the timed path (the pipelines' hashes have fixed
+// shapes: k_mu, k_shake256_2, the samplers).
+template <int RATE>
+__global__ __launch_bounds__(64) void k_xof(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off, uint8_t* __restrict__ out,
+                                            size_t out_len, uint8_t* __restrict__ bad, size_t n_ops) {
+    constexpr int RW = RATE / 4;       // dwords per block
+    constexpr int STRIDE = RW | 1;     // odd row stride: lane rows on distinct banks
+    __shared__ uint32_t blk[64 * STRIDE];
+    const int lane = threadIdx.x;
+    const size_t op = (size_t)blockIdx.x * 64 + lane;
+    const bool valid = op < n_ops;
+    uint32_t* row = blk + lane * STRIDE;
+    const uint8_t* src = nullptr;
+    size_t len = 0;
+    bool live = false;
+    if (valid) {
+        const uint64_t a = off[op], b = off[op + 1];
+        const bool bad_off = !(off[0] <= a && a <= b && b <= off[n_ops]) || (b != a && data == nullptr);
+        if (bad) bad[op] = bad_off ? 1 : 0;
+        live = !bad_off;
+        if (live) { src = data + a; len = (size_t)(b - a); }
+    }
+    const size_t in_blocks = live ? len / RATE + 1 : 0;  // the pad always fits in the last block
+    const size_t out_blocks = live ? (out_len + RATE - 1) / RATE : 0;
+    KeccakState st;
+    keccak_zero(st);
+    for (size_t b = 0; __ballot(b < in_blocks) != 0ull; b++) {
+        if (b < in_blocks) {
+            const size_t base = b * RATE;
+            for (int i = 0; i < RW; i++) {
+                const size_t pos = base + 4 * (size_t)i;
+                uint32_t v = 0;
+                if (pos + 4 <= len) v = load_le32(src + pos);
+                else
+                    for (int t = 0; t < 4; t++) {
+                        const size_t q = pos + t;
+                        v |= (uint32_t)(q < len ? src[q] : q == len ? 0x1Fu : 0u) << (8 * t);
+                    }
+                row[i] = v;
+            }
+            if (b == in_blocks - 1) row[RW - 1] ^= 0x80000000u;
+            static_for_c<0, RATE / 8>([&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+                st.lo[W] ^= row[2 * W];
+                st.hi[W] ^= row[2 * W + 1];
+            });
+            keccak_f1600(st);
+        }
+    }
+    uint8_t* dst = out + op * out_len;
+    for (size_t b = 0; __ballot(b < out_blocks) != 0ull; b++) {
+        if (b < out_blocks) {
+            if (b) keccak_f1600(st);
+            static_for_c<0, RATE / 8>([&](auto wc) {
+                constexpr int W = decltype(wc)::value;
+                row[2 * W] = st.lo[W];
+                row[2 * W + 1] = st.hi[W];
+            });
+            const size_t base = b * RATE, nb = out_len - base < (size_t)RATE ? out_len - base : (size_t)RATE;
+            const uint8_t* rb = reinterpret_cast<const uint8_t*>(row);
+            for (size_t i = 0; i < nb; i++) dst[base + i] = rb[i];
+        }
+    }
+    if (valid && !live)
+        for (size_t i = 0; i < out_len; i++) dst[i] = 0;
+}
+
+int launch_xof(mldsa_ctx*, int bits, const uint8_t* data, const uint64_t* off, uint8_t* out, size_t out_len, uint8_t* bad, size_t n_ops, hipStream_t s) {
+    if (n_ops == 0 || out_len == 0) return MLDSA_OK;
+    const dim3 grid((unsigned)((n_ops + 63) / 64)), block(64);
+    if (bits == 128) hipLaunchKernelGGL(k_xof<SHAKE128_RATE>, grid, block, 0, s, data, off, out, out_len, bad, n_ops);
+    else hipLaunchKernelGGL(k_xof<SHAKE256_RATE>, grid, block, 0, s, data, off, out, out_len, bad, n_ops);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
 }  // namespace mldsa

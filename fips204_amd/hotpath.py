@@ -171,6 +171,16 @@ class HotPath:
         return (out1, out2) if op <= 1 else out1
 
     # ---- codecs as seams (conversion.rs, encodings.rs); every `ok` is a uint8 tensor, 1 = the reference returns Ok
+    def xof(self, bits, data, off, out_len):
+        """h256_xof (bits = 256) / g128_xof (bits = 128) (src/hashing.rs:13-27): data uint8, off int64 / uint64 [n_ops + 1] on the device
+        -> (out uint8 [n_ops, out_len], bad uint8 [n_ops])"""
+        n = off.numel() - 1
+        out = torch.empty((n, out_len), dtype=torch.uint8, device=off.device)
+        bad = torch.empty(n, dtype=torch.uint8, device=off.device)
+        _lib.check(self.lib.mldsa_xof(self._h, bits, _ptr(data) if data is not None and data.numel() else None, _ptr(off), _ptr(out), out_len,
+                                      _ptr(bad), n, _stream(self.device)))
+        return out, bad
+
     def bit_pack(self, w, a, b):
         """bit_pack(w, a, b) (src/conversion.rs:143-186; a = 0: simple_bit_pack) -> uint8 [n_polys, 32 * bitlen(a + b)]"""
         w = _polys(w, "w")

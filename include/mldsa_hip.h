@@ -216,6 +216,14 @@ int mldsa_reduce(mldsa_ctx *ctx, int kind, const int32_t *in, int32_t *out, size
 int mldsa_rounding(mldsa_ctx *ctx, int set, int op, const int32_t *a, const int32_t *b, int32_t *out1, int32_t *out2, size_t n_polys,
                    void *stream);
 
+/* h256_xof / g128_xof (src/hashing.rs:13-27): SHAKE256 (bits = 256) / SHAKE128 (bits = 128) of one byte string per op --
+ * data[off[i] .. off[i + 1]), the reference's list of slices concatenated by the caller -- first out_len bytes to out[i * out_len].
+ * `off` is a device array of n_ops + 1 entries and is untrusted like msg_off: an op with a malformed pair is not read, its output
+ * is zero and bad[i] = 1 (bad may be NULL).  A seam for tests and for callers that need the XOF itself; the pipelines' hashes
+ * (mu, rho'', c_tilde, tr, the samplers) are fixed-shape kernels of their own. */
+int mldsa_xof(mldsa_ctx *ctx, int bits, const uint8_t *data, const uint64_t *off, uint8_t *out, size_t out_len, uint8_t *bad, size_t n_ops,
+              void *stream);
+
 /* The wire-format codecs as seams.  Inside mldsa_verify / mldsa_sign / mldsa_keygen they are fused
  * into the arithmetic kernels (no int32 z, h or w1 ever reaches HBM); these entry points run the same device code on int32
  * polynomials (16-byte aligned) so that every codec of src/conversion.rs and src/encodings.rs can be checked on its own.  `ok`

@@ -248,3 +248,44 @@ def test_w1_encode(hp, pset):
         assert got[i].tobytes() == orc.w1_encode(pset, w1[i]), i
     # the same bytes through the generic packer: w1_encode IS simple_bit_pack per polynomial (encodings.rs:354-358)
     assert np.array_equal(host(hp.bit_pack(dev(w1.reshape(-1, N)), 0, m - 1)).reshape(n, -1), got)
+
+
+@pytest.mark.parametrize("bits", [128, 256])
+def test_xof_seam(hp, bits):
+    """h256_xof / g128_xof (hashing.rs:13-27; SURVEY row A12: the `sha3` crate's SHAKE, pinned here by hashlib): every input length
+    0 .. 2 x rate + 9 (all padding positions, the 0x1F | 0x80 byte at rate - 1), a few long ones, output lengths inside one block,
+    at the block boundary and over several blocks; a malformed offset pair refuses only its own op."""
+    import hashlib
+    rate = 168 if bits == 128 else 136
+    fn = hashlib.shake_128 if bits == 128 else hashlib.shake_256
+    rng = np.random.default_rng(bits)
+    lens = list(range(0, 2 * rate + 10)) + [1000, 1312, 2592, 4627, 7727]
+    items = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in lens]
+    flat = np.frombuffer(b"".join(items), dtype=np.uint8)
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    d_flat, d_off = dev(flat), torch.from_numpy(off.view(np.int64)).cuda()
+    for out_len in (1, 32, 64, rate - 1, rate, rate + 1, 640, 3 * rate + 5):
+        out, bad = hp.xof(bits, d_flat, d_off, out_len)
+        out = host(out)
+        assert not host(bad).any()
+        for i, m in enumerate(items):
+            assert out[i].tobytes() == fn(m).digest(out_len), (len(m), out_len)
+    # the oracle's own sponge agrees (it is what every other parity test leans on)
+    assert orc.shake(bits, items[200], 99) == fn(items[200]).digest(99)
+    # untrusted offsets: op 3 decreasing, op 7 past the end; their neighbours unaffected
+    evil = off.copy()
+    evil[4] = evil[3] - 1 if evil[3] else 0
+    evil[4] = 2
+    evil[8] = np.uint64(2 ** 63)
+    out, bad = hp.xof(bits, d_flat, torch.from_numpy(evil.view(np.int64)).cuda(), 32)
+    out, bad = host(out), host(bad)
+    for i in range(len(items)):
+        lo, hi = int(evil[i]), int(evil[i + 1])
+        ok_pair = int(evil[0]) <= lo <= hi <= int(evil[-1])
+        assert bool(bad[i]) == (not ok_pair), i
+        assert out[i].tobytes() == (fn(flat[lo:hi].tobytes()).digest(32) if ok_pair else bytes(32)), i
+    assert bad.sum() >= 2
+    p = C.c_void_p(d_off.data_ptr())
+    assert hp.lib.mldsa_xof(hp._h, 512, p, p, p, 32, None, 1, None) == _lib.ERR_PARAM
+    assert hp.lib.mldsa_xof(hp._h, 256, None, None, None, 32, None, 0, None) == _lib.OK
