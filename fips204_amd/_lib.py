@@ -52,6 +52,10 @@ class Stats(C.Structure):
         "graphs_captured", "graph_replays", "direct_calls", "workspace_growths", "sign_extra_rounds", "workspace_shrinks")]
 
 
+class BatcherStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("batches", "requests", "largest_batch", "distinct_keys")]
+
+
 OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
 OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE, OPT_SIGN_ROUNDS = 1, 2, 3, 4, 5, 6
 OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD, OPT_WORKSPACE_CAP_MB = 7, 8, 9, 10, 11
@@ -75,6 +79,12 @@ _SIGNATURES = {
     "mldsa_sign_group": [_P, _I, _I, _P, _I],
     "mldsa_keygen_group": [_P, _I, _P, _I],
     "mldsa_group_sync": [_P],
+    "mldsa_batcher_destroy": [_P],
+    "mldsa_batcher_create": [_P, _I, _SZ, C.c_uint, _P],
+    "mldsa_batcher_verify": [_P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
+    "mldsa_batcher_sign": [_P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
+    "mldsa_batcher_keygen": [_P, _P, _P, _P],
+    "mldsa_batcher_get_stats": [_P, _P],
     "mldsa_ctx_device": [_P],
     "mldsa_reserve": [_P, _I, _I, _SZ],
     "mldsa_ctx_set_workspace": [_P, _P, _SZ],
@@ -144,7 +154,7 @@ _SIGNATURES = {
     "mldsa_group_allgather": [_P, C.POINTER(_P), _SZ, _I],
 }
 _RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p, "mldsa_get_option": C.c_long,
-             "mldsa_group_destroy": None, "mldsa_group_ctx": _P}
+             "mldsa_group_destroy": None, "mldsa_group_ctx": _P, "mldsa_batcher_destroy": None}
 
 _lib = None
 

@@ -586,3 +586,65 @@ class MlDsaGroup(MlDsa):
         a, c = C.c_size_t(), C.c_size_t()
         _lib.check(self.lib.mldsa_group_shard(n_ops, len(self), part, C.byref(a), C.byref(c)))
         return a.value, c.value
+
+
+class MlDsaBatcher:
+    """mldsa_batcher_*: the reference's ONE-operation-per-call surface (src/traits.rs:118-308, 330-362) for many host threads at once.
+    verify / sign / keygen block the calling thread (ctypes releases the GIL for the duration), the library coalesces whatever
+    the threads submit into batched calls on one context.  Byte strings in, byte strings / bool out."""
+
+    def __init__(self, pset, device=0, max_batch=4096, max_wait_us=0, hotpath=None):
+        self.pset = pset
+        self.hp = hotpath or HotPath(device)
+        self.lib = self.hp.lib
+        p = _lib.get_params(pset)
+        self.PK_LEN, self.SK_LEN, self.SIG_LEN = p.pk_len, p.sk_len, p.sig_len
+        h = C.c_void_p()
+        _lib.check(self.lib.mldsa_batcher_create(self.hp._h, pset, max_batch, max_wait_us, C.byref(h)))
+        self._b = h
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self.lib.mldsa_batcher_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _fixed(b, n, what):
+        b = bytes(b)
+        if len(b) != n:
+            raise ValueError(f"{what}: {len(b)} bytes, expected {n}")
+        return b
+
+    def verify(self, pk, message, sig, ctx=b"", mode=MODE_PURE):
+        """PublicKey::try_from_bytes(pk)?.verify(message, sig, ctx) (src/lib.rs:364-380)"""
+        pk, sig = self._fixed(pk, self.PK_LEN, "pk"), self._fixed(sig, self.SIG_LEN, "sig")
+        message, ctx = bytes(message), bytes(ctx)
+        ok = C.c_uint8(0)
+        _lib.check(self.lib.mldsa_batcher_verify(self._b, mode, pk, message, len(message), ctx, len(ctx), sig, C.byref(ok)))
+        return bool(ok.value)
+
+    def sign(self, sk, message, rnd, ctx=b"", mode=MODE_PURE):
+        """PrivateKey::try_from_bytes(sk)?.try_sign_with_seed(rnd, message, ctx) (src/lib.rs:268-296); raises MldsaError for |ctx| > 255"""
+        sk, rnd = self._fixed(sk, self.SK_LEN, "sk"), self._fixed(rnd, 32, "rnd")
+        message, ctx = bytes(message), bytes(ctx)
+        sig = (C.c_uint8 * self.SIG_LEN)()
+        _lib.check(self.lib.mldsa_batcher_sign(self._b, mode, sk, message, len(message), ctx, len(ctx), rnd, sig))
+        return bytes(sig)
+
+    def keygen_from_seed(self, xi):
+        """KG::keygen_from_seed(xi) (src/lib.rs:247-250) -> (pk bytes, sk bytes)"""
+        xi = self._fixed(xi, 32, "xi")
+        pk, sk = (C.c_uint8 * self.PK_LEN)(), (C.c_uint8 * self.SK_LEN)()
+        _lib.check(self.lib.mldsa_batcher_keygen(self._b, xi, pk, sk))
+        return bytes(pk), bytes(sk)
+
+    def stats(self):
+        st = _lib.BatcherStats()
+        _lib.check(self.lib.mldsa_batcher_get_stats(self._b, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}

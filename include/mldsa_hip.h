@@ -524,6 +524,34 @@ int mldsa_group_sync(mldsa_group *g); /* waits for the streams of the last devic
  * call); buffers filled by anything else must be complete before the call.  Returns when every buffer is gathered. */
 int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, int use_rccl);
 
+/* ---- single-operation callers: a batcher in front of the batched path ---------------------------
+ * The reference's API is ONE operation per call (src/traits.rs:118-308 Signer, 330-362 Verifier, 28-104 KeyGen); a shim that keeps
+ * that surface would call this library with n_ops = 1, where a GPU call is all latency.  A batcher coalesces the calls of many
+ * host threads: each of the three calls below BLOCKS its caller, copies the arguments into the batch that is currently filling
+ * (page-locked arrays), a dispatcher thread of the batcher hands every batch to mldsa_verify_host / mldsa_sign_host /
+ * mldsa_keygen_host as one call on `ctx`, and the caller returns with its own result -- the same bytes and verdicts as the
+ * batched entry points give.  While one batch runs on the device the next one fills, so batch sizes follow the load;
+ * max_wait_us > 0 additionally keeps a batch open that long after its first request (0: never wait for company).  Requests with
+ * equal key bytes share one try_from_bytes per batch.  Thread-safe; any number of threads may call concurrently.  `ctx` must
+ * outlive the batcher; destroy it only when no call is in flight.
+ *   mldsa_batcher_verify   PublicKey::try_from_bytes(pk)?.verify(msg, sig, ctx) (lib.rs:364-380, 471-475): *ok = 1 / 0
+ *   mldsa_batcher_sign     PrivateKey::try_from_bytes(sk)?.try_sign_with_seed(rnd, msg, ctx) (lib.rs:268-296): MLDSA_ERR_CTX_LEN for a
+ *                          ctx longer than 255 bytes (the signature is then all zero)
+ *   mldsa_batcher_keygen   KG::keygen_from_seed(xi) (lib.rs:247-250)
+ * mode as in mldsa_verify / mldsa_sign (MLDSA_MODE_PREHASH: msg = OID | PH(M)). */
+typedef struct mldsa_batcher mldsa_batcher;
+typedef struct {
+    uint64_t batches, requests, largest_batch, distinct_keys; /* batches run, requests served, largest batch, keys expanded */
+} mldsa_batcher_stats;
+int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, mldsa_batcher **out);
+void mldsa_batcher_destroy(mldsa_batcher *b);
+int mldsa_batcher_verify(mldsa_batcher *b, int mode, const uint8_t *pk, const uint8_t *msg, size_t msg_len, const uint8_t *ctx, size_t ctx_len,
+                         const uint8_t *sig, uint8_t *ok);
+int mldsa_batcher_sign(mldsa_batcher *b, int mode, const uint8_t *sk, const uint8_t *msg, size_t msg_len, const uint8_t *ctx, size_t ctx_len,
+                       const uint8_t *rnd, uint8_t *sig);
+int mldsa_batcher_keygen(mldsa_batcher *b, const uint8_t *xi, uint8_t *pk, uint8_t *sk);
+int mldsa_batcher_get_stats(mldsa_batcher *b, mldsa_batcher_stats *out);
+
 #ifdef __cplusplus
 }
 #endif

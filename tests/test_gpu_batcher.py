@@ -1,0 +1,149 @@
+"""mldsa_batcher_*: many host threads each making the reference's ONE-operation calls (src/traits.rs:118-308 Signer, 330-362 Verifier,
+28-104 KeyGen; src/lib.rs:247-296, 364-380), coalesced inside the library into batched calls.  Every caller must get exactly what the
+reference gives for ITS arguments -- byte-exact keys and signatures, the verdict of its own signature -- whatever it was batched with."""
+import ctypes as C
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from fips204_amd import _lib
+from fips204_amd.ml_dsa import MODE_INTERNAL, MODE_PREHASH, MODE_PURE, MlDsaBatcher
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    from fips204_amd.hotpath import HotPath
+    h = HotPath(0)
+    yield h
+    h.close()
+
+
+def requests_for(pset, n, n_keys, seed):
+    rng = np.random.default_rng(seed)
+    xis = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_keys)]
+    keys = [orc.keygen_from_seed(pset, xi) for xi in xis]
+    pkb = [orc.pk_into_bytes(pset, pk) for pk, _ in keys]
+    skb = [orc.sk_into_bytes(pset, sk) for _, sk in keys]
+    reqs = []
+    for i in range(n):
+        k = int(rng.integers(0, n_keys))
+        msg = rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes()
+        ctx = rng.integers(0, 256, int(rng.integers(0, 40)) if i % 3 else 0, dtype=np.uint8).tobytes()
+        rnd = rng.integers(0, 256, 32, dtype=np.uint8).tobytes() if i % 4 else bytes(32)
+        reqs.append((k, msg, ctx, rnd))
+    return xis, keys, pkb, skb, reqs
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_many_threads_single_op_calls(hp, pset):
+    """48 threads, 240 keygen + sign + verify requests with their own keys, message and ctx lengths: keys and signatures byte-exact
+    with the oracle's, verdicts of good, damaged and wrong-ctx signatures as the oracle gives them; the library ran fewer batches
+    than requests (it coalesced) and expanded fewer keys than requests (it de-duplicated)."""
+    xis, keys, pkb, skb, reqs = requests_for(pset, 240, 6, 300 + pset)
+    b = MlDsaBatcher(pset, hotpath=hp, max_batch=64)
+    try:
+        with ThreadPoolExecutor(48) as pool:
+            made = list(pool.map(b.keygen_from_seed, xis * 8))
+            for (pk, sk), i in zip(made, list(range(6)) * 8):
+                assert pk == pkb[i] and sk == skb[i]
+            sigs = list(pool.map(lambda r: b.sign(skb[r[0]], r[1], r[3], ctx=r[2]), reqs))
+            for (k, msg, ctx, rnd), sig in zip(reqs[:60], sigs):
+                assert sig == orc.sign_internal(pset, keys[k][1], msg, rnd, ctx=ctx, mode=orc.MODE_PURE)
+
+            def check(j):
+                k, msg, ctx, _ = reqs[j]
+                sig = bytearray(sigs[j])
+                kind = j % 4
+                if kind == 1:
+                    sig[(j * 131) % len(sig)] ^= 1 << (j % 8)
+                use_ctx = ctx + b"x" if kind == 2 else ctx
+                use_pk = pkb[(k + 1) % 6] if kind == 3 else pkb[k]
+                return b.verify(use_pk, msg, bytes(sig), ctx=use_ctx), kind, (use_pk, msg, bytes(sig), use_ctx)
+            res = list(pool.map(check, range(len(reqs))))
+        for j, (got, kind, (pk, msg, sig, ctx)) in enumerate(res):
+            want = orc.verify_internal(pset, orc.pk_try_from_bytes(pset, pk), msg, sig, ctx=ctx, mode=orc.MODE_PURE)
+            assert got == want, (j, kind)
+            assert got == (kind == 0), (j, kind)
+        st = b.stats()
+        assert st["requests"] == 48 + 240 + 240 and st["batches"] < st["requests"] // 2 and st["largest_batch"] > 8
+        assert st["distinct_keys"] < 480
+    finally:
+        b.close()
+
+
+def test_modes_long_ctx_and_large_messages(hp):
+    """ML-DSA-65: the three message modes mixed by concurrent callers (a batch holds one mode; the others wait for the next), a ctx
+    of 256 bytes (lib.rs:274: Err for sign; 368: false for verify, nothing runs), a 300 000-byte message (larger than the staging
+    array of a fresh batch), an empty message."""
+    pset = 65
+    xis, keys, pkb, skb, _ = requests_for(pset, 1, 2, 99)
+    b = MlDsaBatcher(pset, hotpath=hp, max_batch=16)
+    rng = np.random.default_rng(4)
+    try:
+        big = rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes()
+        oid_ph = b"".join(orc.hash_message(b"abc", "SHA512"))
+        jobs = []
+        for i in range(36):
+            mode = (MODE_PURE, MODE_INTERNAL, MODE_PREHASH)[i % 3]
+            msg = oid_ph if mode == MODE_PREHASH else big if i == 6 else b"" if i == 9 else bytes([i]) * (i + 1)
+            jobs.append((i % 2, mode, msg, b"ctx%d" % i if mode != MODE_INTERNAL else b"", bytes([i]) * 32))
+        with ThreadPoolExecutor(12) as pool:
+            sigs = list(pool.map(lambda j: b.sign(skb[j[0]], j[2], j[4], ctx=j[3], mode=j[1]), jobs))
+            for (k, mode, msg, ctx, rnd), sig in zip(jobs, sigs):
+                assert sig == orc.sign_internal(pset, keys[k][1], msg, rnd, ctx=ctx, mode=mode), (mode, len(msg))
+            oks = list(pool.map(lambda js: b.verify(pkb[js[0][0]], js[0][2], js[1], ctx=js[0][3], mode=js[0][1]), zip(jobs, sigs)))
+            assert all(oks)
+            # a signature made in one mode does not verify in another
+            assert not b.verify(pkb[jobs[0][0]], jobs[0][2], sigs[0], ctx=jobs[0][3], mode=MODE_INTERNAL)
+        with pytest.raises(_lib.MldsaError) as e:
+            b.sign(skb[0], b"m", bytes(32), ctx=bytes(256))
+        assert e.value.code == _lib.ERR_CTX_LEN
+        assert b.verify(pkb[0], b"m", sigs[0], ctx=bytes(256)) is False
+        n_before = b.stats()["requests"]
+        assert b.verify(pkb[0], b"m", sigs[0], ctx=bytes(300)) is False and b.stats()["requests"] == n_before
+    finally:
+        b.close()
+
+
+def test_max_wait_collects_a_batch(hp):
+    """max_wait_us = 20 000: eight callers that arrive within a few milliseconds of each other leave in ONE batch"""
+    pset = 44
+    xis, keys, pkb, skb, reqs = requests_for(pset, 8, 1, 5)
+    b = MlDsaBatcher(pset, hotpath=hp, max_batch=64, max_wait_us=20_000)
+    try:
+        b.keygen_from_seed(xis[0])  # warm-up: the context's workspace
+        s0 = b.stats()
+        start = threading.Barrier(8)
+
+        def one(r):
+            start.wait()
+            return b.sign(skb[0], r[1], r[3], ctx=r[2])
+        with ThreadPoolExecutor(8) as pool:
+            sigs = list(pool.map(one, reqs))
+        s1 = b.stats()
+        assert s1["requests"] - s0["requests"] == 8 and s1["batches"] - s0["batches"] == 1 and s1["distinct_keys"] - s0["distinct_keys"] == 1
+        for r, sig in zip(reqs, sigs):
+            assert sig == orc.sign_internal(pset, keys[0][1], r[1], r[3], ctx=r[2], mode=orc.MODE_PURE)
+    finally:
+        b.close()
+
+
+def test_batcher_argument_errors(hp):
+    lib = hp.lib
+    h = C.c_void_p()
+    assert lib.mldsa_batcher_create(hp._h, 50, 16, 0, C.byref(h)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_create(hp._h, 65, 0, 0, C.byref(h)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_create(None, 65, 16, 0, C.byref(h)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_create(hp._h, 65, 16, 0, C.byref(h)) == _lib.OK
+    ok = C.c_uint8(7)
+    assert lib.mldsa_batcher_verify(h, 0, None, b"", 0, b"", 0, b"x", C.byref(ok)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_verify(h, 9, b"x", b"", 0, b"", 0, b"x", C.byref(ok)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_verify(h, 0, b"x", None, 5, b"", 0, b"x", C.byref(ok)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_keygen(h, None, None, None) == _lib.ERR_PARAM
+    lib.mldsa_batcher_destroy(h)
+    lib.mldsa_batcher_destroy(None)
