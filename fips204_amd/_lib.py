@@ -53,7 +53,7 @@ class Stats(C.Structure):
 
 
 class BatcherStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("batches", "requests", "largest_batch", "distinct_keys")]
+    _fields_ = [(n, C.c_uint64) for n in ("batches", "requests", "largest_batch", "keys_expanded", "key_hits")]
 
 
 OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
@@ -80,7 +80,7 @@ _SIGNATURES = {
     "mldsa_keygen_group": [_P, _I, _P, _I],
     "mldsa_group_sync": [_P],
     "mldsa_batcher_destroy": [_P],
-    "mldsa_batcher_create": [_P, _I, _SZ, C.c_uint, _P],
+    "mldsa_batcher_create": [_P, _I, _SZ, C.c_uint, _SZ, _P],
     "mldsa_batcher_verify": [_P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
     "mldsa_batcher_sign": [_P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
     "mldsa_batcher_keygen": [_P, _P, _P, _P],

@@ -7,10 +7,16 @@
 // _keygen, its arguments are copied into the page-locked arrays of the batch that is filling, a dispatcher thread hands
 // whatever has arrived to mldsa_verify_host / mldsa_sign_host / mldsa_keygen_host as ONE call, and every caller returns with
 // its own result.  While a batch runs on the device the next one fills, so the batch size follows the load by itself
-// (max_wait_us > 0 additionally holds a batch open for that long after its first request).  Keys are de-duplicated per batch
-// (requests that carry the same key bytes share one try_from_bytes), results are exactly those of the batched entry points.
+// (max_wait_us > 0 additionally holds a batch open for that long after its first request).
 //
-// Host code only (plain C++, no kernels): everything on the device goes through the ordinary host-memory entry points (host_api.hip).
+// Keys.  In the reference a key is deserialised once (`try_from_bytes` -> PublicKey / PrivateKey, src/ml_dsa.rs:445-498) and then
+// used for many calls; callers of the batcher pass wire-format bytes with every call, and the batcher keeps what try_from_bytes
+// produces -- the expanded fields AND A_hat = ExpandA(rho), the pre-compute benches/README.md:4-8 names -- in a device-resident
+// table of `cache_keys` slots, found again by the key's bytes (a keyed 64-bit hash, then memcmp: a hit is exact).  A batch expands
+// only the keys the table does not hold (FIFO replacement, never a key of the batch itself) and runs mldsa_verify_cached_a /
+// mldsa_sign_cached_a with the table as its key array: results are bit for bit those of mldsa_verify / mldsa_sign.
+//
+// Host code only (plain C++, no kernels): the device work goes through the library's own entry points.
 #include <linux/futex.h>
 #include <sys/syscall.h>
 #include <time.h>
@@ -86,6 +92,7 @@ struct Batch {
     State state = FREE;
     size_t n = 0, n_keys = 0;
     size_t msg_used = 0, ctx_used = 0;
+    size_t key_hits = 0, keys_expanded = 0;  // of this batch (dispatcher)
     std::atomic<size_t> copying{0}, readers{0};  // callers still copying their arguments in / their results out
     // bumped when the batch's results are ready.  Waking is a tree: the dispatcher wakes two callers, every caller that wakes up
     // wakes two more -- the dispatcher is back at the next batch after one system call, not after one wake-up per caller.
@@ -95,7 +102,27 @@ struct Batch {
     std::string err;
     // staging, all page-locked.  keys: distinct wire-format keys of the batch; in0: signatures (verify) / rnd (sign) / xi (keygen)
     PinnedBuf keys, msgs, ctxs, in0, out0, out1, kidx, moff, coff, status;
-    std::unordered_multimap<uint64_t, uint32_t> key_slots;  // first 8 bytes of a key -> its slot (memcmp decides)
+    PinnedBuf kslot;                                         // per op: the key's slot in the device-resident table (dispatcher)
+    std::vector<uint64_t> key_hash;                          // per distinct key of the batch
+    std::unordered_multimap<uint64_t, uint32_t> key_slots;   // keyed hash of a key -> its index in `keys` (memcmp decides)
+};
+
+// Device-resident table of expanded keys + A_hat (one for public, one for private keys): a ring of `cap` slots
+struct KeyTable {
+    size_t cap = 0, hand = 0;
+    bool is_private = false;
+    uint8_t *rho = nullptr, *cap_k = nullptr, *tr = nullptr;
+    int32_t *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;  // public: t1_d2_hat_mont; private: s_1_hat_mont, s_2_hat_mont, t_0_hat_mont
+    int32_t *a_hat = nullptr;
+    std::vector<uint8_t> wire;        // host copy of every slot's wire bytes: what a lookup compares against
+    std::vector<uint8_t> valid;
+    std::vector<uint64_t> hash, last_batch;
+    std::unordered_multimap<uint64_t, uint32_t> index;  // keyed hash -> slot
+};
+
+struct DevBuf {
+    uint8_t *p = nullptr;
+    size_t bytes = 0;
 };
 
 }  // namespace
@@ -113,6 +140,13 @@ struct mldsa_batcher {
     Batch batches[N_OPS][NB];
     Batch *open[N_OPS] = {nullptr, nullptr, nullptr};
     mldsa_batcher_stats stats{};
+    // dispatcher-only state: the key tables, device staging of the batch that runs, its stream
+    size_t cache_keys = 0;
+    uint64_t hash_seed = 0, batch_id = 0;
+    KeyTable tables[2];  // [OP_VERIFY] public keys, [OP_SIGN] private keys
+    hipStream_t stream = nullptr;
+    DevBuf d_kslot, d_moff, d_coff, d_msgs, d_ctxs, d_in0, d_out0, d_status, d_kstage;
+    PinnedBuf kstage;    // wire bytes of the keys a batch has to expand
 };
 
 namespace {
@@ -129,6 +163,8 @@ int alloc_batch(mldsa_batcher *b, Batch &t, int op) {
         need(t.msgs, std::max<size_t>(n * 256, 1 << 16));
         need(t.ctxs, n * 255);
         need(t.kidx, n * sizeof(uint32_t));
+        need(t.kslot, n * sizeof(uint32_t));
+        t.key_hash.resize(n);
         need(t.moff, (n + 1) * sizeof(uint64_t));
         need(t.coff, (n + 1) * sizeof(uint64_t));
     }
@@ -179,7 +215,7 @@ Batch *open_batch(mldsa_batcher *b, Lock &lk, int op, int mode, size_t msg_len, 
         }
         t->state = OPEN;
         t->mode = mode;
-        t->n = t->n_keys = t->msg_used = t->ctx_used = 0;
+        t->n = t->n_keys = t->msg_used = t->ctx_used = t->key_hits = t->keys_expanded = 0;
         t->rc = MLDSA_OK;
         t->err.clear();
         t->key_slots.clear();
@@ -187,35 +223,232 @@ Batch *open_batch(mldsa_batcher *b, Lock &lk, int op, int mode, size_t msg_len, 
     }
 }
 
-// slot of `key` in the batch's table of distinct keys (copied in on first sight); lock held
-uint32_t key_slot(mldsa_batcher *b, Batch *t, const uint8_t *key) {
+// 64-bit hash of a whole key under the batcher's random seed (PK_LEN / SK_LEN are multiples of 8): only ever a shortcut to the
+// memcmp that decides, so it needs to spread, not to resist -- the seed keeps a caller from aiming keys at one bucket
+uint64_t hash_key(uint64_t seed, const uint8_t *key, size_t len) {
+    uint64_t h = seed ^ (len * 0x9E3779B97F4A7C15ull);
+    for (size_t i = 0; i + 8 <= len; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, key + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+
+// index of `key` among the batch's distinct keys (copied in on first sight); lock held
+uint32_t key_slot(mldsa_batcher *b, Batch *t, const uint8_t *key, uint64_t h) {
     const size_t kl = key_len(b, t->op);
-    uint64_t tag;
-    std::memcpy(&tag, key, sizeof(tag));
-    auto range = t->key_slots.equal_range(tag);
+    auto range = t->key_slots.equal_range(h);
     for (auto it = range.first; it != range.second; ++it)
         if (std::memcmp(t->keys.p + (size_t)it->second * kl, key, kl) == 0) return it->second;
     const uint32_t slot = (uint32_t)t->n_keys++;
     std::memcpy(t->keys.p + (size_t)slot * kl, key, kl);
-    t->key_slots.emplace(tag, slot);
+    t->key_hash[slot] = h;
+    t->key_slots.emplace(h, slot);
     return slot;
 }
 
-void run_batch(mldsa_batcher *b, Batch *t) {
+#define BCHECK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "mldsa_batcher: " #expr, e_); \
+    } while (0)
+#define BTRY(expr) do { const int rc_ = (expr); if (rc_ != MLDSA_OK) return rc_; } while (0)
+
+int dev_reserve(DevBuf &d, size_t bytes, bool secret = false) {
+    if (bytes <= d.bytes) return MLDSA_OK;
+    if (d.p) {
+        if (secret) (void)hipMemset(d.p, 0, d.bytes);
+        BCHECK(hipFree(d.p));
+        d.p = nullptr;
+        d.bytes = 0;
+    }
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return set_error(MLDSA_ERR_NOMEM, "mldsa_batcher: device staging allocation"); }
+    d.p = static_cast<uint8_t *>(q);
+    d.bytes = bytes;
+    return MLDSA_OK;
+}
+
+void dev_release(DevBuf &d, bool secret = false) {
+    if (d.p) {
+        if (secret) (void)hipMemset(d.p, 0, d.bytes);
+        (void)hipFree(d.p);
+    }
+    d.p = nullptr;
+    d.bytes = 0;
+}
+
+int table_alloc(mldsa_batcher *b, KeyTable &kt, bool is_private) {
+    if (kt.cap) return MLDSA_OK;
     const mldsa_params *p = b->p;
-    int rc;
-    if (t->op == OP_KEYGEN) {
-        rc = mldsa_keygen_host(b->ctx, p->set, t->in0.p, t->out0.p, t->out1.p, t->n);
+    const size_t n = b->cache_keys, K = (size_t)p->k, L = (size_t)p->l, kl = is_private ? (size_t)p->sk_len : (size_t)p->pk_len;
+    kt.is_private = is_private;
+    auto get = [&](void **q, size_t bytes) -> int {
+        if (hipMalloc(q, bytes) != hipSuccess) { (void)hipGetLastError(); return set_error(MLDSA_ERR_NOMEM, "mldsa_batcher: key table allocation"); }
+        return MLDSA_OK;
+    };
+    BTRY(get((void **)&kt.rho, n * 32));
+    BTRY(get((void **)&kt.tr, n * 64));
+    BTRY(get((void **)&kt.a_hat, n * K * L * 1024));
+    if (is_private) {
+        BTRY(get((void **)&kt.cap_k, n * 32));
+        BTRY(get((void **)&kt.f0, n * L * 1024));
+        BTRY(get((void **)&kt.f1, n * K * 1024));
+        BTRY(get((void **)&kt.f2, n * K * 1024));
     } else {
-        uint64_t *moff = reinterpret_cast<uint64_t *>(t->moff.p), *coff = reinterpret_cast<uint64_t *>(t->coff.p);
-        moff[t->n] = t->msg_used;
-        coff[t->n] = t->ctx_used;
-        const uint32_t *kidx = reinterpret_cast<const uint32_t *>(t->kidx.p);
-        if (t->op == OP_VERIFY)
-            rc = mldsa_verify_host(b->ctx, p->set, t->mode, t->keys.p, t->n_keys, kidx, t->msgs.p, moff, t->ctxs.p, coff, t->in0.p, t->out0.p, t->n);
-        else
-            rc = mldsa_sign_host(b->ctx, p->set, t->mode, t->keys.p, t->n_keys, kidx, t->msgs.p, moff, t->ctxs.p, coff, t->in0.p, t->out0.p,
-                                 reinterpret_cast<int32_t *>(t->status.p), t->n);
+        BTRY(get((void **)&kt.f0, n * K * 1024));
+    }
+    kt.wire.assign(n * kl, 0);
+    kt.valid.assign(n, 0);
+    kt.hash.assign(n, 0);
+    kt.last_batch.assign(n, 0);
+    kt.cap = n;
+    return MLDSA_OK;
+}
+
+void table_free(mldsa_batcher *b, KeyTable &kt) {
+    const size_t n = kt.cap, K = (size_t)b->p->k, L = (size_t)b->p->l;
+    if (kt.is_private && n) {  // expanded private keys (types.rs:19 ZeroizeOnDrop)
+        if (kt.cap_k) (void)hipMemset(kt.cap_k, 0, n * 32);
+        if (kt.f0) (void)hipMemset(kt.f0, 0, n * L * 1024);
+        if (kt.f1) (void)hipMemset(kt.f1, 0, n * K * 1024);
+        if (kt.f2) (void)hipMemset(kt.f2, 0, n * K * 1024);
+        (void)hipDeviceSynchronize();
+        std::memset(kt.wire.data(), 0, kt.wire.size());
+    }
+    for (void *q : {(void *)kt.rho, (void *)kt.cap_k, (void *)kt.tr, (void *)kt.f0, (void *)kt.f1, (void *)kt.f2, (void *)kt.a_hat})
+        if (q) (void)hipFree(q);
+    kt = KeyTable();
+}
+
+// Every distinct key of the batch -> a slot of the device-resident table; the keys the table does not hold are expanded into
+// free slots (try_from_bytes + ExpandA, once per key for as long as it stays in the table).  Dispatcher thread only.
+int resolve_keys(mldsa_batcher *b, Batch *t, std::vector<uint32_t> &slot_of) {
+    const mldsa_params *p = b->p;
+    const bool priv = t->op == OP_SIGN;
+    KeyTable &kt = b->tables[t->op];
+    BTRY(table_alloc(b, kt, priv));
+    const size_t kl = key_len(b, t->op), K = (size_t)p->k, L = (size_t)p->l;
+    const uint64_t id = ++b->batch_id;
+    slot_of.assign(t->n_keys, 0);
+    std::vector<uint32_t> miss;
+    for (size_t j = 0; j < t->n_keys; j++) {
+        const uint8_t *key = t->keys.p + j * kl;
+        bool hit = false;
+        auto range = kt.index.equal_range(t->key_hash[j]);
+        for (auto it = range.first; it != range.second && !hit; ++it)
+            if (std::memcmp(kt.wire.data() + (size_t)it->second * kl, key, kl) == 0) {
+                slot_of[j] = it->second;
+                kt.last_batch[it->second] = id;
+                hit = true;
+            }
+        if (!hit) miss.push_back((uint32_t)j);
+    }
+    t->key_hits = t->n_keys - miss.size();
+    t->keys_expanded = miss.size();
+    if (miss.empty()) return MLDSA_OK;
+    // slots for the new keys, in ring order, skipping what this batch itself uses; consecutive slots form one expansion call
+    struct Run { size_t first_slot, first_miss, count; };
+    std::vector<Run> runs;
+    auto drop = [&](uint32_t s) {
+        auto range = kt.index.equal_range(kt.hash[s]);
+        for (auto it = range.first; it != range.second; ++it)
+            if (it->second == s) { kt.index.erase(it); break; }
+        kt.valid[s] = 0;
+    };
+    BTRY(b->kstage.reserve(miss.size() * kl));
+    for (size_t m = 0; m < miss.size(); m++) {
+        size_t s = kt.hand;
+        while (kt.valid[s] && kt.last_batch[s] == id) s = (s + 1) % kt.cap;  // cap >= max_batch >= n_keys: ends
+        kt.hand = (s + 1) % kt.cap;
+        if (kt.valid[s]) drop((uint32_t)s);
+        const uint8_t *key = t->keys.p + (size_t)miss[m] * kl;
+        std::memcpy(kt.wire.data() + s * kl, key, kl);
+        std::memcpy(b->kstage.p + m * kl, key, kl);
+        kt.hash[s] = t->key_hash[miss[m]];
+        kt.last_batch[s] = id;
+        kt.valid[s] = 1;
+        kt.index.emplace(kt.hash[s], (uint32_t)s);
+        slot_of[miss[m]] = (uint32_t)s;
+        if (!runs.empty() && runs.back().first_slot + runs.back().count == s) runs.back().count++;
+        else runs.push_back({s, m, 1});
+    }
+    int rc = dev_reserve(b->d_kstage, miss.size() * kl, priv);
+    if (rc == MLDSA_OK && hipMemcpyAsync(b->d_kstage.p, b->kstage.p, miss.size() * kl, hipMemcpyHostToDevice, b->stream) != hipSuccess)
+        rc = set_error(MLDSA_ERR_DEVICE, "mldsa_batcher: key upload");
+    for (size_t r = 0; r < runs.size() && rc == MLDSA_OK; r++) {
+        const Run &u = runs[r];
+        const uint8_t *src = b->d_kstage.p + u.first_miss * kl;
+        const size_t s = u.first_slot;
+        if (priv) rc = mldsa_sk_expand(b->ctx, p->set, src, kt.rho + s * 32, kt.cap_k + s * 32, kt.tr + s * 64, kt.f0 + s * L * 256, kt.f1 + s * K * 256,
+                                       kt.f2 + s * K * 256, u.count, b->stream);
+        else rc = mldsa_pk_expand(b->ctx, p->set, src, kt.rho + s * 32, kt.tr + s * 64, kt.f0 + s * K * 256, u.count, b->stream);
+        if (rc == MLDSA_OK) rc = mldsa_expand_a(b->ctx, p->set, kt.rho + s * 32, kt.a_hat + s * K * L * 256, u.count, b->stream);
+    }
+    if (priv) {  // the wire bytes of private keys leave the staging buffers with the batch
+        if (rc == MLDSA_OK && hipMemsetAsync(b->d_kstage.p, 0, miss.size() * kl, b->stream) != hipSuccess) (void)hipGetLastError();
+        if (hipStreamSynchronize(b->stream) != hipSuccess) (void)hipGetLastError();  // the upload has read the page-locked copy
+        std::memset(b->kstage.p, 0, miss.size() * kl);
+    }
+    if (rc != MLDSA_OK)  // nothing half-expanded stays findable
+        for (uint32_t j : miss) drop(slot_of[j]);
+    return rc;
+}
+
+// verify / sign of one batch on the device-resident key table
+int run_keyed(mldsa_batcher *b, Batch *t) {
+    const mldsa_params *p = b->p;
+    const size_t n = t->n, sgl = (size_t)p->sig_len;
+    DeviceGuard dg(b->ctx->device);
+    if (!b->stream) BCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    std::vector<uint32_t> slot_of;
+    BTRY(resolve_keys(b, t, slot_of));
+    KeyTable &kt = b->tables[t->op];
+    uint32_t *kslot = reinterpret_cast<uint32_t *>(t->kslot.p);
+    const uint32_t *kidx = reinterpret_cast<const uint32_t *>(t->kidx.p);
+    for (size_t i = 0; i < n; i++) kslot[i] = slot_of[kidx[i]];
+    uint64_t *moff = reinterpret_cast<uint64_t *>(t->moff.p), *coff = reinterpret_cast<uint64_t *>(t->coff.p);
+    moff[n] = t->msg_used;
+    coff[n] = t->ctx_used;
+    const size_t in_len = t->op == OP_VERIFY ? sgl : 32, out_len = t->op == OP_VERIFY ? 1 : sgl;
+    BTRY(dev_reserve(b->d_kslot, n * 4));
+    BTRY(dev_reserve(b->d_moff, (n + 1) * 8));
+    BTRY(dev_reserve(b->d_coff, (n + 1) * 8));
+    BTRY(dev_reserve(b->d_msgs, std::max<size_t>(t->msg_used, 64)));
+    BTRY(dev_reserve(b->d_ctxs, std::max<size_t>(t->ctx_used, 64)));
+    BTRY(dev_reserve(b->d_in0, n * in_len, t->op == OP_SIGN));
+    BTRY(dev_reserve(b->d_out0, n * out_len));
+    if (t->op == OP_SIGN) BTRY(dev_reserve(b->d_status, n * 4));
+    hipStream_t st = b->stream;
+    BCHECK(hipMemcpyAsync(b->d_kslot.p, kslot, n * 4, hipMemcpyHostToDevice, st));
+    BCHECK(hipMemcpyAsync(b->d_moff.p, moff, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    BCHECK(hipMemcpyAsync(b->d_coff.p, coff, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    if (t->msg_used) BCHECK(hipMemcpyAsync(b->d_msgs.p, t->msgs.p, t->msg_used, hipMemcpyHostToDevice, st));
+    if (t->ctx_used) BCHECK(hipMemcpyAsync(b->d_ctxs.p, t->ctxs.p, t->ctx_used, hipMemcpyHostToDevice, st));
+    BCHECK(hipMemcpyAsync(b->d_in0.p, t->in0.p, n * in_len, hipMemcpyHostToDevice, st));
+    const uint32_t *dk = reinterpret_cast<const uint32_t *>(b->d_kslot.p);
+    const uint64_t *dm = reinterpret_cast<const uint64_t *>(b->d_moff.p), *dc = reinterpret_cast<const uint64_t *>(b->d_coff.p);
+    if (t->op == OP_VERIFY) {
+        BTRY(mldsa_verify_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.tr, kt.f0, kt.cap, dk, b->d_msgs.p, dm, b->d_ctxs.p, dc, b->d_in0.p, b->d_out0.p, n, st));
+    } else {
+        BTRY(mldsa_sign_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.cap_k, kt.tr, kt.f0, kt.f1, kt.f2, kt.cap, dk, b->d_msgs.p, dm, b->d_ctxs.p, dc,
+                                 b->d_in0.p, b->d_out0.p, reinterpret_cast<int32_t *>(b->d_status.p), n, st));
+        BCHECK(hipMemcpyAsync(t->status.p, b->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+        BCHECK(hipMemsetAsync(b->d_in0.p, 0, n * 32, st));  // rnd
+    }
+    BCHECK(hipMemcpyAsync(t->out0.p, b->d_out0.p, n * out_len, hipMemcpyDeviceToHost, st));
+    BCHECK(hipStreamSynchronize(st));
+    return MLDSA_OK;
+}
+
+void run_batch(mldsa_batcher *b, Batch *t) {
+    int rc;
+    if (t->op == OP_KEYGEN) rc = mldsa_keygen_host(b->ctx, b->p->set, t->in0.p, t->out0.p, t->out1.p, t->n);
+    else {
+        rc = run_keyed(b, t);
+        if (rc != MLDSA_OK && b->stream) { DeviceGuard dg(b->ctx->device); (void)hipStreamSynchronize(b->stream); }
     }
     t->rc = rc;
     if (rc != MLDSA_OK) { const char *e = mldsa_last_error(); t->err = e ? e : ""; }
@@ -268,7 +501,8 @@ void dispatcher(mldsa_batcher *b) {
         b->stats.batches++;
         b->stats.requests += t->n;
         if (t->n > b->stats.largest_batch) b->stats.largest_batch = t->n;
-        b->stats.distinct_keys += t->n_keys;
+        b->stats.key_hits += t->key_hits;
+        b->stats.keys_expanded += t->keys_expanded;
         t->state = DONE;
         t->readers.store(t->n, std::memory_order_relaxed);
         t->done_gen.fetch_add(1, std::memory_order_release);
@@ -287,6 +521,7 @@ struct Req {
 
 int submit(mldsa_batcher *b, const Req &r) {
     const mldsa_params *p = b->p;
+    const uint64_t kh = r.op == OP_KEYGEN ? 0 : hash_key(b->hash_seed, r.key, key_len(b, r.op));  // before the lock: 0.3 us of arithmetic
     Lock lk(b->mu);
     int err = E_NONE;
     bool wake = false;
@@ -300,7 +535,7 @@ int submit(mldsa_batcher *b, const Req &r) {
     const size_t i = t->n++;
     size_t m0 = 0, c0 = 0;
     if (r.op != OP_KEYGEN) {
-        reinterpret_cast<uint32_t *>(t->kidx.p)[i] = key_slot(b, t, r.key);
+        reinterpret_cast<uint32_t *>(t->kidx.p)[i] = key_slot(b, t, r.key, kh);
         m0 = t->msg_used;
         c0 = t->ctx_used;
         reinterpret_cast<uint64_t *>(t->moff.p)[i] = m0;
@@ -362,7 +597,7 @@ int submit(mldsa_batcher *b, const Req &r) {
 
 extern "C" {
 
-int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, mldsa_batcher **out) {
+int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out) {
     REQUIRE(out, "mldsa_batcher_create: NULL out");
     *out = nullptr;
     REQUIRE(ctx, "mldsa_batcher_create: NULL context");
@@ -375,6 +610,14 @@ int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max
     b->p = p;
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
+    // a batch never evicts its own keys, so the table holds at least one batch's worth; default: 1 024 keys or one batch
+    b->cache_keys = std::max(max_batch, cache_keys ? cache_keys : (size_t)1024);
+    REQUIRE(b->cache_keys <= (1u << 22), "mldsa_batcher_create: cache_keys up to 2^22");
+    {   // the seed of the key hash: unpredictable to callers, nothing more (clock, addresses)
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        b->hash_seed = ((uint64_t)ts.tv_nsec * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)ts.tv_sec << 32) ^ (uint64_t)(uintptr_t)b.get() ^ ((uint64_t)getpid() << 48);
+    }
     for (int op = 0; op < N_OPS; op++)
         for (Batch &t : b->batches[op]) {
             const int rc = alloc_batch(b.get(), t, op);
@@ -405,6 +648,14 @@ void mldsa_batcher_destroy(mldsa_batcher *b) {
         }
         if (!busy) break;
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    {
+        DeviceGuard dg(b->ctx->device);
+        if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+        for (KeyTable &kt : b->tables) table_free(b, kt);
+        for (DevBuf *d : {&b->d_kslot, &b->d_moff, &b->d_coff, &b->d_msgs, &b->d_ctxs, &b->d_out0, &b->d_status}) dev_release(*d);
+        dev_release(b->d_in0, true);
+        dev_release(b->d_kstage, true);
     }
     delete b;
 }

@@ -1063,6 +1063,7 @@ void drop_graphs(mldsa_ctx *ctx) {
     for (auto &g : ctx->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
+        if (g.done) (void)hipEventDestroy(g.done);
     }
     ctx->graphs.clear();
 }
@@ -1094,12 +1095,13 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
         if ((long)ctx->graphs.size() >= ctx->opt_graph_cache) {
             auto lru = std::min_element(ctx->graphs.begin(), ctx->graphs.end(),
                                         [](const GraphEntry &a, const GraphEntry &b) { return a.last_use < b.last_use; });
-            // the evicted graph may still be executing (asynchronous calls, the *_host paths): wait for the stream it ran on
+            // the evicted graph may still be executing (asynchronous calls, the *_host paths): wait for its last launch
             if (lru->exec) {
-                (void)hipStreamSynchronize(lru->last_stream);
+                if (lru->done) (void)hipEventSynchronize(lru->done);
                 (void)hipGraphExecDestroy(lru->exec);
             }
             if (lru->graph) (void)hipGraphDestroy(lru->graph);
+            if (lru->done) (void)hipEventDestroy(lru->done);
             ctx->graphs.erase(lru);
         }
         GraphEntry e;
@@ -1140,14 +1142,22 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
             (void)hipGraphDestroy(graph);
             return set_error(MLDSA_ERR_DEVICE, "hipGraphInstantiate", ei);
         }
+        hipEvent_t done = nullptr;
+        const hipError_t ev = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (ev != hipSuccess) {
+            (void)hipGraphExecDestroy(exec);
+            (void)hipGraphDestroy(graph);
+            return set_error(MLDSA_ERR_DEVICE, "hipEventCreateWithFlags", ev);
+        }
         hit->graph = graph;
         hit->exec = exec;
+        hit->done = done;
         ctx->stats.graphs_captured++;
     } else {
         ctx->stats.graph_replays++;
     }
     MLDSA_HIP_CHECK(hipGraphLaunch(hit->exec, gs));
-    hit->last_stream = gs;
+    MLDSA_HIP_CHECK(hipEventRecord(hit->done, gs));
     if (!s) {
         MLDSA_HIP_CHECK(hipEventRecord(ctx->graph_join_ev, gs));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->graph_join_ev, 0));

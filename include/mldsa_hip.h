@@ -531,9 +531,13 @@ int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, in
  * (page-locked arrays), a dispatcher thread of the batcher hands every batch to mldsa_verify_host / mldsa_sign_host /
  * mldsa_keygen_host as one call on `ctx`, and the caller returns with its own result -- the same bytes and verdicts as the
  * batched entry points give.  While one batch runs on the device the next one fills, so batch sizes follow the load;
- * max_wait_us > 0 additionally keeps a batch open that long after its first request (0: never wait for company).  Requests with
- * equal key bytes share one try_from_bytes per batch.  Thread-safe; any number of threads may call concurrently.  `ctx` must
- * outlive the batcher; destroy it only when no call is in flight.
+ * max_wait_us > 0 additionally keeps a batch open that long after its first request (0: never wait for company).
+ * Keys: callers pass wire-format bytes with every call; what try_from_bytes makes of them (src/ml_dsa.rs:445-498) -- and A_hat =
+ * ExpandA(rho), the pre-compute benches/README.md:4-8 names -- stays in a device-resident table of `cache_keys` slots (0: 1 024; at
+ * least max_batch) and is found again by the key's bytes (keyed hash, then memcmp), so a key is expanded once for as long as it stays
+ * in the table (FIFO replacement); batches run mldsa_verify_cached_a / mldsa_sign_cached_a on the table.  Private keys in the table
+ * are cleared on replacement and when the batcher is destroyed.  Thread-safe; any number of threads may call concurrently.  `ctx`
+ * must outlive the batcher; destroy it only when no call is in flight.
  *   mldsa_batcher_verify   PublicKey::try_from_bytes(pk)?.verify(msg, sig, ctx) (lib.rs:364-380, 471-475): *ok = 1 / 0
  *   mldsa_batcher_sign     PrivateKey::try_from_bytes(sk)?.try_sign_with_seed(rnd, msg, ctx) (lib.rs:268-296): MLDSA_ERR_CTX_LEN for a
  *                          ctx longer than 255 bytes (the signature is then all zero)
@@ -541,9 +545,10 @@ int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, in
  * mode as in mldsa_verify / mldsa_sign (MLDSA_MODE_PREHASH: msg = OID | PH(M)). */
 typedef struct mldsa_batcher mldsa_batcher;
 typedef struct {
-    uint64_t batches, requests, largest_batch, distinct_keys; /* batches run, requests served, largest batch, keys expanded */
+    uint64_t batches, requests, largest_batch; /* batches run, requests served, largest batch */
+    uint64_t keys_expanded, key_hits;          /* per batch and distinct key: expanded (try_from_bytes + ExpandA) / found in the table */
 } mldsa_batcher_stats;
-int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, mldsa_batcher **out);
+int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out);
 void mldsa_batcher_destroy(mldsa_batcher *b);
 int mldsa_batcher_verify(mldsa_batcher *b, int mode, const uint8_t *pk, const uint8_t *msg, size_t msg_len, const uint8_t *ctx, size_t ctx_len,
                          const uint8_t *sig, uint8_t *ok);

@@ -43,7 +43,7 @@ def requests_for(pset, n, n_keys, seed):
 def test_many_threads_single_op_calls(hp, pset):
     """48 threads, 240 keygen + sign + verify requests with their own keys, message and ctx lengths: keys and signatures byte-exact
     with the oracle's, verdicts of good, damaged and wrong-ctx signatures as the oracle gives them; the library ran fewer batches
-    than requests (it coalesced) and expanded fewer keys than requests (it de-duplicated)."""
+    than requests (it coalesced) and expanded every key once (the device-resident key table)."""
     xis, keys, pkb, skb, reqs = requests_for(pset, 240, 6, 300 + pset)
     b = MlDsaBatcher(pset, hotpath=hp, max_batch=64)
     try:
@@ -71,7 +71,8 @@ def test_many_threads_single_op_calls(hp, pset):
             assert got == (kind == 0), (j, kind)
         st = b.stats()
         assert st["requests"] == 48 + 240 + 240 and st["batches"] < st["requests"] // 2 and st["largest_batch"] > 8
-        assert st["distinct_keys"] < 480
+        # six public and six private keys: each expanded ONCE (try_from_bytes + ExpandA), found in the table from then on
+        assert st["keys_expanded"] == 12 and st["key_hits"] > 0
     finally:
         b.close()
 
@@ -126,9 +127,39 @@ def test_max_wait_collects_a_batch(hp):
         with ThreadPoolExecutor(8) as pool:
             sigs = list(pool.map(one, reqs))
         s1 = b.stats()
-        assert s1["requests"] - s0["requests"] == 8 and s1["batches"] - s0["batches"] == 1 and s1["distinct_keys"] - s0["distinct_keys"] == 1
+        assert s1["requests"] - s0["requests"] == 8 and s1["batches"] - s0["batches"] == 1 and s1["keys_expanded"] - s0["keys_expanded"] == 1
         for r, sig in zip(reqs, sigs):
             assert sig == orc.sign_internal(pset, keys[0][1], r[1], r[3], ctx=r[2], mode=orc.MODE_PURE)
+    finally:
+        b.close()
+
+
+def test_key_table_replacement(hp):
+    """A table of FOUR slots (cache_keys = max_batch = 4) and twelve keys taking turns: every key is expanded again after it has
+    been replaced, a batch never loses a key it uses itself, and every result still equals the oracle's -- verdicts included for
+    signatures checked against ANOTHER key that sits in the table (a stale slot would accept or reject wrongly)."""
+    pset = 44
+    xis, keys, pkb, skb, _ = requests_for(pset, 1, 12, 77)
+    b = MlDsaBatcher(pset, hotpath=hp, max_batch=4, cache_keys=1)
+    rng = np.random.default_rng(8)
+    try:
+        jobs = [(int(k), bytes([j]) * (1 + j % 50), rng.integers(0, 256, 32, dtype=np.uint8).tobytes())
+                for j, k in enumerate(list(range(12)) * 3 + list(rng.integers(0, 12, 60)))]
+        with ThreadPoolExecutor(6) as pool:
+            sigs = list(pool.map(lambda j: b.sign(skb[j[0]], j[1], j[2]), jobs))
+            for (k, msg, rnd), sig in zip(jobs, sigs):
+                assert sig == orc.sign_internal(pset, keys[k][1], msg, rnd, mode=orc.MODE_PURE)
+            oks = list(pool.map(lambda js: b.verify(pkb[js[0][0]], js[0][1], js[1]), zip(jobs, sigs)))
+            wrong = list(pool.map(lambda js: b.verify(pkb[(js[0][0] + 1) % 12], js[0][1], js[1]), zip(jobs, sigs)))
+        assert all(oks) and not any(wrong)
+        st = b.stats()
+        assert st["keys_expanded"] > 24 and st["largest_batch"] <= 4   # 12 + 12 keys, more than once each
+        # one key over and over: expanded once
+        s0 = b.stats()
+        for i in range(6):
+            assert b.verify(pkb[3], jobs[3][1], sigs[3])
+        s1 = b.stats()
+        assert s1["keys_expanded"] - s0["keys_expanded"] <= 1 and s1["key_hits"] - s0["key_hits"] >= 5
     finally:
         b.close()
 
@@ -136,10 +167,10 @@ def test_max_wait_collects_a_batch(hp):
 def test_batcher_argument_errors(hp):
     lib = hp.lib
     h = C.c_void_p()
-    assert lib.mldsa_batcher_create(hp._h, 50, 16, 0, C.byref(h)) == _lib.ERR_PARAM
-    assert lib.mldsa_batcher_create(hp._h, 65, 0, 0, C.byref(h)) == _lib.ERR_PARAM
-    assert lib.mldsa_batcher_create(None, 65, 16, 0, C.byref(h)) == _lib.ERR_PARAM
-    assert lib.mldsa_batcher_create(hp._h, 65, 16, 0, C.byref(h)) == _lib.OK
+    assert lib.mldsa_batcher_create(hp._h, 50, 16, 0, 0, C.byref(h)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_create(hp._h, 65, 0, 0, 0, C.byref(h)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_create(None, 65, 16, 0, 0, C.byref(h)) == _lib.ERR_PARAM
+    assert lib.mldsa_batcher_create(hp._h, 65, 16, 0, 0, C.byref(h)) == _lib.OK
     ok = C.c_uint8(7)
     assert lib.mldsa_batcher_verify(h, 0, None, b"", 0, b"", 0, b"x", C.byref(ok)) == _lib.ERR_PARAM
     assert lib.mldsa_batcher_verify(h, 9, b"x", b"", 0, b"", 0, b"x", C.byref(ok)) == _lib.ERR_PARAM

@@ -708,3 +708,41 @@ def test_rounding_functions_as_a_seam(hp, pset):
     assert hp.lib.mldsa_rounding(hp._h, pset, _lib.ROUND_MAKE_HINT, p, None, p, None, 1, None) == _lib.ERR_PARAM
     assert hp.lib.mldsa_rounding(hp._h, pset, _lib.ROUND_DECOMPOSE, p, None, p, None, 1, None) == _lib.ERR_PARAM
     assert hp.lib.mldsa_rounding(hp._h, pset, _lib.ROUND_DECOMPOSE, None, None, None, None, 0, None) == _lib.OK
+
+
+def test_graph_cache_outlives_the_stream_it_was_filled_on(sets):
+    """Small signing calls replay as hipGraphs, kept in a cache of 24 shapes (MLDSA_OPT_GRAPH_CACHE).  A caller may DESTROY the
+    stream it made those calls on; shapes replaced later must not touch that stream again (the library used to wait for the
+    entry's last stream before destroying its graph: a dangling handle -- found as hangs and a crash in 3 of 10 runs of
+    tests/test_gpu_batcher.py, whose every batcher owns and destroys a stream; 0 of 31 runs since each entry carries its own
+    event).  What a dangling handle does is up to the allocator, so this test exercises the path rather than proving the fix:
+    30 shapes on a stream, stream destroyed, 30 more on a second one; signatures against the oracle."""
+    m = sets[44]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(12)
+    xi = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    sks = m.private_keys_from_bytes(m.keygen_from_seed(dev(xi))[1])
+    _, sk_o = orc.keygen_from_seed(44, xi[0].tobytes())
+    captured0 = m.hp.stats()["graphs_captured"]
+    raws = [C.c_void_p(), C.c_void_p()]  # both made first: the second must not get the handle the first one had
+    for raw in raws:
+        assert hip.hipStreamCreate(C.byref(raw)) == 0
+    for leg, raw in enumerate(raws):
+        with torch.cuda.stream(torch.cuda.ExternalStream(raw.value)):
+            for n in range(1 + 30 * leg, 31 + 30 * leg):
+                msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                rnd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+                d_msg, d_off, d_rnd = dev(msgs.reshape(-1)), dev_off(np.arange(n + 1) * 32), dev(rnd)
+                kidx = torch.zeros(n, dtype=torch.int32, device="cuda")
+                sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+                for _ in range(3):  # first sighting: direct; second: captured; third: replayed
+                    m.sign_device(sks, d_msg, d_off, d_rnd, sig, n, key_idx=kidx)
+                torch.cuda.current_stream().synchronize()
+                got = sig.cpu().numpy()
+                j = int(rng.integers(0, n))
+                assert got[j].tobytes() == orc.sign_internal(44, sk_o, msgs[j].tobytes(), rnd[j].tobytes(), mode=orc.MODE_PURE)
+        assert hip.hipStreamDestroy(raw) == 0
+    st = m.hp.stats()
+    assert st["graphs_captured"] - captured0 >= 50   # more shapes than the cache holds: entries of the dead stream were replaced

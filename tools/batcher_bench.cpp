@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
         bool first = true;
         for (int T : {1, 8, 64, 256, 1024}) {
             mldsa_batcher *b;
-            CHECK(mldsa_batcher_create(ctx, set, 8192, max_wait, &b));
+            CHECK(mldsa_batcher_create(ctx, set, 8192, max_wait, 0, &b));
             std::atomic<bool> go{false}, stop{false};
             std::atomic<uint64_t> bad{0};
             std::vector<std::vector<float>> lat((size_t)T);
