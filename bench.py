@@ -1214,6 +1214,33 @@ def run_small_calls(pset=65, sizes=(64, 1024), contexts=(1, 2, 4, 8, 16), calls=
     return out
 
 
+def run_single_op_callers(pset=65, seconds=1.5, threads="1,8,32,64"):
+    """The reference's own call shape -- ONE operation per call (benches/benchmark.rs:28-62 times exactly that) -- from T host threads
+    through mldsa_batcher_* (the library coalesces concurrent calls into batches and keeps expanded keys + A_hat in a device-resident
+    table), next to the same calls made one at a time with n_ops = 1.  The load generator is tools/batcher_bench.cpp (host threads in
+    C++: Python's GIL would be the bottleneck), built here with g++; returns its JSON object or {"skipped": reason}."""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    if not shutil.which("g++"):
+        return {"skipped": "g++ not found"}
+    libdir = os.path.join(root, "fips204_amd", "csrc")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "batcher_bench")
+        try:
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "batcher_bench.cpp"),
+                                   "-o", exe, f"-L{libdir}", "-lmldsa_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+            out = subprocess.run([exe, str(pset), str(seconds), "0", threads], capture_output=True, text=True, timeout=600)
+        except (subprocess.CalledProcessError, subprocess.TimeoutExpired) as e:
+            return {"skipped": f"tools/batcher_bench.cpp: {e}"}
+        if out.returncode != 0:
+            return {"skipped": "tools/batcher_bench.cpp failed: " + out.stderr[-300:]}
+        res = json.loads(out.stdout)
+    res["usable_cores"] = usable_cores()
+    return res
+
+
 def run_inproc_resident(args):
     """`--inproc --resident`: the contract's HBM-resident `value` from ONE process.  One mldsa_group over N devices (devices reused
     round-robin when fewer GPUs are visible: a functional run, labelled), slice i of the job resident on device i -- expanded keys,
@@ -1381,6 +1408,7 @@ def main():
             raise SystemExit("bench.py: --workload sweep is a single-GPU measurement")
         sw = run_sweep(hp, cpu=not args.no_cpu_baseline)
         sw["concurrent_small_verify_calls"] = run_small_calls()
+        sw["single_op_callers"] = run_single_op_callers()  # (a process of its own, with its own context)
         v = next(pt for pt in sw["ops"]["verify"]["points"] if pt["n_ops"] == 65536)
         line = {"metric": "ML-DSA-65 verifies/sec per GPU (batched); batch-size sweep through the C ABI", "value": v["best_ops_per_s"], "unit": "verifies/s",
                 "n_gpus": 1, "steps": v["direct"]["calls_timed"], "warmup": 3, "ms_per_step": v["best_ms_per_call"], "higher_is_better": True,

@@ -39,6 +39,7 @@ using namespace mldsa;
 namespace {
 
 enum { OP_VERIFY = 0, OP_SIGN = 1, OP_KEYGEN = 2, N_OPS = 3 };
+constexpr size_t ZERO_COPY_MAX_OPS = 256;
 enum State { FREE, OPEN, SEALED, RUNNING, DONE };
 
 // Synchronisation.  Hundreds of callers pass through the batcher per batch, each for a fraction of a microsecond (reserve a slot,
@@ -413,32 +414,53 @@ int run_keyed(mldsa_batcher *b, Batch *t) {
     moff[n] = t->msg_used;
     coff[n] = t->ctx_used;
     const size_t in_len = t->op == OP_VERIFY ? sgl : 32, out_len = t->op == OP_VERIFY ? 1 : sgl;
-    BTRY(dev_reserve(b->d_kslot, n * 4));
-    BTRY(dev_reserve(b->d_moff, (n + 1) * 8));
-    BTRY(dev_reserve(b->d_coff, (n + 1) * 8));
-    BTRY(dev_reserve(b->d_msgs, std::max<size_t>(t->msg_used, 64)));
-    BTRY(dev_reserve(b->d_ctxs, std::max<size_t>(t->ctx_used, 64)));
-    BTRY(dev_reserve(b->d_in0, n * in_len, t->op == OP_SIGN));
-    BTRY(dev_reserve(b->d_out0, n * out_len));
-    if (t->op == OP_SIGN) BTRY(dev_reserve(b->d_status, n * 4));
     hipStream_t st = b->stream;
-    BCHECK(hipMemcpyAsync(b->d_kslot.p, kslot, n * 4, hipMemcpyHostToDevice, st));
-    BCHECK(hipMemcpyAsync(b->d_moff.p, moff, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    BCHECK(hipMemcpyAsync(b->d_coff.p, coff, (n + 1) * 8, hipMemcpyHostToDevice, st));
-    if (t->msg_used) BCHECK(hipMemcpyAsync(b->d_msgs.p, t->msgs.p, t->msg_used, hipMemcpyHostToDevice, st));
-    if (t->ctx_used) BCHECK(hipMemcpyAsync(b->d_ctxs.p, t->ctxs.p, t->ctx_used, hipMemcpyHostToDevice, st));
-    BCHECK(hipMemcpyAsync(b->d_in0.p, t->in0.p, n * in_len, hipMemcpyHostToDevice, st));
-    const uint32_t *dk = reinterpret_cast<const uint32_t *>(b->d_kslot.p);
-    const uint64_t *dm = reinterpret_cast<const uint64_t *>(b->d_moff.p), *dc = reinterpret_cast<const uint64_t *>(b->d_coff.p);
-    if (t->op == OP_VERIFY) {
-        BTRY(mldsa_verify_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.tr, kt.f0, kt.cap, dk, b->d_msgs.p, dm, b->d_ctxs.p, dc, b->d_in0.p, b->d_out0.p, n, st));
+    // Small batches are all latency: six uploads and a download, one after the other on the stream, cost more than the 4 KB per op
+    // they move.  Up to ZERO_COPY_MAX_OPS ops the kernels read the page-locked staging arrays in place and write the results
+    // straight into them (hipHostMalloc memory is mapped into the device's address space; a batch of that size crosses PCIe in
+    // microseconds either way); larger batches are staged through device memory by DMA.
+    const bool zero_copy = n <= ZERO_COPY_MAX_OPS;
+    const uint32_t *dk;
+    const uint64_t *dm, *dc;
+    const uint8_t *d_msgs, *d_ctxs, *d_in;
+    uint8_t *d_out;
+    int32_t *d_status = nullptr;
+    if (zero_copy) {
+        dk = kslot; dm = moff; dc = coff;
+        d_msgs = t->msgs.p; d_ctxs = t->ctxs.p; d_in = t->in0.p; d_out = t->out0.p;
+        d_status = reinterpret_cast<int32_t *>(t->status.p);
     } else {
-        BTRY(mldsa_sign_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.cap_k, kt.tr, kt.f0, kt.f1, kt.f2, kt.cap, dk, b->d_msgs.p, dm, b->d_ctxs.p, dc,
-                                 b->d_in0.p, b->d_out0.p, reinterpret_cast<int32_t *>(b->d_status.p), n, st));
-        BCHECK(hipMemcpyAsync(t->status.p, b->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
-        BCHECK(hipMemsetAsync(b->d_in0.p, 0, n * 32, st));  // rnd
+        BTRY(dev_reserve(b->d_kslot, n * 4));
+        BTRY(dev_reserve(b->d_moff, (n + 1) * 8));
+        BTRY(dev_reserve(b->d_coff, (n + 1) * 8));
+        BTRY(dev_reserve(b->d_msgs, std::max<size_t>(t->msg_used, 64)));
+        BTRY(dev_reserve(b->d_ctxs, std::max<size_t>(t->ctx_used, 64)));
+        BTRY(dev_reserve(b->d_in0, n * in_len, t->op == OP_SIGN));
+        BTRY(dev_reserve(b->d_out0, n * out_len));
+        if (t->op == OP_SIGN) BTRY(dev_reserve(b->d_status, n * 4));
+        BCHECK(hipMemcpyAsync(b->d_kslot.p, kslot, n * 4, hipMemcpyHostToDevice, st));
+        BCHECK(hipMemcpyAsync(b->d_moff.p, moff, (n + 1) * 8, hipMemcpyHostToDevice, st));
+        BCHECK(hipMemcpyAsync(b->d_coff.p, coff, (n + 1) * 8, hipMemcpyHostToDevice, st));
+        if (t->msg_used) BCHECK(hipMemcpyAsync(b->d_msgs.p, t->msgs.p, t->msg_used, hipMemcpyHostToDevice, st));
+        if (t->ctx_used) BCHECK(hipMemcpyAsync(b->d_ctxs.p, t->ctxs.p, t->ctx_used, hipMemcpyHostToDevice, st));
+        BCHECK(hipMemcpyAsync(b->d_in0.p, t->in0.p, n * in_len, hipMemcpyHostToDevice, st));
+        dk = reinterpret_cast<const uint32_t *>(b->d_kslot.p);
+        dm = reinterpret_cast<const uint64_t *>(b->d_moff.p);
+        dc = reinterpret_cast<const uint64_t *>(b->d_coff.p);
+        d_msgs = b->d_msgs.p; d_ctxs = b->d_ctxs.p; d_in = b->d_in0.p; d_out = b->d_out0.p;
+        d_status = reinterpret_cast<int32_t *>(b->d_status.p);
     }
-    BCHECK(hipMemcpyAsync(t->out0.p, b->d_out0.p, n * out_len, hipMemcpyDeviceToHost, st));
+    if (t->op == OP_VERIFY) {
+        BTRY(mldsa_verify_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.tr, kt.f0, kt.cap, dk, d_msgs, dm, d_ctxs, dc, d_in, d_out, n, st));
+    } else {
+        BTRY(mldsa_sign_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.cap_k, kt.tr, kt.f0, kt.f1, kt.f2, kt.cap, dk, d_msgs, dm, d_ctxs, dc, d_in, d_out,
+                                 d_status, n, st));
+        if (!zero_copy) {
+            BCHECK(hipMemcpyAsync(t->status.p, b->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+            BCHECK(hipMemsetAsync(b->d_in0.p, 0, n * 32, st));  // rnd
+        }
+    }
+    if (!zero_copy) BCHECK(hipMemcpyAsync(t->out0.p, b->d_out0.p, n * out_len, hipMemcpyDeviceToHost, st));
     BCHECK(hipStreamSynchronize(st));
     return MLDSA_OK;
 }

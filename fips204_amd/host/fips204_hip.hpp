@@ -407,6 +407,51 @@ struct ParamSet {
         mldsa_group* g_ = nullptr;
     };
 
+    // ---- single-operation calls from many host threads (mldsa_batcher_*) -----------------------------
+    // The reference's one-call-per-operation surface -- pk.verify(message, sig, ctx), sk.try_sign_with_seed(rnd, message, ctx),
+    // KG::keygen_from_seed(xi) -- for any number of threads at once: each call blocks its caller, the library coalesces the calls
+    // that are in flight into batched ones, keeps every key's expanded form (and A_hat) in a device-resident table, and returns
+    // each caller its own result.  Wire-format keys in, as a server holds them.
+    class Batcher {
+      public:
+        explicit Batcher(size_t max_batch = 4096, unsigned max_wait_us = 0, size_t cache_keys = 0) {
+            check(mldsa_batcher_create(Device::get().ctx(), SET, max_batch, max_wait_us, cache_keys, &b_), "mldsa_batcher_create");
+        }
+        ~Batcher() { mldsa_batcher_destroy(b_); }
+        Batcher(const Batcher&) = delete;
+        Batcher& operator=(const Batcher&) = delete;
+        // Verifier::verify (src/lib.rs:364-380) after PublicKey::try_from_bytes
+        bool verify(const PkBytes& pk, const std::vector<uint8_t>& message, const Signature& sig, const std::vector<uint8_t>& ctx,
+                    int mode = MLDSA_MODE_PURE) const {
+            uint8_t ok = 0;
+            check(mldsa_batcher_verify(b_, mode, pk.data(), message.data(), message.size(), ctx.data(), ctx.size(), sig.data(), &ok),
+                  "mldsa_batcher_verify");
+            return ok != 0;
+        }
+        // Signer::try_sign_with_seed (src/lib.rs:268-296) after PrivateKey::try_from_bytes; throws for a ctx longer than 255 bytes
+        Signature try_sign_with_seed(const SkBytes& sk, const std::array<uint8_t, 32>& rnd, const std::vector<uint8_t>& message,
+                                     const std::vector<uint8_t>& ctx, int mode = MLDSA_MODE_PURE) const {
+            Signature sig;
+            const int rc = mldsa_batcher_sign(b_, mode, sk.data(), message.data(), message.size(), ctx.data(), ctx.size(), rnd.data(), sig.data());
+            if (rc == MLDSA_ERR_CTX_LEN) throw Error("ML-DSA.Sign: ctx too long");
+            check(rc, "mldsa_batcher_sign");
+            return sig;
+        }
+        // KeyGen::keygen_from_seed (src/lib.rs:247-250)
+        std::pair<PkBytes, SkBytes> keygen_from_seed(const std::array<uint8_t, 32>& xi) const {
+            std::pair<PkBytes, SkBytes> out;
+            check(mldsa_batcher_keygen(b_, xi.data(), out.first.data(), out.second.data()), "mldsa_batcher_keygen");
+            return out;
+        }
+        mldsa_batcher_stats stats() const {
+            mldsa_batcher_stats st;
+            check(mldsa_batcher_get_stats(b_, &st), "mldsa_batcher_get_stats");
+            return st;
+        }
+      private:
+        mldsa_batcher* b_ = nullptr;
+    };
+
     // ---- single-key objects with the reference's method names -------------------------------------
     class PublicKey {
       public:

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 
 #include "../../fips204_amd/host/fips204_hip.hpp"
 
@@ -233,6 +234,42 @@ int main(int argc, char** argv) {
             for (size_t j = 0; j < n; j++) ASSERT(ok[j] == 1);
         }
         ASSERT(mldsa_abi_version() == MLDSA_ABI_VERSION);
+    }
+    // single-operation calls from 24 host threads through a Batcher: every caller gets the signature / verdict the batched
+    // calls give for its own arguments (try_sign_with_seed is deterministic given rnd)
+    {
+        using P = ml_dsa_65;
+        const size_t n = 96;
+        std::vector<std::array<uint8_t, 32>> xi(4), rnd(n);
+        for (int i = 0; i < 4; i++) xi[i].fill((uint8_t)(40 + i));
+        for (size_t i = 0; i < n; i++) rnd[i].fill((uint8_t)(3 * i + 2));
+        auto ks = P::keygen_many(xi);
+        auto sks = P::PrivateKeys::try_from_bytes(ks.second);
+        std::vector<uint32_t> kidx(n);
+        std::vector<std::vector<uint8_t>> msgs(n), ctxs(n);
+        for (size_t i = 0; i < n; i++) { kidx[i] = (uint32_t)(i % 4); msgs[i].assign(1 + i * 3, (uint8_t)i); ctxs[i].assign(i % 5, 9); }
+        auto want = P::sign_many(sks, kidx, msgs, ctxs, rnd);
+        P::Batcher b(32);
+        std::vector<P::Signature> got(n);
+        std::vector<int> good(n, 0), bad(n, 1);
+        std::vector<std::thread> th;
+        for (int t = 0; t < 24; t++)
+            th.emplace_back([&, t] {
+                for (size_t i = (size_t)t; i < n; i += 24) {
+                    got[i] = b.try_sign_with_seed(ks.second[kidx[i]], rnd[i], msgs[i], ctxs[i]);
+                    good[i] = b.verify(ks.first[kidx[i]], msgs[i], got[i], ctxs[i]);
+                    bad[i] = b.verify(ks.first[(kidx[i] + 1) % 4], msgs[i], got[i], ctxs[i]);
+                }
+            });
+        for (auto& x : th) x.join();
+        for (size_t i = 0; i < n; i++) ASSERT(got[i] == want[i] && good[i] == 1 && bad[i] == 0);
+        auto kp = b.keygen_from_seed(xi[2]);
+        ASSERT(kp.first == ks.first[2] && kp.second == ks.second[2]);
+        const mldsa_batcher_stats st = b.stats();
+        ASSERT(st.requests == 3 * n + 1 && st.batches < st.requests && st.keys_expanded == 8);
+        bool threw = false;
+        try { b.try_sign_with_seed(ks.second[0], rnd[0], msgs[0], std::vector<uint8_t>(256, 1)); } catch (const Error&) { threw = true; }
+        ASSERT(threw);
     }
     std::printf("OK\n");
     return 0;

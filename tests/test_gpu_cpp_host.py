@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cpp_host_mirror(tmp_path, ref_hex):
     exe = tmp_path / "test_host_mirror"
     libdir = os.path.join(ROOT, "fips204_amd", "csrc")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp"), "-o", str(exe),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp"), "-o", str(exe),
                            f"-L{libdir}", "-lmldsa_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     rng = ChaCha8Rng(123)
     xi, rnd = rng.fill_bytes(32), rng.fill_bytes(32)

@@ -1,3 +1,5 @@
+// (a container's CPU quota is not visible here: with a quota of 16 CPUs, as on the pool's boxes, points above ~64 threads measure the
+// quota's throttling -- p99 of tens of milliseconds -- not the batcher)
 // Many host threads making the reference's ONE-operation calls (pk.verify(msg, sig, ctx), sk.try_sign_with_seed(..), src/lib.rs:268-296,
 // 364-380) through mldsa_batcher_* -- calls per second, batch sizes the library formed, latency of a call as its caller sees it --
 // next to the same calls made one at a time with n_ops = 1 (mldsa_verify_host / mldsa_sign_host), which is what a shim without a
@@ -5,7 +7,7 @@
 //
 //   g++ -O2 -std=c++17 -I include tools/batcher_bench.cpp -o /tmp/batcher_bench -L fips204_amd/csrc -lmldsa_hip \
 //       -Wl,-rpath,$PWD/fips204_amd/csrc -Wl,-rpath,/opt/rocm/lib -lpthread
-//   /tmp/batcher_bench [set = 65] [seconds per point = 2] [max_wait_us = 0]        -> one JSON object on stdout
+//   /tmp/batcher_bench [set = 65] [seconds per point = 2] [max_wait_us = 0] [threads = 1,8,64,256]     -> one JSON object on stdout
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -29,6 +31,12 @@ int main(int argc, char **argv) {
     const int set = argc > 1 ? atoi(argv[1]) : 65;
     const double dur = argc > 2 ? atof(argv[2]) : 2.0;
     const unsigned max_wait = argc > 3 ? (unsigned)atoi(argv[3]) : 0;
+    std::vector<int> thread_counts;
+    for (const char *q = argc > 4 ? argv[4] : "1,8,64,256"; *q;) {
+        thread_counts.push_back(atoi(q));
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+    }
     mldsa_params p;
     CHECK(mldsa_get_params(set, &p));
     mldsa_ctx *ctx;
@@ -66,14 +74,14 @@ int main(int argc, char **argv) {
     }
 
     std::string json = "{\"tool\": \"tools/batcher_bench.cpp\", \"set\": " + std::to_string(set) + ", \"seconds_per_point\": " + std::to_string(dur) +
-                       ", \"max_wait_us\": " + std::to_string(max_wait) + ", \"keys\": " + std::to_string(NK) +
+                       ", \"max_wait_us\": " + std::to_string(max_wait) + ", \"keys\": " + std::to_string(NK) + ", \"host_cpus_online\": " + std::to_string(std::thread::hardware_concurrency()) +
                        ", \"one_call_at_a_time_n_ops_1\": {\"verify_us\": " + std::to_string(direct_us[0]) + ", \"sign_us\": " + std::to_string(direct_us[1]) +
                        ", \"verify_calls_per_s\": " + std::to_string(1e6 / direct_us[0]) + ", \"sign_calls_per_s\": " + std::to_string(1e6 / direct_us[1]) + "}";
     const char *names[2] = {"verify", "sign"};
     for (int op = 0; op < 2; op++) {
         json += std::string(", \"") + names[op] + "\": [";
         bool first = true;
-        for (int T : {1, 8, 64, 256, 1024}) {
+        for (int T : thread_counts) {
             mldsa_batcher *b;
             CHECK(mldsa_batcher_create(ctx, set, 8192, max_wait, 0, &b));
             std::atomic<bool> go{false}, stop{false};
