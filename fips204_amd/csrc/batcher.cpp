@@ -139,6 +139,10 @@ struct mldsa_batcher {
     bool quit = false, dispatcher_idle = false;
     static constexpr int NB = 3;  // per operation: one running, one filling, one being read out
     Batch batches[N_OPS][NB];
+    // the page-locked arrays of an operation's batches are made on its first request (tens of MB each for a large max_batch:
+    // a verify-only host never pays for signing and key generation)
+    std::once_flag alloc_once[N_OPS];
+    int alloc_rc[N_OPS] = {MLDSA_OK, MLDSA_OK, MLDSA_OK};
     Batch *open[N_OPS] = {nullptr, nullptr, nullptr};
     mldsa_batcher_stats stats{};
     // dispatcher-only state: the key tables, device staging of the batch that runs, its stream
@@ -192,7 +196,8 @@ Batch *open_batch(mldsa_batcher *b, Lock &lk, int op, int mode, size_t msg_len, 
         if (b->quit) { err = E_QUIT; return nullptr; }
         Batch *t = b->open[op];
         if (t) {
-            const bool fits = t->n < b->max_batch && t->mode == mode && (op == OP_KEYGEN || t->msg_used + msg_len <= t->msgs.bytes);
+            const bool fits = t->n < b->max_batch && t->mode == mode &&
+                              (op == OP_KEYGEN || (msg_len <= t->msgs.bytes && t->msg_used <= t->msgs.bytes - msg_len));
             if (fits) return t;
             if (t->n == 0 && t->mode == mode) {  // one message larger than the whole staging array: grow it while nobody else is inside
                 if (t->msgs.reserve(msg_len) != MLDSA_OK) { err = E_NOMEM; return nullptr; }  // (rare; the allocation holds the lock)
@@ -543,6 +548,11 @@ struct Req {
 
 int submit(mldsa_batcher *b, const Req &r) {
     const mldsa_params *p = b->p;
+    std::call_once(b->alloc_once[r.op], [&] {
+        for (Batch &t : b->batches[r.op])
+            if (b->alloc_rc[r.op] == MLDSA_OK) b->alloc_rc[r.op] = alloc_batch(b, t, r.op);
+    });
+    if (b->alloc_rc[r.op] != MLDSA_OK) return set_error(b->alloc_rc[r.op], "mldsa_batcher: no page-locked memory for the staging arrays");
     const uint64_t kh = r.op == OP_KEYGEN ? 0 : hash_key(b->hash_seed, r.key, key_len(b, r.op));  // before the lock: 0.3 us of arithmetic
     Lock lk(b->mu);
     int err = E_NONE;
@@ -641,10 +651,7 @@ int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max
         b->hash_seed = ((uint64_t)ts.tv_nsec * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)ts.tv_sec << 32) ^ (uint64_t)(uintptr_t)b.get() ^ ((uint64_t)getpid() << 48);
     }
     for (int op = 0; op < N_OPS; op++)
-        for (Batch &t : b->batches[op]) {
-            const int rc = alloc_batch(b.get(), t, op);
-            if (rc != MLDSA_OK) return rc;  // message of mldsa_host_alloc; the buffers made so far go with `b`
-        }
+        for (Batch &t : b->batches[op]) t.op = op;
     b->th = std::thread(dispatcher, b.get());
     *out = b.release();
     return MLDSA_OK;
