@@ -164,6 +164,72 @@ def test_key_table_replacement(hp):
         b.close()
 
 
+def test_batcher_soak(hp):
+    """MLDSA_SOAK_S seconds (default 10) of 32 threads making random single-operation calls through ONE batcher: signing, verifying
+    (good signatures, signatures of another request, another key), key generation; three modes, messages of 0 ... 3 000 bytes, 40
+    keys over a key table of 16 slots (replacement all the time), batches of at most 16.  Every result is compared with what the
+    oracle gave for the same request before the threads started."""
+    import os
+    import random
+    import time
+    pset = 44
+    seconds = float(os.environ.get("MLDSA_SOAK_S", "10"))
+    rng = np.random.default_rng(2024)
+    n_keys, n_req = 40, 240
+    xis = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n_keys)]
+    keys = [orc.keygen_from_seed(pset, xi) for xi in xis]
+    pkb = [orc.pk_into_bytes(pset, pk) for pk, _ in keys]
+    skb = [orc.sk_into_bytes(pset, sk) for _, sk in keys]
+    oid_ph = b"".join(orc.hash_message(b"soak", "SHA256"))
+    reqs = []
+    for i in range(n_req):
+        mode = (MODE_PURE, MODE_PURE, MODE_INTERNAL, MODE_PREHASH)[i % 4]
+        k = int(rng.integers(0, n_keys))
+        msg = oid_ph if mode == MODE_PREHASH else rng.integers(0, 256, int(rng.choice([0, 1, 32, 135, 136, 137, 500, 3000])), dtype=np.uint8).tobytes()
+        ctx = b"" if mode == MODE_INTERNAL else rng.integers(0, 256, int(rng.choice([0, 0, 7, 255])), dtype=np.uint8).tobytes()
+        rnd = rng.integers(0, 256, 32, dtype=np.uint8).tobytes()
+        reqs.append((k, mode, msg, ctx, rnd, orc.sign_internal(pset, keys[k][1], msg, rnd, ctx=ctx, mode=mode)))
+    b = MlDsaBatcher(pset, hotpath=hp, max_batch=16, cache_keys=16)
+    stop = time.time() + seconds
+    errors, counts = [], [0] * 32
+
+    def worker(tid):
+        r = random.Random(tid)
+        try:
+            while time.time() < stop and not errors:
+                k, mode, msg, ctx, rnd, sig = reqs[r.randrange(n_req)]
+                what = r.randrange(10)
+                if what < 4:
+                    assert b.sign(skb[k], msg, rnd, ctx=ctx, mode=mode) == sig, "signature differs from the oracle's"
+                elif what < 7:
+                    assert b.verify(pkb[k], msg, sig, ctx=ctx, mode=mode) is True, "a good signature was rejected"
+                elif what < 8:
+                    other = reqs[r.randrange(n_req)]
+                    same = other[5] == sig or (other[0] == k and other[1] == mode and other[2] == msg and other[3] == ctx)
+                    assert b.verify(pkb[k], msg, other[5], ctx=ctx, mode=mode) is same, "a signature of another request was accepted"
+                elif what < 9:
+                    assert b.verify(pkb[(k + 1) % n_keys], msg, sig, ctx=ctx, mode=mode) is False, "accepted under another key"
+                else:
+                    j = r.randrange(n_keys)
+                    assert b.keygen_from_seed(xis[j]) == (pkb[j], skb[j]), "key pair differs from the oracle's"
+                counts[tid] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    try:
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(32)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:3]
+        st = b.stats()
+        assert st["requests"] == sum(counts) and st["requests"] > 50 * seconds and st["keys_expanded"] > 2 * n_keys and st["key_hits"] > 0
+        print(f"batcher soak: {sum(counts)} calls in {seconds:.0f} s, {st}")
+    finally:
+        b.close()
+
+
 def test_batcher_argument_errors(hp):
     lib = hp.lib
     h = C.c_void_p()
