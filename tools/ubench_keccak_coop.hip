@@ -71,6 +71,70 @@ __device__ __forceinline__ void coop_round(uint32_t& lo, uint32_t& hi, const Coo
     }
 }
 
+// ---- second cooperative form: the same layout, THREE dependent gather levels per round instead of six --
+//   level 1: the four other words of the lane's column at once (theta's column parity);
+//   level 2: the parities of the two neighbouring columns;
+//   level 3: pi folded into chi's gathers: the lane fetches its own B word and the row's next two straight from the lanes that hold
+//            them BEFORE pi (rho is applied at the source, where the rotation amount belongs)
+// 18 gathers x 2 words per round (the first form: 16), but only three of them wait for each other.
+struct Coop3Idx {
+    int row[4], colm1, colp1, b0, b1, b2, rot;
+    bool active, first;
+};
+
+__device__ __forceinline__ Coop3Idx coop3_idx(int lane) {
+    Coop3Idx c;
+    const int base = lane & 32, i = lane & 31;
+    c.active = i < 25;
+    const int ii = c.active ? i : 0, x = ii % 5, y = ii / 5;
+    auto at = [&](int xx, int yy) { return (base + (xx % 5) + 5 * (yy % 5)) << 2; };  // byte address for ds_bpermute
+    for (int k = 0; k < 4; k++) c.row[k] = at(x, y + 1 + k);
+    c.colm1 = at(x + 4, y); c.colp1 = at(x + 1, y);
+    auto pi_src = [&](int X, int Y) { return at(X + 3 * Y, X); };  // B[X, Y] = rot(A[x, y]) with x = X + 3 Y, y = X
+    c.b0 = pi_src(x, y); c.b1 = pi_src((x + 1) % 5, y); c.b2 = pi_src((x + 2) % 5, y);
+    c.rot = RHO[ii];
+    c.first = i == 0;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t gather4(uint32_t v, int byte_addr) { return (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)v); }
+
+__device__ __forceinline__ void coop3_round(uint32_t& lo, uint32_t& hi, const Coop3Idx& c, int round) {
+    // theta, level 1
+    const uint32_t l1 = gather4(lo, c.row[0]), l2 = gather4(lo, c.row[1]), l3 = gather4(lo, c.row[2]), l4 = gather4(lo, c.row[3]);
+    const uint32_t h1 = gather4(hi, c.row[0]), h2 = gather4(hi, c.row[1]), h3 = gather4(hi, c.row[2]), h4 = gather4(hi, c.row[3]);
+    const uint32_t cl = mldsa::xor3(mldsa::xor3(lo, l1, l2), l3, l4), ch = mldsa::xor3(mldsa::xor3(hi, h1, h2), h3, h4);
+    // level 2
+    const uint32_t ml = gather4(cl, c.colm1), mh = gather4(ch, c.colm1), pl = gather4(cl, c.colp1), ph = gather4(ch, c.colp1);
+    lo ^= ml ^ __funnelshift_l(ph, pl, 1);
+    hi ^= mh ^ __funnelshift_l(pl, ph, 1);
+    // rho at the source
+    const int r = c.rot & 31;
+    uint32_t rl = __funnelshift_l(hi, lo, r), rh = __funnelshift_l(lo, hi, r);
+    if (c.rot & 32) { const uint32_t t = rl; rl = rh; rh = t; }
+    // level 3: pi + chi
+    const uint32_t b0l = gather4(rl, c.b0), b1l = gather4(rl, c.b1), b2l = gather4(rl, c.b2);
+    const uint32_t b0h = gather4(rh, c.b0), b1h = gather4(rh, c.b1), b2h = gather4(rh, c.b2);
+    lo = mldsa::chi(b0l, b1l, b2l);
+    hi = mldsa::chi(b0h, b1h, b2h);
+    if (c.first) {
+        lo ^= mldsa::KECCAK_RC_LO[round];
+        hi ^= ((mldsa::KECCAK_RC_HI_BITS >> round) & 1u) << 31;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_coop3(uint32_t* __restrict__ io, int perms) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const Coop3Idx c = coop3_idx(lane);
+    uint32_t* st = io + (wave * 2 + (lane >> 5)) * 50;
+    uint32_t lo = c.active ? st[2 * (lane & 31)] : 0, hi = c.active ? st[2 * (lane & 31) + 1] : 0;
+    for (int p = 0; p < perms; p++)
+#pragma unroll 1
+        for (int r = 0; r < 24; r++) coop3_round(lo, hi, c, r);
+    if (c.active) { st[2 * (lane & 31)] = lo; st[2 * (lane & 31) + 1] = hi; }
+}
+
 __global__ __launch_bounds__(256) void k_coop(uint32_t* __restrict__ io, int perms) {
     // io: per wave two states x 25 words x (lo, hi); lane i of a half-wave owns word i
     const int lane = threadIdx.x & 63;
@@ -118,6 +182,12 @@ int main() {
         CHECK(hipMemcpy(b.data(), d2, h.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < h.size(); i++)
             if (a[i] != b[i]) { fprintf(stderr, "MISMATCH at word %zu: lane-per-state %08x cooperative %08x\n", i, a[i], b[i]); return 1; }
+        CHECK(hipMemcpy(d2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_coop3, dim3(8), dim3(256), 0, 0, d2, 3);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(b.data(), d2, h.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); i++)
+            if (a[i] != b[i]) { fprintf(stderr, "MISMATCH at word %zu: lane-per-state %08x three-level cooperative %08x\n", i, a[i], b[i]); return 1; }
         printf("cooperative and lane-per-state Keccak-f[1600] agree on %d random states x 3 permutations\n", n_states);
         CHECK(hipFree(d1)); CHECK(hipFree(d2));
     }
@@ -127,7 +197,7 @@ int main() {
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     printf("device: %s, %d CUs\n", prop.name, cus);
     printf("%-18s %10s %12s %22s %20s\n", "form", "waves/SIMD", "ms", "us per permutation/wave", "G permutations/s");
-    for (int form = 0; form < 2; form++)
+    for (int form = 0; form < 3; form++)
         for (int wps : {1, 2, 4, 8}) {
             const int blocks = cus * wps;  // 4 waves per block = 1 per SIMD of a CU
             const size_t words = (size_t)blocks * 256 * 50;
@@ -138,7 +208,8 @@ int main() {
             for (int rep = 0; rep < 5; rep++) {
                 CHECK(hipEventRecord(e0));
                 if (form == 0) hipLaunchKernelGGL(k_lane, dim3(blocks), dim3(256), 0, 0, d, perms);
-                else hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(256), 0, 0, d, perms);
+                else if (form == 1) hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(256), 0, 0, d, perms);
+                else hipLaunchKernelGGL(k_coop3, dim3(blocks), dim3(256), 0, 0, d, perms);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
                 float ms;
@@ -146,7 +217,7 @@ int main() {
                 best = ms < best ? ms : best;
             }
             const double states = (double)blocks * 4 * (form == 0 ? 64 : 2);
-            printf("%-18s %10d %12.3f %22.2f %20.3f\n", form == 0 ? "lane-per-state" : "cooperative (2/wave)", wps, best, best * 1e3 / perms,
+            printf("%-18s %10d %12.3f %22.2f %20.3f\n", form == 0 ? "lane-per-state" : form == 1 ? "cooperative (2/wave)" : "coop, 3 levels (2/wave)", wps, best, best * 1e3 / perms,
                    states * perms / (best * 1e-3) / 1e9);
             CHECK(hipFree(d));
         }
