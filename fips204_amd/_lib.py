@@ -81,6 +81,8 @@ _SIGNATURES = {
     "mldsa_group_sync": [_P],
     "mldsa_batcher_destroy": [_P],
     "mldsa_batcher_create": [_P, _I, _SZ, C.c_uint, _SZ, _P],
+    "mldsa_batcher_create_on": [_P, _I, _I, _SZ, C.c_uint, _SZ, _P],
+    "mldsa_batcher_lanes": [_P],
     "mldsa_batcher_verify": [_P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
     "mldsa_batcher_sign": [_P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
     "mldsa_batcher_keygen": [_P, _P, _P, _P],

@@ -81,7 +81,7 @@ struct PinnedBuf {  // page-locked array (mldsa_host_alloc): the *_host entry po
         return MLDSA_OK;
     }
     void release() {
-        if (p) { std::memset(p, 0, bytes); (void)mldsa_host_free(p); }  // may have held private keys / seeds
+        if (p) { std::memset(p, 0, bytes); (void)mldsa_host_free(p); }  // may have held private keys / seeds (mldsa_host_free: Quiesce)
         p = nullptr;
         bytes = 0;
     }
@@ -126,32 +126,41 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// One dispatcher: a context, a thread, the key tables and the device staging of the batch it runs.  Several lanes take batches
+// from the same queues -- on one GPU two small batches overlap on the device (each is a chain of latency-bound kernels on a
+// fraction of the SIMDs), on several GPUs every device has its own lane.
+struct Lane {
+    mldsa_ctx *ctx = nullptr;
+    bool own_ctx = false;
+    std::thread th;
+    uint64_t batch_id = 0;
+    KeyTable tables[2];  // [OP_VERIFY] public keys, [OP_SIGN] private keys
+    hipStream_t stream = nullptr;
+    DevBuf d_kslot, d_moff, d_coff, d_msgs, d_ctxs, d_in0, d_out0, d_status, d_kstage;
+    PinnedBuf kstage;    // wire bytes of the keys a batch has to expand
+};
+
 }  // namespace
 
 struct mldsa_batcher {
-    mldsa_ctx *ctx = nullptr;
     const mldsa_params *p = nullptr;
     size_t max_batch = 0;
     unsigned max_wait_us = 0;
     SpinLock mu;  // batch states, open[], slot / byte reservations, key tables, stats
     std::atomic<uint32_t> work_seq{0}, free_seq{0};  // futex words: "the dispatcher has something to look at", "a batch became free"
-    std::thread th;
-    bool quit = false, dispatcher_idle = false;
-    static constexpr int NB = 3;  // per operation: one running, one filling, one being read out
-    Batch batches[N_OPS][NB];
+    bool quit = false;
+    int idle_dispatchers = 0;
+    std::vector<std::unique_ptr<Lane>> lanes;
+    // per operation: one batch per lane running, one filling, one being read out
+    std::vector<std::unique_ptr<Batch>> batches[N_OPS];
     // the page-locked arrays of an operation's batches are made on its first request (tens of MB each for a large max_batch:
     // a verify-only host never pays for signing and key generation)
     std::once_flag alloc_once[N_OPS];
     int alloc_rc[N_OPS] = {MLDSA_OK, MLDSA_OK, MLDSA_OK};
     Batch *open[N_OPS] = {nullptr, nullptr, nullptr};
     mldsa_batcher_stats stats{};
-    // dispatcher-only state: the key tables, device staging of the batch that runs, its stream
     size_t cache_keys = 0;
-    uint64_t hash_seed = 0, batch_id = 0;
-    KeyTable tables[2];  // [OP_VERIFY] public keys, [OP_SIGN] private keys
-    hipStream_t stream = nullptr;
-    DevBuf d_kslot, d_moff, d_coff, d_msgs, d_ctxs, d_in0, d_out0, d_status, d_kstage;
-    PinnedBuf kstage;    // wire bytes of the keys a batch has to expand
+    uint64_t hash_seed = 0;
 };
 
 namespace {
@@ -182,7 +191,7 @@ int alloc_batch(mldsa_batcher *b, Batch &t, int op) {
 // with the lock held: tell the dispatcher there is something to look at; returns whether the caller must futex_wake(work_seq)
 // once it has released the lock
 bool poke_dispatcher(mldsa_batcher *b) {
-    if (!b->dispatcher_idle) return false;
+    if (b->idle_dispatchers == 0) return false;
     b->work_seq.fetch_add(1, std::memory_order_release);
     return true;
 }
@@ -209,8 +218,8 @@ Batch *open_batch(mldsa_batcher *b, Lock &lk, int op, int mode, size_t msg_len, 
             wake |= poke_dispatcher(b);
             continue;
         }
-        for (Batch &c : b->batches[op])
-            if (c.state == FREE) { t = &c; break; }
+        for (auto &c : b->batches[op])
+            if (c->state == FREE) { t = c.get(); break; }
         if (!t) {
             const uint32_t seen = b->free_seq.load(std::memory_order_relaxed);
             lk.unlock();
@@ -265,8 +274,8 @@ uint32_t key_slot(mldsa_batcher *b, Batch *t, const uint8_t *key, uint64_t h) {
 int dev_reserve(DevBuf &d, size_t bytes, bool secret = false) {
     if (bytes <= d.bytes) return MLDSA_OK;
     if (d.p) {
-        if (secret) (void)hipMemset(d.p, 0, d.bytes);
-        BCHECK(hipFree(d.p));
+        if (secret) (void)memset_quiesced(d.p, 0, d.bytes);
+        BCHECK(free_quiesced(d.p));  // hipFree waits for every stream of the device: not while another lane or context captures one (ctx.h)
         d.p = nullptr;
         d.bytes = 0;
     }
@@ -279,8 +288,8 @@ int dev_reserve(DevBuf &d, size_t bytes, bool secret = false) {
 
 void dev_release(DevBuf &d, bool secret = false) {
     if (d.p) {
-        if (secret) (void)hipMemset(d.p, 0, d.bytes);
-        (void)hipFree(d.p);
+        if (secret) (void)memset_quiesced(d.p, 0, d.bytes);
+        (void)free_quiesced(d.p);
     }
     d.p = nullptr;
     d.bytes = 0;
@@ -317,27 +326,27 @@ int table_alloc(mldsa_batcher *b, KeyTable &kt, bool is_private) {
 void table_free(mldsa_batcher *b, KeyTable &kt) {
     const size_t n = kt.cap, K = (size_t)b->p->k, L = (size_t)b->p->l;
     if (kt.is_private && n) {  // expanded private keys (types.rs:19 ZeroizeOnDrop)
-        if (kt.cap_k) (void)hipMemset(kt.cap_k, 0, n * 32);
-        if (kt.f0) (void)hipMemset(kt.f0, 0, n * L * 1024);
-        if (kt.f1) (void)hipMemset(kt.f1, 0, n * K * 1024);
-        if (kt.f2) (void)hipMemset(kt.f2, 0, n * K * 1024);
-        (void)hipDeviceSynchronize();
+        if (kt.cap_k) (void)memset_quiesced(kt.cap_k, 0, n * 32);
+        if (kt.f0) (void)memset_quiesced(kt.f0, 0, n * L * 1024);
+        if (kt.f1) (void)memset_quiesced(kt.f1, 0, n * K * 1024);
+        if (kt.f2) (void)memset_quiesced(kt.f2, 0, n * K * 1024);
+        (void)device_sync_quiesced();
         std::memset(kt.wire.data(), 0, kt.wire.size());
     }
     for (void *q : {(void *)kt.rho, (void *)kt.cap_k, (void *)kt.tr, (void *)kt.f0, (void *)kt.f1, (void *)kt.f2, (void *)kt.a_hat})
-        if (q) (void)hipFree(q);
+        if (q) (void)free_quiesced(q);
     kt = KeyTable();
 }
 
 // Every distinct key of the batch -> a slot of the device-resident table; the keys the table does not hold are expanded into
 // free slots (try_from_bytes + ExpandA, once per key for as long as it stays in the table).  Dispatcher thread only.
-int resolve_keys(mldsa_batcher *b, Batch *t, std::vector<uint32_t> &slot_of) {
+int resolve_keys(mldsa_batcher *b, Lane &ln, Batch *t, std::vector<uint32_t> &slot_of) {
     const mldsa_params *p = b->p;
     const bool priv = t->op == OP_SIGN;
-    KeyTable &kt = b->tables[t->op];
+    KeyTable &kt = ln.tables[t->op];
     BTRY(table_alloc(b, kt, priv));
     const size_t kl = key_len(b, t->op), K = (size_t)p->k, L = (size_t)p->l;
-    const uint64_t id = ++b->batch_id;
+    const uint64_t id = ++ln.batch_id;
     slot_of.assign(t->n_keys, 0);
     std::vector<uint32_t> miss;
     for (size_t j = 0; j < t->n_keys; j++) {
@@ -364,7 +373,7 @@ int resolve_keys(mldsa_batcher *b, Batch *t, std::vector<uint32_t> &slot_of) {
             if (it->second == s) { kt.index.erase(it); break; }
         kt.valid[s] = 0;
     };
-    BTRY(b->kstage.reserve(miss.size() * kl));
+    BTRY(ln.kstage.reserve(miss.size() * kl));
     for (size_t m = 0; m < miss.size(); m++) {
         size_t s = kt.hand;
         while (kt.valid[s] && kt.last_batch[s] == id) s = (s + 1) % kt.cap;  // cap >= max_batch >= n_keys: ends
@@ -372,7 +381,7 @@ int resolve_keys(mldsa_batcher *b, Batch *t, std::vector<uint32_t> &slot_of) {
         if (kt.valid[s]) drop((uint32_t)s);
         const uint8_t *key = t->keys.p + (size_t)miss[m] * kl;
         std::memcpy(kt.wire.data() + s * kl, key, kl);
-        std::memcpy(b->kstage.p + m * kl, key, kl);
+        std::memcpy(ln.kstage.p + m * kl, key, kl);
         kt.hash[s] = t->key_hash[miss[m]];
         kt.last_batch[s] = id;
         kt.valid[s] = 1;
@@ -381,22 +390,22 @@ int resolve_keys(mldsa_batcher *b, Batch *t, std::vector<uint32_t> &slot_of) {
         if (!runs.empty() && runs.back().first_slot + runs.back().count == s) runs.back().count++;
         else runs.push_back({s, m, 1});
     }
-    int rc = dev_reserve(b->d_kstage, miss.size() * kl, priv);
-    if (rc == MLDSA_OK && hipMemcpyAsync(b->d_kstage.p, b->kstage.p, miss.size() * kl, hipMemcpyHostToDevice, b->stream) != hipSuccess)
+    int rc = dev_reserve(ln.d_kstage, miss.size() * kl, priv);
+    if (rc == MLDSA_OK && hipMemcpyAsync(ln.d_kstage.p, ln.kstage.p, miss.size() * kl, hipMemcpyHostToDevice, ln.stream) != hipSuccess)
         rc = set_error(MLDSA_ERR_DEVICE, "mldsa_batcher: key upload");
     for (size_t r = 0; r < runs.size() && rc == MLDSA_OK; r++) {
         const Run &u = runs[r];
-        const uint8_t *src = b->d_kstage.p + u.first_miss * kl;
+        const uint8_t *src = ln.d_kstage.p + u.first_miss * kl;
         const size_t s = u.first_slot;
-        if (priv) rc = mldsa_sk_expand(b->ctx, p->set, src, kt.rho + s * 32, kt.cap_k + s * 32, kt.tr + s * 64, kt.f0 + s * L * 256, kt.f1 + s * K * 256,
-                                       kt.f2 + s * K * 256, u.count, b->stream);
-        else rc = mldsa_pk_expand(b->ctx, p->set, src, kt.rho + s * 32, kt.tr + s * 64, kt.f0 + s * K * 256, u.count, b->stream);
-        if (rc == MLDSA_OK) rc = mldsa_expand_a(b->ctx, p->set, kt.rho + s * 32, kt.a_hat + s * K * L * 256, u.count, b->stream);
+        if (priv) rc = mldsa_sk_expand(ln.ctx, p->set, src, kt.rho + s * 32, kt.cap_k + s * 32, kt.tr + s * 64, kt.f0 + s * L * 256, kt.f1 + s * K * 256,
+                                       kt.f2 + s * K * 256, u.count, ln.stream);
+        else rc = mldsa_pk_expand(ln.ctx, p->set, src, kt.rho + s * 32, kt.tr + s * 64, kt.f0 + s * K * 256, u.count, ln.stream);
+        if (rc == MLDSA_OK) rc = mldsa_expand_a(ln.ctx, p->set, kt.rho + s * 32, kt.a_hat + s * K * L * 256, u.count, ln.stream);
     }
     if (priv) {  // the wire bytes of private keys leave the staging buffers with the batch
-        if (rc == MLDSA_OK && hipMemsetAsync(b->d_kstage.p, 0, miss.size() * kl, b->stream) != hipSuccess) (void)hipGetLastError();
-        if (hipStreamSynchronize(b->stream) != hipSuccess) (void)hipGetLastError();  // the upload has read the page-locked copy
-        std::memset(b->kstage.p, 0, miss.size() * kl);
+        if (rc == MLDSA_OK && hipMemsetAsync(ln.d_kstage.p, 0, miss.size() * kl, ln.stream) != hipSuccess) (void)hipGetLastError();
+        if (hipStreamSynchronize(ln.stream) != hipSuccess) (void)hipGetLastError();  // the upload has read the page-locked copy
+        std::memset(ln.kstage.p, 0, miss.size() * kl);
     }
     if (rc != MLDSA_OK)  // nothing half-expanded stays findable
         for (uint32_t j : miss) drop(slot_of[j]);
@@ -404,14 +413,14 @@ int resolve_keys(mldsa_batcher *b, Batch *t, std::vector<uint32_t> &slot_of) {
 }
 
 // verify / sign of one batch on the device-resident key table
-int run_keyed(mldsa_batcher *b, Batch *t) {
+int run_keyed(mldsa_batcher *b, Lane &ln, Batch *t) {
     const mldsa_params *p = b->p;
     const size_t n = t->n, sgl = (size_t)p->sig_len;
-    DeviceGuard dg(b->ctx->device);
-    if (!b->stream) BCHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    DeviceGuard dg(ln.ctx->device);
+    if (!ln.stream) BCHECK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
     std::vector<uint32_t> slot_of;
-    BTRY(resolve_keys(b, t, slot_of));
-    KeyTable &kt = b->tables[t->op];
+    BTRY(resolve_keys(b, ln, t, slot_of));
+    KeyTable &kt = ln.tables[t->op];
     uint32_t *kslot = reinterpret_cast<uint32_t *>(t->kslot.p);
     const uint32_t *kidx = reinterpret_cast<const uint32_t *>(t->kidx.p);
     for (size_t i = 0; i < n; i++) kslot[i] = slot_of[kidx[i]];
@@ -419,7 +428,7 @@ int run_keyed(mldsa_batcher *b, Batch *t) {
     moff[n] = t->msg_used;
     coff[n] = t->ctx_used;
     const size_t in_len = t->op == OP_VERIFY ? sgl : 32, out_len = t->op == OP_VERIFY ? 1 : sgl;
-    hipStream_t st = b->stream;
+    hipStream_t st = ln.stream;
     // Small batches are all latency: six uploads and a download, one after the other on the stream, cost more than the 4 KB per op
     // they move.  Up to ZERO_COPY_MAX_OPS ops the kernels read the page-locked staging arrays in place and write the results
     // straight into them (hipHostMalloc memory is mapped into the device's address space; a batch of that size crosses PCIe in
@@ -435,47 +444,47 @@ int run_keyed(mldsa_batcher *b, Batch *t) {
         d_msgs = t->msgs.p; d_ctxs = t->ctxs.p; d_in = t->in0.p; d_out = t->out0.p;
         d_status = reinterpret_cast<int32_t *>(t->status.p);
     } else {
-        BTRY(dev_reserve(b->d_kslot, n * 4));
-        BTRY(dev_reserve(b->d_moff, (n + 1) * 8));
-        BTRY(dev_reserve(b->d_coff, (n + 1) * 8));
-        BTRY(dev_reserve(b->d_msgs, std::max<size_t>(t->msg_used, 64)));
-        BTRY(dev_reserve(b->d_ctxs, std::max<size_t>(t->ctx_used, 64)));
-        BTRY(dev_reserve(b->d_in0, n * in_len, t->op == OP_SIGN));
-        BTRY(dev_reserve(b->d_out0, n * out_len));
-        if (t->op == OP_SIGN) BTRY(dev_reserve(b->d_status, n * 4));
-        BCHECK(hipMemcpyAsync(b->d_kslot.p, kslot, n * 4, hipMemcpyHostToDevice, st));
-        BCHECK(hipMemcpyAsync(b->d_moff.p, moff, (n + 1) * 8, hipMemcpyHostToDevice, st));
-        BCHECK(hipMemcpyAsync(b->d_coff.p, coff, (n + 1) * 8, hipMemcpyHostToDevice, st));
-        if (t->msg_used) BCHECK(hipMemcpyAsync(b->d_msgs.p, t->msgs.p, t->msg_used, hipMemcpyHostToDevice, st));
-        if (t->ctx_used) BCHECK(hipMemcpyAsync(b->d_ctxs.p, t->ctxs.p, t->ctx_used, hipMemcpyHostToDevice, st));
-        BCHECK(hipMemcpyAsync(b->d_in0.p, t->in0.p, n * in_len, hipMemcpyHostToDevice, st));
-        dk = reinterpret_cast<const uint32_t *>(b->d_kslot.p);
-        dm = reinterpret_cast<const uint64_t *>(b->d_moff.p);
-        dc = reinterpret_cast<const uint64_t *>(b->d_coff.p);
-        d_msgs = b->d_msgs.p; d_ctxs = b->d_ctxs.p; d_in = b->d_in0.p; d_out = b->d_out0.p;
-        d_status = reinterpret_cast<int32_t *>(b->d_status.p);
+        BTRY(dev_reserve(ln.d_kslot, n * 4));
+        BTRY(dev_reserve(ln.d_moff, (n + 1) * 8));
+        BTRY(dev_reserve(ln.d_coff, (n + 1) * 8));
+        BTRY(dev_reserve(ln.d_msgs, std::max<size_t>(t->msg_used, 64)));
+        BTRY(dev_reserve(ln.d_ctxs, std::max<size_t>(t->ctx_used, 64)));
+        BTRY(dev_reserve(ln.d_in0, n * in_len, t->op == OP_SIGN));
+        BTRY(dev_reserve(ln.d_out0, n * out_len));
+        if (t->op == OP_SIGN) BTRY(dev_reserve(ln.d_status, n * 4));
+        BCHECK(hipMemcpyAsync(ln.d_kslot.p, kslot, n * 4, hipMemcpyHostToDevice, st));
+        BCHECK(hipMemcpyAsync(ln.d_moff.p, moff, (n + 1) * 8, hipMemcpyHostToDevice, st));
+        BCHECK(hipMemcpyAsync(ln.d_coff.p, coff, (n + 1) * 8, hipMemcpyHostToDevice, st));
+        if (t->msg_used) BCHECK(hipMemcpyAsync(ln.d_msgs.p, t->msgs.p, t->msg_used, hipMemcpyHostToDevice, st));
+        if (t->ctx_used) BCHECK(hipMemcpyAsync(ln.d_ctxs.p, t->ctxs.p, t->ctx_used, hipMemcpyHostToDevice, st));
+        BCHECK(hipMemcpyAsync(ln.d_in0.p, t->in0.p, n * in_len, hipMemcpyHostToDevice, st));
+        dk = reinterpret_cast<const uint32_t *>(ln.d_kslot.p);
+        dm = reinterpret_cast<const uint64_t *>(ln.d_moff.p);
+        dc = reinterpret_cast<const uint64_t *>(ln.d_coff.p);
+        d_msgs = ln.d_msgs.p; d_ctxs = ln.d_ctxs.p; d_in = ln.d_in0.p; d_out = ln.d_out0.p;
+        d_status = reinterpret_cast<int32_t *>(ln.d_status.p);
     }
     if (t->op == OP_VERIFY) {
-        BTRY(mldsa_verify_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.tr, kt.f0, kt.cap, dk, d_msgs, dm, d_ctxs, dc, d_in, d_out, n, st));
+        BTRY(mldsa_verify_cached_a(ln.ctx, p->set, t->mode, kt.a_hat, kt.tr, kt.f0, kt.cap, dk, d_msgs, dm, d_ctxs, dc, d_in, d_out, n, st));
     } else {
-        BTRY(mldsa_sign_cached_a(b->ctx, p->set, t->mode, kt.a_hat, kt.cap_k, kt.tr, kt.f0, kt.f1, kt.f2, kt.cap, dk, d_msgs, dm, d_ctxs, dc, d_in, d_out,
+        BTRY(mldsa_sign_cached_a(ln.ctx, p->set, t->mode, kt.a_hat, kt.cap_k, kt.tr, kt.f0, kt.f1, kt.f2, kt.cap, dk, d_msgs, dm, d_ctxs, dc, d_in, d_out,
                                  d_status, n, st));
         if (!zero_copy) {
-            BCHECK(hipMemcpyAsync(t->status.p, b->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
-            BCHECK(hipMemsetAsync(b->d_in0.p, 0, n * 32, st));  // rnd
+            BCHECK(hipMemcpyAsync(t->status.p, ln.d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+            BCHECK(hipMemsetAsync(ln.d_in0.p, 0, n * 32, st));  // rnd
         }
     }
-    if (!zero_copy) BCHECK(hipMemcpyAsync(t->out0.p, b->d_out0.p, n * out_len, hipMemcpyDeviceToHost, st));
+    if (!zero_copy) BCHECK(hipMemcpyAsync(t->out0.p, ln.d_out0.p, n * out_len, hipMemcpyDeviceToHost, st));
     BCHECK(hipStreamSynchronize(st));
     return MLDSA_OK;
 }
 
-void run_batch(mldsa_batcher *b, Batch *t) {
+void run_batch(mldsa_batcher *b, Lane &ln, Batch *t) {
     int rc;
-    if (t->op == OP_KEYGEN) rc = mldsa_keygen_host(b->ctx, b->p->set, t->in0.p, t->out0.p, t->out1.p, t->n);
+    if (t->op == OP_KEYGEN) rc = mldsa_keygen_host(ln.ctx, b->p->set, t->in0.p, t->out0.p, t->out1.p, t->n);
     else {
-        rc = run_keyed(b, t);
-        if (rc != MLDSA_OK && b->stream) { DeviceGuard dg(b->ctx->device); (void)hipStreamSynchronize(b->stream); }
+        rc = run_keyed(b, ln, t);
+        if (rc != MLDSA_OK && ln.stream) { DeviceGuard dg(ln.ctx->device); (void)hipStreamSynchronize(ln.stream); }
     }
     t->rc = rc;
     if (rc != MLDSA_OK) { const char *e = mldsa_last_error(); t->err = e ? e : ""; }
@@ -485,22 +494,22 @@ void run_batch(mldsa_batcher *b, Batch *t) {
     }
 }
 
-void dispatcher(mldsa_batcher *b) {
+void dispatcher(mldsa_batcher *b, Lane *ln) {
     Lock lk(b->mu);
     auto sleep_until_poked = [&](const timespec *timeout) {
-        b->dispatcher_idle = true;
+        b->idle_dispatchers++;
         const uint32_t seen = b->work_seq.load(std::memory_order_relaxed);
         lk.unlock();
         futex_wait(&b->work_seq, seen, timeout);  // a poke between the unlock and the wait has changed the word: returns at once
         lk.lock();
-        b->dispatcher_idle = false;
+        b->idle_dispatchers--;
     };
     for (;;) {
         // the oldest batch that has requests (sealed ones first: they were opened before the one that is filling)
         Batch *t = nullptr;
         for (int op = 0; op < N_OPS; op++)
-            for (Batch &c : b->batches[op])
-                if ((c.state == SEALED || (c.state == OPEN && c.n > 0)) && (!t || c.first_arrival < t->first_arrival)) t = &c;
+            for (auto &c : b->batches[op])
+                if ((c->state == SEALED || (c->state == OPEN && c->n > 0)) && (!t || c->first_arrival < t->first_arrival)) t = c.get();
         if (!t) {
             if (b->quit) return;
             sleep_until_poked(nullptr);
@@ -523,7 +532,7 @@ void dispatcher(mldsa_batcher *b) {
         lk.unlock();
         // requests that reserved a slot and are still copying their bytes in: microseconds
         while (t->copying.load(std::memory_order_acquire)) std::this_thread::yield();
-        run_batch(b, t);
+        run_batch(b, *ln, t);
         lk.lock();
         b->stats.batches++;
         b->stats.requests += t->n;
@@ -549,8 +558,8 @@ struct Req {
 int submit(mldsa_batcher *b, const Req &r) {
     const mldsa_params *p = b->p;
     std::call_once(b->alloc_once[r.op], [&] {
-        for (Batch &t : b->batches[r.op])
-            if (b->alloc_rc[r.op] == MLDSA_OK) b->alloc_rc[r.op] = alloc_batch(b, t, r.op);
+        for (auto &t : b->batches[r.op])
+            if (b->alloc_rc[r.op] == MLDSA_OK) b->alloc_rc[r.op] = alloc_batch(b, *t, r.op);
     });
     if (b->alloc_rc[r.op] != MLDSA_OK) return set_error(b->alloc_rc[r.op], "mldsa_batcher: no page-locked memory for the staging arrays");
     const uint64_t kh = r.op == OP_KEYGEN ? 0 : hash_key(b->hash_seed, r.key, key_len(b, r.op));  // before the lock: 0.3 us of arithmetic
@@ -629,33 +638,67 @@ int submit(mldsa_batcher *b, const Req &r) {
 
 extern "C" {
 
-int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out) {
-    REQUIRE(out, "mldsa_batcher_create: NULL out");
-    *out = nullptr;
-    REQUIRE(ctx, "mldsa_batcher_create: NULL context");
+static int batcher_make(const std::vector<mldsa_ctx *> &ctxs, bool own, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys,
+                        mldsa_batcher **out) {
     const mldsa_params *p = params_of(set);
-    REQUIRE(p, "mldsa_batcher_create: unknown parameter set");
-    REQUIRE(max_batch >= 1 && max_batch <= (1u << 20), "mldsa_batcher_create: max_batch in 1 ... 2^20");
     std::unique_ptr<mldsa_batcher> b(new (std::nothrow) mldsa_batcher());
     if (!b) return set_error(MLDSA_ERR_NOMEM, "mldsa_batcher_create: host allocation failed");
-    b->ctx = ctx;
     b->p = p;
     b->max_batch = max_batch;
     b->max_wait_us = max_wait_us;
-    // a batch never evicts its own keys, so the table holds at least one batch's worth; default: 1 024 keys or one batch
+    // a batch never evicts its own keys, so a table holds at least one batch's worth; default: 1 024 keys or one batch
     b->cache_keys = std::max(max_batch, cache_keys ? cache_keys : (size_t)1024);
-    REQUIRE(b->cache_keys <= (1u << 22), "mldsa_batcher_create: cache_keys up to 2^22");
     {   // the seed of the key hash: unpredictable to callers, nothing more (clock, addresses)
         timespec ts;
         clock_gettime(CLOCK_MONOTONIC, &ts);
         b->hash_seed = ((uint64_t)ts.tv_nsec * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)ts.tv_sec << 32) ^ (uint64_t)(uintptr_t)b.get() ^ ((uint64_t)getpid() << 48);
     }
+    for (mldsa_ctx *c : ctxs) {
+        b->lanes.emplace_back(new Lane());
+        b->lanes.back()->ctx = c;
+        b->lanes.back()->own_ctx = own;
+    }
     for (int op = 0; op < N_OPS; op++)
-        for (Batch &t : b->batches[op]) t.op = op;
-    b->th = std::thread(dispatcher, b.get());
+        for (size_t i = 0; i < ctxs.size() + 2; i++) {  // one running per lane, one filling, one being read out
+            b->batches[op].emplace_back(new Batch());
+            b->batches[op].back()->op = op;
+        }
+    for (auto &ln : b->lanes) ln->th = std::thread(dispatcher, b.get(), ln.get());
     *out = b.release();
     return MLDSA_OK;
 }
+
+int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out) {
+    REQUIRE(out, "mldsa_batcher_create: NULL out");
+    *out = nullptr;
+    REQUIRE(ctx, "mldsa_batcher_create: NULL context");
+    REQUIRE(params_of(set), "mldsa_batcher_create: unknown parameter set");
+    REQUIRE(max_batch >= 1 && max_batch <= (1u << 20), "mldsa_batcher_create: max_batch in 1 ... 2^20");
+    REQUIRE(cache_keys <= (1u << 22), "mldsa_batcher_create: cache_keys up to 2^22");
+    return batcher_make({ctx}, false, set, max_batch, max_wait_us, cache_keys, out);
+}
+
+int mldsa_batcher_create_on(const int *device_ids, int n, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out) {
+    REQUIRE(out, "mldsa_batcher_create_on: NULL out");
+    *out = nullptr;
+    REQUIRE(device_ids && n >= 1 && n <= 64, "mldsa_batcher_create_on: 1 ... 64 lanes");
+    REQUIRE(params_of(set), "mldsa_batcher_create_on: unknown parameter set");
+    REQUIRE(max_batch >= 1 && max_batch <= (1u << 20), "mldsa_batcher_create_on: max_batch in 1 ... 2^20");
+    REQUIRE(cache_keys <= (1u << 22), "mldsa_batcher_create_on: cache_keys up to 2^22");
+    std::vector<mldsa_ctx *> ctxs;
+    int rc = MLDSA_OK;
+    for (int i = 0; i < n && rc == MLDSA_OK; i++) {
+        mldsa_ctx *c = nullptr;
+        rc = mldsa_ctx_create(device_ids[i], &c);
+        if (rc == MLDSA_OK) ctxs.push_back(c);
+    }
+    if (rc == MLDSA_OK) rc = batcher_make(ctxs, true, set, max_batch, max_wait_us, cache_keys, out);
+    if (rc != MLDSA_OK)
+        for (mldsa_ctx *c : ctxs) mldsa_ctx_destroy(c);
+    return rc;
+}
+
+int mldsa_batcher_lanes(const mldsa_batcher *b) { return b ? (int)b->lanes.size() : MLDSA_ERR_PARAM; }
 
 void mldsa_batcher_destroy(mldsa_batcher *b) {
     if (!b) return;
@@ -665,26 +708,31 @@ void mldsa_batcher_destroy(mldsa_batcher *b) {
         b->work_seq.fetch_add(1, std::memory_order_release);
         b->free_seq.fetch_add(1, std::memory_order_release);
     }
-    futex_wake(&b->work_seq, 1);
+    futex_wake(&b->work_seq, INT_MAX);
     futex_wake(&b->free_seq, INT_MAX);
-    if (b->th.joinable()) b->th.join();
+    for (auto &ln : b->lanes)
+        if (ln->th.joinable()) ln->th.join();
     for (;;) {  // callers still reading their results out
         bool busy = false;
         {
             Lock lk(b->mu);
             for (int op = 0; op < N_OPS; op++)
-                for (Batch &t : b->batches[op]) busy |= t.state != FREE && !(t.state == OPEN && t.n == 0);
+                for (auto &t : b->batches[op]) busy |= t->state != FREE && !(t->state == OPEN && t->n == 0);
         }
         if (!busy) break;
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
-    {
-        DeviceGuard dg(b->ctx->device);
-        if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-        for (KeyTable &kt : b->tables) table_free(b, kt);
-        for (DevBuf *d : {&b->d_kslot, &b->d_moff, &b->d_coff, &b->d_msgs, &b->d_ctxs, &b->d_out0, &b->d_status}) dev_release(*d);
-        dev_release(b->d_in0, true);
-        dev_release(b->d_kstage, true);
+    for (auto &lp : b->lanes) {
+        Lane &ln = *lp;
+        {
+            DeviceGuard dg(ln.ctx->device);
+            if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+            for (KeyTable &kt : ln.tables) table_free(b, kt);
+            for (DevBuf *d : {&ln.d_kslot, &ln.d_moff, &ln.d_coff, &ln.d_msgs, &ln.d_ctxs, &ln.d_out0, &ln.d_status}) dev_release(*d);
+            dev_release(ln.d_in0, true);
+            dev_release(ln.d_kstage, true);
+        }
+        if (ln.own_ctx) mldsa_ctx_destroy(ln.ctx);
     }
     delete b;
 }

@@ -160,12 +160,12 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
 void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
-    (void)hipDeviceSynchronize();
+    (void)device_sync_quiesced();  // (device-wide waits and frees: never while another context captures a stream, ctx.h)
     drop_graphs(ctx);
     host_stage_destroy(ctx);
     if (ctx->ws) {
-        MLDSA_WIPE(hipMemset(ctx->ws, 0, ctx->ws_bytes));  // secrets (y, rho'', s1..) live here: types.rs:19
-        if (!ctx->ws_external) (void)hipFree(ctx->ws);
+        MLDSA_WIPE(memset_quiesced(ctx->ws, 0, ctx->ws_bytes));  // secrets (y, rho'', s1..) live here: types.rs:19
+        if (!ctx->ws_external) (void)free_quiesced(ctx->ws);
     }
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -173,18 +173,18 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->exp_fork_ev) (void)hipEventDestroy(ctx->exp_fork_ev);
     if (ctx->exp_join_ev) (void)hipEventDestroy(ctx->exp_join_ev);
     for (size_t i = 1; i < ctx->helper_streams.size(); i++) (void)hipStreamDestroy(ctx->helper_streams[i]);  // [0] is aux_stream
-    if (ctx->d_probe) (void)hipFree(ctx->d_probe);
+    if (ctx->d_probe) (void)free_quiesced(ctx->d_probe);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->graph_fork_ev) (void)hipEventDestroy(ctx->graph_fork_ev);
     if (ctx->graph_join_ev) (void)hipEventDestroy(ctx->graph_join_ev);
     if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
-    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
+    if (ctx->h_ctl) (void)host_free_quiesced(ctx->h_ctl);
     if (ctx->ws_ev) (void)hipEventDestroy(ctx->ws_ev);
     if (ctx->zero_fork_ev) (void)hipEventDestroy(ctx->zero_fork_ev);
     if (ctx->zero_ev) (void)hipEventDestroy(ctx->zero_ev);
     if (ctx->zero_head_ev) (void)hipEventDestroy(ctx->zero_head_ev);
-    if (ctx->d_fwd_tw) (void)hipFree(ctx->d_fwd_tw);
-    if (ctx->d_inv_tw) (void)hipFree(ctx->d_inv_tw);
+    if (ctx->d_fwd_tw) (void)free_quiesced(ctx->d_fwd_tw);
+    if (ctx->d_inv_tw) (void)free_quiesced(ctx->d_inv_tw);
     delete ctx;
 }
 
@@ -233,7 +233,7 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             REQUIRE(value == 0 || value == 1, "mldsa_set_option: MLDSA_OPT_SIGN_CT0_EXACT is 0 or 1");
             if (ctx->opt_ct0_exact != value) {  // the flag is a kernel argument of captured launches
                 DeviceGuard dg(ctx->device);
-                MLDSA_HIP_CHECK(hipDeviceSynchronize());  // a replayed graph may still be running
+                MLDSA_HIP_CHECK(device_sync_quiesced());  // a replayed graph may still be running
                 drop_graphs(ctx);
             }
             ctx->opt_ct0_exact = value;
@@ -281,12 +281,12 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes) {
     REQUIRE((dev_buf != nullptr) == (bytes != 0), "mldsa_ctx_set_workspace: a buffer and its size, or NULL and 0");
     REQUIRE(((uintptr_t)dev_buf & 255) == 0, "mldsa_ctx_set_workspace: the buffer must be 256-byte aligned");
     std::lock_guard<std::mutex> lk(ctx->op_mutex);
-    MLDSA_HIP_CHECK(hipDeviceSynchronize());  // nothing of the context still runs in the old buffer
+    MLDSA_HIP_CHECK(device_sync_quiesced());  // nothing of the context still runs in the old buffer
     ctx->zero_pending = ctx->zero_head_valid = ctx->zero_wait_after_ea = false;
     drop_graphs(ctx);                         // captured launches point into it
     if (ctx->ws) {
-        MLDSA_WIPE(hipMemset(ctx->ws, 0, ctx->ws_bytes));
-        if (!ctx->ws_external) MLDSA_HIP_CHECK(hipFree(ctx->ws));
+        MLDSA_WIPE(memset_quiesced(ctx->ws, 0, ctx->ws_bytes));
+        if (!ctx->ws_external) MLDSA_HIP_CHECK(free_quiesced(ctx->ws));
     }
     ctx->secret_spans.clear();
     ctx->ws = dev_buf;
@@ -316,7 +316,7 @@ int mldsa_debug_secret_residue(mldsa_ctx *ctx, size_t *scanned_bytes, size_t *no
     std::lock_guard<std::mutex> host_lk(ctx->host_mutex);
     std::lock_guard<std::mutex> lk(ctx->op_mutex);
     // everything the context enqueued has run, the background clearing of the last call included; nothing is cleared HERE
-    MLDSA_HIP_CHECK(hipDeviceSynchronize());
+    MLDSA_HIP_CHECK(device_sync_quiesced());
     size_t scanned = 0, nonzero = 0;
     for (const auto &sp : ctx->secret_spans) {
         if (!ctx->ws || sp.first + sp.second > ctx->ws_bytes) continue;  // the workspace was replaced since (cleared before it was freed)
@@ -348,7 +348,7 @@ int mldsa_ctx_malloc(mldsa_ctx *ctx, void **dev_ptr, size_t bytes) {
 }
 
 int mldsa_free(void *dev_ptr) {
-    if (dev_ptr) MLDSA_HIP_CHECK(hipFree(dev_ptr));
+    if (dev_ptr) MLDSA_HIP_CHECK(free_quiesced(dev_ptr));  // hipFree waits for every stream of the device
     return MLDSA_OK;
 }
 
@@ -356,13 +356,13 @@ int mldsa_host_alloc(void **host_ptr, size_t bytes) {
     REQUIRE(host_ptr, "mldsa_host_alloc: NULL out");
     *host_ptr = nullptr;
     if (bytes == 0) return MLDSA_OK;
-    hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocPortable);
+    hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocPortable | hipHostMallocMapped);  // mapped: small batches of the batcher are read in place
     if (e != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "mldsa_host_alloc", e);
     return MLDSA_OK;
 }
 
 int mldsa_host_free(void *host_ptr) {
-    if (host_ptr) MLDSA_HIP_CHECK(hipHostFree(host_ptr));
+    if (host_ptr) MLDSA_HIP_CHECK(host_free_quiesced(host_ptr));
     return MLDSA_OK;
 }
 
@@ -407,7 +407,7 @@ int mldsa_profile_report(mldsa_ctx *ctx, char *buf, size_t buf_len) {
     REQUIRE(buf && buf_len > 2, "mldsa_profile_report: bad argument");
     ENTER(ctx, "mldsa_profile_report");
     std::lock_guard<std::mutex> lk(ctx->op_mutex);
-    MLDSA_HIP_CHECK(hipDeviceSynchronize());
+    MLDSA_HIP_CHECK(device_sync_quiesced());
     struct Acc { const char *name; double ms; size_t calls; };
     std::vector<Acc> acc;
     for (size_t i = 0; i < ctx->prof_used; i++) {

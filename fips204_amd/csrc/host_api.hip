@@ -99,7 +99,7 @@ bool is_pinned(const void *p, size_t bytes) {
 
 int grow_dev(Buf &b, size_t bytes) {
     if (b.cap >= bytes) return MLDSA_OK;
-    if (b.dev) { HCHECK(hipDeviceSynchronize()); MLDSA_WIPE(hipMemset(b.dev, 0, b.cap)); HCHECK(hipFree(b.dev)); b.dev = nullptr; b.cap = 0; }
+    if (b.dev) { HCHECK(device_sync_quiesced()); MLDSA_WIPE(memset_quiesced(b.dev, 0, b.cap)); HCHECK(free_quiesced(b.dev)); b.dev = nullptr; b.cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
     if (hipMalloc((void **)&b.dev, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: device staging allocation");
     b.cap = want;
@@ -108,7 +108,7 @@ int grow_dev(Buf &b, size_t bytes) {
 
 int grow_pin(Buf &b, size_t bytes) {
     if (b.pin_cap >= bytes) return MLDSA_OK;
-    if (b.pin) { HCHECK(hipDeviceSynchronize()); MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); HCHECK(hipHostFree(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
+    if (b.pin) { HCHECK(device_sync_quiesced()); MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); HCHECK(host_free_quiesced(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
     if (hipHostMalloc((void **)&b.pin, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: page-locked staging allocation");
     b.pin_cap = want;
@@ -197,8 +197,8 @@ void wipe_buf(Buf &b, hipStream_t st) {
 }
 
 void free_buf(Buf &b) {
-    if (b.dev) { MLDSA_WIPE(hipMemset(b.dev, 0, b.cap)); (void)hipFree(b.dev); }
-    if (b.pin) { MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); (void)hipHostFree(b.pin); }
+    if (b.dev) { MLDSA_WIPE(memset_quiesced(b.dev, 0, b.cap)); (void)free_quiesced(b.dev); }
+    if (b.pin) { MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); (void)host_free_quiesced(b.pin); }
     b = Buf();
 }
 
@@ -419,7 +419,7 @@ int mldsa_verify_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *pk, size
         const int r2 = reclaim(sl);
         if (rc == MLDSA_OK) rc = r2;
     }
-    if (rc != MLDSA_OK) (void)hipDeviceSynchronize();
+    if (rc != MLDSA_OK) (void)device_sync_quiesced();
     return rc;
 }
 
@@ -606,7 +606,7 @@ int mldsa_sign_host(mldsa_ctx *ctx, int set, int mode, const uint8_t *sk, size_t
     }();
     // the private keys (wire bytes and expanded fields) and the per-signature randomness leave the staging buffers
     // (the reference zeroizes on drop, types.rs:19)
-    if (rc_all != MLDSA_OK) (void)hipDeviceSynchronize();  // copies of a failed call may still be in flight
+    if (rc_all != MLDSA_OK) (void)device_sync_quiesced();  // copies of a failed call may still be in flight
     for (Buf *b : {&hs->key_bytes, &hs->k_capk, &hs->k_a, &hs->k_b, &hs->k_c}) wipe_buf(*b, hs->comp);
     for (auto &sl : hs->slot) wipe_buf(sl.rnd, hs->comp);
     (void)hipStreamSynchronize(hs->comp);
@@ -666,7 +666,7 @@ int mldsa_keygen_host(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, u
     }
     return rc;
     }();
-    if (rc_all != MLDSA_OK) (void)hipDeviceSynchronize();
+    if (rc_all != MLDSA_OK) (void)device_sync_quiesced();
     for (auto &sl : hs->slot) { wipe_buf(sl.xi, hs->comp); wipe_buf(sl.sk, hs->comp); }  // seeds and private keys
     (void)hipStreamSynchronize(hs->comp);
     return rc_all;

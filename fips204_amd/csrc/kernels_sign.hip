@@ -956,14 +956,14 @@ int count_nonzero_dev(const void* dev, size_t bytes, size_t* nonzero) {
     unsigned long long* d_cnt = nullptr;
     if (hipMalloc((void**)&d_cnt, sizeof(*d_cnt)) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "count_nonzero: counter allocation");
     unsigned long long h_cnt = 0;
-    hipError_t e = hipMemset(d_cnt, 0, sizeof(*d_cnt));
+    hipError_t e = memset_quiesced(d_cnt, 0, sizeof(*d_cnt));
     if (e == hipSuccess) {
         const size_t blocks = std::min<size_t>((bytes / 16 + 256) / 256, 8192);
         hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)blocks), dim3(256), 0, nullptr, static_cast<const uint8_t*>(dev), bytes, d_cnt);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
-    (void)hipFree(d_cnt);
+    (void)free_quiesced(d_cnt);
     if (e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "count_nonzero", e);
     *nonzero = (size_t)h_cnt;
     return MLDSA_OK;

@@ -57,19 +57,24 @@ int reserve_workspace(mldsa_ctx *ctx, const mldsa_params *p, int op, size_t n_op
     }
 }
 
+std::shared_mutex &capture_mutex() {
+    static std::shared_mutex m;
+    return m;
+}
+
 int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return MLDSA_OK;
     if (ctx->ws_external) return set_error(MLDSA_ERR_NOMEM, "workspace: the caller's buffer (mldsa_ctx_set_workspace) is too small for a pass");
     // MLDSA_OPT_WORKSPACE_CAP_MB: a host that shares the device bounds what the context may take
     if (ctx->opt_ws_cap_bytes && bytes > ctx->opt_ws_cap_bytes) return set_error(MLDSA_ERR_NOMEM, "workspace: above MLDSA_OPT_WORKSPACE_CAP_MB");
     // growing replaces the buffer every captured graph points into: wait for whatever still runs, then drop them
-    MLDSA_HIP_CHECK(hipDeviceSynchronize());
+    MLDSA_HIP_CHECK(device_sync_quiesced());  // (no other context of the process captures a stream while the device is waited for)
     // (a background clearing of the previous call's secrets has finished with the device: nothing is pending on the old buffer)
     ctx->zero_pending = ctx->zero_head_valid = ctx->zero_wait_after_ea = false;
     drop_graphs(ctx);
     if (ctx->ws) {
-        MLDSA_WIPE(hipMemset(ctx->ws, 0, ctx->ws_bytes));  // may hold secrets of a previous sign / keygen call
-        MLDSA_HIP_CHECK(hipFree(ctx->ws));
+        MLDSA_WIPE(memset_quiesced(ctx->ws, 0, ctx->ws_bytes));  // may hold secrets of a previous sign / keygen call
+        MLDSA_HIP_CHECK(free_quiesced(ctx->ws));
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
     }
@@ -1125,29 +1130,36 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
         MLDSA_HIP_CHECK(hipEventRecord(ctx->graph_fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(gs, ctx->graph_fork_ev, 0));
     }
+    if (hit->never) {
+        ctx->stats.direct_calls++;
+        return enqueue(s);
+    }
     if (!hit->exec) {
-        // second sighting: capture and instantiate
-        MLDSA_HIP_CHECK(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue(gs);
+        // second sighting: capture and instantiate.  A capture that does not end well -- the application freed device memory on
+        // another thread, which waits for every stream of the device and invalidates captures -- is not an error of the call:
+        // the shape is launched directly, now and from then on.
         hipGraph_t graph = nullptr;
-        const hipError_t ee = hipStreamEndCapture(gs, &graph);
-        if (rc != MLDSA_OK) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
+        int rc;
+        hipError_t ee;
+        {
+            std::shared_lock<std::shared_mutex> cap(capture_mutex());
+            MLDSA_HIP_CHECK(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
+            rc = enqueue(gs);
+            ee = hipStreamEndCapture(gs, &graph);
         }
-        if (ee != hipSuccess || !graph) return set_error(MLDSA_ERR_DEVICE, "hipStreamEndCapture", ee);
         hipGraphExec_t exec = nullptr;
-        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (ei != hipSuccess) {
-            (void)hipGraphDestroy(graph);
-            return set_error(MLDSA_ERR_DEVICE, "hipGraphInstantiate", ei);
-        }
         hipEvent_t done = nullptr;
-        const hipError_t ev = hipEventCreateWithFlags(&done, hipEventDisableTiming);
-        if (ev != hipSuccess) {
-            (void)hipGraphExecDestroy(exec);
-            (void)hipGraphDestroy(graph);
-            return set_error(MLDSA_ERR_DEVICE, "hipEventCreateWithFlags", ev);
+        bool good = rc == MLDSA_OK && ee == hipSuccess && graph;
+        if (good && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { exec = nullptr; good = false; }
+        if (good && hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) { done = nullptr; good = false; }
+        if (!good) {
+            (void)hipGetLastError();
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            hit->never = true;
+            ctx->stats.direct_calls++;
+            if (!s) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->graph_fork_ev, 0));
+            return enqueue(s);  // (a call that failed for a reason of its own fails again here, with its own message)
         }
         hit->graph = graph;
         hit->exec = exec;

@@ -593,14 +593,22 @@ class MlDsaBatcher:
     verify / sign / keygen block the calling thread (ctypes releases the GIL for the duration), the library coalesces whatever
     the threads submit into batched calls on one context.  Byte strings in, byte strings / bool out."""
 
-    def __init__(self, pset, device=0, max_batch=4096, max_wait_us=0, cache_keys=0, hotpath=None):
+    def __init__(self, pset, device=0, max_batch=4096, max_wait_us=0, cache_keys=0, hotpath=None, device_ids=None):
+        """device_ids: mldsa_batcher_create_on -- one lane (context + dispatcher thread + key table) per entry, owned by the batcher;
+        otherwise one lane on `hotpath`'s context (or a new one on `device`)."""
         self.pset = pset
-        self.hp = hotpath or HotPath(device)
-        self.lib = self.hp.lib
         p = _lib.get_params(pset)
         self.PK_LEN, self.SK_LEN, self.SIG_LEN = p.pk_len, p.sk_len, p.sig_len
         h = C.c_void_p()
-        _lib.check(self.lib.mldsa_batcher_create(self.hp._h, pset, max_batch, max_wait_us, cache_keys, C.byref(h)))
+        if device_ids is not None:
+            self.hp = None
+            self.lib = _lib.load()
+            ids = (C.c_int * len(device_ids))(*device_ids)
+            _lib.check(self.lib.mldsa_batcher_create_on(ids, len(device_ids), pset, max_batch, max_wait_us, cache_keys, C.byref(h)))
+        else:
+            self.hp = hotpath or HotPath(device)
+            self.lib = self.hp.lib
+            _lib.check(self.lib.mldsa_batcher_create(self.hp._h, pset, max_batch, max_wait_us, cache_keys, C.byref(h)))
         self._b = h
 
     def close(self):

@@ -7,7 +7,8 @@
 //
 //   g++ -O2 -std=c++17 -I include tools/batcher_bench.cpp -o /tmp/batcher_bench -L fips204_amd/csrc -lmldsa_hip \
 //       -Wl,-rpath,$PWD/fips204_amd/csrc -Wl,-rpath,/opt/rocm/lib -lpthread
-//   /tmp/batcher_bench [set = 65] [seconds per point = 2] [max_wait_us = 0] [threads = 1,8,64,256]     -> one JSON object on stdout
+//   /tmp/batcher_bench [set = 65] [seconds per point = 2] [max_wait_us = 0] [threads = 1,8,64,256] [lanes = 1]   -> one JSON object on stdout
+// lanes > 1: mldsa_batcher_create_on({0, 0, ...}): that many dispatchers (contexts) on GPU 0
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -37,6 +38,7 @@ int main(int argc, char **argv) {
         while (*q && *q != ',') q++;
         if (*q == ',') q++;
     }
+    const int lanes = argc > 5 ? atoi(argv[5]) : 1;
     mldsa_params p;
     CHECK(mldsa_get_params(set, &p));
     mldsa_ctx *ctx;
@@ -74,7 +76,7 @@ int main(int argc, char **argv) {
     }
 
     std::string json = "{\"tool\": \"tools/batcher_bench.cpp\", \"set\": " + std::to_string(set) + ", \"seconds_per_point\": " + std::to_string(dur) +
-                       ", \"max_wait_us\": " + std::to_string(max_wait) + ", \"keys\": " + std::to_string(NK) + ", \"host_cpus_online\": " + std::to_string(std::thread::hardware_concurrency()) +
+                       ", \"max_wait_us\": " + std::to_string(max_wait) + ", \"lanes\": " + std::to_string(lanes) + ", \"keys\": " + std::to_string(NK) + ", \"host_cpus_online\": " + std::to_string(std::thread::hardware_concurrency()) +
                        ", \"one_call_at_a_time_n_ops_1\": {\"verify_us\": " + std::to_string(direct_us[0]) + ", \"sign_us\": " + std::to_string(direct_us[1]) +
                        ", \"verify_calls_per_s\": " + std::to_string(1e6 / direct_us[0]) + ", \"sign_calls_per_s\": " + std::to_string(1e6 / direct_us[1]) + "}";
     const char *names[2] = {"verify", "sign"};
@@ -83,7 +85,8 @@ int main(int argc, char **argv) {
         bool first = true;
         for (int T : thread_counts) {
             mldsa_batcher *b;
-            CHECK(mldsa_batcher_create(ctx, set, 8192, max_wait, 0, &b));
+            if (lanes <= 1) CHECK(mldsa_batcher_create(ctx, set, 8192, max_wait, 0, &b));
+            else { std::vector<int> ids((size_t)lanes, 0); CHECK(mldsa_batcher_create_on(ids.data(), lanes, set, 8192, max_wait, 0, &b)); }
             std::atomic<bool> go{false}, stop{false};
             std::atomic<uint64_t> bad{0};
             std::vector<std::vector<float>> lat((size_t)T);
@@ -100,7 +103,9 @@ int main(int argc, char **argv) {
                         if (op == 0) rc = mldsa_batcher_verify(b, MLDSA_MODE_PURE, pk.data() + kidx[i] * (size_t)p.pk_len, msgs.data() + 32 * i, 32, nullptr, 0, sigs.data() + i * (size_t)p.sig_len, &ok1);
                         else rc = mldsa_batcher_sign(b, MLDSA_MODE_PURE, sk.data() + kidx[i] * (size_t)p.sk_len, msgs.data() + 32 * i, 32, nullptr, 0, rnd.data() + 32 * i, s1.data());
                         lat[(size_t)t].push_back((float)(secs(a, clk::now()) * 1e6));
-                        if (rc != MLDSA_OK || (op == 0 && !ok1) || (op == 1 && memcmp(s1.data(), sigs.data() + i * (size_t)p.sig_len, (size_t)p.sig_len))) bad++;
+                        if (rc != MLDSA_OK || (op == 0 && !ok1) || (op == 1 && memcmp(s1.data(), sigs.data() + i * (size_t)p.sig_len, (size_t)p.sig_len))) {
+                            if (bad++ == 0) fprintf(stderr, "first wrong result: rc = %d (%s)\n", rc, rc != MLDSA_OK ? mldsa_last_error() : "result differs");
+                        }
                         i = (i + 977) % NM;
                     }
                 });
