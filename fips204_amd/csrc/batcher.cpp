@@ -280,7 +280,7 @@ int dev_reserve(DevBuf &d, size_t bytes, bool secret = false) {
         d.bytes = 0;
     }
     void *q = nullptr;
-    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return set_error(MLDSA_ERR_NOMEM, "mldsa_batcher: device staging allocation"); }
+    if (malloc_quiesced(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return set_error(MLDSA_ERR_NOMEM, "mldsa_batcher: device staging allocation"); }
     d.p = static_cast<uint8_t *>(q);
     d.bytes = bytes;
     return MLDSA_OK;
@@ -301,7 +301,7 @@ int table_alloc(mldsa_batcher *b, KeyTable &kt, bool is_private) {
     const size_t n = b->cache_keys, K = (size_t)p->k, L = (size_t)p->l, kl = is_private ? (size_t)p->sk_len : (size_t)p->pk_len;
     kt.is_private = is_private;
     auto get = [&](void **q, size_t bytes) -> int {
-        if (hipMalloc(q, bytes) != hipSuccess) { (void)hipGetLastError(); return set_error(MLDSA_ERR_NOMEM, "mldsa_batcher: key table allocation"); }
+        if (malloc_quiesced(q, bytes) != hipSuccess) { (void)hipGetLastError(); return set_error(MLDSA_ERR_NOMEM, "mldsa_batcher: key table allocation"); }
         return MLDSA_OK;
     };
     BTRY(get((void **)&kt.rho, n * 32));

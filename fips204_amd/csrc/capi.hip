@@ -131,10 +131,10 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
         return set_error(MLDSA_ERR_PARAM, e.what());
     }
     static_assert(sizeof(HostTwiddle) == sizeof(Twiddle), "twiddle layout");
-    hipError_t e = hipMalloc((void **)&ctx->d_fwd_tw, f.size() * sizeof(Twiddle));
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_inv_tw, i.size() * sizeof(Twiddle));
-    if (e == hipSuccess) e = hipMemcpy(ctx->d_fwd_tw, f.data(), f.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(ctx->d_inv_tw, i.data(), i.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
+    hipError_t e = malloc_quiesced((void **)&ctx->d_fwd_tw, f.size() * sizeof(Twiddle));
+    if (e == hipSuccess) e = malloc_quiesced((void **)&ctx->d_inv_tw, i.size() * sizeof(Twiddle));
+    if (e == hipSuccess) e = memcpy_quiesced(ctx->d_fwd_tw, f.data(), f.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = memcpy_quiesced(ctx->d_inv_tw, i.data(), i.size() * sizeof(Twiddle), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
@@ -147,7 +147,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->h_ctl, 2 * sizeof(RoundCtl));
+    if (e == hipSuccess) e = host_malloc_quiesced((void **)&ctx->h_ctl, 2 * sizeof(RoundCtl));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
@@ -337,7 +337,7 @@ int mldsa_malloc(void **dev_ptr, size_t bytes) {
     REQUIRE(dev_ptr, "mldsa_malloc: NULL out");
     *dev_ptr = nullptr;
     if (bytes == 0) return MLDSA_OK;
-    hipError_t e = hipMalloc(dev_ptr, bytes);
+    hipError_t e = malloc_quiesced(dev_ptr, bytes);
     if (e != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "mldsa_malloc", e);
     return MLDSA_OK;
 }
@@ -356,7 +356,7 @@ int mldsa_host_alloc(void **host_ptr, size_t bytes) {
     REQUIRE(host_ptr, "mldsa_host_alloc: NULL out");
     *host_ptr = nullptr;
     if (bytes == 0) return MLDSA_OK;
-    hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocPortable | hipHostMallocMapped);  // mapped: small batches of the batcher are read in place
+    hipError_t e = host_malloc_quiesced(host_ptr, bytes, hipHostMallocPortable | hipHostMallocMapped);  // mapped: small batches of the batcher are read in place
     if (e != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "mldsa_host_alloc", e);
     return MLDSA_OK;
 }

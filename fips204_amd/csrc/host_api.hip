@@ -101,7 +101,7 @@ int grow_dev(Buf &b, size_t bytes) {
     if (b.cap >= bytes) return MLDSA_OK;
     if (b.dev) { HCHECK(device_sync_quiesced()); MLDSA_WIPE(memset_quiesced(b.dev, 0, b.cap)); HCHECK(free_quiesced(b.dev)); b.dev = nullptr; b.cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    if (hipMalloc((void **)&b.dev, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: device staging allocation");
+    if (malloc_quiesced((void **)&b.dev, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: device staging allocation");
     b.cap = want;
     return MLDSA_OK;
 }
@@ -110,7 +110,7 @@ int grow_pin(Buf &b, size_t bytes) {
     if (b.pin_cap >= bytes) return MLDSA_OK;
     if (b.pin) { HCHECK(device_sync_quiesced()); MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); HCHECK(host_free_quiesced(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
-    if (hipHostMalloc((void **)&b.pin, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: page-locked staging allocation");
+    if (host_malloc_quiesced((void **)&b.pin, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: page-locked staging allocation");
     b.pin_cap = want;
     return MLDSA_OK;
 }

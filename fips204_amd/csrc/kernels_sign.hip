@@ -954,7 +954,7 @@ int count_nonzero_dev(const void* dev, size_t bytes, size_t* nonzero) {
     *nonzero = 0;
     if (bytes == 0) return MLDSA_OK;
     unsigned long long* d_cnt = nullptr;
-    if (hipMalloc((void**)&d_cnt, sizeof(*d_cnt)) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "count_nonzero: counter allocation");
+    if (malloc_quiesced((void**)&d_cnt, sizeof(*d_cnt)) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "count_nonzero: counter allocation");
     unsigned long long h_cnt = 0;
     hipError_t e = memset_quiesced(d_cnt, 0, sizeof(*d_cnt));
     if (e == hipSuccess) {
@@ -962,7 +962,7 @@ int count_nonzero_dev(const void* dev, size_t bytes, size_t* nonzero) {
         hipLaunchKernelGGL(k_count_nonzero, dim3((unsigned)blocks), dim3(256), 0, nullptr, static_cast<const uint8_t*>(dev), bytes, d_cnt);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = memcpy_quiesced(&h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
     (void)free_quiesced(d_cnt);
     if (e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "count_nonzero", e);
     *nonzero = (size_t)h_cnt;

@@ -79,7 +79,7 @@ int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
         ctx->ws_bytes = 0;
     }
     ctx->secret_spans.clear();
-    hipError_t e = hipMalloc(&ctx->ws, bytes);
+    hipError_t e = malloc_quiesced(&ctx->ws, bytes);
     if (e != hipSuccess) {
         ctx->ws = nullptr;
         (void)hipGetLastError();
@@ -1022,7 +1022,7 @@ __global__ void k_probe_touch(unsigned *p) {
 
 bool streams_serialise(mldsa_ctx *ctx, hipStream_t a, hipStream_t b) {
     if (a == b) return true;
-    if (!ctx->d_probe && hipMalloc((void **)&ctx->d_probe, 256) != hipSuccess) return false;
+    if (!ctx->d_probe && malloc_quiesced((void **)&ctx->d_probe, 256) != hipSuccess) return false;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     (void)hipStreamSynchronize(a);
     (void)hipStreamSynchronize(b);
@@ -1143,9 +1143,9 @@ int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key,
         hipError_t ee;
         {
             std::shared_lock<std::shared_mutex> cap(capture_mutex());
-            MLDSA_HIP_CHECK(hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal));
-            rc = enqueue(gs);
-            ee = hipStreamEndCapture(gs, &graph);
+            ee = hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal);
+            rc = ee == hipSuccess ? enqueue(gs) : MLDSA_ERR_DEVICE;
+            if (ee == hipSuccess) ee = hipStreamEndCapture(gs, &graph);
         }
         hipGraphExec_t exec = nullptr;
         hipEvent_t done = nullptr;

@@ -746,3 +746,70 @@ def test_graph_cache_outlives_the_stream_it_was_filled_on(sets):
         assert hip.hipStreamDestroy(raw) == 0
     st = m.hp.stats()
     assert st["graphs_captured"] - captured0 >= 50   # more shapes than the cache holds: entries of the dead stream were replaced
+
+
+def test_captures_survive_device_wide_waits_on_other_threads(sets):
+    """hipDeviceSynchronize / hipFree wait for every stream of the device, and waiting for a stream that is being captured invalidates
+    the capture.  While one thread signs small batches of ever new shapes (second sighting = capture, third = replay) two others
+    keep waiting for the device: a second CONTEXT growing its workspace over and over (ensure_workspace: kept apart from captures
+    by the library's lock), and raw hipDeviceSynchronize + hipMalloc / hipFree (invisible to the library: a capture that does not
+    end well falls back to direct launches).  Every call succeeds and every signature equals the oracle's.  (Before: MLDSA_ERR_DEVICE
+    "operation failed due to a previous error during capture" for the call and every later one of its shape -- found with four
+    batcher lanes on one GPU.)"""
+    import threading
+    from fips204_amd.hotpath import HotPath
+    m = sets[44]
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(31)
+    xi = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+    sks = m.private_keys_from_bytes(m.keygen_from_seed(dev(xi))[1])
+    _, sk_o = orc.keygen_from_seed(44, xi[0].tobytes())
+    stop = threading.Event()
+    waits = [0, 0]
+    errors = []
+
+    def grow_another_context():
+        try:
+            torch.cuda.set_device(0)
+            while not stop.is_set():
+                other = HotPath(0)
+                for n in (64, 256, 1024, 4096):   # every step replaces the workspace: device-wide wait + hipFree + hipMalloc
+                    other.reserve(65, 2, n)
+                    waits[0] += 1
+                other.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def wait_raw():
+        torch.cuda.set_device(0)
+        while not stop.is_set():
+            p = C.c_void_p()
+            hip.hipDeviceSynchronize()   # (the runtime may refuse it beside a capture: hipErrorStreamCaptureUnsupported -- the caller's problem)
+            if hip.hipMalloc(C.byref(p), 1 << 20) == 0:
+                hip.hipFree(p)
+            waits[1] += 1
+
+    threads = [threading.Thread(target=grow_another_context), threading.Thread(target=wait_raw)]
+    for t in threads:
+        t.start()
+    try:
+        for n in range(1, 41):
+            msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            rnd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            d_msg, d_off, d_rnd = dev(msgs.reshape(-1)), dev_off(np.arange(n + 1) * 32), dev(rnd)
+            kidx = torch.zeros(n, dtype=torch.int32, device="cuda")
+            sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+            for _ in range(3):
+                sig.zero_()
+                m.sign_device(sks, d_msg, d_off, d_rnd, sig, n, key_idx=kidx)   # raises on any error return
+                got = host(sig)
+                j = int(rng.integers(0, n))
+                assert got[j].tobytes() == orc.sign_internal(44, sk_o, msgs[j].tobytes(), rnd[j].tobytes(), mode=orc.MODE_PURE), (n, j)
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+    assert not errors, errors
+    assert waits[0] > 8 and waits[1] > 20
