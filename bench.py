@@ -1231,12 +1231,14 @@ def run_single_op_callers(pset=65, seconds=1.5, threads="1,8,32,64"):
         try:
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "batcher_bench.cpp"),
                                    "-o", exe, f"-L{libdir}", "-lmldsa_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
-            out = subprocess.run([exe, str(pset), str(seconds), "0", threads], capture_output=True, text=True, timeout=600)
+            res = {}
+            for lanes in (1, 2):  # one dispatcher, and two on the one GPU (mldsa_batcher_create_on: small batches overlap on the device)
+                out = subprocess.run([exe, str(pset), str(seconds), "0", threads, str(lanes)], capture_output=True, text=True, timeout=600)
+                if out.returncode != 0:
+                    return {"skipped": "tools/batcher_bench.cpp failed: " + out.stderr[-300:]}
+                res[f"lanes_{lanes}"] = json.loads(out.stdout)
         except (subprocess.CalledProcessError, subprocess.TimeoutExpired) as e:
             return {"skipped": f"tools/batcher_bench.cpp: {e}"}
-        if out.returncode != 0:
-            return {"skipped": "tools/batcher_bench.cpp failed: " + out.stderr[-300:]}
-        res = json.loads(out.stdout)
     res["usable_cores"] = usable_cores()
     return res
 
