@@ -91,6 +91,27 @@ int main(void) {
     printf("secret residue: %zu non-zero bytes of %zu scanned\n", nonzero, scanned);
     if (nonzero) return 5;
 
+    /* the reference's own call shape, one operation per call (src/lib.rs:268-296, 364-380): through a batcher, which would coalesce the
+     * calls of concurrent threads; here one thread: op 3 signed again (the same bytes as in the batch: rnd is all-zero) and verified */
+    {
+        mldsa_batcher *bt = NULL;
+        mldsa_batcher_stats st;
+        uint8_t *one = malloc((size_t)p.sig_len), ok1 = 0, ok2 = 1;
+        const uint8_t *m3 = msgs + off[3];
+        const size_t l3 = (size_t)(off[4] - off[3]);
+        CHECK(mldsa_batcher_create(ctx, MLDSA_65, 64, 0, 0, &bt));
+        CHECK(mldsa_batcher_sign(bt, MLDSA_MODE_PURE, sk + (size_t)key_idx[3] * p.sk_len, m3, l3, NULL, 0, rnd + 3 * 32, one));
+        CHECK(mldsa_batcher_verify(bt, MLDSA_MODE_PURE, pk + (size_t)key_idx[3] * p.pk_len, m3, l3, NULL, 0, one, &ok1));
+        CHECK(mldsa_batcher_verify(bt, MLDSA_MODE_PURE, pk + (size_t)key_idx[2] * p.pk_len, m3, l3, NULL, 0, one, &ok2));
+        CHECK(mldsa_batcher_get_stats(bt, &st));
+        printf("batcher: signature %s the batch's, verified %d, under another key %d, %llu requests in %llu batches\n",
+               memcmp(one, sig + 3 * (size_t)p.sig_len, (size_t)p.sig_len) ? "differs from" : "equals", ok1, ok2,
+               (unsigned long long)st.requests, (unsigned long long)st.batches);
+        if (memcmp(one, sig + 3 * (size_t)p.sig_len, (size_t)p.sig_len) || !ok1 || ok2 || st.requests != 3) return 6;
+        mldsa_batcher_destroy(bt);
+        free(one);
+    }
+
     mldsa_free(d_pk); mldsa_free(d_msgs); mldsa_free(d_off); mldsa_free(d_kidx); mldsa_free(d_sig); mldsa_free(d_ok);
     mldsa_ctx_destroy(ctx);
     free(pk); free(sk); free(sig);
