@@ -22,6 +22,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <climits>
@@ -31,8 +32,9 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <vector>
 
-#include "ctx.h"
+#include "host_common.h"
 
 using namespace mldsa;
 
@@ -275,7 +277,7 @@ int dev_reserve(DevBuf &d, size_t bytes, bool secret = false) {
     if (bytes <= d.bytes) return MLDSA_OK;
     if (d.p) {
         if (secret) (void)memset_quiesced(d.p, 0, d.bytes);
-        BCHECK(free_quiesced(d.p));  // hipFree waits for every stream of the device: not while another lane or context captures one (ctx.h)
+        BCHECK(free_quiesced(d.p));  // hipFree waits for every stream of the device: not while another lane or context captures one (host_common.h)
         d.p = nullptr;
         d.bytes = 0;
     }
@@ -416,7 +418,7 @@ int resolve_keys(mldsa_batcher *b, Lane &ln, Batch *t, std::vector<uint32_t> &sl
 int run_keyed(mldsa_batcher *b, Lane &ln, Batch *t) {
     const mldsa_params *p = b->p;
     const size_t n = t->n, sgl = (size_t)p->sig_len;
-    DeviceGuard dg(ln.ctx->device);
+    DeviceGuard dg(mldsa_ctx_device(ln.ctx));
     if (!ln.stream) BCHECK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
     std::vector<uint32_t> slot_of;
     BTRY(resolve_keys(b, ln, t, slot_of));
@@ -484,7 +486,7 @@ void run_batch(mldsa_batcher *b, Lane &ln, Batch *t) {
     if (t->op == OP_KEYGEN) rc = mldsa_keygen_host(ln.ctx, b->p->set, t->in0.p, t->out0.p, t->out1.p, t->n);
     else {
         rc = run_keyed(b, ln, t);
-        if (rc != MLDSA_OK && ln.stream) { DeviceGuard dg(ln.ctx->device); (void)hipStreamSynchronize(ln.stream); }
+        if (rc != MLDSA_OK && ln.stream) { DeviceGuard dg(mldsa_ctx_device(ln.ctx)); (void)hipStreamSynchronize(ln.stream); }
     }
     t->rc = rc;
     if (rc != MLDSA_OK) { const char *e = mldsa_last_error(); t->err = e ? e : ""; }
@@ -725,7 +727,7 @@ void mldsa_batcher_destroy(mldsa_batcher *b) {
     for (auto &lp : b->lanes) {
         Lane &ln = *lp;
         {
-            DeviceGuard dg(ln.ctx->device);
+            DeviceGuard dg(mldsa_ctx_device(ln.ctx));
             if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
             for (KeyTable &kt : ln.tables) table_free(b, kt);
             for (DevBuf *d : {&ln.d_kslot, &ln.d_moff, &ln.d_coff, &ln.d_msgs, &ln.d_ctxs, &ln.d_out0, &ln.d_status}) dev_release(*d);

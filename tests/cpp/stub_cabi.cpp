@@ -254,6 +254,49 @@ int mldsa_verify_host(mldsa_ctx *c, int set, int mode, const uint8_t *pk, size_t
     return verify_core(p, mode, rho.data(), tr.data(), n_keys, key_idx, msgs, moff, ctxs, coff, sigs, ok, n_ops);
 }
 
+// ---- what csrc/batcher.cpp calls (tests/cpp/test_batcher_tsan.cpp runs the REAL batcher over these stand-ins under ThreadSanitizer):
+// page-locked memory = heap memory; "A_hat" of a key = its rho in the first eight coefficients, so that the *_cached_a calls can
+// form the same digests as mldsa_sign / mldsa_verify and a stale or foreign table slot shows as a wrong signature / verdict
+int mldsa_host_alloc(void **p, size_t n) { *p = n ? std::calloc(1, n) : nullptr; return (n && !*p) ? fail(MLDSA_ERR_NOMEM, "host_alloc") : 0; }
+int mldsa_host_free(void *p) { std::free(p); return 0; }
+int mldsa_expand_a(mldsa_ctx *c, int set, const uint8_t *rho, int32_t *a_hat, size_t n, void *) {
+    const mldsa_params *p = pp(set);
+    if (!c || !p) return fail(MLDSA_ERR_PARAM, "expand_a");
+    const size_t per = (size_t)p->k * (size_t)p->l * 256;
+    for (size_t i = 0; i < n; i++) {
+        Fnv f; f.add(rho + 32 * i, 32);
+        for (size_t j = 0; j < per; j++) a_hat[i * per + j] = (int32_t)((f.h + j * 2654435761u) & 0x7FFFFF);
+        std::memcpy(a_hat + i * per, rho + 32 * i, 32);
+    }
+    return 0;
+}
+static void rho_of_a(const mldsa_params *p, const int32_t *a_hat, size_t n_keys, std::vector<uint8_t> &rho) {
+    const size_t per = (size_t)p->k * (size_t)p->l * 256;
+    rho.resize(n_keys * 32);
+    for (size_t i = 0; i < n_keys; i++) std::memcpy(&rho[32 * i], a_hat + i * per, 32);
+}
+int mldsa_verify_cached_a(mldsa_ctx *c, int set, int mode, const int32_t *a_hat, const uint8_t *tr, const int32_t *t1, size_t n_keys, const uint32_t *key_idx,
+                          const uint8_t *msgs, const uint64_t *moff, const uint8_t *ctxs, const uint64_t *coff, const uint8_t *sigs, uint8_t *ok, size_t n_ops,
+                          void *) {
+    const mldsa_params *p = pp(set);
+    if (!c || !p) return fail(MLDSA_ERR_PARAM, "verify_cached_a");
+    (void)t1;  // (the table has slots that were never filled: only the slots the ops name are read)
+    std::vector<uint8_t> rho;
+    rho_of_a(p, a_hat, n_keys, rho);
+    return verify_core(p, mode, rho.data(), tr, n_keys, key_idx, msgs, moff, ctxs, coff, sigs, ok, n_ops);
+}
+int mldsa_sign_cached_a(mldsa_ctx *c, int set, int mode, const int32_t *a_hat, const uint8_t *cap_k, const uint8_t *tr, const int32_t *s1, const int32_t *s2,
+                        const int32_t *t0, size_t n_keys, const uint32_t *key_idx, const uint8_t *msgs, const uint64_t *moff, const uint8_t *ctxs,
+                        const uint64_t *coff, const uint8_t *rnd, uint8_t *sigs, int32_t *status, size_t n_ops, void *) {
+    const mldsa_params *p = pp(set);
+    if (!c || !p) return fail(MLDSA_ERR_PARAM, "sign_cached_a");
+    (void)cap_k; (void)s1; (void)s2; (void)t0;
+    Fnv touch; touch.add(rnd, n_ops * 32); (void)touch.h;
+    std::vector<uint8_t> rho;
+    rho_of_a(p, a_hat, n_keys, rho);
+    return sign_core(p, mode, rho.data(), tr, n_keys, key_idx, msgs, moff, ctxs, coff, sigs, status, n_ops);
+}
+
 // ---- groups: the real library's slice arithmetic (csrc/group.hip), run sequentially
 int mldsa_group_shard(size_t n_ops, int n_parts, int part, size_t *first, size_t *count) {
     if (n_parts < 1 || part < 0 || part >= n_parts || !first || !count) return fail(MLDSA_ERR_PARAM, "shard");

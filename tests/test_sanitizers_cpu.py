@@ -4,7 +4,9 @@ GPU AddressSanitizer does not exist on the pool, so the CPU-side code runs under
   * the oracle (oracle/mldsa_oracle.c built as liboracle_asan.so, oracle/Makefile) through the reference's ACVP KATs and
     through arbitrary / out-of-range key bytes, in a subprocess with the ASan runtime preloaded;
   * the C++ host mirror (fips204_amd/host/fips204_hip.hpp: argument packing, RAII device buffers, group calls) and its
-    SHA-256 / SHA-512 / SHAKE128 (prehash.hpp) over a stub C ABI whose buffers are exactly sized (tests/cpp/stub_cabi.cpp).
+    SHA-256 / SHA-512 / SHAKE128 (prehash.hpp) over a stub C ABI whose buffers are exactly sized (tests/cpp/stub_cabi.cpp);
+  * the REAL csrc/batcher.cpp (host code: queues, spinlock, futex wake-ups, key table) over stand-ins for the device
+    (stub_cabi.cpp, stub_hip.cpp) under ThreadSanitizer, and once more under ASan + UBSan.
 """
 import hashlib
 import os
@@ -37,6 +39,26 @@ def test_cpp_mirror_under_asan_ubsan(tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     assert out.stdout.startswith("OK 69 hash vectors"), out.stdout
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_batcher_under_sanitizers(tmp_path, sanitizer):
+    """csrc/batcher.cpp is plain C++ over the C ABI and a dozen HIP runtime calls: built here with g++ against stand-ins for both,
+    24 threads of random single-operation calls (one and three lanes, 40 keys over 16 table slots, batches of 8), every result
+    compared with the batched stand-in's.  ThreadSanitizer sees every access to the shared state (the synchronisation is C++
+    atomics; the futex calls only park threads); ASan + UBSan see the staging arithmetic."""
+    if sanitizer == "thread" and not _runtime("libtsan.so"):
+        pytest.skip("no libtsan.so next to gcc")
+    exe = tmp_path / "batcher_san"
+    src = [os.path.join(ROOT, "fips204_amd", "csrc", "batcher.cpp")] + [os.path.join(ROOT, "tests", "cpp", f) for f in
+                                                                        ("stub_cabi.cpp", "stub_hip.cpp", "test_batcher_tsan.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all", "-pthread", "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "fips204_amd", "csrc")] + src + ["-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1",
+                                  UBSAN_OPTIONS="print_stacktrace=1"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.stdout[-1000:], out.stderr[-4000:])
+    assert "ThreadSanitizer" not in out.stderr and "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-4000:]
 
 
 _ARBITRARY_KEYS = r"""
