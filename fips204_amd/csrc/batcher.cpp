@@ -405,7 +405,7 @@ int resolve_keys(mldsa_batcher *b, Lane &ln, Batch *t, std::vector<uint32_t> &sl
         if (rc == MLDSA_OK) rc = mldsa_expand_a(ln.ctx, p->set, kt.rho + s * 32, kt.a_hat + s * K * L * 256, u.count, ln.stream);
     }
     if (priv) {  // the wire bytes of private keys leave the staging buffers with the batch
-        if (rc == MLDSA_OK && hipMemsetAsync(ln.d_kstage.p, 0, miss.size() * kl, ln.stream) != hipSuccess) (void)hipGetLastError();
+        if (ln.d_kstage.p && hipMemsetAsync(ln.d_kstage.p, 0, std::min(ln.d_kstage.bytes, miss.size() * kl), ln.stream) != hipSuccess) (void)hipGetLastError();
         if (hipStreamSynchronize(ln.stream) != hipSuccess) (void)hipGetLastError();  // the upload has read the page-locked copy
         std::memset(ln.kstage.p, 0, miss.size() * kl);
     }
