@@ -238,6 +238,15 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             }
             ctx->opt_ct0_exact = value;
             return MLDSA_OK;
+        case MLDSA_OPT_COOP_HASH:
+            REQUIRE(value == 0 || value == 1, "mldsa_set_option: MLDSA_OPT_COOP_HASH is 0 or 1");
+            if (ctx->opt_coop_hash != value) {  // which kernel a captured call launches
+                DeviceGuard dg(ctx->device);
+                MLDSA_HIP_CHECK(device_sync_quiesced());
+                drop_graphs(ctx);
+            }
+            ctx->opt_coop_hash = value;
+            return MLDSA_OK;
         case MLDSA_OPT_WORKSPACE_CAP_MB:
             REQUIRE(value >= 0 && value <= (1L << 20), "mldsa_set_option: MLDSA_OPT_WORKSPACE_CAP_MB out of range");
             ctx->opt_ws_cap_bytes = (size_t)value << 20;
@@ -260,6 +269,7 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option) {
         case MLDSA_OPT_SIGN_LOOKAHEAD: return ctx->opt_lookahead;
         case MLDSA_OPT_SIGN_ASYNC_EXP: return std::lround(-std::log10(ctx->async_stop));
         case MLDSA_OPT_WORKSPACE_CAP_MB: return (long)(ctx->opt_ws_cap_bytes >> 20);
+        case MLDSA_OPT_COOP_HASH: return ctx->opt_coop_hash;
         default: return MLDSA_ERR_PARAM;
     }
 }

@@ -11,6 +11,7 @@
 #include "challenge_dev.h"
 #include "sampler_dev.h"
 #include "keccak.h"
+#include "keccak_coop.h"
 #include "ntt_wave.h"
 #include "rounding.h"
 
@@ -18,6 +19,7 @@ namespace mldsa {
 
 constexpr int CWAVES = 4;
 constexpr int CBLOCK = 64 * CWAVES;
+constexpr size_t COOP_HASH_MAX_OPS = 4096;  // (MLDSA_OPT_COOP_HASH = 0 switches the cooperative form off)
 
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for_c(F&& f) {
@@ -394,6 +396,64 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
     }
 }
 
+// The same hash for SMALL batches: one state per half-wave (keccak_coop.h), 3.8 instead of 9.4 us per permutation.  Same arguments, same
+// results (ALIGNED is not needed: every load is a byte-granular dword load).  Lanes holding state words 0 .. 16 fetch their eight
+// bytes of each rate block straight from A | B | tail | pad; the digest leaves through the lanes holding words 0 .. OUT / 8 - 1.
+template <int OUT>
+__global__ __launch_bounds__(CBLOCK) void k_shake256_2_coop(const uint8_t* __restrict__ a, size_t sa, int la, const uint32_t* __restrict__ a_idx,
+                                                            const uint8_t* __restrict__ b, size_t sb, int lb, uint32_t tail, int tail_len,
+                                                            uint8_t* __restrict__ out, size_t so, size_t n_ops, const uint32_t* __restrict__ n_dev,
+                                                            VerdictArgs vd, const uint32_t* __restrict__ b_idx) {
+    const int lane = threadIdx.x & 63, half = lane >> 5;
+    const CoopLane c = coop_lane(lane);
+    if (n_dev) n_ops = *n_dev;
+    const int total = la + lb + tail_len, blocks = total / SHAKE256_RATE + 1;  // the pad always fits in the last block
+    const size_t wave0 = ((size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6)) * 2, stride = (size_t)gridDim.x * CWAVES * 2;
+    for (size_t op0 = wave0; op0 < n_ops; op0 += stride) {  // wave-uniform
+        const size_t op = op0 + half;
+        const bool valid = op < n_ops;
+        const size_t opc = valid ? op : op0;  // the odd half of the last pair recomputes its neighbour's hash: loads stay legal
+        const uint8_t* pa = a + (a_idx ? a_idx[opc] : opc) * sa;
+        const uint8_t* pb = b ? b + (b_idx ? b_idx[opc] : opc) * sb : pa;
+        auto msg_dword = [&](int off) -> uint32_t {  // la, lb are multiples of 4: a dword never straddles A | B
+            if (off + 4 <= la) return load_le32(pa + off);
+            if (off + 4 <= la + lb) return load_le32(pb + (off - la));
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = off + k - (la + lb);  // position in tail | pad
+                const uint32_t byte = t < tail_len ? (tail >> (8 * t)) & 0xFFu : t == tail_len ? 0x1Fu : 0u;
+                v |= byte << (8 * k);
+            }
+            if (off + 4 == blocks * SHAKE256_RATE) v |= 0x80000000u;
+            return v;
+        };
+        uint32_t lo = 0, hi = 0;
+        const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
+        for (int blk = 0; blk < blocks; blk++) {
+            if (absorbs) {
+                const int off = blk * SHAKE256_RATE + 8 * c.word;
+                lo ^= msg_dword(off);
+                hi ^= msg_dword(off + 4);
+            }
+            keccak_f1600_coop(lo, hi, c);
+        }
+        const bool digest = c.active && c.word < OUT / 8;
+        if (vd.ok) {
+            const uint8_t* c0 = vd.sigs + opc * vd.sig_len + 8 * c.word;  // c_tilde opens the signature (encodings.rs:251)
+            const bool differs = digest && ((lo ^ load_le32(c0)) | (hi ^ load_le32(c0 + 4))) != 0;
+            const unsigned long long any = __ballot(differs);
+            const uint32_t mine = half ? (uint32_t)(any >> 32) : (uint32_t)any;
+            if (valid && c.first) vd.ok[op] = (uint8_t)(mine == 0 && vd.znorm[op] < vd.zbound && vd.hvalid[op] && !vd.ctx_bad[op]);
+        } else if (valid && digest) {
+            typedef uint32_t __attribute__((aligned(1))) u32_unaligned;  // (any alignment: pk / sk rows are odd-sized)
+            uint8_t* po = out + op * so + 8 * c.word;
+            *reinterpret_cast<u32_unaligned*>(po) = lo;
+            *reinterpret_cast<u32_unaligned*>(po + 4) = hi;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------- launchers
 static inline unsigned lane_blocks(size_t n) { return (unsigned)((n + CBLOCK - 1) / CBLOCK); }
 
@@ -428,30 +488,47 @@ int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* k
     return MLDSA_OK;
 }
 
-static int launch_shake256_2v(int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
+static int launch_shake256_2v(mldsa_ctx* ctx, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                               size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
                               const uint32_t* n_dev, const VerdictArgs& vd, const uint32_t* b_idx = nullptr);
 
-int launch_shake256_2(mldsa_ctx*, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
+int launch_shake256_2(mldsa_ctx* ctx, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                       size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
                       const uint32_t* n_dev, const uint32_t* b_idx) {
     VerdictArgs none{};
-    return launch_shake256_2v(out_len, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, s, n_dev, none, b_idx);
+    return launch_shake256_2v(ctx, out_len, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, s, n_dev, none, b_idx);
 }
 
 // c_tilde' = H(mu | w1Encode(w1')) and the final verdict of verify_internal in one kernel (ml_dsa.rs:429-436)
-int launch_ctilde_verdict(mldsa_ctx*, const mldsa_params* p, const uint8_t* mu_w1, size_t mw, const uint8_t* sigs, const int32_t* znorm,
+int launch_ctilde_verdict(mldsa_ctx* ctx, const mldsa_params* p, const uint8_t* mu_w1, size_t mw, const uint8_t* sigs, const int32_t* znorm,
                           const int32_t* hvalid, const int32_t* ctx_bad, uint8_t* ok, size_t n_ops, hipStream_t s) {
     VerdictArgs vd{sigs, (size_t)p->sig_len, znorm, p->gamma1 - p->beta, hvalid, ctx_bad, ok};
-    return launch_shake256_2v(p->ctilde_len, mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, n_ops, s, nullptr, vd);
+    return launch_shake256_2v(ctx, p->ctilde_len, mu_w1, mw, (int)mw, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, n_ops, s, nullptr, vd);
 }
 
-static int launch_shake256_2v(int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
+static int launch_shake256_2v(mldsa_ctx* ctx, int out_len, const uint8_t* a, size_t sa, int la, const uint32_t* a_idx, const uint8_t* b,
                               size_t sb, int lb, uint32_t tail, int tail_len, uint8_t* out, size_t so, size_t n_ops, hipStream_t s,
                               const uint32_t* n_dev, const VerdictArgs& vd, const uint32_t* b_idx) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     dim3 grid(lane_blocks(n_ops ? n_ops : 1)), block(CBLOCK);
     if ((la & 3) != 0 || (lb & 3) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: segment lengths must be multiples of 4 bytes");
+    // Small batches (for the signer's rounds: small expected row counts): the wave-cooperative form, two ops per wavefront.  Up to
+    // COOP_HASH_MAX_OPS ops that is at most two waves per SIMD, where it still runs a permutation in 5.7 us against 9.4.
+    if (ctx->opt_coop_hash && n_ops <= COOP_HASH_MAX_OPS) {
+        const dim3 cgrid((unsigned)((std::max<size_t>(n_ops, 1) + 2 * CWAVES - 1) / (2 * CWAVES)));
+#define MLDSA_COOP_CASE(O)                                                                                                                           \
+    case O: hipLaunchKernelGGL((k_shake256_2_coop<O>), cgrid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd, b_idx); break;
+        switch (out_len) {
+            MLDSA_COOP_CASE(32)
+            MLDSA_COOP_CASE(48)
+            MLDSA_COOP_CASE(64)
+            MLDSA_COOP_CASE(128)
+            default: return set_error(MLDSA_ERR_PARAM, "shake256_2: unsupported output length");
+        }
+#undef MLDSA_COOP_CASE
+        MLDSA_HIP_CHECK(hipGetLastError());
+        return MLDSA_OK;
+    }
     const bool al = (((uintptr_t)a | (uintptr_t)sa | (uintptr_t)b | (uintptr_t)sb) & 3) == 0;
 #define MLDSA_SHAKE_CASE(O)                                                                                              \
     case O:                                                                                                              \

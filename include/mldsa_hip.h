@@ -134,6 +134,9 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                        per speculative round -- MLDSA_OPT_SPEC_TARGET reads back smaller -- and then its ops per pass, and keeps
                                        the smaller values); results are identical.  For hosts
                                        that share the GPU with other work; a cap too small even for a 1024-op pass fails the call with MLDSA_ERR_NOMEM */
+#define MLDSA_OPT_COOP_HASH 12 /* 1 (default): the fixed-shape SHAKE256 hashes (c_tilde, rho'', tr, the keygen seed) of calls of up to 4 096 ops run
+                                * wave-cooperatively, one state over 25 lanes: 3.8 instead of 9.4 us per permutation of a latency-bound small call
+                                * (csrc/keccak_coop.h).  0: always the lane-per-state form of the large batches.  Results are identical. */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,

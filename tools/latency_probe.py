@@ -16,6 +16,7 @@ op, n = sys.argv[1], int(sys.argv[2])
 calls = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 hp = HotPath(0)
 hp.set_option(1, int(__import__("os").environ.get("GRAPHS", "0")))
+hp.set_option(12, int(__import__("os").environ.get("COOP", "1")))  # MLDSA_OPT_COOP_HASH
 wl = bench.WholeOp(hp, 65, "verify", max(n, 64), 0)
 ml = wl.ml
 xi = torch.randint(0, 256, (max(n, 64), 32), dtype=torch.uint8, device="cuda")

@@ -135,6 +135,88 @@ __global__ __launch_bounds__(256) void k_coop3(uint32_t* __restrict__ io, int pe
     if (c.active) { st[2 * (lane & 31)] = lo; st[2 * (lane & 31) + 1] = hi; }
 }
 
+// ---- third cooperative form: data movement with DPP where the layout allows it, ds_bpermute only where it does not -------------
+// Layout per 32-lane half: planes y = 0, 1, 2 at lanes 5 y + x of the first 16-lane row, y = 3, 4 at lanes 16 + 5 (y - 3) + x of the
+// second.  theta: the parity of the planes of one row by two DPP row shifts (VALU rate), one gather to add the two rows' parts,
+// two gathers for the neighbouring columns; pi: one gather; chi: the row's next two words by DPP shifts inside the plane's five
+// lanes (with a select for the wrap-around).  4 gathers x 2 words per round instead of 16 / 18.
+struct Coop4Idx {
+    int partner, colm1, colp1, pi_src, rot;
+    bool active, first, wrap1, wrap2;   // wrap1: x == 4 (x + 1 wraps); wrap2: x >= 3 (x + 2 wraps)
+};
+
+__device__ __forceinline__ int pos4(int x, int y) { x %= 5; y %= 5; return y < 3 ? 5 * y + x : 16 + 5 * (y - 3) + x; }
+
+__device__ __forceinline__ Coop4Idx coop4_idx(int lane) {
+    Coop4Idx c;
+    const int base = lane & 32, i = lane & 31;
+    c.active = i < 15 || (i >= 16 && i < 26);
+    int x = 0, y = 0;
+    if (c.active) { const int r = i < 16 ? i : i - 16; x = r % 5; y = r / 5 + (i < 16 ? 0 : 3); }
+    // where the column parities end up after the row shifts: lanes 10 + x (planes 0-2) and 21 + x (planes 3, 4); the full parity
+    // is assembled in lanes 10 + x
+    c.partner = (base + (i >= 10 && i < 15 ? 21 + (i - 10) : i)) << 2;   // only lanes 10 .. 14 need it
+    c.colm1 = (base + 10 + (x + 4) % 5) << 2;
+    c.colp1 = (base + 10 + (x + 1) % 5) << 2;
+    c.pi_src = (base + pos4(x + 3 * y, x)) << 2;   // B[X, Y] = rot(A[x, y]) with x = X + 3 Y, y = X
+    c.rot = c.active ? RHO[x + 5 * y] : 0;
+    c.first = i == 0;
+    c.wrap1 = x == 4;
+    c.wrap2 = x >= 3;
+    return c;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+
+__device__ __forceinline__ void coop4_round(uint32_t& lo, uint32_t& hi, const Coop4Idx& c, int round) {
+    // theta: row-local parity (row_shr:5 = 0x115, row_shr:10 = 0x11A), rows added in lanes 10 + x, neighbours fetched from there
+    const uint32_t tl = lo ^ dpp0<0x115>(lo) ^ dpp0<0x11A>(lo), th = hi ^ dpp0<0x115>(hi) ^ dpp0<0x11A>(hi);
+#ifdef COOP4_THETA_TWO_LEVELS
+    const uint32_t cl = tl ^ gather4(tl, c.partner), ch = th ^ gather4(th, c.partner);   // complete in lanes 10 .. 14 (partner = self elsewhere: junk, unused)
+    const uint32_t ml = gather4(cl, c.colm1), mh = gather4(ch, c.colm1), pl = gather4(cl, c.colp1), ph = gather4(ch, c.colp1);
+#else
+    // both rows' parts of both neighbouring columns at once (colm1 / colp1 name lanes 10 + x'; the other row's part sits 11 lanes up)
+    const uint32_t ml = gather4(tl, c.colm1) ^ gather4(tl, c.colm1 + 44), mh = gather4(th, c.colm1) ^ gather4(th, c.colm1 + 44);
+    const uint32_t pl = gather4(tl, c.colp1) ^ gather4(tl, c.colp1 + 44), ph = gather4(th, c.colp1) ^ gather4(th, c.colp1 + 44);
+#endif
+    lo ^= ml ^ __funnelshift_l(ph, pl, 1);
+    hi ^= mh ^ __funnelshift_l(pl, ph, 1);
+    // rho
+    const int r = c.rot & 31;
+    uint32_t rl = __funnelshift_l(hi, lo, r), rh = __funnelshift_l(lo, hi, r);
+    if (c.rot & 32) { const uint32_t t = rl; rl = rh; rh = t; }
+    // pi
+    const uint32_t bl = gather4(rl, c.pi_src), bh = gather4(rh, c.pi_src);
+    // chi: B[x + 1], B[x + 2] of the same plane: row_shl:1 / row_shl:2 (0x101, 0x102), wrapped lanes take row_shr:4 / row_shr:3 (0x114, 0x113)
+    // (every shift is executed by the whole wave; the select comes afterwards)
+    const uint32_t s1l = dpp0<0x101>(bl), w1l = dpp0<0x114>(bl), s1h = dpp0<0x101>(bh), w1h = dpp0<0x114>(bh);
+    const uint32_t s2l = dpp0<0x102>(bl), w2l = dpp0<0x113>(bl), s2h = dpp0<0x102>(bh), w2h = dpp0<0x113>(bh);
+    const uint32_t b1l = c.wrap1 ? w1l : s1l, b1h = c.wrap1 ? w1h : s1h;
+    const uint32_t b2l = c.wrap2 ? w2l : s2l, b2h = c.wrap2 ? w2h : s2h;
+    lo = mldsa::chi(bl, b1l, b2l);
+    hi = mldsa::chi(bh, b1h, b2h);
+    if (c.first) {
+        lo ^= mldsa::KECCAK_RC_LO[round];
+        hi ^= ((mldsa::KECCAK_RC_HI_BITS >> round) & 1u) << 31;
+    }
+}
+
+// io: per wave two states x 25 words x (lo, hi) in the canonical order x + 5 y; the kernel maps them to its lanes
+__global__ __launch_bounds__(256) void k_coop4(uint32_t* __restrict__ io, int perms) {
+    const int lane = threadIdx.x & 63, i = lane & 31;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const Coop4Idx c = coop4_idx(lane);
+    int w = 0;
+    if (c.active) { const int r = i < 16 ? i : i - 16; w = (r % 5) + 5 * (r / 5 + (i < 16 ? 0 : 3)); }
+    uint32_t* st = io + (wave * 2 + (lane >> 5)) * 50;
+    uint32_t lo = c.active ? st[2 * w] : 0, hi = c.active ? st[2 * w + 1] : 0;
+    for (int p = 0; p < perms; p++)
+#pragma unroll
+        for (int r = 0; r < 24; r++) coop4_round(lo, hi, c, r);
+    if (c.active) { st[2 * w] = lo; st[2 * w + 1] = hi; }
+}
+
 __global__ __launch_bounds__(256) void k_coop(uint32_t* __restrict__ io, int perms) {
     // io: per wave two states x 25 words x (lo, hi); lane i of a half-wave owns word i
     const int lane = threadIdx.x & 63;
@@ -188,6 +270,12 @@ int main() {
         CHECK(hipMemcpy(b.data(), d2, h.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < h.size(); i++)
             if (a[i] != b[i]) { fprintf(stderr, "MISMATCH at word %zu: lane-per-state %08x three-level cooperative %08x\n", i, a[i], b[i]); return 1; }
+        CHECK(hipMemcpy(d2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_coop4, dim3(8), dim3(256), 0, 0, d2, 3);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(b.data(), d2, h.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); i++)
+            if (a[i] != b[i]) { fprintf(stderr, "MISMATCH at word %zu: lane-per-state %08x DPP cooperative %08x\n", i, a[i], b[i]); return 1; }
         printf("cooperative and lane-per-state Keccak-f[1600] agree on %d random states x 3 permutations\n", n_states);
         CHECK(hipFree(d1)); CHECK(hipFree(d2));
     }
@@ -197,7 +285,7 @@ int main() {
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     printf("device: %s, %d CUs\n", prop.name, cus);
     printf("%-18s %10s %12s %22s %20s\n", "form", "waves/SIMD", "ms", "us per permutation/wave", "G permutations/s");
-    for (int form = 0; form < 3; form++)
+    for (int form = 0; form < 4; form++)
         for (int wps : {1, 2, 4, 8}) {
             const int blocks = cus * wps;  // 4 waves per block = 1 per SIMD of a CU
             const size_t words = (size_t)blocks * 256 * 50;
@@ -209,7 +297,8 @@ int main() {
                 CHECK(hipEventRecord(e0));
                 if (form == 0) hipLaunchKernelGGL(k_lane, dim3(blocks), dim3(256), 0, 0, d, perms);
                 else if (form == 1) hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(256), 0, 0, d, perms);
-                else hipLaunchKernelGGL(k_coop3, dim3(blocks), dim3(256), 0, 0, d, perms);
+                else if (form == 2) hipLaunchKernelGGL(k_coop3, dim3(blocks), dim3(256), 0, 0, d, perms);
+                else hipLaunchKernelGGL(k_coop4, dim3(blocks), dim3(256), 0, 0, d, perms);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
                 float ms;
@@ -217,7 +306,7 @@ int main() {
                 best = ms < best ? ms : best;
             }
             const double states = (double)blocks * 4 * (form == 0 ? 64 : 2);
-            printf("%-18s %10d %12.3f %22.2f %20.3f\n", form == 0 ? "lane-per-state" : form == 1 ? "cooperative (2/wave)" : "coop, 3 levels (2/wave)", wps, best, best * 1e3 / perms,
+            printf("%-18s %10d %12.3f %22.2f %20.3f\n", form == 0 ? "lane-per-state" : form == 1 ? "cooperative (2/wave)" : form == 2 ? "coop, 3 levels (2/wave)" : "coop, DPP + 4 gathers", wps, best, best * 1e3 / perms,
                    states * perms / (best * 1e-3) / 1e9);
             CHECK(hipFree(d));
         }
