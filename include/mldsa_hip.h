@@ -554,8 +554,8 @@ typedef struct {
 int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out);
 /* Several dispatchers ("lanes") behind the same calls: one context, thread and key table per entry of device_ids, all created and owned
  * by the batcher; whichever lane is idle takes the next batch.  A device may be listed more than once: TWO lanes on one GPU overlap
- * small batches on the device (each is a chain of latency-bound kernels on a fraction of the SIMDs: 64 callers, ML-DSA-65: 235 k
- * instead of 184 k verifications/s, p50 0.27 instead of 0.34 ms; more lanes than that share the device's four hardware queues and
+ * small batches on the device (each is a chain of latency-bound kernels on a fraction of the SIMDs: 64 callers, ML-DSA-65: 302 k
+ * instead of 243 k verifications/s, p50 0.21 instead of 0.26 ms; more lanes than that share the device's four hardware queues and
  * lose again; signing gains nothing); one lane per GPU of a node spreads the callers' operations over the GPUs (a key is then
  * expanded once per lane that meets it). */
 int mldsa_batcher_create_on(const int *device_ids, int n, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out);
