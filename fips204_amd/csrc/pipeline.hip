@@ -223,8 +223,11 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         }
         {
             // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
-            ProfScope ps(ctx, aux, "sample_in_ball");
-            TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, aux, nullptr, true));
+            // (behind mu on the second stream while ExpandA keeps the first one busy; with A_hat kept by the caller the first
+            //  stream is idle until the join, and a small call -- all latency -- runs the two hashes side by side: 17 us of ~125)
+            hipStream_t cs = a_hat_keys ? s : aux;
+            ProfScope ps(ctx, cs, "sample_in_ball");
+            TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, cs, nullptr, true));
         }
         MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, aux));
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
