@@ -134,9 +134,10 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                        per speculative round -- MLDSA_OPT_SPEC_TARGET reads back smaller -- and then its ops per pass, and keeps
                                        the smaller values); results are identical.  For hosts
                                        that share the GPU with other work; a cap too small even for a 1024-op pass fails the call with MLDSA_ERR_NOMEM */
-#define MLDSA_OPT_COOP_HASH 12 /* 1 (default): the fixed-shape SHAKE256 hashes (c_tilde, rho'', tr, the keygen seed) of calls of up to 4 096 ops run
-                                * wave-cooperatively, one state over 25 lanes: 3.8 instead of 9.4 us per permutation of a latency-bound small call
-                                * (csrc/keccak_coop.h).  0: always the lane-per-state form of the large batches.  Results are identical. */
+#define MLDSA_OPT_COOP_HASH 12 /* 1 (default): the sponges of SMALL calls -- the fixed-shape SHAKE256 hashes (c_tilde, rho'', tr, the keygen seed) up to
+                                * 4 096 ops, the signer's ExpandMask and ExpandA up to 4 096 polynomials -- run wave-cooperatively, one state over 25
+                                * lanes: 3.8 instead of 9.4 us per permutation of a latency-bound call (csrc/keccak_coop.h).  0: always the
+                                * lane-per-state form of the large batches.  Results are identical. */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,
@@ -554,8 +555,8 @@ typedef struct {
 int mldsa_batcher_create(mldsa_ctx *ctx, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out);
 /* Several dispatchers ("lanes") behind the same calls: one context, thread and key table per entry of device_ids, all created and owned
  * by the batcher; whichever lane is idle takes the next batch.  A device may be listed more than once: TWO lanes on one GPU overlap
- * small batches on the device (each is a chain of latency-bound kernels on a fraction of the SIMDs: 64 callers, ML-DSA-65: 302 k
- * instead of 243 k verifications/s, p50 0.21 instead of 0.26 ms; more lanes than that share the device's four hardware queues and
+ * small batches on the device (each is a chain of latency-bound kernels on a fraction of the SIMDs: 64 callers, ML-DSA-65: 364 k
+ * instead of 278 k verifications/s, p50 0.17 instead of 0.23 ms; more lanes than that share the device's four hardware queues and
  * lose again; signing gains nothing); one lane per GPU of a node spreads the callers' operations over the GPUs (a key is then
  * expanded once per lane that meets it). */
 int mldsa_batcher_create_on(const int *device_ids, int n, int set, size_t max_batch, unsigned max_wait_us, size_t cache_keys, mldsa_batcher **out);
