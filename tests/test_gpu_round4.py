@@ -813,3 +813,41 @@ def test_captures_survive_device_wide_waits_on_other_threads(sets):
             t.join()
     assert not errors, errors
     assert waits[0] > 8 and waits[1] > 20
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_cooperative_and_lane_per_state_sponges_agree(hp, sets, pset):
+    """MLDSA_OPT_COOP_HASH: small calls run ExpandA, ExpandMask and the fixed-shape hashes wave-cooperatively (csrc/keccak_coop.h), large
+    ones lane-per-state.  Same bytes either way: keys, signatures and verdicts of 1, 2, 7, 64, 137 and 700 ops (the last beyond the
+    cooperative ExpandA's range, inside the hashes') with the option off and on, and against the oracle."""
+    from fips204_amd import _lib
+    m = sets[pset]
+    rng = np.random.default_rng(90 + pset)
+    old = hp.get_option(_lib.OPT_COOP_HASH)
+    assert old == 1
+    try:
+        for n in (1, 2, 7, 64, 137, 700):
+            xi = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            msgs = [rng.integers(0, 256, int(rng.integers(0, 120)), dtype=np.uint8).tobytes() for _ in range(n)]
+            rnd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            out = {}
+            for coop in (0, 1):
+                hp.set_option(_lib.OPT_COOP_HASH, coop)
+                assert hp.get_option(_lib.OPT_COOP_HASH) == coop
+                pk, sk = m.keygen_from_seed(dev(xi))
+                sig = m.try_sign_with_seed(m.private_keys_from_bytes(sk), msgs, [r.tobytes() for r in rnd])
+                bad = sig.clone()
+                bad[::3, 40] ^= 1
+                pks = m.public_keys_from_bytes(pk)
+                as_np = lambda t: host(t) if hasattr(t, "cpu") else np.asarray(t)
+                out[coop] = (host(pk), host(sk), host(sig), as_np(m.verify(pks, msgs, sig)), as_np(m.verify(pks, msgs, bad)))
+            for a, b in zip(out[0], out[1]):
+                assert np.array_equal(a, b), n
+            assert out[1][3].all() and not out[1][4][::3].any() and out[1][4][1::3].all()
+            j = int(rng.integers(0, n))
+            pk_o, sk_o = orc.keygen_from_seed(pset, xi[j].tobytes())
+            assert out[1][0][j].tobytes() == orc.pk_into_bytes(pset, pk_o) and out[1][1][j].tobytes() == orc.sk_into_bytes(pset, sk_o)
+            assert out[1][2][j].tobytes() == orc.sign_internal(pset, sk_o, msgs[j], rnd[j].tobytes(), mode=orc.MODE_PURE)
+    finally:
+        hp.set_option(_lib.OPT_COOP_HASH, old)
+    assert hp.lib.mldsa_set_option(hp._h, _lib.OPT_COOP_HASH, 2) == _lib.ERR_PARAM
