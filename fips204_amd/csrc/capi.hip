@@ -106,6 +106,9 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     // experiment knobs: the environment only sets the initial value of the per-context options
     ctx->opt_graphs = env_long("MLDSA_GRAPHS", 0, 2, ctx->opt_graphs);
     ctx->opt_coop_hash = env_long("MLDSA_COOP_HASH", 0, 1, ctx->opt_coop_hash);
+    ctx->coop_hash_max = (size_t)env_long("MLDSA_COOP_HASH_MAX", 0, 1 << 20, (long)ctx->coop_hash_max);
+    ctx->coop_mask_max = (size_t)env_long("MLDSA_COOP_MASK_MAX", 0, 1 << 20, (long)ctx->coop_mask_max);
+    ctx->coop_a_max = (size_t)env_long("MLDSA_COOP_A_MAX", 0, 1 << 20, (long)ctx->coop_a_max);
     ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 524288, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
     ctx->opt_spec_rows = env_long("MLDSA_SPEC_ROWS", 1, 524288, ctx->opt_spec_rows);

@@ -19,7 +19,6 @@ namespace mldsa {
 
 constexpr int CWAVES = 4;
 constexpr int CBLOCK = 64 * CWAVES;
-constexpr size_t COOP_HASH_MAX_OPS = 4096;  // (MLDSA_OPT_COOP_HASH = 0 switches the cooperative form off)
 
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for_c(F&& f) {
@@ -513,8 +512,8 @@ static int launch_shake256_2v(mldsa_ctx* ctx, int out_len, const uint8_t* a, siz
     dim3 grid(lane_blocks(n_ops ? n_ops : 1)), block(CBLOCK);
     if ((la & 3) != 0 || (lb & 3) != 0) return set_error(MLDSA_ERR_PARAM, "shake256_2: segment lengths must be multiples of 4 bytes");
     // Small batches (for the signer's rounds: small expected row counts): the wave-cooperative form, two ops per wavefront.  Up to
-    // COOP_HASH_MAX_OPS ops that is at most two waves per SIMD, where it still runs a permutation in 5.7 us against 9.4.
-    if (ctx->opt_coop_hash && n_ops <= COOP_HASH_MAX_OPS) {
+    // 4 096 ops (mldsa_ctx::coop_hash_max) that is at most two waves per SIMD, where it still runs a permutation in 5.7 us against 9.4.
+    if (ctx->opt_coop_hash && n_ops <= ctx->coop_hash_max) {
         const dim3 cgrid((unsigned)((std::max<size_t>(n_ops, 1) + 2 * CWAVES - 1) / (2 * CWAVES)));
 #define MLDSA_COOP_CASE(O)                                                                                                                           \
     case O: hipLaunchKernelGGL((k_shake256_2_coop<O>), cgrid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd, b_idx); break;

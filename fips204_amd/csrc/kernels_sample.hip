@@ -13,8 +13,6 @@
 #include "keccak_coop.h"
 
 namespace mldsa {
-constexpr size_t COOP_A_MAX_STREAMS = 4096;     // ExpandA calls (24-bit form) of at most this many polynomials take the wave-cooperative form
-constexpr size_t COOP_MASK_MAX_STREAMS = 4096;  // RAW ExpandMask rounds of at most this many polynomials take the wave-cooperative form
 
 // ------------------------------------------------------------------------------------
 // ExpandA (hashing.rs:225-239) = K*L x RejNTTPoly (hashing.rs:111-146):
@@ -427,7 +425,7 @@ int launch_expand_a(mldsa_ctx* ctx, int set, const uint8_t* rho, size_t rho_stri
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_a: unknown parameter set");
     dim3 grid(stream_blocks(n_ops * (size_t)(p->k * p->l))), block(64 * SWAVES);
-    if (pack24 && ctx->opt_coop_hash && n_ops * (size_t)(p->k * p->l) <= COOP_A_MAX_STREAMS) {  // a small call: all latency
+    if (pack24 && ctx->opt_coop_hash && n_ops * (size_t)(p->k * p->l) <= ctx->coop_a_max) {  // a small call: all latency
         const dim3 cgrid((unsigned)((n_ops * (size_t)(p->k * p->l) + 2 * SWAVES - 1) / (2 * SWAVES)));
         if (set == MLDSA_44) hipLaunchKernelGGL((k_expand_a_coop<4, 4>), cgrid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops, n_keys);
         else if (set == MLDSA_65) hipLaunchKernelGGL((k_expand_a_coop<6, 5>), cgrid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops, n_keys);
@@ -511,7 +509,7 @@ int launch_expand_mask(mldsa_ctx* ctx, int set, const uint8_t* rho_pp, size_t rh
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
     dim3 grid(stream_blocks((n_ops ? n_ops : 1) * (size_t)p->l)), block(64 * SWAVES);
-    if (raw && ctx->opt_coop_hash && (n_ops ? n_ops : 1) * (size_t)p->l <= COOP_MASK_MAX_STREAMS) {  // a small round: all latency
+    if (raw && ctx->opt_coop_hash && (n_ops ? n_ops : 1) * (size_t)p->l <= ctx->coop_mask_max) {  // a small round: all latency
         const dim3 cgrid((unsigned)(((n_ops ? n_ops : 1) * (size_t)p->l + 2 * SWAVES - 1) / (2 * SWAVES)));
         if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask_coop<17>), cgrid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev);
         else hipLaunchKernelGGL((k_expand_mask_coop<19>), cgrid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev);
