@@ -106,6 +106,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     // experiment knobs: the environment only sets the initial value of the per-context options
     ctx->opt_graphs = env_long("MLDSA_GRAPHS", 0, 2, ctx->opt_graphs);
     ctx->opt_coop_hash = env_long("MLDSA_COOP_HASH", 0, 1, ctx->opt_coop_hash);
+    ctx->opt_sib_third = env_long("MLDSA_SIB_THIRD_STREAM", 0, 1, ctx->opt_sib_third);
     ctx->coop_hash_max = (size_t)env_long("MLDSA_COOP_HASH_MAX", 0, 1 << 20, (long)ctx->coop_hash_max);
     ctx->coop_mask_max = (size_t)env_long("MLDSA_COOP_MASK_MAX", 0, 1 << 20, (long)ctx->coop_mask_max);
     ctx->coop_a_max = (size_t)env_long("MLDSA_COOP_A_MAX", 0, 1 << 20, (long)ctx->coop_a_max);
@@ -142,6 +143,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->join2_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->exp_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->exp_join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_ev, hipEventDisableTiming);
@@ -174,6 +176,7 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
+    if (ctx->join2_ev) (void)hipEventDestroy(ctx->join2_ev);
     if (ctx->exp_fork_ev) (void)hipEventDestroy(ctx->exp_fork_ev);
     if (ctx->exp_join_ev) (void)hipEventDestroy(ctx->exp_join_ev);
     for (size_t i = 1; i < ctx->helper_streams.size(); i++) (void)hipStreamDestroy(ctx->helper_streams[i]);  // [0] is aux_stream

@@ -216,6 +216,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
             tr_keys = w.tr_w;   // rows of the keys just expanded: by op for the identity mapping, by key index for a table
             t1_keys = w.t1_w;
         }
+        hipStream_t sib_stream = s;
         {
             // 7: mu <- H(tr || M', 64)                                        ml_dsa.rs:386-397
             ProfScope ps(ctx, aux, "mu");
@@ -223,12 +224,24 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         }
         {
             // 8: c <- SampleInBall(c_tilde)                                   ml_dsa.rs:400
-            // (behind mu on the second stream while ExpandA keeps the first one busy; with A_hat kept by the caller the first
-            //  stream is idle until the join, and a small call -- all latency -- runs the two hashes side by side: 17 us of ~125)
-            hipStream_t cs = a_hat_keys ? s : aux;
+            // Needs nothing but the signature.  With A_hat kept by the caller the first stream is idle until the join and takes it,
+            // beside mu.  Otherwise it follows mu on the second stream under ExpandA -- except in a SMALL call (the size the
+            // cooperative ExpandA takes: 22 us), where that chain (key check, mu, SampleInBall: 38 us) had become the longest one: a
+            // third stream then (one-op verify 116 -> 111 us; same-box A/B: from 1 024 ops up a third stream costs 4-5 %, at 65 536
+            // ops 0.3 %: not used there).
+            hipStream_t cs = s;
+            const bool small_call = ctx->opt_coop_hash && n * (size_t)(p->k * p->l) <= ctx->coop_a_max;
+            if (!a_hat_keys && !(ctx->opt_sib_third && small_call)) cs = aux;
+            else if (!a_hat_keys) {
+                cs = parallel_stream(ctx, s, aux);
+                if (cs != aux && cs != s) MLDSA_HIP_CHECK(hipStreamWaitEvent(cs, ctx->fork_ev, 0));
+                else cs = aux;  // (no third stream to be had: behind mu as before)
+            }
             ProfScope ps(ctx, cs, "sample_in_ball");
             TRY(launch_sample_in_ball(ctx, set, sg, (size_t)p->sig_len, w.c, n, cs, nullptr, true));
+            sib_stream = cs;
         }
+        if (sib_stream != s && sib_stream != aux) MLDSA_HIP_CHECK(hipEventRecord(ctx->join2_ev, sib_stream));
         MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, aux));
         // 5: A_hat <- ExpandA(rho)                                        ml_dsa.rs:406
         // (skipped when the caller keeps A_hat with its keys: the optimisation the reference's benches/README.md
@@ -238,6 +251,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
             STAGE("expand_a", launch_expand_a(ctx, set, rho_rows, wire ? pkl : 32, key_idx ? key_idx + o : nullptr, w.a_hat, n, s, true, key_idx ? n_keys : 0));
         }
         MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join_ev, 0));  // join
+        if (sib_stream != s && sib_stream != aux) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->join2_ev, 0));
         // 2: (c_tilde, z, h) <- sigDecode(sigma), inside k_verify_main                      ml_dsa.rs:368-376
         // 9-10: w1' <- UseHint(h, invNTT(A_hat o NTT(z) - NTT(c) o NTT(t1 2^d))), w1Encode   ml_dsa.rs:407-428
         STAGE("verify_main", launch_verify_main(ctx, p, a_hat_keys ? a_hat_keys + key_base * kl_coeffs : w.a_hat, sg, w.c,
@@ -1043,9 +1057,13 @@ bool streams_serialise(mldsa_ctx *ctx, hipStream_t a, hipStream_t b) {
 hipStream_t parallel_stream(mldsa_ctx *ctx, hipStream_t s, hipStream_t avoid) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return ctx->aux_stream;
-    if (!avoid)
+    if (!avoid) {
         for (const auto &pr : ctx->parallel_of)
             if (pr.first == s) return pr.second;
+    } else {
+        for (const auto &t : ctx->parallel2_of)
+            if (t.s == s && t.avoid == avoid) return t.found;
+    }
     if (ctx->helper_streams.empty()) ctx->helper_streams.push_back(ctx->aux_stream);
     hipStream_t found = nullptr;
     for (size_t i = 0; i < 8 && !found; i++) {
@@ -1060,6 +1078,7 @@ hipStream_t parallel_stream(mldsa_ctx *ctx, hipStream_t s, hipStream_t avoid) {
     }
     if (!found) found = ctx->aux_stream;  // every candidate shares a queue: still correct, just not concurrent
     if (!avoid) ctx->parallel_of.emplace_back(s, found);
+    else ctx->parallel2_of.push_back({s, avoid, found});
     return found;
 }
 
