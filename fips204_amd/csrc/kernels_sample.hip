@@ -446,12 +446,73 @@ int launch_expand_a(mldsa_ctx* ctx, int set, const uint8_t* rho, size_t rho_stri
     return MLDSA_OK;
 }
 
-int launch_expand_s(mldsa_ctx*, int set, const uint8_t* rho_prime, size_t rho_stride, int32_t* s12, size_t n_ops, hipStream_t s, bool s8) {
+// ExpandS (one byte per coefficient: key generation's own s1 / s2) for SMALL calls: one polynomial per half-wave (keccak_coop.h).  The
+// 136-byte block goes through the half's LDS row; its 272 half-byte candidates (low nibble first, hashing.rs:177-180) are tested in
+// nine passes of 32, ranked with a ballot and stored at their coefficient index -- the bytes k_expand_s<ETA, true> writes.
+template <int ETA>
+__global__ __launch_bounds__(64 * SWAVES) void k_expand_s_coop(const uint8_t* __restrict__ rho_prime, size_t rho_stride, int32_t* __restrict__ s12,
+                                                               int polys_per_op, size_t n_ops) {
+    constexpr int BLK_DWORDS = 36;
+    __shared__ uint32_t blk_lds[SWAVES * 2 * BLK_DWORDS];
+    const int lane = threadIdx.x & 63, half = lane >> 5, i = lane & 31;
+    const CoopLane c = coop_lane(lane);
+    uint32_t* blk = blk_lds + ((threadIdx.x >> 6) * 2 + half) * BLK_DWORDS;
+    uint8_t* out8 = reinterpret_cast<uint8_t*>(s12);
+    const size_t n_streams = n_ops * (size_t)polys_per_op;
+    const size_t wave0 = ((size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6)) * 2, stride = (size_t)gridDim.x * SWAVES * 2;
+    for (size_t g0 = wave0; g0 < n_streams; g0 += stride) {  // wave-uniform
+        const size_t g = g0 + half;
+        const bool valid = g < n_streams;
+        const size_t gc = valid ? g : g0;
+        const size_t op = gc / polys_per_op;
+        const uint32_t r = (uint32_t)(gc % polys_per_op);
+        uint32_t lo = 0, hi = 0;
+        if (c.active && c.word < 8) {
+            const uint8_t* src = rho_prime + op * rho_stride + 8 * c.word;
+            lo = load_le32(src);
+            hi = load_le32(src + 4);
+        }
+        if (c.active && c.word == 8) lo = r | (0x1Fu << 16);  // hashing.rs:260/266: rho' || r || 0  (then pad)
+        if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi = 0x80000000u;
+        uint8_t* row = out8 + g * (size_t)N;
+        int count = valid ? 0 : N;
+        while (__any(count < N)) {
+            keccak_f1600_coop(lo, hi, c);
+            if (c.active && c.word < SHAKE256_RATE / 8) { blk[2 * c.word] = lo; blk[2 * c.word + 1] = hi; }
+            wave_lds_sync();
+#pragma unroll
+            for (int pass = 0; pass < 9; pass++) {
+                const int cand = 32 * pass + i;  // half-byte index: byte cand >> 1, low nibble first
+                bool acc = false;
+                int32_t v = 0;
+                if (cand < 2 * SHAKE256_RATE) {
+                    const uint32_t b = (blk[cand >> 3] >> (4 * (cand & 7))) & 15u;
+                    acc = half_byte<ETA>(b, v);
+                }
+                const unsigned long long all = __ballot(acc);
+                const uint32_t mine = half ? (uint32_t)(all >> 32) : (uint32_t)all;
+                const int idx = count + __popc(mine & ((1u << i) - 1u));
+                if (acc && idx < N) row[idx] = (uint8_t)v;
+                count += __popc(mine);
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+int launch_expand_s(mldsa_ctx* ctx, int set, const uint8_t* rho_prime, size_t rho_stride, int32_t* s12, size_t n_ops, hipStream_t s, bool s8) {
     if (n_ops == 0) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_s: unknown parameter set");
     const int ppo = p->k + p->l;
     dim3 grid(stream_blocks(n_ops * (size_t)ppo)), block(64 * SWAVES);
+    if (s8 && ctx->opt_coop_hash && n_ops * (size_t)ppo <= ctx->coop_a_max) {  // a small key generation: all latency
+        const dim3 cgrid((unsigned)((n_ops * (size_t)ppo + 2 * SWAVES - 1) / (2 * SWAVES)));
+        if (p->eta == 2) hipLaunchKernelGGL((k_expand_s_coop<2>), cgrid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
+        else hipLaunchKernelGGL((k_expand_s_coop<4>), cgrid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
+        MLDSA_HIP_CHECK(hipGetLastError());
+        return MLDSA_OK;
+    }
     if (s8) {
         if (p->eta == 2) hipLaunchKernelGGL((k_expand_s<2, true>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
         else hipLaunchKernelGGL((k_expand_s<4, true>), grid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
