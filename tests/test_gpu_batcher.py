@@ -79,6 +79,44 @@ def test_many_threads_single_op_calls(hp, pset, lanes):
         b.close()
 
 
+def test_acvp_vectors_through_single_op_calls(hp, acvp_keygen, acvp_siggen, acvp_sigver):
+    """The reference's NIST ACVP vectors (tests/nist_vectors/mod.rs:56-203: 75 keyGen, 60 sigGen, 45 sigVer) through the ONE-operation
+    calls of the batcher -- KG::keygen_from_seed, _internal_sign (MLDSA_MODE_INTERNAL, rnd as given or all-zero), _internal_verify --
+    issued by 16 threads at once, so that the vectors of one group meet in the same batches.  Byte-exact keys and signatures, the
+    expected verdict of every sigVer case (the three failure classes included)."""
+    from conftest import PSET
+    n = {"keygen": 0, "siggen": 0, "sigver": 0}
+    batchers = {ps: MlDsaBatcher(ps, hotpath=hp, max_batch=32) for ps in (44, 65, 87)}
+    try:
+        with ThreadPoolExecutor(16) as pool:
+            for g in acvp_keygen["testGroups"]:
+                b = batchers[PSET[g["parameterSet"]]]
+                got = list(pool.map(lambda t: b.keygen_from_seed(bytes.fromhex(t["seed"])), g["tests"]))
+                for t, (pk, sk) in zip(g["tests"], got):
+                    assert pk == bytes.fromhex(t["pk"]) and sk == bytes.fromhex(t["sk"]), t["tcId"]
+                    n["keygen"] += 1
+            for g in acvp_siggen["testGroups"]:
+                b = batchers[PSET[g["parameterSet"]]]
+                got = list(pool.map(lambda t: b.sign(bytes.fromhex(t["sk"]), bytes.fromhex(t["message"]),
+                                                     bytes.fromhex(t["rnd"]) if "rnd" in t else bytes(32), mode=MODE_INTERNAL), g["tests"]))
+                for t, sig in zip(g["tests"], got):
+                    assert sig == bytes.fromhex(t["signature"]), t["tcId"]
+                    n["siggen"] += 1
+            for g in acvp_sigver["testGroups"]:
+                b = batchers[PSET[g["parameterSet"]]]
+                pk = bytes.fromhex(g["pk"])
+                got = list(pool.map(lambda t: b.verify(pk, bytes.fromhex(t["message"]), bytes.fromhex(t["signature"]), mode=MODE_INTERNAL), g["tests"]))
+                for t, ok in zip(g["tests"], got):
+                    assert ok == t["testPassed"], (t["tcId"], t.get("reason"))
+                    n["sigver"] += 1
+        assert n == {"keygen": 75, "siggen": 60, "sigver": 45}
+        st = {ps: b.stats() for ps, b in batchers.items()}
+        assert sum(s_["requests"] for s_ in st.values()) == 180 and all(s_["batches"] < s_["requests"] for s_ in st.values())
+    finally:
+        for b in batchers.values():
+            b.close()
+
+
 def test_modes_long_ctx_and_large_messages(hp):
     """ML-DSA-65: the three message modes mixed by concurrent callers (a batch holds one mode; the others wait for the next), a ctx
     of 256 bytes (lib.rs:274: Err for sign; 368: false for verify, nothing runs), a 300 000-byte message (larger than the staging
