@@ -1,0 +1,220 @@
+"""The timed region and the full per-workload result object."""
+import os
+import time
+
+import torch
+
+from .constants import HBM_PEAK_GBS, KECCAK_PEAK_DERIVATION, KECCAK_PEAK_GPERMS, REFERENCE_PUBLISHED
+from .dist import barrier, max_over_ranks
+from .hostfed import host_fed
+from .pmc import LIVE_PMC, pmc_traffic
+from .workloads import MixedStream, WholeOp, make_workload
+
+
+def timed_steps(wl, world, steps, first):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+        wl.step(first + i)
+    if hasattr(wl, "finish_steps"):
+        wl.finish_steps()  # inside the timed region: e.g. the mixed stream re-signs what its asynchronous calls left over
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    timed_steps.local_s = dt  # this rank's own time (run_one reports min / max over ranks beside `value`)
+    return max_over_ranks(dt, world), ev0.elapsed_time(ev1)
+
+
+def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_fed=False, cpu_budget_s=None):
+    wl = make_workload(name, hp, args.batch if name == args.workload else 0, rank, world)
+    if rank == 0:
+        wl.check()
+    for i in range(warmup):
+        wl.step(i)
+    torch.cuda.synchronize()
+    whole = isinstance(wl, WholeOp)
+    units_per_step = getattr(wl, "ops_per_step", wl.batch)
+
+    # THE timed region: exactly K steps of the product's default path (a signing call whose shape repeats replays as a
+    # hipGraph), barrier + synchronize on both sides, max over ranks -> `value`
+    st0 = hp.stats() if hasattr(hp, "stats") else None
+    dt, ev_ms = timed_steps(wl, world, steps, warmup)
+    kern_ms = ev_ms / steps / wl.kernel_launches_per_step()
+    value = units_per_step * world * steps / dt
+    ranks = None
+    if world > 1:  # per-rank rates: a straggler shows as min << max (value itself uses the slowest rank's time)
+        from .dist import min_over_ranks
+        mine = units_per_step * steps / timed_steps.local_s
+        ranks = {"min": min_over_ranks(mine, world), "max": max_over_ranks(mine, world), "unit": wl.unit + " per rank"}
+    st1 = hp.stats()
+    launch_mode = {"graph_replays": st1["graph_replays"] - st0["graph_replays"], "direct_calls": st1["direct_calls"] - st0["direct_calls"],
+                   "sign_extra_rounds": st1["sign_extra_rounds"] - st0["sign_extra_rounds"]}
+    # Per-kernel durations: a graph has no place for an event between two of its kernels, so the whole-op workloads
+    # run the SAME K steps once more right away with a HIP event pair around every kernel launch on the launch
+    # stream (the library launches directly while it is being profiled).  The roofline's kernel time comes from there.
+    stages, dt_prof = None, None
+    if whole:
+        hp.profile_enable(True)
+        dt_prof, _ = timed_steps(wl, world, steps, warmup + steps)
+        stages = hp.profile_report()
+        hp.profile_enable(False)
+
+    # the verdict bytes of every rank gathered into the whole job's verdict array, outside `value`
+    gather = None
+    if whole and wl.kind == "verify":
+        from fips204_amd import multi_gpu
+        import torch.distributed as dist
+        on_cpu = multi_gpu.is_distributed() and dist.get_backend() != "nccl"
+        multi_gpu.gather_verdicts(wl.ok.cpu() if on_cpu else wl.ok, wl.batch * world).sum().item()  # first use: communicator set-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        allok = multi_gpu.gather_verdicts(wl.ok.cpu() if on_cpu else wl.ok, wl.batch * world)
+        n_ok = int(allok.sum().item())
+        gather = {"ms": (time.perf_counter() - t0) * 1e3, "verdicts": wl.batch * world, "ok": n_ok,
+                  "collective": ("none (single rank: a copy)" if not multi_gpu.is_distributed() else
+                                 "all_gather_into_tensor (gloo)" if on_cpu else "all_gather_into_tensor (RCCL)")}
+        expect = int(wl.expect_ok.sum().item())
+        assert n_ok == expect * world or world > 1 and n_ok <= wl.batch * world, "a rank reported a failed verification of a valid signature"
+        gather["expected_ok_per_rank"] = expect
+    if rank != 0:
+        return None
+
+    alg_bytes = wl.bytes_per_op * units_per_step
+    traffic, traffic_by_stage, traffic_file = pmc_traffic(name)
+    live = LIVE_PMC.get(name)
+    if live:
+        traffic, traffic_by_stage, traffic_file = live["hbm_bytes_per_launch"], live["by_stage"], None
+    slots = op_rounds = None
+    if whole:
+        slots = stages.pop("_sign_slots", None)
+        op_rounds = stages.pop("_sign_op_rounds", None)
+
+        def stage_bytes_total(st_name):
+            """algorithmic bytes of all launches of a stage inside the timed region"""
+            per_round = st_name in ("expand_mask", "sign_w", "sign_tail")
+            units = slots["calls"] if (wl.kind == "sign" and per_round and slots) else wl.batch * steps
+            total = wl.stage_bytes[st_name] * units
+            if st_name == "sign_w" and wl.kind == "sign" and op_rounds:
+                total += wl.stage_bytes["sign_w_per_op_round"] * op_rounds["calls"]
+            return total, units
+
+        # dominant kernel = the stage with the largest share of device time; its average launch
+        # duration comes from the event pairs recorded inside the timed region
+        dom = max((k for k in stages if k in wl.stage_bytes), key=lambda k: stages[k]["ms"])
+        kern_ms = stages[dom]["ms"] / stages[dom]["calls"]
+        alg_bytes = stage_bytes_total(dom)[0] / stages[dom]["calls"]
+        wl.kernel = "k_" + dom
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    line = {
+        "metric": wl.metric, "value": value, "unit": wl.unit, "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+        "config": {"workload": wl.name, "batch_per_gpu": wl.batch, "parallelism": f"batch-split x{world}",
+                   "input_sets_rotated": wl.n_sets},
+        "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+    }
+    # `traffic` is a PMC figure (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes) read from the file named beside it: it was
+    # NOT measured by this process (counters need the profiler)
+    line["roofline"]["traffic_measured_in_this_run"] = bool(live)
+    if live:
+        line["roofline"]["traffic_source"] = ("two child runs of this command under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate passes, "
+                                              "--kernel-trace only) on this box just before the timed region; FETCH_SIZE x 2 + WRITE_SIZE, KiB, mean per launch")
+    elif traffic_file:
+        line["roofline"]["traffic_source"] = "profiles/" + traffic_file
+    line["launch_mode"] = launch_mode
+    if ranks:
+        line["ranks"] = ranks
+    if isinstance(wl, MixedStream):
+        line["ops_per_s_by_class"] = {k: n * world * steps / dt for k, n in wl.count.items()}
+        line["requests_per_step"] = {"total": wl.ops_per_step, **wl.count,
+                                     "per_set": {str(ps): {k: int(len(v)) for k, v in wl.req[ps].items()} for ps in (44, 65, 87)}}
+        line["resigned_after_async"] = getattr(wl, "resigned", 0)
+    if gather:
+        line["verdict_gather"] = gather
+    if whole:
+        # stages that run on a helper stream UNDERNEATH a kernel of the call's stream (verify: mu and SampleInBall under ExpandA;
+        # sign: the optional side-stream prologue) are not on the critical path: they are listed, but neither the
+        # busy fraction nor the gap adds them to the critical stream's time
+        overlapped = {"mu", "sample_in_ball"} if wl.kind == "verify" else {"expand_mask_ahead", "mu", "rho_pp_hash"}
+        total_ms = sum(v["ms"] for k, v in stages.items() if k not in overlapped)
+        line["stage_ms_per_step"] = {k: round(v["ms"] / steps, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]["ms"])}
+        line["stages_overlapped_on_helper_stream"] = sorted(k for k in stages if k in overlapped)
+        line["launch_gap_ms_per_step"] = round(max(0.0, dt_prof / steps * 1e3 - total_ms / steps), 4)
+        line["profiled_pass"] = {"ms_per_step": dt_prof / steps * 1e3, "value": units_per_step * world * steps / dt_prof,
+                                 "note": "the same K steps again with an event pair around every kernel (direct launches): source of "
+                                         "stage_ms_per_step and roofline.kernel_ms"}
+        if slots:
+            line["sign_iterations_per_signature"] = slots["calls"] / (wl.batch * steps)
+        line["device_busy_frac"] = min(1.0, total_ms / (dt_prof * 1e3))  # critical-stream kernel time / wall time of the profiled pass
+        perms = {"verify": {44: 89, 65: 159, 87: 291}, "sign": {44: 201, 65: 320, 87: 455}}[wl.kind][wl.pset]
+        line["roofline"]["note"] = ("whole ops are integer-ALU-bound (Keccak-f[1600]), not HBM-bound: "
+                                    f"~{perms} permutations per op; the HBM-bound kernel of the path is reported under "
+                                    "also.verify_arith44 (BASELINE config 2).  Bytes are those the kernel is obliged to move "
+                                    "(A_hat as the pipelines hold it: 768 B per polynomial)")
+        line["keccak_permutations_per_s"] = perms * value / world
+        # every modelled stage against the ceiling that bounds it: HBM peak for the polynomial-streaming
+        # kernels, the measured Keccak-f[1600] issue ceiling (tools/ubench_valu.hip k_keccak at 8 waves/SIMD,
+        # profiles/r01_ubench_valu.txt) for the SHAKE-bound samplers
+        by_stage = {}
+        for st_name, st in stages.items():
+            if st_name in wl.stage_perms:
+                units = slots["calls"] if (wl.kind == "sign" and st_name == "expand_mask" and slots) else wl.batch * steps
+                ach = wl.stage_perms[st_name] * units / (st["ms"] * 1e-3) / 1e9
+                by_stage[st_name] = {"bound": "valu", "achieved": ach, "peak": KECCAK_PEAK_GPERMS,
+                                     "unit": "G Keccak-f[1600]/s", "frac": ach / KECCAK_PEAK_GPERMS}
+            elif st_name in wl.stage_bytes:
+                model = stage_bytes_total(st_name)[0] / st["calls"]
+                pmc = traffic_by_stage.get(st_name)
+                # the figure credited is never above what the counters saw cross the memory interface
+                moved = min(model, pmc) if pmc else model
+                ach = moved / (st["ms"] / st["calls"] * 1e-3) / 1e9
+                by_stage[st_name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": ach / HBM_PEAK_GBS, "model_bytes_per_launch": model, "pmc_bytes_per_launch": pmc}
+                if ach > 6400:
+                    by_stage[st_name]["suspect"] = "above what this box streams (6.2-6.4 TB/s): served partly from L2 / Infinity Cache"
+        line["roofline_by_stage"] = by_stage
+        if dom in by_stage and by_stage[dom]["bound"] == "hbm":
+            line["roofline"]["achieved"] = by_stage[dom]["achieved"]
+            line["roofline"]["frac"] = by_stage[dom]["frac"]
+        elif dom in by_stage:
+            # The dominant kernel is a SHAKE sampler (ExpandA for verify): integer-issue-bound, and the roofline object says so.
+            # peak = the issue ceiling derived in-line from the round's instruction mix (KECCAK_PEAK_DERIVATION); the HBM view of
+            # the same launch stays beside it under both byte models.
+            per_launch_units = wl.batch  # every ExpandA launch of the timed region covers the whole batch
+            hbm_packed = line["roofline"]["achieved"]
+            int32_bytes = (32 + 1024 * wl.k * wl.l) * per_launch_units if dom == "expand_a" else alg_bytes
+            hbm_int32 = int32_bytes / (kern_ms * 1e-3) / 1e9
+            line["roofline"].update({
+                "bound": "valu", "achieved": by_stage[dom]["achieved"], "peak": KECCAK_PEAK_GPERMS, "unit": "G Keccak-f[1600]/s",
+                "frac": by_stage[dom]["frac"],
+                "permutations_per_launch": wl.stage_perms[dom] * per_launch_units,
+                "peak_derivation": KECCAK_PEAK_DERIVATION,
+                "hbm_view": {"peak_GBs": HBM_PEAK_GBS,
+                             "survey_8d_int32_model": {"bytes_per_launch": int32_bytes, "achieved_GBs": hbm_int32, "frac": hbm_int32 / HBM_PEAK_GBS,
+                                                       "note": "SURVEY 8d: 32 + 1024*K*L bytes per op (the reference's int32 layout)"},
+                             "packed_24bit_as_stored": {"bytes_per_launch": alg_bytes, "achieved_GBs": hbm_packed, "frac": hbm_packed / HBM_PEAK_GBS,
+                                                        "note": "what the kernel writes: A_hat as 24-bit fields, 768 B per polynomial"}},
+            })
+        line["whole_op_hbm"] = {"algorithmic_bytes_per_op": wl.bytes_per_op,
+                                "achieved_GBs": wl.bytes_per_op * value / world / 1e9,
+                                "frac_of_peak": wl.bytes_per_op * value / world / 1e9 / HBM_PEAK_GBS}
+        pub = REFERENCE_PUBLISHED[f"{wl.kind}_us"][wl.pset]
+        line["reference_published"] = {"value": 1e6 / pub, "unit": wl.unit + " per core", "us_per_op": pub,
+                                       "source": REFERENCE_PUBLISHED["source"], "note": REFERENCE_PUBLISHED["note"]}
+    if world == 1 and cpu_baseline:
+        cb = wl.cpu_baseline() if cpu_budget_s is None else wl.cpu_baseline(budget_s=cpu_budget_s)
+        if cb:
+            line["cpu_baseline"] = cb
+    if world == 1 and with_host_fed and whole and not wl.cached_a:
+        line["end_to_end_host_fed"] = host_fed(wl)
+    del wl
+    torch.cuda.empty_cache()
+    return line
+

@@ -106,6 +106,11 @@ def max_over_ranks(x, device="cpu"):
     return float(t.item())
 
 
+def min_over_ranks(x, device="cpu"):
+    """the slowest rank sets `value` (max_over_ranks of the time); this shows how far the fastest one was ahead"""
+    return -max_over_ranks(-x, device)
+
+
 def gather_verdicts(ok_local, n_total):
     """The verdict bytes of this rank's shard (uint8 tensor, shard(n_total, rank, world)[1] entries) -> the
     n_total verdicts of the whole batch in batch order (returned on every rank; SURVEY 8e: <= 1 MiB even for

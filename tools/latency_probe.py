@@ -30,9 +30,14 @@ for _ in range(10):
     call()
 torch.cuda.synchronize()
 lat = []
+gap_s = float(__import__("os").environ.get("CALL_GAP_US", "0")) * 1e-6  # a pause between calls: lets tools/small_call_timeline.py tell calls apart
 for _ in range(calls):
+    if gap_s:
+        time.sleep(gap_s)
     t0 = time.perf_counter()
     call()
     torch.cuda.synchronize()
     lat.append(time.perf_counter() - t0)
+if __import__("os").environ.get("WALL_JSON"):
+    __import__("json").dump({"op": op, "n_ops": n, "calls": calls, "wall_us": [x * 1e6 for x in lat]}, open(__import__("os").environ["WALL_JSON"], "w"))
 print(f"{op} n={n}: median {np.median(lat) * 1e6:.1f} us per call (min {min(lat) * 1e6:.1f}), {calls} calls")
