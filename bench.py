@@ -116,9 +116,11 @@ def main():
     # live HBM-traffic counters (rocprofv3 child passes) BEFORE this process touches the GPU: single-GPU runs only
     single = args.gpus == 1 and "RANK" not in os.environ
     if single and not args.no_pmc and (args.pmc or (args.workload == "verify65" and not args.no_extras)):
-        got = measure_pmc_traffic(args.workload)
-        if got:
-            LIVE_PMC[args.workload] = got
+        # the headline workload, and in the default run config[1]'s kernel too (also.verify_arith44.traffic_ratio: PMC bytes / algorithmic bytes)
+        for name in (args.workload,) + (("verify_arith44",) if args.workload == "verify65" and not args.no_extras else ()):
+            got = measure_pmc_traffic(name)
+            if got:
+                LIVE_PMC[name] = got
     rank, local_rank, world = dist_setup(args)
     from fips204_amd import multi_gpu
     from fips204_amd.hotpath import HotPath

@@ -58,7 +58,9 @@ def compact_roofline(full):
 
 def compact_cpu(full):
     cb = full.get("cpu_baseline")
-    return _pick(cb, CPU_KEYS) if cb else None
+    if not cb:
+        return None
+    return _pick(dict(cb, sample=cb.get("sample_short", cb.get("sample", ""))), CPU_KEYS)
 
 
 def compact_line(full, also=None, extras_file=EXTRAS_FILE):

@@ -392,6 +392,7 @@ class WholeOp:
         rate = run(n_ops, cores, repeat)
         dt = time.perf_counter() - t0
         return dict(value=rate, unit=self.unit, cores=cores, kind="port", single_thread_value=one_rate,
+                    sample_short=f"{n_ops * repeat} {self.kind} ops (first {n_ops} of the batch x {repeat}), {cores} threads, {dt:.1f} s",
                     sample=f"{n_ops * repeat} whole {self.kind} ops{' incl. try_from_bytes of the key' if self.wire else ''} (the batch's first {n_ops} ops x {repeat} passes) on {cores} "
                            f"host threads (pthreads; = the container's CPU quota on a {os.cpu_count()}-CPU host), oracle/liboracle.so = KAT-pinned C "
                            f"restatement with per-op ExpandA, {dt:.1f} s")

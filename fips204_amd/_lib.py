@@ -60,7 +60,7 @@ OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
 OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE, OPT_SIGN_ROUNDS = 1, 2, 3, 4, 5, 6
 OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD, OPT_WORKSPACE_CAP_MB = 7, 8, 9, 10, 11
 OPT_COOP_HASH = 12
-ABI_VERSION = 4
+ABI_VERSION = 5
 ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
 ROUND_POWER2ROUND, ROUND_DECOMPOSE, ROUND_HIGH_BITS, ROUND_LOW_BITS, ROUND_MAKE_HINT, ROUND_USE_HINT = range(6)
 
@@ -88,6 +88,9 @@ _SIGNATURES = {
     "mldsa_batcher_sign": [_P, _I, _P, _P, _SZ, _P, _SZ, _P, _P],
     "mldsa_batcher_keygen": [_P, _P, _P, _P],
     "mldsa_batcher_get_stats": [_P, _P],
+    "mldsa_batcher_forget_key": [_P, _P, _SZ],
+    "mldsa_batcher_flush_keys": [_P],
+    "mldsa_batcher_set_private_key_cache": [_P, _I],
     "mldsa_ctx_device": [_P],
     "mldsa_reserve": [_P, _I, _I, _SZ],
     "mldsa_ctx_set_workspace": [_P, _P, _SZ],

@@ -17,10 +17,22 @@
 // mldsa_sign_cached_a with the table as its key array: results are bit for bit those of mldsa_verify / mldsa_sign.
 //
 // Host code only (plain C++, no kernels): the device work goes through the library's own entry points.
+//
+// Platform.  Written for the platform ROCm runs on -- Linux on x86-64: sleeping and waking go through raw futex words
+// (FUTEX_WAIT_PRIVATE / FUTEX_WAKE_PRIVATE) and the spin loop uses the x86 `pause` hint.  Everything else is ISO C++17.  On another
+// OS or architecture (or with -DMLDSA_BATCHER_PORTABLE, which the CPU test-suite also builds and runs) the same two primitives fall
+// back to a mutex + condition variable per batcher and std::this_thread::yield: same semantics, more wake-up latency.
+#if defined(__linux__) && !defined(MLDSA_BATCHER_PORTABLE)
+#define MLDSA_BATCHER_FUTEX 1
 #include <linux/futex.h>
+#include <sys/mman.h>
 #include <sys/syscall.h>
-#include <time.h>
 #include <unistd.h>
+#else
+#define MLDSA_BATCHER_FUTEX 0
+#include <condition_variable>
+#endif
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -48,13 +60,23 @@ enum State { FREE, OPEN, SEALED, RUNNING, DONE };
 // look the key up): a std::mutex under that load turns into a convoy of futex hand-offs (measured with 256 callers: 29 k calls/s,
 // against 166 k with what follows), so the shared state sits behind a spinlock, and everything that SLEEPS -- callers waiting for
 // their batch, the idle dispatcher, callers waiting for a free batch -- sleeps on a futex word and is woken without any lock.
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 struct SpinLock {
     std::atomic<uint32_t> v{0};
     void lock() {
         int spins = 0;
         while (v.exchange(1, std::memory_order_acquire))
             while (v.load(std::memory_order_relaxed)) {
-                if (++spins < 256) __builtin_ia32_pause();
+                if (++spins < 256) cpu_relax();
                 else { std::this_thread::yield(); spins = 0; }
             }
     }
@@ -62,12 +84,31 @@ struct SpinLock {
 };
 using Lock = std::unique_lock<SpinLock>;
 
+#if MLDSA_BATCHER_FUTEX
 inline void futex_wait(std::atomic<uint32_t> *w, uint32_t seen, const timespec *timeout = nullptr) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAIT_PRIVATE, seen, timeout, nullptr, 0);
 }
 inline void futex_wake(std::atomic<uint32_t> *w, int n) {
     (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(w), FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0);
 }
+inline void no_core_dump(void *p, size_t bytes) { (void)madvise(p, bytes, MADV_DONTDUMP); }
+#else
+// Portable stand-in for the two futex calls: one process-wide mutex + condition variable.  "Sleep while *w == seen" and "wake the
+// sleepers of w" keep their meaning (every wake-up re-checks the word); n is ignored: everybody looks again.
+inline std::mutex &park_mu() { static std::mutex m; return m; }
+inline std::condition_variable &park_cv() { static std::condition_variable c; return c; }
+inline void futex_wait(std::atomic<uint32_t> *w, uint32_t seen, const timespec *timeout = nullptr) {
+    std::unique_lock<std::mutex> lk(park_mu());
+    auto changed = [&] { return w->load(std::memory_order_acquire) != seen; };
+    if (timeout) park_cv().wait_for(lk, std::chrono::seconds(timeout->tv_sec) + std::chrono::nanoseconds(timeout->tv_nsec), changed);
+    else park_cv().wait(lk, changed);
+}
+inline void futex_wake(std::atomic<uint32_t> *, int) {
+    { std::lock_guard<std::mutex> lk(park_mu()); }
+    park_cv().notify_all();
+}
+inline void no_core_dump(void *, size_t) {}
+#endif
 
 struct PinnedBuf {  // page-locked array (mldsa_host_alloc): the *_host entry points copy from / to it by DMA
     uint8_t *p = nullptr;
@@ -83,7 +124,7 @@ struct PinnedBuf {  // page-locked array (mldsa_host_alloc): the *_host entry po
         return MLDSA_OK;
     }
     void release() {
-        if (p) { std::memset(p, 0, bytes); (void)mldsa_host_free(p); }  // may have held private keys / seeds (mldsa_host_free: Quiesce)
+        if (p) { wipe_host(p, bytes); (void)mldsa_host_free(p); }  // may have held private keys / seeds (mldsa_host_free: Quiesce)
         p = nullptr;
         bytes = 0;
     }
@@ -117,7 +158,11 @@ struct KeyTable {
     uint8_t *rho = nullptr, *cap_k = nullptr, *tr = nullptr;
     int32_t *f0 = nullptr, *f1 = nullptr, *f2 = nullptr;  // public: t1_d2_hat_mont; private: s_1_hat_mont, s_2_hat_mont, t_0_hat_mont
     int32_t *a_hat = nullptr;
-    std::vector<uint8_t> wire;        // host copy of every slot's wire bytes: what a lookup compares against
+    // host copy of every slot's wire bytes: what a lookup compares against.  Page-locked (never swapped), excluded from core dumps
+    // (MADV_DONTDUMP), cleared slot by slot when a key leaves the table and as a whole before it is freed: a private key lives here
+    // exactly as long as its expanded form lives in device memory, and mldsa_batcher_forget_key / _flush_keys /
+    // _set_private_key_cache end both.
+    PinnedBuf wire;
     std::vector<uint8_t> valid;
     std::vector<uint64_t> hash, last_batch;
     std::unordered_multimap<uint64_t, uint32_t> index;  // keyed hash -> slot
@@ -137,6 +182,7 @@ struct Lane {
     std::thread th;
     uint64_t batch_id = 0;
     KeyTable tables[2];  // [OP_VERIFY] public keys, [OP_SIGN] private keys
+    std::mutex table_mu;  // the dispatcher holds it while a keyed batch runs; mldsa_batcher_forget_key / _flush_keys take it from outside
     hipStream_t stream = nullptr;
     DevBuf d_kslot, d_moff, d_coff, d_msgs, d_ctxs, d_in0, d_out0, d_status, d_kstage;
     PinnedBuf kstage;    // wire bytes of the keys a batch has to expand
@@ -163,6 +209,7 @@ struct mldsa_batcher {
     mldsa_batcher_stats stats{};
     size_t cache_keys = 0;
     uint64_t hash_seed = 0;
+    std::atomic<int> private_key_cache{1};  // 0: a private key leaves the table (host copy and device fields wiped) with the batch that used it
 };
 
 namespace {
@@ -190,8 +237,9 @@ int alloc_batch(mldsa_batcher *b, Batch &t, int op) {
     return rc;
 }
 
-// with the lock held: tell the dispatcher there is something to look at; returns whether the caller must futex_wake(work_seq)
-// once it has released the lock
+// with the lock held: tell the dispatchers there is something to look at; returns whether the caller must futex_wake(work_seq)
+// once it has released the lock.  EVERY sleeping dispatcher is woken (there are as many as lanes: a handful): waking one arbitrary
+// sleeper could pick the lane that sits in a timed sleep on an open batch and goes back to sleep, while an idle lane sleeps on.
 bool poke_dispatcher(mldsa_batcher *b) {
     if (b->idle_dispatchers == 0) return false;
     b->work_seq.fetch_add(1, std::memory_order_release);
@@ -210,9 +258,22 @@ Batch *open_batch(mldsa_batcher *b, Lock &lk, int op, int mode, size_t msg_len, 
             const bool fits = t->n < b->max_batch && t->mode == mode &&
                               (op == OP_KEYGEN || (msg_len <= t->msgs.bytes && t->msg_used <= t->msgs.bytes - msg_len));
             if (fits) return t;
-            if (t->n == 0 && t->mode == mode) {  // one message larger than the whole staging array: grow it while nobody else is inside
-                if (t->msgs.reserve(msg_len) != MLDSA_OK) { err = E_NOMEM; return nullptr; }  // (rare; the allocation holds the lock)
-                return t;
+            if (t->n == 0 && t->mode == mode) {
+                // One message larger than the whole staging array: grow it while nobody else is inside.  The allocation (hipHostMalloc:
+                // milliseconds, and it takes the capture lock) runs OUTSIDE the spinlock: the batch is taken out of circulation
+                // (RUNNING: neither callers nor dispatchers touch it), grown, and put back as the open batch.
+                b->open[op] = nullptr;
+                t->state = RUNNING;
+                lk.unlock();
+                const int grow_rc = t->msgs.reserve(msg_len);
+                lk.lock();
+                t->state = FREE;
+                b->free_seq.fetch_add(1, std::memory_order_release);
+                lk.unlock();
+                futex_wake(&b->free_seq, INT_MAX);
+                lk.lock();
+                if (grow_rc != MLDSA_OK) { err = E_NOMEM; return nullptr; }
+                continue;  // (another caller may have opened a batch meanwhile: look again; the grown one is FREE and will be found)
             }
             if (t->n == 0) { t->mode = mode; continue; }
             t->state = SEALED;  // full, or a request of another mode: it runs as it is
@@ -225,7 +286,7 @@ Batch *open_batch(mldsa_batcher *b, Lock &lk, int op, int mode, size_t msg_len, 
         if (!t) {
             const uint32_t seen = b->free_seq.load(std::memory_order_relaxed);
             lk.unlock();
-            if (wake) { futex_wake(&b->work_seq, 1); wake = false; }
+            if (wake) { futex_wake(&b->work_seq, INT_MAX); wake = false; }
             futex_wait(&b->free_seq, seen);
             lk.lock();
             continue;
@@ -317,7 +378,9 @@ int table_alloc(mldsa_batcher *b, KeyTable &kt, bool is_private) {
     } else {
         BTRY(get((void **)&kt.f0, n * K * 1024));
     }
-    kt.wire.assign(n * kl, 0);
+    BTRY(kt.wire.reserve(n * kl));
+    std::memset(kt.wire.p, 0, n * kl);
+    if (is_private) no_core_dump(kt.wire.p, kt.wire.bytes);
     kt.valid.assign(n, 0);
     kt.hash.assign(n, 0);
     kt.last_batch.assign(n, 0);
@@ -333,11 +396,30 @@ void table_free(mldsa_batcher *b, KeyTable &kt) {
         if (kt.f1) (void)memset_quiesced(kt.f1, 0, n * K * 1024);
         if (kt.f2) (void)memset_quiesced(kt.f2, 0, n * K * 1024);
         (void)device_sync_quiesced();
-        std::memset(kt.wire.data(), 0, kt.wire.size());
     }
     for (void *q : {(void *)kt.rho, (void *)kt.cap_k, (void *)kt.tr, (void *)kt.f0, (void *)kt.f1, (void *)kt.f2, (void *)kt.a_hat})
         if (q) (void)free_quiesced(q);
-    kt = KeyTable();
+    kt.wire.release();  // (wipes before it frees)
+    kt.rho = kt.cap_k = kt.tr = nullptr;
+    kt.f0 = kt.f1 = kt.f2 = kt.a_hat = nullptr;
+    kt.cap = kt.hand = 0;
+    kt.valid.clear(); kt.hash.clear(); kt.last_batch.clear(); kt.index.clear();
+}
+
+// Take slot s out of the table.  For a private table the key is gone afterwards: the host copy of its wire bytes is cleared and the
+// secret fields of the device slot (K, s1, s2, t0 in NTT form) are zeroed on the lane's stream (rho, tr and A_hat are public).
+// The caller synchronises the stream before it reports the key as forgotten.
+void table_drop(mldsa_batcher *b, Lane &ln, KeyTable &kt, uint32_t s) {
+    auto range = kt.index.equal_range(kt.hash[s]);
+    for (auto it = range.first; it != range.second; ++it)
+        if (it->second == s) { kt.index.erase(it); break; }
+    kt.valid[s] = 0;
+    if (!kt.is_private) return;
+    const size_t K = (size_t)b->p->k, L = (size_t)b->p->l, kl = (size_t)b->p->sk_len;
+    wipe_host(kt.wire.p + (size_t)s * kl, kl);
+    if (hipMemsetAsync(kt.cap_k + (size_t)s * 32, 0, 32, ln.stream) != hipSuccess || hipMemsetAsync(kt.f0 + (size_t)s * L * 256, 0, L * 1024, ln.stream) != hipSuccess ||
+        hipMemsetAsync(kt.f1 + (size_t)s * K * 256, 0, K * 1024, ln.stream) != hipSuccess || hipMemsetAsync(kt.f2 + (size_t)s * K * 256, 0, K * 1024, ln.stream) != hipSuccess)
+        (void)hipGetLastError();
 }
 
 // Every distinct key of the batch -> a slot of the device-resident table; the keys the table does not hold are expanded into
@@ -356,7 +438,7 @@ int resolve_keys(mldsa_batcher *b, Lane &ln, Batch *t, std::vector<uint32_t> &sl
         bool hit = false;
         auto range = kt.index.equal_range(t->key_hash[j]);
         for (auto it = range.first; it != range.second && !hit; ++it)
-            if (std::memcmp(kt.wire.data() + (size_t)it->second * kl, key, kl) == 0) {
+            if (std::memcmp(kt.wire.p + (size_t)it->second * kl, key, kl) == 0) {
                 slot_of[j] = it->second;
                 kt.last_batch[it->second] = id;
                 hit = true;
@@ -369,12 +451,7 @@ int resolve_keys(mldsa_batcher *b, Lane &ln, Batch *t, std::vector<uint32_t> &sl
     // slots for the new keys, in ring order, skipping what this batch itself uses; consecutive slots form one expansion call
     struct Run { size_t first_slot, first_miss, count; };
     std::vector<Run> runs;
-    auto drop = [&](uint32_t s) {
-        auto range = kt.index.equal_range(kt.hash[s]);
-        for (auto it = range.first; it != range.second; ++it)
-            if (it->second == s) { kt.index.erase(it); break; }
-        kt.valid[s] = 0;
-    };
+    auto drop = [&](uint32_t s) { table_drop(b, ln, kt, s); };
     BTRY(ln.kstage.reserve(miss.size() * kl));
     for (size_t m = 0; m < miss.size(); m++) {
         size_t s = kt.hand;
@@ -382,7 +459,7 @@ int resolve_keys(mldsa_batcher *b, Lane &ln, Batch *t, std::vector<uint32_t> &sl
         kt.hand = (s + 1) % kt.cap;
         if (kt.valid[s]) drop((uint32_t)s);
         const uint8_t *key = t->keys.p + (size_t)miss[m] * kl;
-        std::memcpy(kt.wire.data() + s * kl, key, kl);
+        std::memcpy(kt.wire.p + s * kl, key, kl);
         std::memcpy(ln.kstage.p + m * kl, key, kl);
         kt.hash[s] = t->key_hash[miss[m]];
         kt.last_batch[s] = id;
@@ -407,7 +484,7 @@ int resolve_keys(mldsa_batcher *b, Lane &ln, Batch *t, std::vector<uint32_t> &sl
     if (priv) {  // the wire bytes of private keys leave the staging buffers with the batch
         if (ln.d_kstage.p && hipMemsetAsync(ln.d_kstage.p, 0, std::min(ln.d_kstage.bytes, miss.size() * kl), ln.stream) != hipSuccess) (void)hipGetLastError();
         if (hipStreamSynchronize(ln.stream) != hipSuccess) (void)hipGetLastError();  // the upload has read the page-locked copy
-        std::memset(ln.kstage.p, 0, miss.size() * kl);
+        wipe_host(ln.kstage.p, miss.size() * kl);
     }
     if (rc != MLDSA_OK)  // nothing half-expanded stays findable
         for (uint32_t j : miss) drop(slot_of[j]);
@@ -485,14 +562,27 @@ void run_batch(mldsa_batcher *b, Lane &ln, Batch *t) {
     int rc;
     if (t->op == OP_KEYGEN) rc = mldsa_keygen_host(ln.ctx, b->p->set, t->in0.p, t->out0.p, t->out1.p, t->n);
     else {
+        std::lock_guard<std::mutex> tl(ln.table_mu);  // (mldsa_batcher_forget_key / _flush_keys wait for the batch, not the other way round)
         rc = run_keyed(b, ln, t);
-        if (rc != MLDSA_OK && ln.stream) { DeviceGuard dg(mldsa_ctx_device(ln.ctx)); (void)hipStreamSynchronize(ln.stream); }
+        if (rc != MLDSA_OK) { const char *e = mldsa_last_error(); t->err = e ? e : ""; }
+        DeviceGuard dg(mldsa_ctx_device(ln.ctx));
+        if (rc != MLDSA_OK && ln.stream) (void)hipStreamSynchronize(ln.stream);
+        if (t->op == OP_SIGN) {
+            // a staged (n > 256) batch that failed half-way left before its own clearing of the uploaded rnd values
+            if (rc != MLDSA_OK && ln.d_in0.p && ln.stream && hipMemsetAsync(ln.d_in0.p, 0, ln.d_in0.bytes, ln.stream) != hipSuccess) (void)hipGetLastError();
+            if (!b->private_key_cache.load(std::memory_order_relaxed)) {  // no private key outlives the batch that used it
+                KeyTable &kt = ln.tables[OP_SIGN];
+                for (size_t s = 0; s < kt.cap; s++)
+                    if (kt.valid[s]) table_drop(b, ln, kt, (uint32_t)s);
+            }
+            if (ln.stream && hipStreamSynchronize(ln.stream) != hipSuccess) (void)hipGetLastError();
+        }
     }
     t->rc = rc;
-    if (rc != MLDSA_OK) { const char *e = mldsa_last_error(); t->err = e ? e : ""; }
+    if (rc != MLDSA_OK && t->err.empty()) { const char *e = mldsa_last_error(); t->err = e ? e : ""; }
     if (t->op != OP_VERIFY) {  // private keys and seeds do not outlive the call (types.rs:19)
-        if (t->op == OP_SIGN) std::memset(t->keys.p, 0, t->n_keys * key_len(b, OP_SIGN));
-        std::memset(t->in0.p, 0, t->n * 32);
+        if (t->op == OP_SIGN) wipe_host(t->keys.p, t->n_keys * key_len(b, OP_SIGN));
+        wipe_host(t->in0.p, t->n * 32);
     }
 }
 
@@ -507,11 +597,16 @@ void dispatcher(mldsa_batcher *b, Lane *ln) {
         b->idle_dispatchers--;
     };
     for (;;) {
-        // the oldest batch that has requests (sealed ones first: they were opened before the one that is filling)
-        Batch *t = nullptr;
+        // What runs next: the oldest SEALED batch (full, or closed by a request of another mode) if there is one -- it is runnable
+        // now, whatever open batch of another operation may be older and still inside its max_wait_us window -- else the oldest
+        // open batch that has requests.
+        Batch *t = nullptr, *open_t = nullptr;
         for (int op = 0; op < N_OPS; op++)
-            for (auto &c : b->batches[op])
-                if ((c->state == SEALED || (c->state == OPEN && c->n > 0)) && (!t || c->first_arrival < t->first_arrival)) t = c.get();
+            for (auto &c : b->batches[op]) {
+                if (c->state == SEALED && (!t || c->first_arrival < t->first_arrival)) t = c.get();
+                if (c->state == OPEN && c->n > 0 && (!open_t || c->first_arrival < open_t->first_arrival)) open_t = c.get();
+            }
+        if (!t) t = open_t;
         if (!t) {
             if (b->quit) return;
             sleep_until_poked(nullptr);
@@ -571,7 +666,7 @@ int submit(mldsa_batcher *b, const Req &r) {
     Batch *t = open_batch(b, lk, r.op, r.mode, r.msg_len, err, wake);
     if (!t) {
         lk.unlock();
-        if (wake) futex_wake(&b->work_seq, 1);
+        if (wake) futex_wake(&b->work_seq, INT_MAX);
         return err == E_QUIT ? set_error(MLDSA_ERR_PARAM, "mldsa_batcher: destroyed while in use")
                              : set_error(MLDSA_ERR_NOMEM, "mldsa_batcher: no page-locked memory for a message of this size");
     }
@@ -598,7 +693,7 @@ int submit(mldsa_batcher *b, const Req &r) {
         wake |= poke_dispatcher(b);
     }
     lk.unlock();
-    if (wake) futex_wake(&b->work_seq, 1);
+    if (wake) futex_wake(&b->work_seq, INT_MAX);
     // the request's own bytes, outside the lock (other callers fill their slots at the same time)
     if (r.op != OP_KEYGEN) {
         if (r.msg_len) std::memcpy(t->msgs.p + m0, r.msg, r.msg_len);
@@ -612,8 +707,12 @@ int submit(mldsa_batcher *b, const Req &r) {
     while (t->done_gen.load(std::memory_order_acquire) == gen) { futex_wait(&t->done_gen, gen); slept = true; }
     if (slept) futex_wake(&t->done_gen, 2);
     int rc = t->rc;
-    if (rc != MLDSA_OK) set_error(rc, ("mldsa_batcher: " + t->err).c_str());
-    else if (r.op == OP_VERIFY) *r.out0 = t->out0.p[i];
+    if (rc != MLDSA_OK) {
+        // the header's promise for a failed operation: ok = 0 (set by the entry point), an all-zero signature, all-zero keys
+        set_error(rc, ("mldsa_batcher: " + t->err).c_str());
+        if (r.op == OP_SIGN) std::memset(r.out0, 0, (size_t)p->sig_len);
+        if (r.op == OP_KEYGEN) { std::memset(r.out0, 0, (size_t)p->pk_len); wipe_host(r.out1, (size_t)p->sk_len); }
+    } else if (r.op == OP_VERIFY) *r.out0 = t->out0.p[i];
     else if (r.op == OP_SIGN) {
         std::memcpy(r.out0, t->out0.p + i * (size_t)p->sig_len, (size_t)p->sig_len);
         const int32_t st = reinterpret_cast<const int32_t *>(t->status.p)[i];
@@ -623,7 +722,7 @@ int submit(mldsa_batcher *b, const Req &r) {
         std::memcpy(r.out1, t->out1.p + i * (size_t)p->sk_len, (size_t)p->sk_len);
     }
     if (t->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // the last caller out returns the batch
-        if (t->op == OP_KEYGEN) std::memset(t->out1.p, 0, t->n * (size_t)p->sk_len);
+        if (t->op == OP_KEYGEN) wipe_host(t->out1.p, t->n * (size_t)p->sk_len);
         lk.lock();
         t->state = FREE;
         b->free_seq.fetch_add(1, std::memory_order_release);
@@ -650,10 +749,11 @@ static int batcher_make(const std::vector<mldsa_ctx *> &ctxs, bool own, int set,
     b->max_wait_us = max_wait_us;
     // a batch never evicts its own keys, so a table holds at least one batch's worth; default: 1 024 keys or one batch
     b->cache_keys = std::max(max_batch, cache_keys ? cache_keys : (size_t)1024);
-    {   // the seed of the key hash: unpredictable to callers, nothing more (clock, addresses)
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        b->hash_seed = ((uint64_t)ts.tv_nsec * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)ts.tv_sec << 32) ^ (uint64_t)(uintptr_t)b.get() ^ ((uint64_t)getpid() << 48);
+    {   // the seed of the key hash: unpredictable to callers, nothing more (clocks, addresses, the thread)
+        const uint64_t t0 = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+        const uint64_t t1 = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
+        const uint64_t tid = (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id());
+        b->hash_seed = (t0 * 0x9E3779B97F4A7C15ull) ^ (t1 << 32) ^ (uint64_t)(uintptr_t)b.get() ^ (tid << 48) ^ (tid >> 16);
     }
     for (mldsa_ctx *c : ctxs) {
         b->lanes.emplace_back(new Lane());
@@ -769,6 +869,63 @@ int mldsa_batcher_keygen(mldsa_batcher *b, const uint8_t *xi, uint8_t *pk, uint8
     REQUIRE(b && xi && pk && sk, "mldsa_batcher_keygen: NULL pointer");
     const Req r{OP_KEYGEN, 0, nullptr, nullptr, nullptr, xi, 0, 0, pk, sk};
     return submit(b, r);
+}
+
+// Key lifetime.  Take `key` (PK_LEN or SK_LEN wire bytes) out of every lane's table / empty the tables / stop keeping private keys
+// between batches.  Each waits for the batch a lane is running (the table belongs to it for that long) and returns when the host
+// copy of the wire bytes is cleared and the device slot's secret fields are zero.
+static int forget_in_lane(mldsa_batcher *b, Lane &ln, int op, const uint8_t *key, size_t kl, uint64_t h) {
+    std::lock_guard<std::mutex> tl(ln.table_mu);
+    KeyTable &kt = ln.tables[op];
+    if (!kt.cap) return MLDSA_OK;
+    DeviceGuard dg(mldsa_ctx_device(ln.ctx));
+    bool any = false;
+    if (key) {
+        auto range = kt.index.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (std::memcmp(kt.wire.p + (size_t)it->second * kl, key, kl) == 0) { table_drop(b, ln, kt, it->second); any = true; break; }
+    } else {
+        for (size_t s = 0; s < kt.cap; s++)
+            if (kt.valid[s]) { table_drop(b, ln, kt, (uint32_t)s); any = true; }
+    }
+    if (any && kt.is_private && ln.stream) BCHECK(hipStreamSynchronize(ln.stream));
+    return MLDSA_OK;
+}
+
+int mldsa_batcher_forget_key(mldsa_batcher *b, const uint8_t *key, size_t key_len_) {
+    REQUIRE(b && key, "mldsa_batcher_forget_key: NULL pointer");
+    const int op = key_len_ == (size_t)b->p->sk_len ? OP_SIGN : key_len_ == (size_t)b->p->pk_len ? OP_VERIFY : -1;
+    REQUIRE(op >= 0, "mldsa_batcher_forget_key: key_len is neither PK_LEN nor SK_LEN of the batcher's parameter set");
+    const uint64_t h = hash_key(b->hash_seed, key, key_len_);
+    int rc = MLDSA_OK;
+    for (auto &ln : b->lanes) {
+        const int r = forget_in_lane(b, *ln, op, key, key_len_, h);
+        if (rc == MLDSA_OK) rc = r;
+    }
+    return rc;
+}
+
+int mldsa_batcher_flush_keys(mldsa_batcher *b) {
+    REQUIRE(b, "mldsa_batcher_flush_keys: NULL batcher");
+    int rc = MLDSA_OK;
+    for (auto &ln : b->lanes)
+        for (int op : {OP_SIGN, OP_VERIFY}) {
+            const int r = forget_in_lane(b, *ln, op, nullptr, 0, 0);
+            if (rc == MLDSA_OK) rc = r;
+        }
+    return rc;
+}
+
+int mldsa_batcher_set_private_key_cache(mldsa_batcher *b, int on) {
+    REQUIRE(b, "mldsa_batcher_set_private_key_cache: NULL batcher");
+    b->private_key_cache.store(on ? 1 : 0, std::memory_order_relaxed);
+    if (on) return MLDSA_OK;
+    int rc = MLDSA_OK;  // switching it off also drops what is there now
+    for (auto &ln : b->lanes) {
+        const int r = forget_in_lane(b, *ln, OP_SIGN, nullptr, 0, 0);
+        if (rc == MLDSA_OK) rc = r;
+    }
+    return rc;
 }
 
 int mldsa_batcher_get_stats(mldsa_batcher *b, mldsa_batcher_stats *out) {

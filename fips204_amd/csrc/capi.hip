@@ -124,6 +124,9 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_ws_cap_bytes = (size_t)env_long("MLDSA_WORKSPACE_CAP_MB", 0, 1L << 20, 0) << 20;
     ctx->pass_ops = (size_t)env_long("MLDSA_PASS_OPS", 256, 1 << 20, (long)ctx->pass_ops);
     ctx->pass_ops_sign = (size_t)env_long("MLDSA_PASS_OPS_SIGN", 256, 1 << 20, (long)ctx->pass_ops_sign);
+    ctx->pass_ops_cfg = ctx->pass_ops;
+    ctx->pass_ops_sign_cfg = ctx->pass_ops_sign;
+    ctx->opt_spec_rows_cfg = ctx->opt_spec_rows;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cu = prop.multiProcessorCount;
@@ -257,6 +260,7 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
         case MLDSA_OPT_WORKSPACE_CAP_MB:
             REQUIRE(value >= 0 && value <= (1L << 20), "mldsa_set_option: MLDSA_OPT_WORKSPACE_CAP_MB out of range");
             ctx->opt_ws_cap_bytes = (size_t)value << 20;
+            restore_pass_sizes(ctx);  // a new cap: the passes start from the configured sizes again (reserve_workspace)
             return MLDSA_OK;
         default: return set_error(MLDSA_ERR_PARAM, "mldsa_set_option: unknown option");
     }
@@ -309,6 +313,7 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes) {
     ctx->ws = dev_buf;
     ctx->ws_bytes = bytes;
     ctx->ws_external = dev_buf != nullptr;
+    restore_pass_sizes(ctx);  // another buffer (or the context's own again): pass sizes a smaller one forced do not stick
     return MLDSA_OK;
 }
 

@@ -108,7 +108,7 @@ int grow_dev(Buf &b, size_t bytes) {
 
 int grow_pin(Buf &b, size_t bytes) {
     if (b.pin_cap >= bytes) return MLDSA_OK;
-    if (b.pin) { HCHECK(device_sync_quiesced()); MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); HCHECK(host_free_quiesced(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
+    if (b.pin) { HCHECK(device_sync_quiesced()); MLDSA_WIPE(wipe_host(b.pin, b.pin_cap)); HCHECK(host_free_quiesced(b.pin)); b.pin = nullptr; b.pin_cap = 0; }
     const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
     if (host_malloc_quiesced((void **)&b.pin, want) != hipSuccess) return set_error(MLDSA_ERR_NOMEM, "host path: page-locked staging allocation");
     b.pin_cap = want;
@@ -193,12 +193,12 @@ int stage_get(mldsa_ctx *ctx, HostStage **out) {
 // secrets must not outlive the call in the staging buffers (the reference zeroizes on drop, types.rs:19)
 void wipe_buf(Buf &b, hipStream_t st) {
     if (b.dev) MLDSA_WIPE(hipMemsetAsync(b.dev, 0, b.cap, st));
-    if (b.pin) MLDSA_WIPE(memset(b.pin, 0, b.pin_cap));
+    if (b.pin) MLDSA_WIPE(wipe_host(b.pin, b.pin_cap));
 }
 
 void free_buf(Buf &b) {
     if (b.dev) { MLDSA_WIPE(memset_quiesced(b.dev, 0, b.cap)); (void)free_quiesced(b.dev); }
-    if (b.pin) { MLDSA_WIPE(memset(b.pin, 0, b.pin_cap)); (void)host_free_quiesced(b.pin); }
+    if (b.pin) { MLDSA_WIPE(wipe_host(b.pin, b.pin_cap)); (void)host_free_quiesced(b.pin); }
     b = Buf();
 }
 

@@ -59,4 +59,24 @@ inline hipError_t host_malloc_quiesced(void **host_ptr, size_t bytes, unsigned f
 inline hipError_t memcpy_quiesced(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) { Quiesce q; return hipMemcpy(dst, src, bytes, kind); }
 inline hipError_t memset_quiesced(void *dev_ptr, int value, size_t bytes) { Quiesce q; return hipMemset(dev_ptr, value, bytes); }
 
+// Host-side clearing of secret bytes (staged private keys, seeds, rnd; the reference's `zeroize`, types.rs:19, 45).  A plain memset
+// of memory that is freed or never read again is a dead store the compiler may drop; this one cannot be: volatile stores, then a
+// compiler barrier that names the memory.  Every host-side clearing site of the library goes through it
+// (tests/test_sanitizers_cpu.py checks a freed staging buffer of the batcher for key bytes).
+inline void wipe_host(void *p, size_t bytes) {
+#ifdef MLDSA_TEST_NO_ZEROISE
+    (void)p; (void)bytes;  // negative control of the residue tests: the probe must FIND the secrets when nothing clears them
+    return;
+#endif
+    if (!p || !bytes) return;
+    volatile unsigned char *v = static_cast<volatile unsigned char *>(p);
+    size_t i = 0;
+    if ((reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+        volatile uint64_t *w = static_cast<volatile uint64_t *>(p);
+        for (; i + 8 <= bytes; i += 8) w[i >> 3] = 0;
+    }
+    for (; i < bytes; i++) v[i] = 0;
+    __asm__ __volatile__("" : : "r"(p) : "memory");
+}
+
 }  // namespace mldsa

@@ -11,6 +11,7 @@
 // hipGraph (one graph launch instead of 10 ... 100 kernel launches) and falls back to direct launches for
 // shapes it has not seen twice.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstring>
 
@@ -33,28 +34,54 @@ constexpr size_t MIN_PASS_OPS = 1024, MIN_SPEC_ROWS = 1024;
 // pass takes 15 GB of the 288); on a device that cannot give that much -- smaller, partitioned, or shared with other work --
 // the context falls back to smaller passes (more of them per call, results identical) instead of failing the call.
 int reserve_workspace(mldsa_ctx *ctx, const mldsa_params *p, int op, size_t n_ops, bool own_a, size_t wire_table_keys, int wire_mode) {
+    // The shrinking below is TENTATIVE: the context's pass sizes change for good only when a smaller layout is actually obtained.  A
+    // call that cannot be served at any size -- a caller-owned buffer or MLDSA_OPT_WORKSPACE_CAP_MB too small even for the smallest
+    // pass -- leaves the context exactly as it found it (one oversized call must not turn every later call into 1 024-op passes),
+    // and the user's MLDSA_OPT_SPEC_TARGET is never written here: the effective target is min(option, opt_spec_rows) where it is used.
+    const size_t pass0 = ctx->pass_ops, pass_sign0 = ctx->pass_ops_sign;
+    const long rows0 = ctx->opt_spec_rows, cap0 = ctx->spec_target_cap;
+    unsigned long long shrinks = 0;
+    auto undo = [&] { ctx->pass_ops = pass0; ctx->pass_ops_sign = pass_sign0; ctx->opt_spec_rows = rows0; ctx->spec_target_cap = cap0; };
     for (;;) {
         const size_t bytes = op == MLDSA_OP_SIGN ? sign_workspace_bytes(ctx, p, n_ops, own_a)
                              : op == MLDSA_OP_VERIFY ? verify_workspace_bytes(ctx, p, n_ops, own_a, wire_table_keys, wire_mode)
                                                      : keygen_workspace_bytes(ctx, p, n_ops);
         const int rc = ensure_workspace(ctx, bytes);
         size_t &pass = op == MLDSA_OP_SIGN ? ctx->pass_ops_sign : ctx->pass_ops;
-        if (rc != MLDSA_ERR_NOMEM) return rc;
-        // A signing pass holds one row set (y, w, c ...) per candidate of a speculative round -- up to MLDSA_OPT_SPEC_TARGET rows
+        if (rc != MLDSA_ERR_NOMEM) {
+            if (rc == MLDSA_OK) ctx->stats.workspace_shrinks += shrinks;  // committed
+            else undo();
+            return rc;
+        }
+        // A signing pass holds one row set (y, w, c ...) per candidate of a speculative round -- up to opt_spec_rows rows
         // whatever the batch size: those come down first, to the size of the pass.  (Speculation only trades rounds for width:
         // the signatures do not depend on it.)
         const size_t resident = std::min(pass, n_ops);
         if (op == MLDSA_OP_SIGN && (size_t)ctx->opt_spec_rows > std::max(resident, MIN_SPEC_ROWS)) {
             ctx->opt_spec_rows = (long)std::max<size_t>((size_t)ctx->opt_spec_rows / 2, MIN_SPEC_ROWS);
-            ctx->opt_spec_target = std::min(ctx->opt_spec_target, ctx->opt_spec_rows);
+            ctx->spec_target_cap = std::min(ctx->spec_target_cap, ctx->opt_spec_rows);  // (rows = max(target, rows): the target has to follow)
         } else {
-            if (pass <= MIN_PASS_OPS) return rc;
-            // The workspace follows min(n_ops, pass): the pass size is halved until it is BELOW the call's size (halving a pass
-            // that is still larger than the call would ask for the same bytes again); the call then runs in two or more passes.
+            // The workspace follows min(n_ops, pass): halving helps only while that minimum can still come down.  A call of at most
+            // MIN_PASS_OPS ops asks for the same bytes at every pass size: it fails at once.
+            if (pass <= MIN_PASS_OPS || n_ops <= MIN_PASS_OPS) {
+                undo();
+                return rc;
+            }
+            // the pass size is halved until it is BELOW the call's size (halving a pass that is still larger than the call would
+            // ask for the same bytes again); the call then runs in two or more passes.
             do pass /= 2; while (pass > MIN_PASS_OPS && pass >= n_ops);
         }
-        ctx->stats.workspace_shrinks++;
+        shrinks++;
     }
+}
+
+// A larger (or no) caller-owned buffer, a raised or removed cap: the passes go back to what the context was configured with; the next
+// call that does not fit shrinks them again (mldsa_ctx_set_workspace, MLDSA_OPT_WORKSPACE_CAP_MB).
+void restore_pass_sizes(mldsa_ctx *ctx) {
+    ctx->pass_ops = ctx->pass_ops_cfg;
+    ctx->pass_ops_sign = ctx->pass_ops_sign_cfg;
+    ctx->opt_spec_rows = ctx->opt_spec_rows_cfg;
+    ctx->spec_target_cap = LONG_MAX;
 }
 
 std::shared_mutex &capture_mutex() {
@@ -526,7 +553,8 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
     pl.spec_max = (uint32_t)ctx->opt_spec_max;
     // a small batch cannot fill the target however many candidates each op gets: cap it so that the
     // workspace and the grids follow the batch
-    const size_t tgt = std::min<size_t>((size_t)ctx->opt_spec_target, std::max<size_t>(n * pl.spec_max, 1));
+    // (effective target: the user's option under the cap reserve_workspace sets when it has to halve the rows of a round)
+    const size_t tgt = std::min<size_t>((size_t)std::min(ctx->opt_spec_target, ctx->spec_target_cap), std::max<size_t>(n * pl.spec_max, 1));
     pl.spec_target = (uint32_t)tgt;
     // candidates per speculative round (>= the threshold above): rows = what such a round generates
     const size_t rows = std::max(tgt, std::min<size_t>((size_t)ctx->opt_spec_rows, std::max<size_t>(n * pl.spec_max, 1)));
@@ -977,7 +1005,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         const size_t n_chunk = (n_ops - o) < chunk ? (n_ops - o) : chunk;
         struct { int op, n_lanes; long spec_target, spec_rows, spec_alpha, spec_max, rounds, ahead; SignArgs a[2]; } key;
         memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
-        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = ctx->opt_spec_target; key.spec_rows = ctx->opt_spec_rows; key.spec_alpha = ctx->opt_spec_alpha; key.spec_max = ctx->opt_spec_max;
+        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = std::min(ctx->opt_spec_target, ctx->spec_target_cap); key.spec_rows = ctx->opt_spec_rows; key.spec_alpha = ctx->opt_spec_alpha; key.spec_max = ctx->opt_spec_max;
         key.rounds = (long)pl.m_hint.size();  // the planned rounds (options, the asynchronous stop threshold) shape the launch sequence
         key.ahead = ctx->opt_lookahead;
         int live = 0;

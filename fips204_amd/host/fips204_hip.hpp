@@ -443,6 +443,11 @@ struct ParamSet {
             check(mldsa_batcher_keygen(b_, xi.data(), out.first.data(), out.second.data()), "mldsa_batcher_keygen");
             return out;
         }
+        // key lifetime: the table's copy of a key ends with the caller's (the reference's PrivateKey is ZeroizeOnDrop, src/types.rs:19)
+        void forget_key(const SkBytes& sk) const { check(mldsa_batcher_forget_key(b_, sk.data(), sk.size()), "mldsa_batcher_forget_key"); }
+        void forget_public_key(const PkBytes& pk) const { check(mldsa_batcher_forget_key(b_, pk.data(), pk.size()), "mldsa_batcher_forget_key"); }
+        void flush_keys() const { check(mldsa_batcher_flush_keys(b_), "mldsa_batcher_flush_keys"); }
+        void set_private_key_cache(bool on) const { check(mldsa_batcher_set_private_key_cache(b_, on ? 1 : 0), "mldsa_batcher_set_private_key_cache"); }
         mldsa_batcher_stats stats() const {
             mldsa_batcher_stats st;
             check(mldsa_batcher_get_stats(b_, &st), "mldsa_batcher_get_stats");

@@ -448,7 +448,13 @@ class MlDsa:
         self.sign_device(sks, msg_buf, msg_off, rnd, sigs, n_ops, ctx_buf, ctx_off, kidx, mode, status)
         torch.cuda.synchronize(self.device)
         if n_ops and int(status[:n_ops].min()) < 0:
-            raise ValueError("ML-DSA.Sign: ctx too long")
+            st = status[:n_ops].cpu().numpy()
+            bad = int(np.flatnonzero(st < 0)[0])
+            code = int(st[bad])
+            what = {_lib.ERR_CTX_LEN: "ML-DSA.Sign: ctx too long",
+                    _lib.ERR_PARAM: "ML-DSA.Sign: operation refused (malformed offsets or key index out of range)",
+                    _lib.ERR_AGAIN: "ML-DSA.Sign: operation left unfinished by an asynchronous call"}.get(code, f"ML-DSA.Sign: status {code}")
+            raise ValueError(f"{what} (op {bad})")
         return sigs[:n_ops]
 
     def try_hash_sign_with_seed(self, sks, messages, rnd, ctxs=None, ph=PH_SHA512, key_idx=None):
@@ -651,6 +657,18 @@ class MlDsaBatcher:
         pk, sk = (C.c_uint8 * self.PK_LEN)(), (C.c_uint8 * self.SK_LEN)()
         _lib.check(self.lib.mldsa_batcher_keygen(self._b, xi, pk, sk))
         return bytes(pk), bytes(sk)
+
+    def forget_key(self, key):
+        """take one key (pk or sk wire bytes) out of the device-resident tables: the host copy is cleared, a private key's device fields zeroed"""
+        key = bytes(key)
+        _lib.check(self.lib.mldsa_batcher_forget_key(self._b, key, len(key)))
+
+    def flush_keys(self):
+        _lib.check(self.lib.mldsa_batcher_flush_keys(self._b))
+
+    def set_private_key_cache(self, on):
+        """False: no private key stays in the table beyond the batch that used it (the caller's zeroize then ends the key's life)"""
+        _lib.check(self.lib.mldsa_batcher_set_private_key_cache(self._b, 1 if on else 0))
 
     def stats(self):
         st = _lib.BatcherStats()

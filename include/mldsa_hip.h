@@ -74,8 +74,9 @@ extern "C" {
 #define MLDSA_MODE_PREHASH 2   /* mu = H(tr | 0x01 | len(ctx) | ctx | OID | PH(M)); msg = OID|PH(M) */
 
 /* Bumped whenever a struct of this header grows or an entry point changes its meaning (4: mldsa_stats has 6 fields, the group
- * calls take device-resident slices, offset tables are validated).  mldsa_abi_version() reports the library's. */
-#define MLDSA_ABI_VERSION 4
+ * calls take device-resident slices, offset tables are validated; 5: key-lifetime calls of the batcher, MLDSA_OPT_SMALL_FUSED).
+ * mldsa_abi_version() reports the library's. */
+#define MLDSA_ABI_VERSION 5
 int mldsa_abi_version(void);
 
 typedef struct mldsa_ctx mldsa_ctx;
@@ -568,6 +569,18 @@ int mldsa_batcher_sign(mldsa_batcher *b, int mode, const uint8_t *sk, const uint
                        const uint8_t *rnd, uint8_t *sig);
 int mldsa_batcher_keygen(mldsa_batcher *b, const uint8_t *xi, uint8_t *pk, uint8_t *sk);
 int mldsa_batcher_get_stats(mldsa_batcher *b, mldsa_batcher_stats *out);
+/* Key lifetime (the reference's caller owns a ZeroizeOnDrop PrivateKey, src/types.rs:19: dropping it ends the key's life; here the
+ * table would keep it).  What the table holds of a key: its wire bytes in page-locked host memory that is excluded from core dumps
+ * (what a lookup compares against) and the expanded fields + A_hat in device memory.
+ *   mldsa_batcher_forget_key(b, key, key_len)    takes that key (PK_LEN or SK_LEN bytes) out of every lane's table;
+ *   mldsa_batcher_flush_keys(b)                  empties the tables;
+ *   mldsa_batcher_set_private_key_cache(b, 0)    from now on no private key stays in the table beyond the batch that used it
+ *                                                (every signing call then pays try_from_bytes + ExpandA); 1 (default) keeps them.
+ * Each returns once the host copy is cleared and, for private keys, the device slot's secret fields (K, s1, s2, t0) are zero; a call
+ * waits for the batch a lane is running.  Forgetting a key that is not in the table is not an error. */
+int mldsa_batcher_forget_key(mldsa_batcher *b, const uint8_t *key, size_t key_len);
+int mldsa_batcher_flush_keys(mldsa_batcher *b);
+int mldsa_batcher_set_private_key_cache(mldsa_batcher *b, int on);
 
 #ifdef __cplusplus
 }

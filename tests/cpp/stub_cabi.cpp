@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -257,8 +259,24 @@ int mldsa_verify_host(mldsa_ctx *c, int set, int mode, const uint8_t *pk, size_t
 // ---- what csrc/batcher.cpp calls (tests/cpp/test_batcher_tsan.cpp runs the REAL batcher over these stand-ins under ThreadSanitizer):
 // page-locked memory = heap memory; "A_hat" of a key = its rho in the first eight coefficients, so that the *_cached_a calls can
 // form the same digests as mldsa_sign / mldsa_verify and a stale or foreign table slot shows as a wrong signature / verdict
-int mldsa_host_alloc(void **p, size_t n) { *p = n ? std::calloc(1, n) : nullptr; return (n && !*p) ? fail(MLDSA_ERR_NOMEM, "host_alloc") : 0; }
-int mldsa_host_free(void *p) { std::free(p); return 0; }
+// (every release is shown to stub_free_hook first, when the test program defines one: tests/cpp/test_batcher_tsan.cpp looks for key bytes
+// in what the batcher hands back)
+extern "C" void stub_free_hook(const void *p, size_t bytes) __attribute__((weak));
+static std::mutex g_host_mu;
+static std::map<void *, size_t> g_host_sizes;
+int mldsa_host_alloc(void **p, size_t n) {
+    *p = n ? std::calloc(1, n) : nullptr;
+    if (n && !*p) return fail(MLDSA_ERR_NOMEM, "host_alloc");
+    if (*p) { std::lock_guard<std::mutex> lk(g_host_mu); g_host_sizes[*p] = n; }
+    return 0;
+}
+int mldsa_host_free(void *p) {
+    size_t n = 0;
+    if (p) { std::lock_guard<std::mutex> lk(g_host_mu); auto it = g_host_sizes.find(p); if (it != g_host_sizes.end()) { n = it->second; g_host_sizes.erase(it); } }
+    if (p && n && stub_free_hook) stub_free_hook(p, n);
+    std::free(p);
+    return 0;
+}
 int mldsa_expand_a(mldsa_ctx *c, int set, const uint8_t *rho, int32_t *a_hat, size_t n, void *) {
     const mldsa_params *p = pp(set);
     if (!c || !p) return fail(MLDSA_ERR_PARAM, "expand_a");

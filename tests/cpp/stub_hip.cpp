@@ -6,6 +6,8 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <shared_mutex>
 #include <string>
 
@@ -14,8 +16,21 @@
 extern "C" {
 hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+void stub_free_hook(const void *p, size_t bytes) __attribute__((weak));
+static std::mutex g_dev_mu;
+static std::map<void *, size_t> g_dev_sizes;
+hipError_t hipMalloc(void **p, size_t n) {
+    *p = std::calloc(1, n ? n : 1);
+    if (*p) { std::lock_guard<std::mutex> lk(g_dev_mu); g_dev_sizes[*p] = n; }
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void *p) {
+    size_t n = 0;
+    if (p) { std::lock_guard<std::mutex> lk(g_dev_mu); auto it = g_dev_sizes.find(p); if (it != g_dev_sizes.end()) { n = it->second; g_dev_sizes.erase(it); } }
+    if (p && n && stub_free_hook) stub_free_hook(p, n);  // "device" memory the batcher gives back: the test looks for key bytes in it
+    std::free(p);
+    return hipSuccess;
+}
 hipError_t hipMemset(void *p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }

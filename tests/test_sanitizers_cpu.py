@@ -41,19 +41,24 @@ def test_cpp_mirror_under_asan_ubsan(tmp_path):
     assert out.stdout.startswith("OK 69 hash vectors"), out.stdout
 
 
-@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
-def test_batcher_under_sanitizers(tmp_path, sanitizer):
+@pytest.mark.parametrize("sanitizer,extra", [("thread", ()), ("address,undefined", ()), ("address,undefined", ("-DMLDSA_BATCHER_PORTABLE",)),
+                                             ("address,undefined", ("-DMLDSA_TEST_NO_ZEROISE",))])
+def test_batcher_under_sanitizers(tmp_path, sanitizer, extra):
     """csrc/batcher.cpp is plain C++ over the C ABI and a dozen HIP runtime calls: built here with g++ against stand-ins for both,
     24 threads of random single-operation calls (one and three lanes, 40 keys over 16 table slots, batches of 8), every result
     compared with the batched stand-in's.  ThreadSanitizer sees every access to the shared state (the synchronisation is C++
-    atomics; the futex calls only park threads); ASan + UBSan see the staging arithmetic."""
+    atomics; the futex calls only park threads); ASan + UBSan see the staging arithmetic.  Beside the callers a thread forgets keys,
+    flushes the tables and switches the private-key cache off and on.  Every buffer the batcher releases (page-locked staging, device
+    memory) is scanned for private-key bytes by a hook of the stand-ins: none in the library build, some in the build whose wipe_host does
+    nothing (-DMLDSA_TEST_NO_ZEROISE: the probe's negative control).  -DMLDSA_BATCHER_PORTABLE: the condition-variable fallback of the two
+    futex calls (what a non-Linux host gets) passes the same run."""
     if sanitizer == "thread" and not _runtime("libtsan.so"):
         pytest.skip("no libtsan.so next to gcc")
     exe = tmp_path / "batcher_san"
     src = [os.path.join(ROOT, "fips204_amd", "csrc", "batcher.cpp")] + [os.path.join(ROOT, "tests", "cpp", f) for f in
                                                                         ("stub_cabi.cpp", "stub_hip.cpp", "test_batcher_tsan.cpp")]
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all", "-pthread", "-D__HIP_PLATFORM_AMD__",
-                           "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "fips204_amd", "csrc")] + src + ["-o", str(exe)])
+                           "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "fips204_amd", "csrc")] + list(extra) + src + ["-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1",
                                   UBSAN_OPTIONS="print_stacktrace=1"))
