@@ -60,6 +60,7 @@ OP_KEYGEN, OP_SIGN, OP_VERIFY = 1, 2, 3
 OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE, OPT_SIGN_ROUNDS = 1, 2, 3, 4, 5, 6
 OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD, OPT_WORKSPACE_CAP_MB = 7, 8, 9, 10, 11
 OPT_COOP_HASH = 12
+OPT_SMALL_FUSED = 13
 ABI_VERSION = 5
 ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
 ROUND_POWER2ROUND, ROUND_DECOMPOSE, ROUND_HIGH_BITS, ROUND_LOW_BITS, ROUND_MAKE_HINT, ROUND_USE_HINT = range(6)

@@ -107,6 +107,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_graphs = env_long("MLDSA_GRAPHS", 0, 2, ctx->opt_graphs);
     ctx->opt_coop_hash = env_long("MLDSA_COOP_HASH", 0, 1, ctx->opt_coop_hash);
     ctx->opt_sib_third = env_long("MLDSA_SIB_THIRD_STREAM", 0, 1, ctx->opt_sib_third);
+    ctx->opt_small_fused = env_long("MLDSA_SMALL_FUSED", 0, (long)SMALL_FUSED_MAX, ctx->opt_small_fused);
     ctx->coop_hash_max = (size_t)env_long("MLDSA_COOP_HASH_MAX", 0, 1 << 20, (long)ctx->coop_hash_max);
     ctx->coop_mask_max = (size_t)env_long("MLDSA_COOP_MASK_MAX", 0, 1 << 20, (long)ctx->coop_mask_max);
     ctx->coop_a_max = (size_t)env_long("MLDSA_COOP_A_MAX", 0, 1 << 20, (long)ctx->coop_a_max);
@@ -157,11 +158,29 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = host_malloc_quiesced((void **)&ctx->h_ctl, 2 * sizeof(RoundCtl));
+    if (e == hipSuccess) e = malloc_quiesced((void **)&ctx->d_small_ctr, SMALL_FUSED_MAX * sizeof(uint32_t));
+    if (e == hipSuccess) e = memset_quiesced(ctx->d_small_ctr, 0, SMALL_FUSED_MAX * sizeof(uint32_t));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
     }
     memset(ctx->h_ctl, 0, 2 * sizeof(RoundCtl));
+    {   // the signing tail reads some of its arguments straight from the kernarg segment (kernels_sign.hip late_arg): check, once per
+        // context, that this toolchain and driver lay the segment out the way that code assumes -- a mismatch fails here, loudly
+        uint32_t *d_word = nullptr, h_word = 0;
+        e = malloc_quiesced((void **)&d_word, sizeof(uint32_t));
+        if (e == hipSuccess) e = memset_quiesced(d_word, 0, sizeof(uint32_t));
+        int rc = e == hipSuccess ? late_arg_selftest(ctx->aux_stream, d_word) : MLDSA_ERR_DEVICE;
+        if (rc == MLDSA_OK && hipStreamSynchronize(ctx->aux_stream) != hipSuccess) rc = MLDSA_ERR_DEVICE;
+        if (rc == MLDSA_OK && memcpy_quiesced(&h_word, d_word, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = MLDSA_ERR_DEVICE;
+        if (d_word) (void)free_quiesced(d_word);
+        if (rc != MLDSA_OK || h_word != 0x80000000u) {
+            (void)hipGetLastError();
+            mldsa_ctx_destroy(ctx);
+            return set_error(MLDSA_ERR_DEVICE, rc != MLDSA_OK ? "mldsa_ctx_create: kernel-argument self-test did not run"
+                                                               : "mldsa_ctx_create: kernel arguments are not where late_arg() reads them (toolchain / code-object ABI changed): refusing to sign with this build");
+        }
+    }
     *out = ctx;
     return MLDSA_OK;
 }
@@ -189,6 +208,7 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->graph_join_ev) (void)hipEventDestroy(ctx->graph_join_ev);
     if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
     if (ctx->h_ctl) (void)host_free_quiesced(ctx->h_ctl);
+    if (ctx->d_small_ctr) (void)free_quiesced(ctx->d_small_ctr);
     if (ctx->ws_ev) (void)hipEventDestroy(ctx->ws_ev);
     if (ctx->zero_fork_ev) (void)hipEventDestroy(ctx->zero_fork_ev);
     if (ctx->zero_ev) (void)hipEventDestroy(ctx->zero_ev);
@@ -257,6 +277,15 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             }
             ctx->opt_coop_hash = value;
             return MLDSA_OK;
+        case MLDSA_OPT_SMALL_FUSED:
+            REQUIRE(value >= 0 && value <= (long)SMALL_FUSED_MAX, "mldsa_set_option: MLDSA_OPT_SMALL_FUSED is 0 ... 1024");
+            if (ctx->opt_small_fused != value) {  // which kernels a captured call launches
+                DeviceGuard dg(ctx->device);
+                MLDSA_HIP_CHECK(device_sync_quiesced());
+                drop_graphs(ctx);
+            }
+            ctx->opt_small_fused = value;
+            return MLDSA_OK;
         case MLDSA_OPT_WORKSPACE_CAP_MB:
             REQUIRE(value >= 0 && value <= (1L << 20), "mldsa_set_option: MLDSA_OPT_WORKSPACE_CAP_MB out of range");
             ctx->opt_ws_cap_bytes = (size_t)value << 20;
@@ -281,6 +310,7 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option) {
         case MLDSA_OPT_SIGN_ASYNC_EXP: return std::lround(-std::log10(ctx->async_stop));
         case MLDSA_OPT_WORKSPACE_CAP_MB: return (long)(ctx->opt_ws_cap_bytes >> 20);
         case MLDSA_OPT_COOP_HASH: return ctx->opt_coop_hash;
+        case MLDSA_OPT_SMALL_FUSED: return ctx->opt_small_fused;
         default: return MLDSA_ERR_PARAM;
     }
 }

@@ -11,6 +11,7 @@
 #include "challenge_dev.h"
 #include "sampler_dev.h"
 #include "keccak_coop.h"
+#include "expand_coop_dev.h"
 
 namespace mldsa {
 
@@ -362,60 +363,14 @@ static inline unsigned stream_blocks(size_t n_streams) { return (unsigned)((n_st
 template <int K, int L>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_a_coop(const uint8_t* __restrict__ rho, size_t rho_stride, const uint32_t* __restrict__ key_idx,
                                                                int32_t* __restrict__ a_hat, size_t n_ops, uint32_t n_keys) {
-    constexpr int ROW = PACKED_POLY_DWORDS * 4, BLK_DWORDS = 44;  // 168 bytes + the read-ahead of the last candidate
-    __shared__ uint32_t blk_lds[SWAVES * 2 * BLK_DWORDS];
-    const int lane = threadIdx.x & 63, half = lane >> 5, i = lane & 31;
+    __shared__ uint32_t blk_lds[SWAVES * 2 * EA_COOP_BLK_DWORDS];
+    const int lane = threadIdx.x & 63;
     const CoopLane c = coop_lane(lane);
-    uint32_t* blk = blk_lds + ((threadIdx.x >> 6) * 2 + half) * BLK_DWORDS;
+    uint32_t* blk = blk_lds + ((threadIdx.x >> 6) * 2 + (lane >> 5)) * EA_COOP_BLK_DWORDS;
     const size_t n_streams = n_ops * (size_t)(K * L);
     const size_t wave0 = ((size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6)) * 2, stride = (size_t)gridDim.x * SWAVES * 2;
-    for (size_t g0 = wave0; g0 < n_streams; g0 += stride) {  // wave-uniform
-        const size_t g = g0 + half;
-        const bool valid = g < n_streams;
-        const size_t gc = valid ? g : g0;
-        const size_t op = gc / (K * L);
-        const int rs = (int)(gc % (K * L)), r = rs / L, sidx = rs % L;
-        size_t key = key_idx ? key_idx[op] : op;
-        if (n_keys && key >= n_keys) key = 0;  // (refused beside this kernel: see k_expand_a)
-        uint32_t lo = 0, hi = 0;
-        if (c.active && c.word < 4) {
-            const uint8_t* src = rho + key * rho_stride + 8 * c.word;
-            lo = load_le32(src);
-            hi = load_le32(src + 4);
-        }
-        if (c.active && c.word == 4) lo = (uint32_t)sidx | ((uint32_t)r << 8) | (0x1Fu << 16);
-        if (c.active && c.word == SHAKE128_RATE / 8 - 1) hi = 0x80000000u;
-        uint8_t* row = reinterpret_cast<uint8_t*>(a_hat) + g * (size_t)ROW;
-        int count = valid ? 0 : N;  // coefficients stored so far (the same in every lane of the half)
-        while (__any(count < N)) {
-            keccak_f1600_coop(lo, hi, c);
-            if (c.active && c.word < SHAKE128_RATE / 8) { blk[2 * c.word] = lo; blk[2 * c.word + 1] = hi; }
-            wave_lds_sync();
-#pragma unroll
-            for (int pass = 0; pass < 2; pass++) {
-                const int cand = 28 * pass + i;
-                bool acc = false;
-                uint32_t z = 0;
-                if (i < 28) {
-                    const int bo = 3 * cand;  // byte offset of the candidate: two aligned dwords hold it
-                    const uint64_t two = ((uint64_t)blk[(bo >> 2) + 1] << 32) | blk[bo >> 2];
-                    z = (uint32_t)(two >> (8 * (bo & 3))) & 0x7FFFFFu;
-                    acc = z < (uint32_t)Q;
-                }
-                const unsigned long long all = __ballot(acc);
-                const uint32_t mine = half ? (uint32_t)(all >> 32) : (uint32_t)all;
-                const int idx = count + __popc(mine & ((1u << i) - 1u));
-                if (acc && idx < N) {
-                    uint8_t* dst = row + 3 * idx;
-                    dst[0] = (uint8_t)z;
-                    dst[1] = (uint8_t)(z >> 8);
-                    dst[2] = (uint8_t)(z >> 16);
-                }
-                count += __popc(mine);
-            }
-            wave_lds_sync();
-        }
-    }
+    for (size_t g0 = wave0; g0 < n_streams; g0 += stride)  // wave-uniform
+        expand_a_coop_pair<K, L>(rho, rho_stride, key_idx, a_hat, g0, n_streams, n_keys, blk, lane, c);
 }
 
 int launch_expand_a(mldsa_ctx* ctx, int set, const uint8_t* rho, size_t rho_stride, const uint32_t* key_idx, int32_t* a_hat,

@@ -831,6 +831,59 @@ static bool tail_consts_match(const mldsa_params* p) {
     return p->set == MLDSA_44 ? tail_consts_are<4, 4>(p) : p->set == MLDSA_65 ? tail_consts_are<6, 5>(p) : p->set == MLDSA_87 && tail_consts_are<8, 7>(p);
 }
 
+// Self-test of late_arg (run by mldsa_ctx_create).  late_arg relies on the code-object ABI putting a kernel's first by-value argument
+// at byte 0 of the kernarg segment with the host's struct layout.  That holds for every ROCm so far, but nothing in the language
+// promises it, and a toolchain that changed it would give silently wrong signatures, not a build error.  This kernel receives a
+// SignTailArgs the way k_sign_tail does, reads every field both ways -- as a normal argument and through late_arg at its
+// offsetof() -- and reports the fields that differ; a context is not created on a mismatch.
+__global__ void k_late_arg_selftest(SignTailArgs args, uint32_t* mismatch) {
+    uint32_t bad = 0;
+    int bit = 0;
+#define MLDSA_LATE_CHECK(ARGS, field, normal)                                    \
+    do {                                                                         \
+        if (LATE(ARGS, field) != (normal)) bad |= 1u << bit;                     \
+        bit++;                                                                   \
+    } while (0)
+    MLDSA_LATE_CHECK(TailPtrs, c_hat, args.a.c_hat);
+    MLDSA_LATE_CHECK(TailPtrs, y, args.a.y);
+    MLDSA_LATE_CHECK(TailPtrs, w, args.a.w);
+    MLDSA_LATE_CHECK(TailPtrs, ctilde, args.a.ctilde);
+    MLDSA_LATE_CHECK(TailPtrs, s1, args.a.s1);
+    MLDSA_LATE_CHECK(TailPtrs, s2, args.a.s2);
+    MLDSA_LATE_CHECK(TailPtrs, t0, args.a.t0);
+    MLDSA_LATE_CHECK(SignTailArgs, sigs, args.sigs);
+    MLDSA_LATE_CHECK(SignTailArgs, ct0_exact, args.ct0_exact);
+    MLDSA_LATE_CHECK(SignTailArgs, oor_by_op, args.oor_by_op);
+    MLDSA_LATE_CHECK(SignTailArgs, ctl, args.ctl);
+    MLDSA_LATE_CHECK(SignTailArgs, inv_tab, args.inv_tab);
+    MLDSA_LATE_CHECK(SignTailArgs, slot_op, args.slot_op);
+    MLDSA_LATE_CHECK(SignTailArgs, slot_y, args.slot_y);
+    MLDSA_LATE_CHECK(SignTailArgs, key_idx, args.key_idx);
+    MLDSA_LATE_CHECK(SignTailArgs, wrisk, args.wrisk);
+    MLDSA_LATE_CHECK(SignTailArgs, yrisk, args.yrisk);
+    MLDSA_LATE_CHECK(SignTailArgs, key_oor, args.key_oor);
+    MLDSA_LATE_CHECK(SignTailArgs, kappa, args.kappa);
+    MLDSA_LATE_CHECK(SignTailArgs, done, args.done);
+    MLDSA_LATE_CHECK(SignTailArgs, accept, args.accept);
+#undef MLDSA_LATE_CHECK
+    if (threadIdx.x == 0 && blockIdx.x == 0) *mismatch = bad | 0x80000000u;  // (bit 31: the kernel ran)
+}
+
+int late_arg_selftest(hipStream_t s, uint32_t* d_word) {
+    SignTailArgs args;
+    // distinct, recognisable values in every field (never dereferenced)
+    auto tag = [](uintptr_t i) { return (uintptr_t)0x5A5A000000000000ull + i * 0x0101010101ull; };
+    args.a = TailPtrs{(const int32_t*)tag(1), (const int32_t*)tag(2), (const int32_t*)tag(3), (const uint8_t*)tag(4), (const int32_t*)tag(5),
+                      (const int32_t*)tag(6), (const int32_t*)tag(7)};
+    args.sigs = (uint8_t*)tag(8); args.ct0_exact = 0x1234567; args.oor_by_op = -0x7654321; args.ctl = (const RoundCtl*)tag(9);
+    args.inv_tab = (const Twiddle*)tag(10); args.slot_op = (const uint32_t*)tag(11); args.slot_y = (const uint32_t*)tag(12);
+    args.key_idx = (const uint32_t*)tag(13); args.wrisk = (const uint8_t*)tag(14); args.yrisk = (const uint8_t*)tag(15);
+    args.key_oor = (const uint8_t*)tag(16); args.kappa = (uint16_t*)tag(17); args.done = (int32_t*)tag(18); args.accept = (int32_t*)tag(19);
+    hipLaunchKernelGGL(k_late_arg_selftest, dim3(1), dim3(64), 0, s, args, d_word);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
 int launch_sign_tail(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* c, const int32_t* y, const int32_t* w, const uint8_t* ctilde,
                      const uint32_t* slot_op, const uint32_t* key_idx, const int32_t* s1, const int32_t* s2, const int32_t* t0,
                      uint16_t* kappa, int32_t* done, uint8_t* sigs, const RoundCtl* ctl, int32_t* accept, size_t slots_hint,

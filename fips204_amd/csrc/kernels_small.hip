@@ -1,0 +1,378 @@
+// verify_internal (src/ml_dsa.rs:351-437) for SMALL calls as ONE kernel launch.
+//
+// A verification call of a few operations is all latency: the batch pipeline (pipeline.hip verify_batch) is six dependent launches on
+// three streams -- key check, mu, SampleInBall, ExpandA, the fused arithmetic, the c~ hash -- and its kernel timeline
+// (profiles/r05_small_call_timeline_verify_n1.json) shows 100 us of device time for a chain whose kernels add up to 66 us on the
+// critical path: ExpandA starts 28 us after the first kernel (the host enqueues the helper-stream kernels first), every cross-stream
+// join costs ~10 us, and the arithmetic of one operation runs on one wave.  This kernel runs the same device code in one launch:
+//
+//   phase 1   every operation owns a CLUSTER of workgroups (4 waves each).  Each wave takes one role: ExpandA for two polynomials of
+//             A_hat (expand_a_coop_pair, one per half-wave; absent when the caller keeps A_hat with its keys), mu = H(tr | M')
+//             (ml_dsa.rs:386-397) or c = SampleInBall(c~) (ml_dsa.rs:400) -- all three on the wave-cooperative sponge (keccak_coop.h).
+//             Results go to the call's workspace rows (24-bit A_hat, mu, c as bytes, the refusal flag).
+//   hand-over a workgroup that has finished its roles releases its stores (agent scope) and bumps the operation's counter; the workgroup
+//             that sees the count complete -- the LAST one to arrive -- acquires and carries on.  Nobody waits: no spinning, no
+//             co-residency assumption.  The counter is reset by that workgroup, so the array stays zero between calls.
+//             (A cluster of one workgroup -- A_hat kept by the caller -- needs no counter.)
+//   tail      the last workgroup runs the rest with its four waves side by side: sigDecode + NTT(z_j), NTT(c), the hint decode,
+//             then the rows  w'_i = invNTT(A_i o z_hat - c_hat o t1_hat_i), UseHint, w1Encode  (ml_dsa.rs:407-428) into LDS beside mu,
+//             then c~' = H(mu | w1') on one wave straight from LDS and the verdict (ml_dsa.rs:429-436).
+//
+// Same device functions as the batch kernels (expand_a_coop_pair, ntt_fwd_wave / ntt_inv_wave, hint_unpack_wave, use_hint,
+// pack_w1_strided, keccak_f1600_coop), same bytes in the workspace rows, same verdicts: tests/test_gpu_small_calls.py compares the two
+// paths with each other and with the oracle over the ACVP sigVer vectors, damaged signatures, refused operations and every mode.
+// Workgroup b belongs to XCD b mod 8 (round-robin dispatch): the clusters are laid out so that all workgroups of an operation share
+// an XCD, i.e. the L2 that holds the A_hat rows they hand over.
+#include "ctx.h"
+#include "challenge_dev.h"
+#include "expand_coop_dev.h"
+#include "keccak_coop.h"
+#include "ntt_wave.h"
+#include "rounding.h"
+#include "sampler_dev.h"
+#include "verify_dev.h"
+
+namespace mldsa {
+
+constexpr int SMW = 4;  // waves per workgroup
+
+struct SmallVerifyArgs {
+    const uint8_t* rho;        // ExpandA input: rho rows of the keys (unused when a_keys is set)
+    size_t rho_stride;
+    const int32_t* a_keys;     // A_hat kept by the caller, int32 rows per key (mldsa_verify_cached_a), or nullptr
+    const uint8_t* tr;         // [n_keys][64]
+    const int32_t* t1;         // [n_keys][K][256]
+    const uint32_t* key_idx;   // nullptr: op i uses key i
+    uint32_t n_keys;
+    int mode;
+    const uint8_t* msgs;
+    const uint64_t* msg_off;
+    const uint8_t* ctxs;
+    const uint64_t* ctx_off;
+    const uint8_t* sigs;
+    uint8_t* ok;
+    uint32_t n_ops;
+    // workspace rows of the call
+    int32_t* a_ws;             // [n_ops][K * L] polynomials in the 24-bit form
+    uint32_t* c_ws;            // [n_ops][64] dwords: c as one byte per coefficient
+    uint8_t* mu_ws;            // [n_ops][64]
+    int32_t* flag_ws;          // [n_ops]: 0 = hashed; 1 = ctx too long; 2 = malformed offsets / key index out of range
+    uint32_t* ctr;             // [n_ops] arrival counters, zero between calls
+    const Twiddle *fwd_tab, *inv_tab;
+};
+
+// ---- role: mu = H(tr | M', 64) by one wave, both halves computing the same state (one op per wave).  The checks and the byte layout
+// are k_mu's (kernels_codec.hip): offsets are never trusted, a ctx longer than 255 bytes or a malformed pair refuses the op before
+// a byte of it is read; flag as there.
+__device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t op, int lane, const CoopLane& c) {
+    size_t key = A.key_idx ? A.key_idx[op] : op;
+    int key_bad = 0;
+    if (A.key_idx && key >= A.n_keys) { key = 0; key_bad = 2; }
+    const uint8_t* trp = A.tr + key * 64;
+    const size_t n_call = A.n_ops;
+    const uint64_t m0 = A.msg_off[op], m1 = A.msg_off[op + 1];
+    bool bad_off = !(A.msg_off[0] <= m0 && m0 <= m1 && m1 <= A.msg_off[n_call]);
+    const uint8_t* mp = A.msgs + m0;
+    size_t mlen = (size_t)(m1 - m0), clen = 0;
+    bad_off |= mlen != 0 && A.msgs == nullptr;
+    const uint8_t* cp = nullptr;
+    if (A.ctx_off) {
+        const uint64_t c0 = A.ctx_off[op], c1 = A.ctx_off[op + 1];
+        bad_off |= !(A.ctx_off[0] <= c0 && c0 <= c1 && c1 <= A.ctx_off[n_call]);
+        cp = A.ctxs + c0;
+        clen = (size_t)(c1 - c0);
+        bad_off |= clen != 0 && A.ctxs == nullptr;
+    }
+    const int flag = bad_off ? 2 : clen > 255 ? 1 : key_bad;
+    const bool live = !bad_off && clen <= 255;
+    if (!live) mlen = clen = 0;
+    const int mode = A.mode;
+    const size_t pre = (mode == MLDSA_MODE_INTERNAL) ? 0 : 2 + clen;
+    const size_t total = live ? 64 + pre + mlen : 0;
+    const size_t blocks = live ? total / SHAKE256_RATE + 1 : 0;  // the pad always fits in the last block
+    auto byte_at = [&](size_t pos) -> uint32_t {
+        if (pos < total) {
+            if (pos < 64) return trp[pos];
+            if (pos < 64 + pre) {
+                const size_t q = pos - 64;
+                return q == 0 ? (uint32_t)(mode == MLDSA_MODE_PREHASH ? 1 : 0) : q == 1 ? (uint32_t)clen : cp[q - 2];
+            }
+            return mp[pos - 64 - pre];
+        }
+        return pos == total ? 0x1Fu : 0u;
+    };
+    auto dword_at = [&](size_t pos) -> uint32_t {  // whole dwords of tr and of the message by one byte-granular load, boundaries from bytes
+        if (pos + 4 <= 64) return load_le32(trp + pos);
+        if (pos >= 64 + pre && pos + 4 <= total) return load_le32(mp + (pos - 64 - pre));
+        if (pos > total) return 0u;
+        return byte_at(pos) | (byte_at(pos + 1) << 8) | (byte_at(pos + 2) << 16) | (byte_at(pos + 3) << 24);
+    };
+    uint32_t lo = 0, hi = 0;
+    const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
+    for (size_t b = 0; b < blocks; b++) {  // wave-uniform
+        if (absorbs) {
+            const size_t off = b * SHAKE256_RATE + 8 * (size_t)c.word;
+            lo ^= dword_at(off);
+            hi ^= dword_at(off + 4);
+            if (b == blocks - 1 && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
+        }
+        keccak_f1600_coop(lo, hi, c);
+    }
+    if (lane < 32 && c.active && c.word < 8) {
+        uint32_t* out = reinterpret_cast<uint32_t*>(A.mu_ws + op * 64);
+        out[2 * c.word] = lo;
+        out[2 * c.word + 1] = hi;
+    }
+    if (lane == 0) A.flag_ws[op] = flag;
+}
+
+// ---- role: c = SampleInBall(c~) (hashing.rs:43-100) by one wave: the sponge cooperatively, the Fisher-Yates walk by lane 0 on the
+// wave's LDS rows (c_row: 256 int8, bw: the squeezed block).  Output: the bytes k_sample_in_ball<.., C8> writes.
+template <int CT>
+__device__ __forceinline__ void small_role_sib(const SmallVerifyArgs& A, size_t op, size_t sig_len, int tau, uint32_t* c_row, uint32_t* bw, int lane,
+                                               const CoopLane& c) {
+    const uint8_t* ct = A.sigs + op * sig_len;  // c~ opens the signature (encodings.rs:251)
+    uint32_t lo = 0, hi = 0;
+    if (c.active && c.word < CT / 8) {
+        lo = load_le32(ct + 8 * c.word);
+        hi = load_le32(ct + 8 * c.word + 4);
+    }
+    if (c.active && c.word == CT / 8) lo ^= 0x1Fu;
+    if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
+    c_row[lane] = 0;
+    int pos = 8, i = 256 - tau;
+    uint64_t h64 = 0;
+    bool first = true;
+    for (;;) {  // wave-uniform: i and pos are lane 0's, handed round after its walk
+        keccak_f1600_coop(lo, hi, c);
+        if (lane < 32 && c.active && c.word < SHAKE256_RATE / 8) { bw[2 * c.word] = lo; bw[2 * c.word + 1] = hi; }
+        wave_lds_sync();
+        if (first) h64 = ((uint64_t)bw[1] << 32) | bw[0];  // hashing.rs:55-56
+        first = false;
+        if (lane == 0) {
+            int8_t* cc = reinterpret_cast<int8_t*>(c_row);
+            const uint8_t* bb = reinterpret_cast<const uint8_t*>(bw);
+            while (i < 256 && pos < SHAKE256_RATE) {
+                const int j = bb[pos++];
+                if (j <= i) {  // hashing.rs:68-83
+                    cc[i] = cc[j];
+                    const int index = i + tau - 256;
+                    cc[j] = (int8_t)(1 - 2 * (int)((h64 >> index) & 1u));
+                    i++;
+                }
+            }
+        }
+        i = __builtin_amdgcn_readfirstlane(i);
+        wave_lds_sync();
+        if (i >= 256) break;
+        pos = 0;  // block used up (rare): squeeze the next one
+    }
+    const uint8_t* cb = reinterpret_cast<const uint8_t*>(c_row);
+    A.c_ws[op * 64 + lane] = (uint32_t)cb[lane] | ((uint32_t)cb[64 + lane] << 8) | ((uint32_t)cb[128 + lane] << 16) | ((uint32_t)cb[192 + lane] << 24);
+}
+
+template <int K, int L, int GB, bool G2HI, int CT, bool CACHED>
+__global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A, int tau, int omega, int32_t zbound, size_t sig_len) {
+    constexpr int CB = GB + 1;
+    constexpr int BITS = G2HI ? 4 : 6;
+    constexpr int W1_LEN = K * 32 * BITS;
+    constexpr int NA = CACHED ? 0 : K * L / 2;          // ExpandA roles (two polynomials each)
+    constexpr int ROLES = NA + 2, NB = (ROLES + SMW - 1) / SMW;
+    static_assert((K * L) % 2 == 0, "two polynomials per ExpandA wave");
+    __shared__ uint32_t blk_lds[SMW * 2 * EA_COOP_BLK_DWORDS];                // phase 1: ExpandA blocks | SampleInBall rows
+    __shared__ __attribute__((aligned(16))) int4 zh[L + 1][64];               // tail: z_hat rows and c_hat
+    __shared__ uint32_t hint_lds[HINT_LDS_DWORDS];
+    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t msg_lds[(64 + W1_LEN) / 4];  // mu | w1Encode(w1')
+    __shared__ int s_last, s_zbad, s_hint_ok;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // cluster layout: workgroup b -> XCD b & 7; the NB workgroups of an op are NB consecutive workgroups of one XCD
+    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t member = q % NB;
+    const size_t op = (size_t)(q / NB) * 8 + xcd;
+    if (op >= A.n_ops) return;  // (whole workgroup)
+    const CoopLane c = coop_lane(lane);
+    const int role = (int)member * SMW + wave;
+
+    // ---------------------------------------------------------------- phase 1
+    if (role < NA) {
+        uint32_t* blk = blk_lds + (wave * 2 + (lane >> 5)) * EA_COOP_BLK_DWORDS;
+        const size_t n_streams = (size_t)A.n_ops * (K * L);
+        expand_a_coop_pair<K, L>(A.rho, A.rho_stride, A.key_idx, A.a_ws, op * (K * L) + 2 * (size_t)role, n_streams, A.n_keys, blk, lane, c);
+    } else if (role == NA) {
+        small_role_mu(A, op, lane, c);
+    } else if (role == NA + 1) {
+        // its rows (256 int8 of c, the squeezed block) lie in zh, which nothing else uses before the tail
+        small_role_sib<CT>(A, op, sig_len, tau, reinterpret_cast<uint32_t*>(&zh[0][0]), reinterpret_cast<uint32_t*>(&zh[1][0]), lane, c);
+    }
+
+    // ---------------------------------------------------------------- hand-over
+    __syncthreads();  // (workgroup-scope release of every wave's stores)
+    if (NB > 1) {
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const uint32_t seen = __hip_atomic_fetch_add(&A.ctr[op], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = seen == (uint32_t)(NB - 1);
+            if (last) __hip_atomic_store(&A.ctr[op], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next call
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave: the other workgroups' rows are visible from here on
+    }
+
+    // ---------------------------------------------------------------- tail (this workgroup's four waves)
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * SMW) tw_lds[i] = A.fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * SMW) tw_lds[FWD_TW * 64 + i] = A.inv_tab[i];
+    if (threadIdx.x < 16) msg_lds[threadIdx.x] = reinterpret_cast<const uint32_t*>(A.mu_ws + op * 64)[threadIdx.x];
+    if (threadIdx.x == 0) { s_zbad = 0; s_hint_ok = 1; }
+    __syncthreads();
+    const LdsTw ftw{tw_lds, lane};
+    const LdsTw itw{tw_lds + FWD_TW * 64, lane};
+    size_t key = A.key_idx ? (size_t)__builtin_amdgcn_readfirstlane((int)A.key_idx[op]) : op;
+    if (A.key_idx && key >= A.n_keys) key = 0;  // (the op is refused through its flag)
+    const uint8_t* zsrc = A.sigs + op * sig_len + CT;
+    // forward transforms: z_0 .. z_{L-1} from the signature bytes (bit_unpack, conversion.rs:227-262, with the norm test of
+    // ml_dsa.rs:434), then c; item j by wave j mod 4
+    bool zbad = false;
+#pragma unroll 1
+    for (int j = wave; j <= L; j += SMW) {
+        int32_t r[4];
+        if (j < L) {
+            const uint8_t* src = zsrc + (size_t)j * (32 * CB);
+            int32_t mx = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                r[k] = y_from_raw<CB>(y_raw_dword<CB>(src, k, lane), lane);
+                const int32_t a = r[k] < 0 ? -r[k] : r[k];
+                mx = a > mx ? a : mx;
+            }
+            zbad |= mx >= zbound;
+        } else {
+            const uint32_t d = A.c_ws[op * 64 + lane];
+            r[0] = (int8_t)(d & 0xFF); r[1] = (int8_t)((d >> 8) & 0xFF); r[2] = (int8_t)((d >> 16) & 0xFF); r[3] = (int8_t)(d >> 24);
+        }
+        ntt_fwd_wave(r, ftw, lane);
+        if (j == L) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = mont_mul(r[k], 1);  // c_hat * 2^-32
+        }
+        zh[j][lane] = make_int4(r[0], r[1], r[2], r[3]);
+    }
+    if (__ballot(zbad) != 0ull && lane == 0) atomicOr(&s_zbad, 1);
+    if (wave == SMW - 1) {  // the wave with the fewest forward items also decodes the hint section
+        const HintBytes hbytes = hint_load(zsrc + L * (32 * CB), omega, K, lane);
+        const bool hint_ok = hint_unpack_wave<K>(hbytes, omega, hint_lds, lane);
+        if (lane == 0) s_hint_ok = hint_ok ? 1 : 0;
+    }
+    __syncthreads();
+    // rows: i by wave i mod 4
+    using ARow = std::conditional_t<!CACHED, Packed3, int4>;
+    const size_t aop = CACHED ? key : op;
+    const ARow* arow = !CACHED ? reinterpret_cast<const ARow*>(reinterpret_cast<const uint32_t*>(A.a_ws) + (aop * K * (size_t)L) * PACKED_POLY_DWORDS)
+                               : reinterpret_cast<const ARow*>(A.a_keys + (aop * K * (size_t)L) * N);
+    auto coeffs = [](const ARow& v) -> int4 {
+        if constexpr (!CACHED) return unpack24(v); else return v;
+    };
+    const int4* trow = reinterpret_cast<const int4*>(A.t1 + (key * K) * (size_t)N);
+#pragma unroll 1
+    for (int i = wave; i < K; i += SMW) {
+        ARow av[L];
+#pragma unroll
+        for (int j = 0; j < L; j++) av[j] = arow[(unsigned)((i * L + j) * 64) + (unsigned)lane];
+        const int4 tv = trow[(unsigned)(i * 64) + (unsigned)lane];
+        int64_t acc64[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const int4 zv = zh[j][lane];
+            const int4 a4 = coeffs(av[j]);
+            acc64[0] += (int64_t)a4.x * zv.x;
+            acc64[1] += (int64_t)a4.y * zv.y;
+            acc64[2] += (int64_t)a4.z * zv.z;
+            acc64[3] += (int64_t)a4.w * zv.w;
+        }
+        const int4 cv = zh[L][lane];
+        acc64[0] -= (int64_t)cv.x * tv.x;
+        acc64[1] -= (int64_t)cv.y * tv.y;
+        acc64[2] -= (int64_t)cv.z * tv.z;
+        acc64[3] -= (int64_t)cv.w * tv.w;
+        const uint32_t hword = hint_lds[24 + i * 8 + (lane & 7)];
+        int32_t acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = mont_reduce64(acc64[k]);
+        ntt_inv_wave(acc, itw, lane, F_MONT2);
+        uint8_t* dst = reinterpret_cast<uint8_t*>(msg_lds) + 64 + (size_t)i * (32 * BITS);
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)hword, 2 * k), whi = (uint32_t)__builtin_amdgcn_readlane((int)hword, 2 * k + 1);
+            const uint32_t hwk = lane < 32 ? wlo : whi;
+            const uint32_t h = (hwk >> (lane & 31)) & 1u;
+            v[k] = (uint32_t)use_hint<G2HI>((int32_t)h, acc[k]);
+        }
+        pack_w1_strided<G2HI>(v, dst, lane);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // c~' = H(mu | w1Encode(w1'), lambda / 4) from LDS, both halves on the same state; the verdict of ml_dsa.rs:429-436
+    {
+        constexpr int DATA = 64 + W1_LEN, BLOCKS = DATA / SHAKE256_RATE + 1;
+        auto msg_dword = [&](int off) -> uint32_t {
+            if (off + 4 <= DATA) return msg_lds[off >> 2];
+            uint32_t v = off == DATA ? 0x1Fu : 0u;  // (DATA is a multiple of 4)
+            if (off + 4 == BLOCKS * SHAKE256_RATE) v |= 0x80000000u;
+            return v;
+        };
+        uint32_t lo = 0, hi = 0;
+        const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
+#pragma unroll 1
+        for (int blk = 0; blk < BLOCKS; blk++) {
+            if (absorbs) {
+                const int off = blk * SHAKE256_RATE + 8 * c.word;
+                lo ^= msg_dword(off);
+                hi ^= msg_dword(off + 4);
+            }
+            keccak_f1600_coop(lo, hi, c);
+        }
+        const bool digest = c.active && c.word < CT / 8;
+        const uint8_t* c0 = A.sigs + op * sig_len + 8 * c.word;
+        const bool differs = digest && ((lo ^ load_le32(c0)) | (hi ^ load_le32(c0 + 4))) != 0;
+        const unsigned long long any = __ballot(differs);
+        if (lane == 0) A.ok[op] = (uint8_t)((uint32_t)any == 0u && !s_zbad && s_hint_ok && !A.flag_ws[op]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ launcher
+// workspace rows of a call of n ops (the caller carves them from the context's workspace) and the launch itself
+size_t verify_small_counter_bytes(size_t n_ops) { return ((n_ops + 7) / 8 * 8) * sizeof(uint32_t); }
+
+int launch_verify_small(mldsa_ctx* ctx, const mldsa_params* p, int mode, const uint8_t* rho, size_t rho_stride, const int32_t* a_keys, const uint8_t* tr,
+                        const int32_t* t1, size_t n_keys, const uint32_t* key_idx, const uint8_t* msgs, const uint64_t* msg_off, const uint8_t* ctxs,
+                        const uint64_t* ctx_off, const uint8_t* sigs, uint8_t* ok, size_t n_ops, int32_t* a_ws, int32_t* c_ws, uint8_t* mu_ws,
+                        int32_t* flag_ws, uint32_t* ctr, hipStream_t s) {
+    if (n_ops == 0) return MLDSA_OK;
+    SmallVerifyArgs A;
+    A.rho = rho; A.rho_stride = rho_stride; A.a_keys = a_keys; A.tr = tr; A.t1 = t1; A.key_idx = key_idx;
+    A.n_keys = (uint32_t)std::min<size_t>(n_keys, 0xFFFFFFFFu);
+    A.mode = mode; A.msgs = msgs; A.msg_off = msg_off; A.ctxs = ctxs; A.ctx_off = ctx_off; A.sigs = sigs; A.ok = ok; A.n_ops = (uint32_t)n_ops;
+    A.a_ws = a_ws; A.c_ws = reinterpret_cast<uint32_t*>(c_ws); A.mu_ws = mu_ws; A.flag_ws = flag_ws; A.ctr = ctr;
+    A.fwd_tab = ctx->d_fwd_tw; A.inv_tab = ctx->d_inv_tw;
+    const bool cached = a_keys != nullptr;
+    const int roles = (cached ? 0 : p->k * p->l / 2) + 2, nb = (roles + SMW - 1) / SMW;
+    const dim3 grid((unsigned)(((n_ops + 7) / 8) * 8 * (size_t)nb)), block(64 * SMW);
+    const int32_t zbound = p->gamma1 - p->beta;
+#define MLDSA_SMALL(KK, LL, GB, G2, CT)                                                                                                      \
+    do {                                                                                                                                     \
+        if (cached) hipLaunchKernelGGL((k_verify_small<KK, LL, GB, G2, CT, true>), grid, block, 0, s, A, p->tau, p->omega, zbound, (size_t)p->sig_len); \
+        else hipLaunchKernelGGL((k_verify_small<KK, LL, GB, G2, CT, false>), grid, block, 0, s, A, p->tau, p->omega, zbound, (size_t)p->sig_len);       \
+    } while (0)
+    if (p->set == MLDSA_44) MLDSA_SMALL(4, 4, 17, false, 32);
+    else if (p->set == MLDSA_65) MLDSA_SMALL(6, 5, 19, true, 48);
+    else MLDSA_SMALL(8, 7, 19, true, 64);
+#undef MLDSA_SMALL
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+}  // namespace mldsa

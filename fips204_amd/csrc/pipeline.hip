@@ -211,6 +211,15 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
         return set_error(MLDSA_ERR_NOMEM, "verify: workspace not reserved");
     const size_t mw = (size_t)(64 + p->w1_len);
     const size_t kl_coeffs = (size_t)(p->k * p->l) * N;
+    // A SMALL call is all latency: it runs as ONE launch (kernels_small.hip: per op a cluster of workgroups for ExpandA | mu | SampleInBall,
+    // the last one to finish carries on with the arithmetic, the c~ hash and the verdict) instead of the six launches on three
+    // streams below.  Same device code, same workspace rows, same verdicts (MLDSA_OPT_SMALL_FUSED: the largest such call; 0 = never).
+    if (!wire && ctx->opt_coop_hash && n_ops <= (size_t)ctx->opt_small_fused && n_ops <= SMALL_FUSED_MAX && n_ops <= chunk) {
+        VerifyWs w(ctx->ws, p, chunk, a_hat_keys == nullptr, wire_keys);
+        STAGE("verify_small", launch_verify_small(ctx, p, mode, rho, 32, a_hat_keys, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok,
+                                                  n_ops, w.a_hat, w.c, w.mu_w1, w.ctx_bad, ctx->d_small_ctr, s));
+        return MLDSA_OK;
+    }
     for (size_t o = 0; o < n_ops; o += chunk) {
         const size_t n = (n_ops - o) < chunk ? (n_ops - o) : chunk;
         VerifyWs w(ctx->ws, p, chunk, a_hat_keys == nullptr, wire_keys);

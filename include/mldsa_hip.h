@@ -139,6 +139,10 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                 * 4 096 ops, the signer's ExpandMask and ExpandA up to 4 096 polynomials -- run wave-cooperatively, one state over 25
                                 * lanes: 3.8 instead of 9.4 us per permutation of a latency-bound call (csrc/keccak_coop.h).  0: always the
                                 * lane-per-state form of the large batches.  Results are identical. */
+#define MLDSA_OPT_SMALL_FUSED 13 /* most ops of a verification call that runs as ONE kernel launch (csrc/kernels_small.hip: every op owns a cluster of
+                                    workgroups for ExpandA, mu and SampleInBall; the last one to finish carries on with the arithmetic, the c_tilde hash
+                                    and the verdict).  Default 64; 0 = always the batch pipeline (six launches on three streams).  Needs
+                                    MLDSA_OPT_COOP_HASH = 1.  Results are bit-identical either way; a one-op call takes ~70 instead of ~105 us. */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,

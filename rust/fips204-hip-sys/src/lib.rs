@@ -49,6 +49,7 @@ pub const MLDSA_OPT_SIGN_ASYNC_EXP: c_int = 9;
 pub const MLDSA_OPT_SIGN_LOOKAHEAD: c_int = 10;
 pub const MLDSA_OPT_WORKSPACE_CAP_MB: c_int = 11;
 pub const MLDSA_OPT_COOP_HASH: c_int = 12;
+pub const MLDSA_OPT_SMALL_FUSED: c_int = 13;
 pub const MLDSA_REDUCE_PARTIAL: c_int = 0;
 pub const MLDSA_REDUCE_FULL: c_int = 1;
 pub const MLDSA_REDUCE_CENTER: c_int = 2;
