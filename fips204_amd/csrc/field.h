@@ -82,4 +82,16 @@ __device__ __forceinline__ int32_t center(int32_t a) {
 // x * 2^32 mod q (reference to_mont, helpers.rs:131-135), result in (-q, q)
 __device__ __forceinline__ int32_t to_mont(int32_t x) { return mont_mul(x, R2_MOD_Q); }
 
+// A kernel argument read from the kernarg segment where it is USED (an s_load that hits the scalar cache) instead of being held in
+// scalar registers from the kernel's entry: the empty asm makes the segment pointer opaque at that point, so the load can neither be
+// hoisted nor kept live across what lies in between.  byte_offset = offsetof(first by-value argument struct, field): relies on the
+// code-object ABI putting that struct at byte 0 of the segment -- checked by a self-test at context creation (k_late_arg_selftest).
+template <class T>
+__device__ __forceinline__ T late_arg(unsigned byte_offset) {
+    typedef const char __attribute__((address_space(4))) * kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *(const T __attribute__((address_space(4)))*)(ka + byte_offset);
+}
+
 }  // namespace mldsa

@@ -108,13 +108,6 @@ template <> struct TailConst<8, 7> { static constexpr int GB = 19, BETA = 120, O
 // those fields from the segment where they are used (an s_load that hits the scalar cache).  The empty asm makes the segment
 // pointer opaque at that point, so the load can neither be hoisted to the kernel's entry nor kept live through the inverse
 // transforms; with all ~20 pointers live the two kernels needed 32-63 more scalar registers than the 102 there are.
-template <class T>
-__device__ __forceinline__ T late_arg(unsigned byte_offset) {
-    typedef const char __attribute__((address_space(4))) * kptr;
-    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    return *(const T __attribute__((address_space(4)))*)(ka + byte_offset);
-}
 #define LATE(ARGS, field) late_arg<decltype(ARGS::field)>((unsigned)offsetof(ARGS, field))
 
 struct SignTailArgs {

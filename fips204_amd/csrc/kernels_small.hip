@@ -6,9 +6,10 @@
 // critical path: ExpandA starts 28 us after the first kernel (the host enqueues the helper-stream kernels first), every cross-stream
 // join costs ~10 us, and the arithmetic of one operation runs on one wave.  This kernel runs the same device code in one launch:
 //
-//   phase 1   every operation owns a CLUSTER of workgroups (4 waves each).  Each wave takes one role: ExpandA for two polynomials of
-//             A_hat (expand_a_coop_pair, one per half-wave; absent when the caller keeps A_hat with its keys), mu = H(tr | M')
-//             (ml_dsa.rs:386-397) or c = SampleInBall(c~) (ml_dsa.rs:400) -- all three on the wave-cooperative sponge (keccak_coop.h).
+//   phase 1   every operation owns a CLUSTER of workgroups (4 waves each).  Each wave takes one role: ExpandA for one polynomial of
+//             A_hat (expand_a_coop2_poly; absent when the caller keeps A_hat with its keys), mu = H(tr | M') (ml_dsa.rs:386-397) or
+//             c = SampleInBall(c~) (ml_dsa.rs:400) -- all three on the one-state-per-wave cooperative sponge (keccak_coop2.h: 2.2 us
+//             per permutation against 3.8 of the two-state form and 9.4 lane-per-state).
 //             Results go to the call's workspace rows (24-bit A_hat, mu, c as bytes, the refusal flag).
 //   hand-over a workgroup that has finished its roles releases its stores (agent scope) and bumps the operation's counter; the workgroup
 //             that sees the count complete -- the LAST one to arrive -- acquires and carries on.  Nobody waits: no spinning, no
@@ -18,15 +19,15 @@
 //             then the rows  w'_i = invNTT(A_i o z_hat - c_hat o t1_hat_i), UseHint, w1Encode  (ml_dsa.rs:407-428) into LDS beside mu,
 //             then c~' = H(mu | w1') on one wave straight from LDS and the verdict (ml_dsa.rs:429-436).
 //
-// Same device functions as the batch kernels (expand_a_coop_pair, ntt_fwd_wave / ntt_inv_wave, hint_unpack_wave, use_hint,
-// pack_w1_strided, keccak_f1600_coop), same bytes in the workspace rows, same verdicts: tests/test_gpu_small_calls.py compares the two
+// Same device functions as the batch kernels (coeff_from_three_bytes ranking of expand_a_coop_pair, ntt_fwd_wave / ntt_inv_wave, hint_unpack_wave, use_hint,
+// pack_w1_strided), same bytes in the workspace rows, same verdicts: tests/test_gpu_small_calls.py compares the two
 // paths with each other and with the oracle over the ACVP sigVer vectors, damaged signatures, refused operations and every mode.
 // Workgroup b belongs to XCD b mod 8 (round-robin dispatch): the clusters are laid out so that all workgroups of an operation share
 // an XCD, i.e. the L2 that holds the A_hat rows they hand over.
 #include "ctx.h"
 #include "challenge_dev.h"
 #include "expand_coop_dev.h"
-#include "keccak_coop.h"
+#include "keccak_coop2.h"
 #include "ntt_wave.h"
 #include "rounding.h"
 #include "sampler_dev.h"
@@ -61,10 +62,22 @@ struct SmallVerifyArgs {
     const Twiddle *fwd_tab, *inv_tab;
 };
 
-// ---- role: mu = H(tr | M', 64) by one wave, both halves computing the same state (one op per wave).  The checks and the byte layout
+// the kernel's first by-value argument, read again from the kernarg segment (see field.h late_arg: same ABI assumption, same self-test)
+template <class T>
+__device__ __forceinline__ void reload_first_kernarg(T& out) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    typedef const uint32_t __attribute__((address_space(4))) * kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    uint32_t* w = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = ka[i];
+}
+
+// ---- role: mu = H(tr | M', 64) by one wave (keccak_coop2.h: one state per wave).  The checks and the byte layout
 // are k_mu's (kernels_codec.hip): offsets are never trusted, a ctx longer than 255 bytes or a malformed pair refuses the op before
 // a byte of it is read; flag as there.
-__device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t op, int lane, const CoopLane& c) {
+__device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t op, int lane, const Coop2Lane& c) {
     size_t key = A.key_idx ? A.key_idx[op] : op;
     int key_bad = 0;
     if (A.key_idx && key >= A.n_keys) { key = 0; key_bad = 2; }
@@ -107,22 +120,21 @@ __device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t o
         if (pos > total) return 0u;
         return byte_at(pos) | (byte_at(pos + 1) << 8) | (byte_at(pos + 2) << 16) | (byte_at(pos + 3) << 24);
     };
-    uint32_t lo = 0, hi = 0;
+    uint32_t v = 0;
     const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
     for (size_t b = 0; b < blocks; b++) {  // wave-uniform
         if (absorbs) {
             const size_t off = b * SHAKE256_RATE + 8 * (size_t)c.word;
-            lo ^= dword_at(off);
-            hi ^= dword_at(off + 4);
+            const uint32_t lo = dword_at(off);
+            uint32_t hi = dword_at(off + 4);
             if (b == blocks - 1 && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
+            v ^= coop2_from_lohi(lo, hi, c);
         }
-        keccak_f1600_coop(lo, hi, c);
+        keccak_f1600_coop2(v, c);
     }
-    if (lane < 32 && c.active && c.word < 8) {
-        uint32_t* out = reinterpret_cast<uint32_t*>(A.mu_ws + op * 64);
-        out[2 * c.word] = lo;
-        out[2 * c.word + 1] = hi;
-    }
+    uint32_t lo, hi;
+    coop2_to_lohi(v, lane, lo, hi);
+    if (c.active && c.word < 8) reinterpret_cast<uint32_t*>(A.mu_ws + op * 64)[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
     if (lane == 0) A.flag_ws[op] = flag;
 }
 
@@ -130,7 +142,7 @@ __device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t o
 // wave's LDS rows (c_row: 256 int8, bw: the squeezed block).  Output: the bytes k_sample_in_ball<.., C8> writes.
 template <int CT>
 __device__ __forceinline__ void small_role_sib(const SmallVerifyArgs& A, size_t op, size_t sig_len, int tau, uint32_t* c_row, uint32_t* bw, int lane,
-                                               const CoopLane& c) {
+                                               const Coop2Lane& c) {
     const uint8_t* ct = A.sigs + op * sig_len;  // c~ opens the signature (encodings.rs:251)
     uint32_t lo = 0, hi = 0;
     if (c.active && c.word < CT / 8) {
@@ -139,13 +151,15 @@ __device__ __forceinline__ void small_role_sib(const SmallVerifyArgs& A, size_t 
     }
     if (c.active && c.word == CT / 8) lo ^= 0x1Fu;
     if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
+    uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
     c_row[lane] = 0;
     int pos = 8, i = 256 - tau;
     uint64_t h64 = 0;
     bool first = true;
     for (;;) {  // wave-uniform: i and pos are lane 0's, handed round after its walk
-        keccak_f1600_coop(lo, hi, c);
-        if (lane < 32 && c.active && c.word < SHAKE256_RATE / 8) { bw[2 * c.word] = lo; bw[2 * c.word + 1] = hi; }
+        keccak_f1600_coop2(v, c);
+        coop2_to_lohi(v, lane, lo, hi);
+        if (c.active && c.word < SHAKE256_RATE / 8) bw[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
         wave_lds_sync();
         if (first) h64 = ((uint64_t)bw[1] << 32) | bw[0];  // hashing.rs:55-56
         first = false;
@@ -172,14 +186,13 @@ __device__ __forceinline__ void small_role_sib(const SmallVerifyArgs& A, size_t 
 }
 
 template <int K, int L, int GB, bool G2HI, int CT, bool CACHED>
-__global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A, int tau, int omega, int32_t zbound, size_t sig_len) {
+__global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A0, int tau, int omega, int32_t zbound, size_t sig_len) {
     constexpr int CB = GB + 1;
     constexpr int BITS = G2HI ? 4 : 6;
     constexpr int W1_LEN = K * 32 * BITS;
-    constexpr int NA = CACHED ? 0 : K * L / 2;          // ExpandA roles (two polynomials each)
+    constexpr int NA = CACHED ? 0 : K * L;              // ExpandA roles (one polynomial each)
     constexpr int ROLES = NA + 2, NB = (ROLES + SMW - 1) / SMW;
-    static_assert((K * L) % 2 == 0, "two polynomials per ExpandA wave");
-    __shared__ uint32_t blk_lds[SMW * 2 * EA_COOP_BLK_DWORDS];                // phase 1: ExpandA blocks | SampleInBall rows
+    __shared__ uint32_t blk_lds[SMW * EA_COOP_BLK_DWORDS];                    // phase 1: the ExpandA waves' blocks
     __shared__ __attribute__((aligned(16))) int4 zh[L + 1][64];               // tail: z_hat rows and c_hat
     __shared__ uint32_t hint_lds[HINT_LDS_DWORDS];
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
@@ -191,20 +204,18 @@ __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A, in
     const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
     const uint32_t member = q % NB;
     const size_t op = (size_t)(q / NB) * 8 + xcd;
-    if (op >= A.n_ops) return;  // (whole workgroup)
-    const CoopLane c = coop_lane(lane);
+    if (op >= A0.n_ops) return;  // (whole workgroup)
+    const Coop2Lane c = coop2_lane(lane);
     const int role = (int)member * SMW + wave;
 
     // ---------------------------------------------------------------- phase 1
     if (role < NA) {
-        uint32_t* blk = blk_lds + (wave * 2 + (lane >> 5)) * EA_COOP_BLK_DWORDS;
-        const size_t n_streams = (size_t)A.n_ops * (K * L);
-        expand_a_coop_pair<K, L>(A.rho, A.rho_stride, A.key_idx, A.a_ws, op * (K * L) + 2 * (size_t)role, n_streams, A.n_keys, blk, lane, c);
+        expand_a_coop2_poly<K, L>(A0.rho, A0.rho_stride, A0.key_idx, A0.a_ws, op * (K * L) + (size_t)role, A0.n_keys, blk_lds + wave * EA_COOP_BLK_DWORDS, lane, c);
     } else if (role == NA) {
-        small_role_mu(A, op, lane, c);
+        small_role_mu(A0, op, lane, c);
     } else if (role == NA + 1) {
         // its rows (256 int8 of c, the squeezed block) lie in zh, which nothing else uses before the tail
-        small_role_sib<CT>(A, op, sig_len, tau, reinterpret_cast<uint32_t*>(&zh[0][0]), reinterpret_cast<uint32_t*>(&zh[1][0]), lane, c);
+        small_role_sib<CT>(A0, op, sig_len, tau, reinterpret_cast<uint32_t*>(&zh[0][0]), reinterpret_cast<uint32_t*>(&zh[1][0]), lane, c);
     }
 
     // ---------------------------------------------------------------- hand-over
@@ -212,9 +223,9 @@ __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A, in
     if (NB > 1) {
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const uint32_t seen = __hip_atomic_fetch_add(&A.ctr[op], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t seen = __hip_atomic_fetch_add(&A0.ctr[op], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = seen == (uint32_t)(NB - 1);
-            if (last) __hip_atomic_store(&A.ctr[op], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next call
+            if (last) __hip_atomic_store(&A0.ctr[op], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next call
             s_last = last;
         }
         __syncthreads();
@@ -223,6 +234,10 @@ __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A, in
     }
 
     // ---------------------------------------------------------------- tail (this workgroup's four waves)
+    // The tail reads its arguments afresh from the kernarg segment (field.h late_arg): what phase 1 used dies with it, what the tail
+    // uses is loaded here -- otherwise all ~25 scalars of the argument struct stay live across both and four of them spill.
+    SmallVerifyArgs A;
+    reload_first_kernarg(A);
     for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * SMW) tw_lds[i] = A.fwd_tab[i];
     for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * SMW) tw_lds[FWD_TW * 64 + i] = A.inv_tab[i];
     if (threadIdx.x < 16) msg_lds[threadIdx.x] = reinterpret_cast<const uint32_t*>(A.mu_ws + op * 64)[threadIdx.x];
@@ -324,22 +339,23 @@ __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A, in
             if (off + 4 == BLOCKS * SHAKE256_RATE) v |= 0x80000000u;
             return v;
         };
-        uint32_t lo = 0, hi = 0;
+        uint32_t v = 0;
         const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
 #pragma unroll 1
         for (int blk = 0; blk < BLOCKS; blk++) {
             if (absorbs) {
                 const int off = blk * SHAKE256_RATE + 8 * c.word;
-                lo ^= msg_dword(off);
-                hi ^= msg_dword(off + 4);
+                v ^= coop2_from_lohi(msg_dword(off), msg_dword(off + 4), c);
             }
-            keccak_f1600_coop(lo, hi, c);
+            keccak_f1600_coop2(v, c);
         }
+        uint32_t lo, hi;
+        coop2_to_lohi(v, lane, lo, hi);
         const bool digest = c.active && c.word < CT / 8;
-        const uint8_t* c0 = A.sigs + op * sig_len + 8 * c.word;
-        const bool differs = digest && ((lo ^ load_le32(c0)) | (hi ^ load_le32(c0 + 4))) != 0;
+        const uint8_t* c0 = A.sigs + op * sig_len + 8 * c.word + 4 * (lane >> 5);  // the E lane compares the word's low dword, the O lane the high one
+        const bool differs = digest && ((lane < 32 ? lo : hi) ^ load_le32(c0)) != 0;
         const unsigned long long any = __ballot(differs);
-        if (lane == 0) A.ok[op] = (uint8_t)((uint32_t)any == 0u && !s_zbad && s_hint_ok && !A.flag_ws[op]);
+        if (lane == 0) A.ok[op] = (uint8_t)(any == 0ull && !s_zbad && s_hint_ok && !A.flag_ws[op]);
     }
 }
 
@@ -359,7 +375,7 @@ int launch_verify_small(mldsa_ctx* ctx, const mldsa_params* p, int mode, const u
     A.a_ws = a_ws; A.c_ws = reinterpret_cast<uint32_t*>(c_ws); A.mu_ws = mu_ws; A.flag_ws = flag_ws; A.ctr = ctr;
     A.fwd_tab = ctx->d_fwd_tw; A.inv_tab = ctx->d_inv_tw;
     const bool cached = a_keys != nullptr;
-    const int roles = (cached ? 0 : p->k * p->l / 2) + 2, nb = (roles + SMW - 1) / SMW;
+    const int roles = (cached ? 0 : p->k * p->l) + 2, nb = (roles + SMW - 1) / SMW;
     const dim3 grid((unsigned)(((n_ops + 7) / 8) * 8 * (size_t)nb)), block(64 * SMW);
     const int32_t zbound = p->gamma1 - p->beta;
 #define MLDSA_SMALL(KK, LL, GB, G2, CT)                                                                                                      \

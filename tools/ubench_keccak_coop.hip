@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../fips204_amd/csrc/keccak.h"
+#include "../fips204_amd/csrc/keccak_coop2.h"
 
 #define CHECK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -217,6 +218,19 @@ __global__ __launch_bounds__(256) void k_coop4(uint32_t* __restrict__ io, int pe
     if (c.active) { st[2 * w] = lo; st[2 * w + 1] = hi; }
 }
 
+// round 5: ONE state per wave, one 32-bit half per lane in the bit-interleaved form, one level of five gathers per round (keccak_coop2.h)
+__global__ __launch_bounds__(256) void k_coop5(uint32_t* __restrict__ io, int perms) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const mldsa::Coop2Lane c = mldsa::coop2_lane(lane);
+    uint32_t* st = io + wave * 50;
+    uint32_t v = c.active ? mldsa::coop2_from_lohi(st[2 * c.word], st[2 * c.word + 1], c) : 0;
+    for (int p = 0; p < perms; p++) mldsa::keccak_f1600_coop2(v, c);
+    uint32_t lo, hi;
+    mldsa::coop2_to_lohi(v, lane, lo, hi);
+    if (c.active) st[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
+}
+
 __global__ __launch_bounds__(256) void k_coop(uint32_t* __restrict__ io, int perms) {
     // io: per wave two states x 25 words x (lo, hi); lane i of a half-wave owns word i
     const int lane = threadIdx.x & 63;
@@ -276,6 +290,12 @@ int main() {
         CHECK(hipMemcpy(b.data(), d2, h.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < h.size(); i++)
             if (a[i] != b[i]) { fprintf(stderr, "MISMATCH at word %zu: lane-per-state %08x DPP cooperative %08x\n", i, a[i], b[i]); return 1; }
+        CHECK(hipMemcpy(d2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_coop5, dim3(n_states / 4), dim3(256), 0, 0, d2, 3);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(b.data(), d2, h.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); i++)
+            if (a[i] != b[i]) { fprintf(stderr, "MISMATCH at word %zu: lane-per-state %08x interleaved cooperative %08x\n", i, a[i], b[i]); return 1; }
         printf("cooperative and lane-per-state Keccak-f[1600] agree on %d random states x 3 permutations\n", n_states);
         CHECK(hipFree(d1)); CHECK(hipFree(d2));
     }
@@ -285,7 +305,7 @@ int main() {
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     printf("device: %s, %d CUs\n", prop.name, cus);
     printf("%-18s %10s %12s %22s %20s\n", "form", "waves/SIMD", "ms", "us per permutation/wave", "G permutations/s");
-    for (int form = 0; form < 4; form++)
+    for (int form = 0; form < 5; form++)
         for (int wps : {1, 2, 4, 8}) {
             const int blocks = cus * wps;  // 4 waves per block = 1 per SIMD of a CU
             const size_t words = (size_t)blocks * 256 * 50;
@@ -298,15 +318,16 @@ int main() {
                 if (form == 0) hipLaunchKernelGGL(k_lane, dim3(blocks), dim3(256), 0, 0, d, perms);
                 else if (form == 1) hipLaunchKernelGGL(k_coop, dim3(blocks), dim3(256), 0, 0, d, perms);
                 else if (form == 2) hipLaunchKernelGGL(k_coop3, dim3(blocks), dim3(256), 0, 0, d, perms);
-                else hipLaunchKernelGGL(k_coop4, dim3(blocks), dim3(256), 0, 0, d, perms);
+                else if (form == 3) hipLaunchKernelGGL(k_coop4, dim3(blocks), dim3(256), 0, 0, d, perms);
+                else hipLaunchKernelGGL(k_coop5, dim3(blocks), dim3(256), 0, 0, d, perms);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipEventSynchronize(e1));
                 float ms;
                 CHECK(hipEventElapsedTime(&ms, e0, e1));
                 best = ms < best ? ms : best;
             }
-            const double states = (double)blocks * 4 * (form == 0 ? 64 : 2);
-            printf("%-18s %10d %12.3f %22.2f %20.3f\n", form == 0 ? "lane-per-state" : form == 1 ? "cooperative (2/wave)" : form == 2 ? "coop, 3 levels (2/wave)" : "coop, DPP + 4 gathers", wps, best, best * 1e3 / perms,
+            const double states = (double)blocks * 4 * (form == 0 ? 64 : form == 4 ? 1 : 2);
+            printf("%-18s %10d %12.3f %22.2f %20.3f\n", form == 0 ? "lane-per-state" : form == 1 ? "cooperative (2/wave)" : form == 2 ? "coop, 3 levels (2/wave)" : form == 3 ? "coop, DPP + 4 gathers" : "interleaved, 1/wave, 5 gathers", wps, best, best * 1e3 / perms,
                    states * perms / (best * 1e-3) / 1e9);
             CHECK(hipFree(d));
         }
