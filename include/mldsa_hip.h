@@ -141,8 +141,9 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                 * lane-per-state form of the large batches.  Results are identical. */
 #define MLDSA_OPT_SMALL_FUSED 13 /* most ops of a verification call that runs as ONE kernel launch (csrc/kernels_small.hip: every op owns a cluster of
                                     workgroups for ExpandA, mu and SampleInBall; the last one to finish carries on with the arithmetic, the c_tilde hash
-                                    and the verdict).  Default 64; 0 = always the batch pipeline (six launches on three streams).  Needs
-                                    MLDSA_OPT_COOP_HASH = 1.  Results are bit-identical either way; a one-op call takes ~70 instead of ~105 us. */
+                                    and the verdict).  Default 256 (measured crossover against the batch pipeline: ~350 ops); 0 = always the batch pipeline (six
+                                    launches on three streams); at most 1024.  Needs MLDSA_OPT_COOP_HASH = 1.  Results are bit-identical either way;
+                                    a one-op call takes 53 instead of 105 us, 64 ops 62 instead of 116, 256 ops 123 instead of 143. */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,

@@ -25,7 +25,7 @@ def env():
     from fips204_amd.hotpath import HotPath
     from fips204_amd.ml_dsa import MlDsa
     hp = HotPath(0)
-    assert hp.get_option(OPT_SMALL_FUSED) == 64            # the default
+    assert hp.get_option(OPT_SMALL_FUSED) == 256           # the default
     yield hp, {s: MlDsa(s, hotpath=hp) for s in (44, 65, 87)}
     hp.close()
 
@@ -66,7 +66,7 @@ def _batch(pset, keys, n_ops, seed, modes=(0,)):
 
 
 def _verify(m, hp, pks, ops, fused, mode, a_hat=None):
-    hp.set_option(OPT_SMALL_FUSED, 64 if fused else 0)
+    hp.set_option(OPT_SMALL_FUSED, 256 if fused else 0)
     from fips204_amd.ml_dsa import _cat_with_offsets
     n = len(ops)
     mb, mo = _cat_with_offsets([o["msg"] for o in ops], m.device)
@@ -80,7 +80,7 @@ def _verify(m, hp, pks, ops, fused, mode, a_hat=None):
 
 
 @pytest.mark.parametrize("pset", [44, 65, 87])
-@pytest.mark.parametrize("n_ops", [1, 7, 8, 9, 64])
+@pytest.mark.parametrize("n_ops", [1, 7, 8, 9, 64, 200])
 def test_fused_equals_pipeline_equals_oracle(env, pset, n_ops):
     hp, sets = env
     m = sets[pset]
@@ -92,7 +92,7 @@ def test_fused_equals_pipeline_equals_oracle(env, pset, n_ops):
         got_u = _verify(m, hp, pks, ops, False, mode)
         assert got_f == want, (pset, n_ops, mode, "fused vs oracle")
         assert got_u == want, (pset, n_ops, mode, "pipeline vs oracle")
-    hp.set_option(OPT_SMALL_FUSED, 64)
+    hp.set_option(OPT_SMALL_FUSED, 256)
 
 
 @pytest.mark.parametrize("pset", [44, 65, 87])
@@ -107,14 +107,14 @@ def test_cached_a_hat_path(env, pset):
         want = [int(o["want"]) for o in ops]
         assert _verify(m, hp, pks, ops, True, 0, a_hat=a_hat) == want
         assert _verify(m, hp, pks, ops, False, 0, a_hat=a_hat) == want
-    hp.set_option(OPT_SMALL_FUSED, 64)
+    hp.set_option(OPT_SMALL_FUSED, 256)
 
 
 def test_acvp_sigver_one_op_per_call(env, acvp_sigver):
     """the reference's own call shape: every ACVP sigVer vector as a call of ONE operation (nist_vectors/mod.rs:148-203)"""
     from conftest import PSET
     hp, sets = env
-    hp.set_option(OPT_SMALL_FUSED, 64)
+    hp.set_option(OPT_SMALL_FUSED, 256)
     n = 0
     for g in acvp_sigver["testGroups"]:
         m = sets[PSET[g["parameterSet"]]]
@@ -151,13 +151,13 @@ def test_refusals_are_per_op_and_identical(env):
         want[i] = 0
     res = {}
     for fused in (True, False):
-        hp.set_option(OPT_SMALL_FUSED, 64 if fused else 0)
+        hp.set_option(OPT_SMALL_FUSED, 256 if fused else 0)
         ok = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
         m.verify_device(pks, mb, mo_bad, sg, ok, n, cb, co, kidx, 0)
         torch.cuda.synchronize()
         res[fused] = ok.cpu().numpy().tolist()
     assert res[True] == want and res[False] == want
-    hp.set_option(OPT_SMALL_FUSED, 64)
+    hp.set_option(OPT_SMALL_FUSED, 256)
 
 
 def test_long_messages_many_rate_blocks(env):
@@ -178,7 +178,7 @@ def test_long_messages_many_rate_blocks(env):
 def test_counters_return_to_zero_and_calls_interleave(env):
     """300 calls back to back, the three parameter sets and the call sizes interleaved, then the counter array is all zero again"""
     hp, sets = env
-    hp.set_option(OPT_SMALL_FUSED, 64)
+    hp.set_option(OPT_SMALL_FUSED, 256)
     prepared = []
     for pset in (44, 65, 87):
         m = sets[pset]
@@ -201,4 +201,4 @@ def test_option_bounds(env):
     lib, h = hp.lib, hp._h
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 1025) != 0 and lib.mldsa_set_option(h, OPT_SMALL_FUSED, -1) != 0
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 0) == 0 and hp.get_option(OPT_SMALL_FUSED) == 0
-    assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 64) == 0
+    assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 256) == 0
