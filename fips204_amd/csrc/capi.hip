@@ -111,6 +111,8 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->coop_hash_max = (size_t)env_long("MLDSA_COOP_HASH_MAX", 0, 1 << 20, (long)ctx->coop_hash_max);
     ctx->coop_mask_max = (size_t)env_long("MLDSA_COOP_MASK_MAX", 0, 1 << 20, (long)ctx->coop_mask_max);
     ctx->coop_a_max = (size_t)env_long("MLDSA_COOP_A_MAX", 0, 1 << 20, (long)ctx->coop_a_max);
+    ctx->coop_mu_max = (size_t)env_long("MLDSA_COOP_MU_MAX", 0, 1 << 20, (long)ctx->coop_mu_max);
+    ctx->coop_sib_max = (size_t)env_long("MLDSA_COOP_SIB_MAX", 0, 1 << 20, (long)ctx->coop_sib_max);
     ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 524288, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
     ctx->opt_spec_rows = env_long("MLDSA_SPEC_ROWS", 1, 524288, ctx->opt_spec_rows);
@@ -169,7 +171,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
         // context, that this toolchain and driver lay the segment out the way that code assumes -- a mismatch fails here, loudly
         uint32_t *d_word = nullptr, h_word = 0;
         e = malloc_quiesced((void **)&d_word, sizeof(uint32_t));
-        if (e == hipSuccess) e = memset_quiesced(d_word, 0, sizeof(uint32_t));
+        // (no memset of the word: the kernel always writes it -- and a NULL-stream memset is not ordered against the non-blocking stream)
         int rc = e == hipSuccess ? late_arg_selftest(ctx->aux_stream, d_word) : MLDSA_ERR_DEVICE;
         if (rc == MLDSA_OK && hipStreamSynchronize(ctx->aux_stream) != hipSuccess) rc = MLDSA_ERR_DEVICE;
         if (rc == MLDSA_OK && memcpy_quiesced(&h_word, d_word, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) rc = MLDSA_ERR_DEVICE;

@@ -11,7 +11,7 @@
 #include "challenge_dev.h"
 #include "sampler_dev.h"
 #include "keccak.h"
-#include "keccak_coop.h"
+#include "keccak_coop2.h"
 #include "ntt_wave.h"
 #include "rounding.h"
 #include "verify_dev.h"
@@ -336,25 +336,23 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
     }
 }
 
-// The same hash for SMALL batches: one state per half-wave (keccak_coop.h), 3.8 instead of 9.4 us per permutation.  Same arguments, same
-// results (ALIGNED is not needed: every load is a byte-granular dword load).  Lanes holding state words 0 .. 16 fetch their eight
-// bytes of each rate block straight from A | B | tail | pad; the digest leaves through the lanes holding words 0 .. OUT / 8 - 1.
+// The same hash for SMALL batches: one state per wave on the interleaved cooperative sponge (keccak_coop2.h), 2.2 instead of 9.4 us per
+// permutation.  Same arguments, same results (ALIGNED is not needed: every load is a byte-granular dword load).  The two lanes holding
+// a state word fetch its eight bytes of each rate block straight from A | B | tail | pad; the digest leaves through the lanes holding
+// words 0 .. OUT / 8 - 1 (the E lane the word's low dword, the O lane the high one).
 template <int OUT>
 __global__ __launch_bounds__(CBLOCK) void k_shake256_2_coop(const uint8_t* __restrict__ a, size_t sa, int la, const uint32_t* __restrict__ a_idx,
                                                             const uint8_t* __restrict__ b, size_t sb, int lb, uint32_t tail, int tail_len,
                                                             uint8_t* __restrict__ out, size_t so, size_t n_ops, const uint32_t* __restrict__ n_dev,
                                                             VerdictArgs vd, const uint32_t* __restrict__ b_idx) {
     const int lane = threadIdx.x & 63, half = lane >> 5;
-    const CoopLane c = coop_lane(lane);
+    const Coop2Lane c = coop2_lane(lane);
     if (n_dev) n_ops = *n_dev;
     const int total = la + lb + tail_len, blocks = total / SHAKE256_RATE + 1;  // the pad always fits in the last block
-    const size_t wave0 = ((size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6)) * 2, stride = (size_t)gridDim.x * CWAVES * 2;
-    for (size_t op0 = wave0; op0 < n_ops; op0 += stride) {  // wave-uniform
-        const size_t op = op0 + half;
-        const bool valid = op < n_ops;
-        const size_t opc = valid ? op : op0;  // the odd half of the last pair recomputes its neighbour's hash: loads stay legal
-        const uint8_t* pa = a + (a_idx ? a_idx[opc] : opc) * sa;
-        const uint8_t* pb = b ? b + (b_idx ? b_idx[opc] : opc) * sb : pa;
+    const size_t wave0 = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * CWAVES;
+    for (size_t op = wave0; op < n_ops; op += stride) {  // wave-uniform
+        const uint8_t* pa = a + (a_idx ? a_idx[op] : op) * sa;
+        const uint8_t* pb = b ? b + (b_idx ? b_idx[op] : op) * sb : pa;
         auto msg_dword = [&](int off) -> uint32_t {  // la, lb are multiples of 4: a dword never straddles A | B
             if (off + 4 <= la) return load_le32(pa + off);
             if (off + 4 <= la + lb) return load_le32(pb + (off - la));
@@ -368,29 +366,94 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2_coop(const uint8_t* __res
             if (off + 4 == blocks * SHAKE256_RATE) v |= 0x80000000u;
             return v;
         };
-        uint32_t lo = 0, hi = 0;
+        uint32_t v = 0;
         const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
         for (int blk = 0; blk < blocks; blk++) {
             if (absorbs) {
                 const int off = blk * SHAKE256_RATE + 8 * c.word;
-                lo ^= msg_dword(off);
-                hi ^= msg_dword(off + 4);
+                v ^= coop2_from_lohi(msg_dword(off), msg_dword(off + 4), c);
             }
-            keccak_f1600_coop(lo, hi, c);
+            keccak_f1600_coop2(v, c);
         }
+        uint32_t lo, hi;
+        coop2_to_lohi(v, lane, lo, hi);
+        const uint32_t mine = half ? hi : lo;  // this lane's dword of the digest: bytes 8 word + 4 half
         const bool digest = c.active && c.word < OUT / 8;
         if (vd.ok) {
-            const uint8_t* c0 = vd.sigs + opc * vd.sig_len + 8 * c.word;  // c_tilde opens the signature (encodings.rs:251)
-            const bool differs = digest && ((lo ^ load_le32(c0)) | (hi ^ load_le32(c0 + 4))) != 0;
+            const uint8_t* c0 = vd.sigs + op * vd.sig_len + 8 * c.word + 4 * half;  // c_tilde opens the signature (encodings.rs:251)
+            const bool differs = digest && (mine ^ load_le32(c0)) != 0;
             const unsigned long long any = __ballot(differs);
-            const uint32_t mine = half ? (uint32_t)(any >> 32) : (uint32_t)any;
-            if (valid && c.first) vd.ok[op] = (uint8_t)(mine == 0 && vd.znorm[op] < vd.zbound && vd.hvalid[op] && !vd.ctx_bad[op]);
-        } else if (valid && digest) {
+            if (lane == 0) vd.ok[op] = (uint8_t)(any == 0ull && vd.znorm[op] < vd.zbound && vd.hvalid[op] && !vd.ctx_bad[op]);
+        } else if (digest) {
             typedef uint32_t __attribute__((aligned(1))) u32_unaligned;  // (any alignment: pk / sk rows are odd-sized)
-            uint8_t* po = out + op * so + 8 * c.word;
-            *reinterpret_cast<u32_unaligned*>(po) = lo;
-            *reinterpret_cast<u32_unaligned*>(po + 4) = hi;
+            *reinterpret_cast<u32_unaligned*>(out + op * so + 8 * c.word + 4 * half) = mine;
         }
+    }
+}
+
+// mu = H(tr | M') for SMALL calls: one op per wave on the same sponge (k_mu's checks, flags and bytes; any message length).
+__global__ __launch_bounds__(CBLOCK) void k_mu_coop(const uint8_t* __restrict__ tr, size_t tr_stride, const uint32_t* __restrict__ key_idx, int mode,
+                                                    const uint8_t* __restrict__ msgs, const uint64_t* __restrict__ msg_off, const uint8_t* __restrict__ ctxs,
+                                                    const uint64_t* __restrict__ ctx_off, uint8_t* __restrict__ mu, size_t mu_stride,
+                                                    int32_t* __restrict__ ctx_bad, const int32_t* __restrict__ key_bad, size_t n_ops, size_t op0,
+                                                    size_t n_call) {
+    const int lane = threadIdx.x & 63;
+    const Coop2Lane c = coop2_lane(lane);
+    const size_t wave0 = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * CWAVES;
+    for (size_t op = wave0; op < n_ops; op += stride) {  // wave-uniform
+        const uint8_t* trp = tr + (key_idx ? key_idx[op] : op) * tr_stride;
+        const uint64_t m0 = msg_off[op0 + op], m1 = msg_off[op0 + op + 1];
+        bool bad_off = !(msg_off[0] <= m0 && m0 <= m1 && m1 <= msg_off[n_call]);
+        const uint8_t* mp = msgs + m0;
+        size_t mlen = (size_t)(m1 - m0), clen = 0;
+        bad_off |= mlen != 0 && msgs == nullptr;  // offsets that name bytes of a NULL array
+        const uint8_t* cp = nullptr;
+        if (ctx_off) {
+            const uint64_t c0 = ctx_off[op0 + op], c1 = ctx_off[op0 + op + 1];
+            bad_off |= !(ctx_off[0] <= c0 && c0 <= c1 && c1 <= ctx_off[n_call]);
+            cp = ctxs + c0;
+            clen = (size_t)(c1 - c0);
+            bad_off |= clen != 0 && ctxs == nullptr;
+        }
+        const int flag = bad_off ? 2 : clen > 255 ? 1 : (key_bad ? key_bad[op] : 0);
+        const bool live = !bad_off && clen <= 255;
+        if (!live) mlen = clen = 0;
+        const size_t pre = (mode == MLDSA_MODE_INTERNAL) ? 0 : 2 + clen;
+        const size_t total = live ? 64 + pre + mlen : 0;
+        const size_t blocks = live ? total / SHAKE256_RATE + 1 : 0;
+        auto byte_at = [&](size_t pos) -> uint32_t {
+            if (pos < total) {
+                if (pos < 64) return trp[pos];
+                if (pos < 64 + pre) {
+                    const size_t q = pos - 64;
+                    return q == 0 ? (uint32_t)(mode == MLDSA_MODE_PREHASH ? 1 : 0) : q == 1 ? (uint32_t)clen : cp[q - 2];
+                }
+                return mp[pos - 64 - pre];
+            }
+            return pos == total ? 0x1Fu : 0u;
+        };
+        auto dword_at = [&](size_t pos) -> uint32_t {
+            if (pos + 4 <= 64) return load_le32(trp + pos);
+            if (pos >= 64 + pre && pos + 4 <= total) return load_le32(mp + (pos - 64 - pre));
+            if (pos > total) return 0u;
+            return byte_at(pos) | (byte_at(pos + 1) << 8) | (byte_at(pos + 2) << 16) | (byte_at(pos + 3) << 24);
+        };
+        uint32_t v = 0;
+        const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
+        for (size_t b = 0; b < blocks; b++) {
+            if (absorbs) {
+                const size_t off = b * SHAKE256_RATE + 8 * (size_t)c.word;
+                const uint32_t lo = dword_at(off);
+                uint32_t hi = dword_at(off + 4);
+                if (b == blocks - 1 && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
+                v ^= coop2_from_lohi(lo, hi, c);
+            }
+            keccak_f1600_coop2(v, c);
+        }
+        uint32_t lo, hi;
+        coop2_to_lohi(v, lane, lo, hi);
+        if (c.active && c.word < 8) reinterpret_cast<uint32_t*>(mu + op * mu_stride)[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
+        if (lane == 0 && ctx_bad) ctx_bad[op] = flag;
     }
 }
 
@@ -419,9 +482,15 @@ int launch_verify_main(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* a_h
     return MLDSA_OK;
 }
 
-int launch_mu(mldsa_ctx*, const uint8_t* tr, size_t tr_stride, const uint32_t* key_idx, int mode, const uint8_t* msgs,
+int launch_mu(mldsa_ctx* ctx, const uint8_t* tr, size_t tr_stride, const uint32_t* key_idx, int mode, const uint8_t* msgs,
               const uint64_t* msg_off, const uint8_t* ctxs, const uint64_t* ctx_off, uint8_t* mu, size_t mu_stride,
               int32_t* ctx_bad, size_t n_ops, hipStream_t s, const int32_t* key_bad, size_t op0, size_t n_call) {
+    if (ctx && ctx->opt_coop_hash && n_ops <= ctx->coop_mu_max) {  // a small call: one op per wave, 2.2 us per permutation instead of 9.4
+        hipLaunchKernelGGL(k_mu_coop, dim3((unsigned)((n_ops + CWAVES - 1) / CWAVES)), dim3(CBLOCK), 0, s, tr, tr_stride, key_idx, mode, msgs, msg_off,
+                           ctxs, ctx_off, mu, mu_stride, ctx_bad, key_bad, n_ops, op0, n_call);
+        MLDSA_HIP_CHECK(hipGetLastError());
+        return MLDSA_OK;
+    }
     hipLaunchKernelGGL(k_mu, dim3((unsigned)((n_ops + 63) / 64)), dim3(64), 0, s, tr, tr_stride, key_idx, mode, msgs, msg_off,
                        ctxs, ctx_off, mu, mu_stride, ctx_bad, key_bad, n_ops, op0, n_call);
     MLDSA_HIP_CHECK(hipGetLastError());
@@ -455,7 +524,7 @@ static int launch_shake256_2v(mldsa_ctx* ctx, int out_len, const uint8_t* a, siz
     // Small batches (for the signer's rounds: small expected row counts): the wave-cooperative form, two ops per wavefront.  Up to
     // 4 096 ops (mldsa_ctx::coop_hash_max) that is at most two waves per SIMD, where it still runs a permutation in 5.7 us against 9.4.
     if (ctx->opt_coop_hash && n_ops <= ctx->coop_hash_max) {
-        const dim3 cgrid((unsigned)((std::max<size_t>(n_ops, 1) + 2 * CWAVES - 1) / (2 * CWAVES)));
+        const dim3 cgrid((unsigned)((std::max<size_t>(n_ops, 1) + CWAVES - 1) / CWAVES));
 #define MLDSA_COOP_CASE(O)                                                                                                                           \
     case O: hipLaunchKernelGGL((k_shake256_2_coop<O>), cgrid, block, 0, s, a, sa, la, a_idx, b, sb, lb, tail, tail_len, out, so, n_ops, n_dev, vd, b_idx); break;
         switch (out_len) {

@@ -356,21 +356,21 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
 // ------------------------------------------------------------------------- launchers
 static inline unsigned stream_blocks(size_t n_streams) { return (unsigned)((n_streams + 64 * SWAVES - 1) / (64 * SWAVES)); }
 
-// ExpandA (24-bit form) for SMALL calls: one polynomial per half-wave (keccak_coop.h).  After every permutation the 21 lanes holding
-// the rate words put the 168-byte block into the half's LDS row; the half's lanes then test its 56 candidates in two passes of 28
-// (coeff_from_three_bytes, conversion.rs:40-61), rank the accepted ones with a ballot and store each as its three bytes at 3 i of the
-// polynomial's 768-byte row -- the same bytes k_expand_a<.., true> writes.
+// ExpandA (24-bit form) for SMALL calls: one polynomial per WAVE on the interleaved cooperative sponge (keccak_coop2.h: 2.2 us per
+// permutation; expand_coop_dev.h expand_a_coop2_poly).  After every permutation the lanes holding the 21 rate words put the 168-byte block
+// into the wave's LDS row; lanes 0-55 test its 56 candidates (coeff_from_three_bytes, conversion.rs:40-61), rank the accepted ones with a
+// ballot and store each as its three bytes at 3 i of the polynomial's 768-byte row -- the same bytes k_expand_a<.., true> writes.
 template <int K, int L>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_a_coop(const uint8_t* __restrict__ rho, size_t rho_stride, const uint32_t* __restrict__ key_idx,
                                                                int32_t* __restrict__ a_hat, size_t n_ops, uint32_t n_keys) {
-    __shared__ uint32_t blk_lds[SWAVES * 2 * EA_COOP_BLK_DWORDS];
+    __shared__ uint32_t blk_lds[SWAVES * EA_COOP_BLK_DWORDS];
     const int lane = threadIdx.x & 63;
-    const CoopLane c = coop_lane(lane);
-    uint32_t* blk = blk_lds + ((threadIdx.x >> 6) * 2 + (lane >> 5)) * EA_COOP_BLK_DWORDS;
+    const Coop2Lane c = coop2_lane(lane);
+    uint32_t* blk = blk_lds + (threadIdx.x >> 6) * EA_COOP_BLK_DWORDS;
     const size_t n_streams = n_ops * (size_t)(K * L);
-    const size_t wave0 = ((size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6)) * 2, stride = (size_t)gridDim.x * SWAVES * 2;
-    for (size_t g0 = wave0; g0 < n_streams; g0 += stride)  // wave-uniform
-        expand_a_coop_pair<K, L>(rho, rho_stride, key_idx, a_hat, g0, n_streams, n_keys, blk, lane, c);
+    const size_t wave0 = (size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * SWAVES;
+    for (size_t g = wave0; g < n_streams; g += stride)  // wave-uniform
+        expand_a_coop2_poly<K, L>(rho, rho_stride, key_idx, a_hat, g, n_keys, blk, lane, c);
 }
 
 int launch_expand_a(mldsa_ctx* ctx, int set, const uint8_t* rho, size_t rho_stride, const uint32_t* key_idx, int32_t* a_hat,
@@ -381,7 +381,7 @@ int launch_expand_a(mldsa_ctx* ctx, int set, const uint8_t* rho, size_t rho_stri
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_a: unknown parameter set");
     dim3 grid(stream_blocks(n_ops * (size_t)(p->k * p->l))), block(64 * SWAVES);
     if (pack24 && ctx->opt_coop_hash && n_ops * (size_t)(p->k * p->l) <= ctx->coop_a_max) {  // a small call: all latency
-        const dim3 cgrid((unsigned)((n_ops * (size_t)(p->k * p->l) + 2 * SWAVES - 1) / (2 * SWAVES)));
+        const dim3 cgrid((unsigned)((n_ops * (size_t)(p->k * p->l) + SWAVES - 1) / SWAVES));
         if (set == MLDSA_44) hipLaunchKernelGGL((k_expand_a_coop<4, 4>), cgrid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops, n_keys);
         else if (set == MLDSA_65) hipLaunchKernelGGL((k_expand_a_coop<6, 5>), cgrid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops, n_keys);
         else hipLaunchKernelGGL((k_expand_a_coop<8, 7>), cgrid, block, 0, s, rho, rho_stride, key_idx, a_hat, n_ops, n_keys);
@@ -401,26 +401,23 @@ int launch_expand_a(mldsa_ctx* ctx, int set, const uint8_t* rho, size_t rho_stri
     return MLDSA_OK;
 }
 
-// ExpandS (one byte per coefficient: key generation's own s1 / s2) for SMALL calls: one polynomial per half-wave (keccak_coop.h).  The
-// 136-byte block goes through the half's LDS row; its 272 half-byte candidates (low nibble first, hashing.rs:177-180) are tested in
-// nine passes of 32, ranked with a ballot and stored at their coefficient index -- the bytes k_expand_s<ETA, true> writes.
+// ExpandS (one byte per coefficient: key generation's own s1 / s2) for SMALL calls: one polynomial per wave (keccak_coop2.h).  The
+// 136-byte block goes through the wave's LDS row; its 272 half-byte candidates (low nibble first, hashing.rs:177-180) are tested in
+// five passes of 64, ranked with a ballot and stored at their coefficient index -- the bytes k_expand_s<ETA, true> writes.
 template <int ETA>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_s_coop(const uint8_t* __restrict__ rho_prime, size_t rho_stride, int32_t* __restrict__ s12,
                                                                int polys_per_op, size_t n_ops) {
     constexpr int BLK_DWORDS = 36;
-    __shared__ uint32_t blk_lds[SWAVES * 2 * BLK_DWORDS];
-    const int lane = threadIdx.x & 63, half = lane >> 5, i = lane & 31;
-    const CoopLane c = coop_lane(lane);
-    uint32_t* blk = blk_lds + ((threadIdx.x >> 6) * 2 + half) * BLK_DWORDS;
+    __shared__ uint32_t blk_lds[SWAVES * BLK_DWORDS];
+    const int lane = threadIdx.x & 63;
+    const Coop2Lane c = coop2_lane(lane);
+    uint32_t* blk = blk_lds + (threadIdx.x >> 6) * BLK_DWORDS;
     uint8_t* out8 = reinterpret_cast<uint8_t*>(s12);
     const size_t n_streams = n_ops * (size_t)polys_per_op;
-    const size_t wave0 = ((size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6)) * 2, stride = (size_t)gridDim.x * SWAVES * 2;
-    for (size_t g0 = wave0; g0 < n_streams; g0 += stride) {  // wave-uniform
-        const size_t g = g0 + half;
-        const bool valid = g < n_streams;
-        const size_t gc = valid ? g : g0;
-        const size_t op = gc / polys_per_op;
-        const uint32_t r = (uint32_t)(gc % polys_per_op);
+    const size_t wave0 = (size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * SWAVES;
+    for (size_t g = wave0; g < n_streams; g += stride) {  // wave-uniform
+        const size_t op = g / polys_per_op;
+        const uint32_t r = (uint32_t)(g % polys_per_op);
         uint32_t lo = 0, hi = 0;
         if (c.active && c.word < 8) {
             const uint8_t* src = rho_prime + op * rho_stride + 8 * c.word;
@@ -429,26 +426,27 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_s_coop(const uint8_t* __
         }
         if (c.active && c.word == 8) lo = r | (0x1Fu << 16);  // hashing.rs:260/266: rho' || r || 0  (then pad)
         if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi = 0x80000000u;
+        uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
         uint8_t* row = out8 + g * (size_t)N;
-        int count = valid ? 0 : N;
-        while (__any(count < N)) {
-            keccak_f1600_coop(lo, hi, c);
-            if (c.active && c.word < SHAKE256_RATE / 8) { blk[2 * c.word] = lo; blk[2 * c.word + 1] = hi; }
+        int count = 0;
+        while (count < N) {
+            keccak_f1600_coop2(v, c);
+            coop2_to_lohi(v, lane, lo, hi);
+            if (c.active && c.word < SHAKE256_RATE / 8) blk[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
             wave_lds_sync();
 #pragma unroll
-            for (int pass = 0; pass < 9; pass++) {
-                const int cand = 32 * pass + i;  // half-byte index: byte cand >> 1, low nibble first
+            for (int pass = 0; pass < 5; pass++) {
+                const int cand = 64 * pass + lane;  // half-byte index: byte cand >> 1, low nibble first
                 bool acc = false;
-                int32_t v = 0;
+                int32_t val = 0;
                 if (cand < 2 * SHAKE256_RATE) {
                     const uint32_t b = (blk[cand >> 3] >> (4 * (cand & 7))) & 15u;
-                    acc = half_byte<ETA>(b, v);
+                    acc = half_byte<ETA>(b, val);
                 }
                 const unsigned long long all = __ballot(acc);
-                const uint32_t mine = half ? (uint32_t)(all >> 32) : (uint32_t)all;
-                const int idx = count + __popc(mine & ((1u << i) - 1u));
-                if (acc && idx < N) row[idx] = (uint8_t)v;
-                count += __popc(mine);
+                const int idx = count + __popcll(all & ((1ull << lane) - 1ull));
+                if (acc && idx < N) row[idx] = (uint8_t)val;
+                count += __popcll(all);
             }
             wave_lds_sync();
         }
@@ -462,7 +460,7 @@ int launch_expand_s(mldsa_ctx* ctx, int set, const uint8_t* rho_prime, size_t rh
     const int ppo = p->k + p->l;
     dim3 grid(stream_blocks(n_ops * (size_t)ppo)), block(64 * SWAVES);
     if (s8 && ctx->opt_coop_hash && n_ops * (size_t)ppo <= ctx->coop_a_max) {  // a small key generation: all latency
-        const dim3 cgrid((unsigned)((n_ops * (size_t)ppo + 2 * SWAVES - 1) / (2 * SWAVES)));
+        const dim3 cgrid((unsigned)((n_ops * (size_t)ppo + SWAVES - 1) / SWAVES));
         if (p->eta == 2) hipLaunchKernelGGL((k_expand_s_coop<2>), cgrid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
         else hipLaunchKernelGGL((k_expand_s_coop<4>), cgrid, block, 0, s, rho_prime, rho_stride, s12, ppo, n_ops);
         MLDSA_HIP_CHECK(hipGetLastError());
@@ -480,25 +478,22 @@ int launch_expand_s(mldsa_ctx* ctx, int set, const uint8_t* rho_prime, size_t rh
     return MLDSA_OK;
 }
 
-// RAW ExpandMask for SMALL rounds: one stream per half-wave (keccak_coop.h: 3.8 instead of 9.4 us per permutation of a latency-bound
-// launch).  Same arguments and the same bytes as k_expand_mask<GB, true>: the lanes holding state words 0 .. 16 store their eight
-// bytes of every squeezed block straight into the stream's row of 32 c bytes.
+// RAW ExpandMask for SMALL rounds: one stream per wave (keccak_coop2.h: 2.2 instead of 9.4 us per permutation of a latency-bound
+// launch).  Same arguments and the same bytes as k_expand_mask<GB, true>: the lanes holding state words 0 .. 16 store their half
+// (the E lane the word's low dword, the O lane the high one) of every squeezed block straight into the stream's row of 32 c bytes.
 template <int GB>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask_coop(const uint8_t* __restrict__ rho_pp, size_t rho_stride, const uint16_t* __restrict__ kappa,
                                                                   int kappa_by_slot, const uint32_t* __restrict__ op_idx, int32_t* __restrict__ y, int l,
                                                                   size_t n_ops, const uint32_t* __restrict__ n_dev) {
     constexpr int ROW_BYTES = 32 * (GB + 1);
-    const int lane = threadIdx.x & 63, half = lane >> 5;
-    const CoopLane c = coop_lane(lane);
+    const int lane = threadIdx.x & 63;
+    const Coop2Lane c = coop2_lane(lane);
     if (n_dev) n_ops = *n_dev;
     const size_t n_streams = n_ops * (size_t)l;
-    const size_t wave0 = ((size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6)) * 2, stride = (size_t)gridDim.x * SWAVES * 2;
-    for (size_t g0 = wave0; g0 < n_streams; g0 += stride) {  // wave-uniform
-        const size_t g = g0 + half;
-        const bool valid = g < n_streams;
-        const size_t gc = valid ? g : g0;
-        const size_t slot = gc / l;
-        const uint32_t r = (uint32_t)(gc % l);
+    const size_t wave0 = (size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * SWAVES;
+    for (size_t g = wave0; g < n_streams; g += stride) {  // wave-uniform
+        const size_t slot = g / l;
+        const uint32_t r = (uint32_t)(g % l);
         const size_t op = op_idx ? op_idx[slot] : slot;
         uint32_t lo = 0, hi = 0;
         if (c.active && c.word < 8) {
@@ -508,12 +503,14 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask_coop(const uint8_t*
         }
         if (c.active && c.word == 8) lo = (((uint32_t)kappa[kappa_by_slot ? slot : op] + r) & 0xFFFFu) | (0x1Fu << 16);  // hashing.rs:293 (u16 arithmetic)
         if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi = 0x80000000u;
+        uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
         uint8_t* row = reinterpret_cast<uint8_t*>(y) + g * (size_t)ROW_BYTES;
 #pragma unroll 1
         for (int blk = 0; blk < 5; blk++) {
-            keccak_f1600_coop(lo, hi, c);
+            keccak_f1600_coop2(v, c);
+            coop2_to_lohi(v, lane, lo, hi);
             const int off = blk * SHAKE256_RATE + 8 * c.word;
-            if (valid && c.active && c.word < SHAKE256_RATE / 8 && off < ROW_BYTES) *reinterpret_cast<uint2*>(row + off) = make_uint2(lo, hi);  // (8-byte aligned: 136, 576, 640)
+            if (c.active && c.word < SHAKE256_RATE / 8 && off < ROW_BYTES) *reinterpret_cast<uint32_t*>(row + off + 4 * (lane >> 5)) = lane < 32 ? lo : hi;  // (rows are 8-byte aligned: 576, 640)
         }
     }
 }
@@ -526,7 +523,7 @@ int launch_expand_mask(mldsa_ctx* ctx, int set, const uint8_t* rho_pp, size_t rh
     if (!p) return set_error(MLDSA_ERR_PARAM, "expand_mask: unknown parameter set");
     dim3 grid(stream_blocks((n_ops ? n_ops : 1) * (size_t)p->l)), block(64 * SWAVES);
     if (raw && ctx->opt_coop_hash && (n_ops ? n_ops : 1) * (size_t)p->l <= ctx->coop_mask_max) {  // a small round: all latency
-        const dim3 cgrid((unsigned)(((n_ops ? n_ops : 1) * (size_t)p->l + 2 * SWAVES - 1) / (2 * SWAVES)));
+        const dim3 cgrid((unsigned)(((n_ops ? n_ops : 1) * (size_t)p->l + SWAVES - 1) / SWAVES));
         if (p->gamma1 == (1 << 17)) hipLaunchKernelGGL((k_expand_mask_coop<17>), cgrid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev);
         else hipLaunchKernelGGL((k_expand_mask_coop<19>), cgrid, block, 0, s, rho_pp, rho_stride, kappa, kappa_by_slot, op_idx, y, p->l, n_ops, n_dev);
         MLDSA_HIP_CHECK(hipGetLastError());
@@ -544,12 +541,78 @@ int launch_expand_mask(mldsa_ctx* ctx, int set, const uint8_t* rho_pp, size_t rh
     return MLDSA_OK;
 }
 
-int launch_sample_in_ball(mldsa_ctx*, int set, const uint8_t* c_tilde, size_t ct_stride, int32_t* c, size_t n_ops, hipStream_t s,
+// SampleInBall (one byte per coefficient) for SMALL calls: one op per wave -- the sponge on the interleaved cooperative form (keccak_coop2.h),
+// the Fisher-Yates walk (hashing.rs:68-83) by lane 0 on the wave's LDS rows.  The bytes k_sample_in_ball<.., true> writes.
+template <int CT>
+__global__ __launch_bounds__(64 * SWAVES) void k_sample_in_ball_coop(const uint8_t* __restrict__ c_tilde, size_t ct_stride, int tau, int32_t* __restrict__ c_out,
+                                                                     size_t n_ops, const uint32_t* __restrict__ n_dev) {
+    __shared__ uint32_t rows[SWAVES * (64 + 36)];
+    const int lane = threadIdx.x & 63;
+    const Coop2Lane c = coop2_lane(lane);
+    uint32_t* c_row = rows + (threadIdx.x >> 6) * (64 + 36);
+    uint32_t* bw = c_row + 64;
+    if (n_dev) n_ops = *n_dev;
+    const size_t wave0 = (size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * SWAVES;
+    for (size_t op = wave0; op < n_ops; op += stride) {  // wave-uniform
+        const uint8_t* ct = c_tilde + op * ct_stride;
+        uint32_t lo = 0, hi = 0;
+        if (c.active && c.word < CT / 8) {
+            lo = load_le32(ct + 8 * c.word);
+            hi = load_le32(ct + 8 * c.word + 4);
+        }
+        if (c.active && c.word == CT / 8) lo ^= 0x1Fu;
+        if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
+        uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
+        c_row[lane] = 0;
+        int pos = 8, i = 256 - tau;
+        uint64_t h64 = 0;
+        bool first = true;
+        for (;;) {  // wave-uniform: i and pos are lane 0's, handed round after its walk
+            keccak_f1600_coop2(v, c);
+            coop2_to_lohi(v, lane, lo, hi);
+            if (c.active && c.word < SHAKE256_RATE / 8) bw[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
+            wave_lds_sync();
+            if (first) h64 = ((uint64_t)bw[1] << 32) | bw[0];  // hashing.rs:55-56
+            first = false;
+            if (lane == 0) {
+                int8_t* cc = reinterpret_cast<int8_t*>(c_row);
+                const uint8_t* bb = reinterpret_cast<const uint8_t*>(bw);
+                while (i < 256 && pos < SHAKE256_RATE) {
+                    const int j = bb[pos++];
+                    if (j <= i) {
+                        cc[i] = cc[j];
+                        const int index = i + tau - 256;
+                        cc[j] = (int8_t)(1 - 2 * (int)((h64 >> index) & 1u));
+                        i++;
+                    }
+                }
+            }
+            i = __builtin_amdgcn_readfirstlane(i);
+            wave_lds_sync();
+            if (i >= 256) break;
+            pos = 0;
+        }
+        const uint8_t* cb = reinterpret_cast<const uint8_t*>(c_row);
+        reinterpret_cast<uint32_t*>(c_out)[op * 64 + lane] =
+            (uint32_t)cb[lane] | ((uint32_t)cb[64 + lane] << 8) | ((uint32_t)cb[128 + lane] << 16) | ((uint32_t)cb[192 + lane] << 24);
+        wave_lds_sync();
+    }
+}
+
+int launch_sample_in_ball(mldsa_ctx* ctx, int set, const uint8_t* c_tilde, size_t ct_stride, int32_t* c, size_t n_ops, hipStream_t s,
                           const uint32_t* n_dev, bool c8) {
     if (n_ops == 0 && !n_dev) return MLDSA_OK;
     const mldsa_params* p = params_of(set);
     if (!p) return set_error(MLDSA_ERR_PARAM, "sample_in_ball: unknown parameter set");
     dim3 grid((unsigned)(((n_ops ? n_ops : 1) + 63) / 64)), block(64);
+    if (c8 && ctx && ctx->opt_coop_hash && (n_ops ? n_ops : 1) <= ctx->coop_sib_max) {  // a small call / round: one op per wave
+        const dim3 cgrid((unsigned)(((n_ops ? n_ops : 1) + SWAVES - 1) / SWAVES)), cblock(64 * SWAVES);
+        if (p->ctilde_len == 32) hipLaunchKernelGGL((k_sample_in_ball_coop<32>), cgrid, cblock, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+        else if (p->ctilde_len == 48) hipLaunchKernelGGL((k_sample_in_ball_coop<48>), cgrid, cblock, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+        else hipLaunchKernelGGL((k_sample_in_ball_coop<64>), cgrid, cblock, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
+        MLDSA_HIP_CHECK(hipGetLastError());
+        return MLDSA_OK;
+    }
     if (c8) {
         if (p->ctilde_len == 32) hipLaunchKernelGGL((k_sample_in_ball<32, true>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
         else if (p->ctilde_len == 48) hipLaunchKernelGGL((k_sample_in_ball<48, true>), grid, block, 0, s, c_tilde, ct_stride, p->tau, c, n_ops, n_dev);
