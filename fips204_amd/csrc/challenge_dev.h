@@ -2,6 +2,7 @@
 // kernel (k_sign_challenge): the fixed-shape two-part SHAKE256 absorb of one op per lane with cooperative loads, and the
 // Fisher-Yates body of SampleInBall on lane-private LDS rows.
 #pragma once
+#include "keccak_coop2.h"
 #include "sampler_dev.h"
 
 namespace mldsa {
@@ -107,6 +108,61 @@ __device__ __forceinline__ void sample_in_ball_lane(KeccakState& st, int tau, bo
             pos = 0;
         }
     }
+}
+
+// SampleInBall (hashing.rs:43-100) for ONE op by a whole wave (small calls): the sponge on the interleaved cooperative form
+// (keccak_coop2.h), the Fisher-Yates walk with everything wave-uniform and in registers -- the squeezed block as one dword per lane
+// (fetched with v_readlane at the walk's byte position), c as the wave's output dword itself (byte k of lane l = c[64 k + l]: what
+// k_sample_in_ball<.., C8> writes), read with v_readlane and updated by the one lane that owns the coefficient.  A step is ~15 scalar /
+// vector instructions instead of four dependent LDS accesses (the walk of ~55 steps: 1.7 instead of 6 us).
+// `ct`: the op's c_tilde (CT bytes); bw: 34 dwords of the wave's LDS (the block on its way from the state's lanes to "dword d in lane d").
+template <int CT>
+__device__ __forceinline__ uint32_t sample_in_ball_coop2(const uint8_t* __restrict__ ct, int tau, uint32_t* bw, int lane, const Coop2Lane& c) {
+    uint32_t lo = 0, hi = 0;
+    if (c.active && c.word < CT / 8) {
+        lo = load_le32(ct + 8 * c.word);
+        hi = load_le32(ct + 8 * c.word + 4);
+    }
+    if (c.active && c.word == CT / 8) lo ^= 0x1Fu;
+    if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
+    uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
+    uint32_t creg = 0;
+    int pos = 8, i = 256 - tau;
+    uint32_t h_lo = 0, h_hi = 0;
+    bool first = true;
+    auto set_byte = [&](int idx, uint32_t val) {  // c[idx] = val (idx wave-uniform)
+        const int sh = 8 * (idx >> 6);
+        if (lane == (idx & 63)) creg = (creg & ~(0xFFu << sh)) | (val << sh);
+    };
+    for (;;) {  // wave-uniform
+        keccak_f1600_coop2(v, c);
+        coop2_to_lohi(v, lane, lo, hi);
+        if (c.active && c.word < SHAKE256_RATE / 8) bw[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
+        wave_lds_sync();
+        const uint32_t blk = lane < SHAKE256_RATE / 4 ? bw[lane] : 0u;  // dword d of the block in lane d
+        wave_lds_sync();
+        if (first) {  // hashing.rs:55-56: the first eight bytes are the sign bits
+            h_lo = (uint32_t)__builtin_amdgcn_readlane((int)blk, 0);
+            h_hi = (uint32_t)__builtin_amdgcn_readlane((int)blk, 1);
+        }
+        first = false;
+        while (i < 256 && pos < SHAKE256_RATE) {
+            const uint32_t dw = (uint32_t)__builtin_amdgcn_readlane((int)blk, __builtin_amdgcn_readfirstlane(pos >> 2));
+            const int j = (int)((dw >> (8 * (pos & 3))) & 0xFFu);
+            pos++;
+            if (j <= i) {  // hashing.rs:68-83
+                const uint32_t cj = ((uint32_t)__builtin_amdgcn_readlane((int)creg, __builtin_amdgcn_readfirstlane(j & 63)) >> (8 * (j >> 6))) & 0xFFu;
+                set_byte(i, cj);
+                const int index = i + tau - 256;
+                const uint32_t bit = ((index < 32 ? h_lo >> index : h_hi >> (index - 32)) & 1u);
+                set_byte(j, bit ? 0xFFu : 0x01u);
+                i++;
+            }
+        }
+        if (i >= 256) break;
+        pos = 0;  // block used up (rare): squeeze the next one
+    }
+    return creg;
 }
 
 }  // namespace mldsa

@@ -541,62 +541,19 @@ int launch_expand_mask(mldsa_ctx* ctx, int set, const uint8_t* rho_pp, size_t rh
     return MLDSA_OK;
 }
 
-// SampleInBall (one byte per coefficient) for SMALL calls: one op per wave -- the sponge on the interleaved cooperative form (keccak_coop2.h),
-// the Fisher-Yates walk (hashing.rs:68-83) by lane 0 on the wave's LDS rows.  The bytes k_sample_in_ball<.., true> writes.
+// SampleInBall (one byte per coefficient) for SMALL calls: one op per wave (challenge_dev.h sample_in_ball_coop2: cooperative sponge, the
+// Fisher-Yates walk of hashing.rs:68-83 wave-uniform in registers).  The bytes k_sample_in_ball<.., true> writes.
 template <int CT>
 __global__ __launch_bounds__(64 * SWAVES) void k_sample_in_ball_coop(const uint8_t* __restrict__ c_tilde, size_t ct_stride, int tau, int32_t* __restrict__ c_out,
                                                                      size_t n_ops, const uint32_t* __restrict__ n_dev) {
-    __shared__ uint32_t rows[SWAVES * (64 + 36)];
+    __shared__ uint32_t rows[SWAVES * 36];
     const int lane = threadIdx.x & 63;
     const Coop2Lane c = coop2_lane(lane);
-    uint32_t* c_row = rows + (threadIdx.x >> 6) * (64 + 36);
-    uint32_t* bw = c_row + 64;
+    uint32_t* bw = rows + (threadIdx.x >> 6) * 36;
     if (n_dev) n_ops = *n_dev;
     const size_t wave0 = (size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * SWAVES;
-    for (size_t op = wave0; op < n_ops; op += stride) {  // wave-uniform
-        const uint8_t* ct = c_tilde + op * ct_stride;
-        uint32_t lo = 0, hi = 0;
-        if (c.active && c.word < CT / 8) {
-            lo = load_le32(ct + 8 * c.word);
-            hi = load_le32(ct + 8 * c.word + 4);
-        }
-        if (c.active && c.word == CT / 8) lo ^= 0x1Fu;
-        if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
-        uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
-        c_row[lane] = 0;
-        int pos = 8, i = 256 - tau;
-        uint64_t h64 = 0;
-        bool first = true;
-        for (;;) {  // wave-uniform: i and pos are lane 0's, handed round after its walk
-            keccak_f1600_coop2(v, c);
-            coop2_to_lohi(v, lane, lo, hi);
-            if (c.active && c.word < SHAKE256_RATE / 8) bw[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
-            wave_lds_sync();
-            if (first) h64 = ((uint64_t)bw[1] << 32) | bw[0];  // hashing.rs:55-56
-            first = false;
-            if (lane == 0) {
-                int8_t* cc = reinterpret_cast<int8_t*>(c_row);
-                const uint8_t* bb = reinterpret_cast<const uint8_t*>(bw);
-                while (i < 256 && pos < SHAKE256_RATE) {
-                    const int j = bb[pos++];
-                    if (j <= i) {
-                        cc[i] = cc[j];
-                        const int index = i + tau - 256;
-                        cc[j] = (int8_t)(1 - 2 * (int)((h64 >> index) & 1u));
-                        i++;
-                    }
-                }
-            }
-            i = __builtin_amdgcn_readfirstlane(i);
-            wave_lds_sync();
-            if (i >= 256) break;
-            pos = 0;
-        }
-        const uint8_t* cb = reinterpret_cast<const uint8_t*>(c_row);
-        reinterpret_cast<uint32_t*>(c_out)[op * 64 + lane] =
-            (uint32_t)cb[lane] | ((uint32_t)cb[64 + lane] << 8) | ((uint32_t)cb[128 + lane] << 16) | ((uint32_t)cb[192 + lane] << 24);
-        wave_lds_sync();
-    }
+    for (size_t op = wave0; op < n_ops; op += stride)  // wave-uniform
+        reinterpret_cast<uint32_t*>(c_out)[op * 64 + lane] = sample_in_ball_coop2<CT>(c_tilde + op * ct_stride, tau, bw, lane, c);
 }
 
 int launch_sample_in_ball(mldsa_ctx* ctx, int set, const uint8_t* c_tilde, size_t ct_stride, int32_t* c, size_t n_ops, hipStream_t s,

@@ -138,53 +138,6 @@ __device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t o
     if (lane == 0) A.flag_ws[op] = flag;
 }
 
-// ---- role: c = SampleInBall(c~) (hashing.rs:43-100) by one wave: the sponge cooperatively, the Fisher-Yates walk by lane 0 on the
-// wave's LDS rows (c_row: 256 int8, bw: the squeezed block).  Output: the bytes k_sample_in_ball<.., C8> writes.
-template <int CT>
-__device__ __forceinline__ void small_role_sib(const SmallVerifyArgs& A, size_t op, size_t sig_len, int tau, uint32_t* c_row, uint32_t* bw, int lane,
-                                               const Coop2Lane& c) {
-    const uint8_t* ct = A.sigs + op * sig_len;  // c~ opens the signature (encodings.rs:251)
-    uint32_t lo = 0, hi = 0;
-    if (c.active && c.word < CT / 8) {
-        lo = load_le32(ct + 8 * c.word);
-        hi = load_le32(ct + 8 * c.word + 4);
-    }
-    if (c.active && c.word == CT / 8) lo ^= 0x1Fu;
-    if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
-    uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
-    c_row[lane] = 0;
-    int pos = 8, i = 256 - tau;
-    uint64_t h64 = 0;
-    bool first = true;
-    for (;;) {  // wave-uniform: i and pos are lane 0's, handed round after its walk
-        keccak_f1600_coop2(v, c);
-        coop2_to_lohi(v, lane, lo, hi);
-        if (c.active && c.word < SHAKE256_RATE / 8) bw[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
-        wave_lds_sync();
-        if (first) h64 = ((uint64_t)bw[1] << 32) | bw[0];  // hashing.rs:55-56
-        first = false;
-        if (lane == 0) {
-            int8_t* cc = reinterpret_cast<int8_t*>(c_row);
-            const uint8_t* bb = reinterpret_cast<const uint8_t*>(bw);
-            while (i < 256 && pos < SHAKE256_RATE) {
-                const int j = bb[pos++];
-                if (j <= i) {  // hashing.rs:68-83
-                    cc[i] = cc[j];
-                    const int index = i + tau - 256;
-                    cc[j] = (int8_t)(1 - 2 * (int)((h64 >> index) & 1u));
-                    i++;
-                }
-            }
-        }
-        i = __builtin_amdgcn_readfirstlane(i);
-        wave_lds_sync();
-        if (i >= 256) break;
-        pos = 0;  // block used up (rare): squeeze the next one
-    }
-    const uint8_t* cb = reinterpret_cast<const uint8_t*>(c_row);
-    A.c_ws[op * 64 + lane] = (uint32_t)cb[lane] | ((uint32_t)cb[64 + lane] << 8) | ((uint32_t)cb[128 + lane] << 16) | ((uint32_t)cb[192 + lane] << 24);
-}
-
 template <int K, int L, int GB, bool G2HI, int CT, bool CACHED>
 __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A0, int tau, int omega, int32_t zbound, size_t sig_len) {
     constexpr int CB = GB + 1;
@@ -214,8 +167,9 @@ __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A0, i
     } else if (role == NA) {
         small_role_mu(A0, op, lane, c);
     } else if (role == NA + 1) {
-        // its rows (256 int8 of c, the squeezed block) lie in zh, which nothing else uses before the tail
-        small_role_sib<CT>(A0, op, sig_len, tau, reinterpret_cast<uint32_t*>(&zh[0][0]), reinterpret_cast<uint32_t*>(&zh[1][0]), lane, c);
+        // c = SampleInBall(c~) (ml_dsa.rs:400; challenge_dev.h).  c~ opens the signature (encodings.rs:251); the block's LDS row lies in zh,
+        // which nothing else uses before the tail
+        A0.c_ws[op * 64 + lane] = sample_in_ball_coop2<CT>(A0.sigs + op * sig_len, tau, reinterpret_cast<uint32_t*>(&zh[0][0]), lane, c);
     }
 
     // ---------------------------------------------------------------- hand-over
