@@ -1,0 +1,61 @@
+"""profiles/r05_MANIFEST.json ties every r05 profile to the code it was measured on (VERDICT r4 'missing' 4: round 4's rocprof files
+predated the kernels the round shipped).  tools/collect_profiles.sh records, on the GPU box, the commit it was given, the sha256 of
+libmldsa_hip.so and a content hash of the library's sources (tools/csrc_hash.py: the box has no .git); tools/finish_profiles.py writes
+the manifest.  Here: the manifest's source hash equals the hash of the sources in this tree -- a change under fips204_amd/csrc or to
+include/mldsa_hip.h after the collection turns this test red until the profiles are re-collected -- every listed file exists, and the
+files bench.py reads for roofline.traffic are among them."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import csrc_hash  # noqa: E402
+
+MANIFEST = os.path.join(ROOT, "profiles", "r05_MANIFEST.json")
+
+
+def test_manifest_matches_the_sources_in_this_tree():
+    man = json.load(open(MANIFEST))
+    assert man["csrc_hash"] == csrc_hash.csrc_hash(), ("fips204_amd/csrc or include/mldsa_hip.h changed after the r05 profiles were collected: "
+                                                        "re-run tools/collect_profiles.sh r05 on the GPU box and tools/finish_profiles.py r05")
+    assert len(man["lib_sha256"]) == 64 and len(man["head"]) >= 7
+    assert len(man["files"]) >= 40
+    for name, meta in man["files"].items():
+        p = os.path.join(ROOT, "profiles", name)
+        assert os.path.exists(p) and os.path.getsize(p) > 0, name
+        assert meta["command"], name
+
+
+def test_manifest_commit_has_the_same_csrc_tree():
+    """when git is here: the commit named in the manifest carries the same fips204_amd/csrc tree as HEAD"""
+    man = json.load(open(MANIFEST))
+    def tree(rev):
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", f"{rev}:fips204_amd/csrc"], capture_output=True, text=True)
+        return out.stdout.strip() if out.returncode == 0 else None
+    head_tree, man_tree = tree("HEAD"), tree(man["head"])
+    if head_tree is None or man_tree is None:
+        import pytest
+        pytest.skip("no git history here (or the manifest's commit is not in it)")
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "fips204_amd/csrc", "include/mldsa_hip.h"], capture_output=True, text=True).stdout.strip()
+    if not dirty:
+        assert man_tree == head_tree
+
+
+def test_the_kernels_design_names_have_rows():
+    """every kernel family of DESIGN.md section 3 appears in a kernel-stats profile taken on this library, the cooperative small-call kernels included"""
+    man = json.load(open(MANIFEST))
+    stats = [n for n in man["files"] if "kernel_stats" in n and n.endswith(".csv")]
+    text = "".join(open(os.path.join(ROOT, "profiles", n)).read() for n in stats)
+    for k in ("k_expand_a<", "k_verify_main<", "k_shake256_2<", "k_mu", "k_sample_in_ball<", "k_verify_arith<", "k_expand_mask<", "k_sign_tail<", "k_resolve<",
+              "k_verify_small<", "k_expand_a_coop<", "k_expand_mask_coop<", "k_expand_s_coop<", "k_shake256_2_coop<", "k_mu_coop", "k_sample_in_ball_coop<"):
+        assert k in text, k
+
+
+def test_bench_reads_only_this_rounds_pmc_files():
+    from benchlib import pmc
+    man = json.load(open(MANIFEST))
+    for w in ("verify65", "verify_arith44", "sign65"):
+        t, by, fn = pmc.pmc_traffic(w)
+        assert fn == f"r05_pmc_{w}.json" and fn in man["files"] and t and t > 0
