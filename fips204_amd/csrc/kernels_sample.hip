@@ -60,17 +60,6 @@ __global__ __launch_bounds__(64 * SWAVES) __attribute__((amdgpu_waves_per_eu(4, 
 // stream (op, r): SHAKE256(rho' || r || 0), r < L -> s1[r], r >= L -> s2[r - L]; each byte
 // gives two half-byte candidates (coeff_from_half_byte, conversion.rs:80-111).
 // Output polys [op][L + K] (s1 then s2) with coefficients in [-eta, eta].
-template <int ETA>
-__device__ __forceinline__ bool half_byte(uint32_t b, int32_t& out) {
-    if constexpr (ETA == 2) {
-        out = 2 - (int32_t)(b - ((b * 13108u) >> 16) * 5u);  // b mod 5 for b < 16 (conversion.rs:91-93)
-        return b < 15;
-    } else {
-        out = 4 - (int32_t)b;
-        return b < 9;
-    }
-}
-
 // S8 (key generation's own s1 / s2): one BYTE per coefficient, 256 bytes per polynomial in coefficient order -- the staging
 // row holds bytes too (132 of them), so a 136-byte block is flushed in three groups of up to 96 candidates instead of twelve of 24,
 // in 16-byte pieces; the seam-level mldsa_expand_s keeps int32[256].
@@ -407,49 +396,15 @@ int launch_expand_a(mldsa_ctx* ctx, int set, const uint8_t* rho, size_t rho_stri
 template <int ETA>
 __global__ __launch_bounds__(64 * SWAVES) void k_expand_s_coop(const uint8_t* __restrict__ rho_prime, size_t rho_stride, int32_t* __restrict__ s12,
                                                                int polys_per_op, size_t n_ops) {
-    constexpr int BLK_DWORDS = 36;
-    __shared__ uint32_t blk_lds[SWAVES * BLK_DWORDS];
+    __shared__ uint32_t blk_lds[SWAVES * ES_COOP_BLK_DWORDS];
     const int lane = threadIdx.x & 63;
     const Coop2Lane c = coop2_lane(lane);
-    uint32_t* blk = blk_lds + (threadIdx.x >> 6) * BLK_DWORDS;
-    uint8_t* out8 = reinterpret_cast<uint8_t*>(s12);
+    uint32_t* blk = blk_lds + (threadIdx.x >> 6) * ES_COOP_BLK_DWORDS;
     const size_t n_streams = n_ops * (size_t)polys_per_op;
     const size_t wave0 = (size_t)blockIdx.x * SWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * SWAVES;
     for (size_t g = wave0; g < n_streams; g += stride) {  // wave-uniform
         const size_t op = g / polys_per_op;
-        const uint32_t r = (uint32_t)(g % polys_per_op);
-        uint32_t lo = 0, hi = 0;
-        if (c.active && c.word < 8) {
-            const uint8_t* src = rho_prime + op * rho_stride + 8 * c.word;
-            lo = load_le32(src);
-            hi = load_le32(src + 4);
-        }
-        if (c.active && c.word == 8) lo = r | (0x1Fu << 16);  // hashing.rs:260/266: rho' || r || 0  (then pad)
-        if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi = 0x80000000u;
-        uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
-        uint8_t* row = out8 + g * (size_t)N;
-        int count = 0;
-        while (count < N) {
-            keccak_f1600_coop2(v, c);
-            coop2_to_lohi(v, lane, lo, hi);
-            if (c.active && c.word < SHAKE256_RATE / 8) blk[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
-            wave_lds_sync();
-#pragma unroll
-            for (int pass = 0; pass < 5; pass++) {
-                const int cand = 64 * pass + lane;  // half-byte index: byte cand >> 1, low nibble first
-                bool acc = false;
-                int32_t val = 0;
-                if (cand < 2 * SHAKE256_RATE) {
-                    const uint32_t b = (blk[cand >> 3] >> (4 * (cand & 7))) & 15u;
-                    acc = half_byte<ETA>(b, val);
-                }
-                const unsigned long long all = __ballot(acc);
-                const int idx = count + __popcll(all & ((1ull << lane) - 1ull));
-                if (acc && idx < N) row[idx] = (uint8_t)val;
-                count += __popcll(all);
-            }
-            wave_lds_sync();
-        }
+        expand_s_coop2_poly<ETA>(rho_prime + op * rho_stride, (uint32_t)(g % polys_per_op), reinterpret_cast<uint8_t*>(s12) + g * (size_t)N, blk, lane, c);
     }
 }
 

@@ -345,4 +345,220 @@ int launch_verify_small(mldsa_ctx* ctx, const mldsa_params* p, int mode, const u
     return MLDSA_OK;
 }
 
+// ====================================================================================================================
+// key_gen_internal (src/ml_dsa.rs:57-134) + into_bytes for SMALL calls as ONE launch, same structure as k_verify_small.
+//
+// The batch pipeline is six launches (seed hash 6 us, ExpandA 15, ExpandS 7, the matrix-vector kernel 14, the seeds' copy 6, tr = H(pk)
+// 32 us for one ML-DSA-65 key: profiles/r05_small_call_timeline_keygen_n1.json).  Here every key owns a cluster of workgroups:
+//   phase 1   one wave per polynomial of A_hat (K * L) and of s1 / s2 (L + K).  Each derives (rho, rho', K) = H(xi | K | L, 128) itself --
+//             one permutation costs less than handing the seed over -- and expands its polynomial (expand_a_coop2_core,
+//             expand_s_coop2_poly) into the call's workspace rows; the first wave also stores the 128 seed bytes for the tail.
+//   tail      the LAST workgroup to arrive (per-key counter, release / acquire at agent scope): NTT(s1_j) by wave j mod 4 with s1's
+//             section of sk packed on the way; rows t_i = invNTT(A_i o s1_hat) + s2_i by wave i mod 4 with s2's section, Power2Round,
+//             t1 -> pk (kept in LDS as well), t0 -> sk; rho, K; then tr = H(pk) by one wave straight from LDS -> sk.
+// Same workspace rows as keygen_batch (so the caller's clearing of rho' / K / s1 / s2 is unchanged), same bytes out.
+struct SmallKeygenArgs {
+    const uint8_t* xi;   // [n][32]
+    uint8_t *pk, *sk;    // wire formats out
+    uint32_t n_keys;
+    int32_t* a_ws;       // [n][K * L] polynomials, 24-bit form
+    uint8_t* hbuf;       // [n][128]: rho | rho' | K
+    uint8_t* s_ws;       // [n][L + K][256]: one byte per coefficient
+    uint32_t* ctr;
+    const Twiddle *fwd_tab, *inv_tab;
+    int wipe;            // the tail clears the key's secret workspace rows (rho' / K, s1, s2) itself: no clearing launches behind a small call
+};
+
+template <int K, int L, int ETA>
+__global__ __launch_bounds__(64 * SMW) void k_keygen_small(SmallKeygenArgs A0) {
+    constexpr int EB = ETA == 2 ? 3 : 4;
+    constexpr int PK_LEN = 32 + 320 * K, SK_LEN = 128 + 32 * EB * (K + L) + 416 * K;
+    constexpr size_t T0_OFF = 128 + 32 * EB * (K + L);
+    constexpr int NA = K * L, ROLES = K * L + K + L, NB = (ROLES + SMW - 1) / SMW;
+    __shared__ uint32_t blk_lds[SMW * EA_COOP_BLK_DWORDS];
+    __shared__ uint32_t seed_lds[SMW][32];
+    __shared__ __attribute__((aligned(16))) int4 zh[L][64];
+    __shared__ __attribute__((aligned(16))) int32_t xp[SMW][N];
+    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t pk_lds[PK_LEN / 4];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t member = q % NB;
+    const size_t op = (size_t)(q / NB) * 8 + xcd;
+    if (op >= A0.n_keys) return;  // (whole workgroup)
+    const Coop2Lane c = coop2_lane(lane);
+    const int role = (int)member * SMW + wave;
+
+    // ---------------------------------------------------------------- phase 1
+    if (role < ROLES) {
+        // (rho, rho', K) <- H(xi || K || L, 128)                              ml_dsa.rs:68-74
+        uint32_t lo = 0, hi = 0;
+        if (c.active && c.word < 4) {
+            lo = load_le32(A0.xi + op * 32 + 8 * c.word);
+            hi = load_le32(A0.xi + op * 32 + 8 * c.word + 4);
+        }
+        if (c.active && c.word == 4) lo = (uint32_t)K | ((uint32_t)L << 8) | (0x1Fu << 16);
+        if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi = 0x80000000u;
+        uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
+        keccak_f1600_coop2(v, c);
+        coop2_to_lohi(v, lane, lo, hi);
+        uint32_t* seed = seed_lds[wave];
+        if (c.active && c.word < 16) seed[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
+        wave_lds_sync();
+        if (role == 0 && lane < 32) reinterpret_cast<uint32_t*>(A0.hbuf + op * 128)[lane] = seed[lane];
+        const uint8_t* sb = reinterpret_cast<const uint8_t*>(seed);
+        if (role < NA) {  // A_hat[r][s] <- RejNTTPoly(rho || s || r)                 ml_dsa.rs:85
+            uint8_t* row = reinterpret_cast<uint8_t*>(A0.a_ws) + (op * NA + (size_t)role) * (size_t)(PACKED_POLY_DWORDS * 4);
+            expand_a_coop2_core(sb, role / L, role % L, row, blk_lds + wave * EA_COOP_BLK_DWORDS, lane, c);
+        } else {          // s1 / s2 <- ExpandS(rho')                                  ml_dsa.rs:79
+            const uint32_t r = (uint32_t)(role - NA);
+            expand_s_coop2_poly<ETA>(sb + 32, r, A0.s_ws + (op * (size_t)(K + L) + r) * N, blk_lds + wave * EA_COOP_BLK_DWORDS, lane, c);
+        }
+    }
+
+    // ---------------------------------------------------------------- hand-over
+    __syncthreads();
+    if (NB > 1) {
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const uint32_t seen = __hip_atomic_fetch_add(&A0.ctr[op], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = seen == (uint32_t)(NB - 1);
+            if (last) __hip_atomic_store(&A0.ctr[op], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+
+    // ---------------------------------------------------------------- tail
+    SmallKeygenArgs A;
+    reload_first_kernarg(A);
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * SMW) tw_lds[i] = A.fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * SMW) tw_lds[FWD_TW * 64 + i] = A.inv_tab[i];
+    uint8_t* pkb = reinterpret_cast<uint8_t*>(pk_lds);
+    uint8_t* sk = A.sk + op * (size_t)SK_LEN;
+    if (threadIdx.x < 32) {  // rho -> pk, sk; K -> sk                         encodings.rs:29, 110-116
+        const uint8_t r = A.hbuf[op * 128 + threadIdx.x];
+        pkb[threadIdx.x] = r;
+        sk[threadIdx.x] = r;
+        sk[32 + threadIdx.x] = A.hbuf[op * 128 + 96 + threadIdx.x];
+    }
+    __syncthreads();
+    const LdsTw ftw{tw_lds, lane};
+    const LdsTw itw{tw_lds + FWD_TW * 64, lane};
+    const uint32_t* srows = reinterpret_cast<const uint32_t*>(A.s_ws) + op * (size_t)(K + L) * (N / 4);  // dword d of a row = coefficients 4 d .. 4 d + 3
+    auto eta_fields = [&](uint32_t d, uint32_t (&f)[4]) {
+        f[0] = (uint32_t)(ETA - (int8_t)(d & 0xFF)); f[1] = (uint32_t)(ETA - (int8_t)((d >> 8) & 0xFF));
+        f[2] = (uint32_t)(ETA - (int8_t)((d >> 16) & 0xFF)); f[3] = (uint32_t)(ETA - (int8_t)(d >> 24));
+    };
+#pragma unroll 1
+    for (int j = wave; j < L; j += SMW) {  // s1_j: its section of sk (encodings.rs:118-134) and its transform
+        const uint32_t* src = srows + (size_t)j * (N / 4);
+        uint32_t f[4];
+        eta_fields(src[lane], f);
+        store_fields(sk + 128 + (size_t)j * (32 * EB), f, EB, lane);
+        int32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = (int32_t)(int8_t)(src[16 * k + (lane >> 2)] >> (8 * (lane & 3)));  // coefficient 64 k + lane
+        ntt_fwd_wave(r, ftw, lane);
+        zh[j][lane] = make_int4(r[0], r[1], r[2], r[3]);
+    }
+    __syncthreads();
+    const Packed3* arow = reinterpret_cast<const Packed3*>(reinterpret_cast<const uint32_t*>(A.a_ws) + (op * NA) * (size_t)PACKED_POLY_DWORDS);
+#pragma unroll 1
+    for (int i = wave; i < K; i += SMW) {  // t_i = invNTT(A_i o s1_hat) + s2_i, Power2Round, t1 -> pk, t0 -> sk      ml_dsa.rs:86-92
+        int64_t acc64[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const int4 zv = zh[j][lane];
+            const int4 a4 = unpack24(arow[(unsigned)((i * L + j) * 64) + (unsigned)lane]);
+            acc64[0] += (int64_t)a4.x * zv.x;
+            acc64[1] += (int64_t)a4.y * zv.y;
+            acc64[2] += (int64_t)a4.z * zv.z;
+            acc64[3] += (int64_t)a4.w * zv.w;
+        }
+        int32_t acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = mont_reduce64(acc64[k]);
+        ntt_inv_wave(acc, itw, lane, F_MONT2);
+        const uint32_t* s2row = srows + (size_t)(L + i) * (N / 4);
+        {
+            uint32_t f[4];
+            eta_fields(s2row[lane], f);
+            store_fields(sk + 128 + (size_t)(L + i) * (32 * EB), f, EB, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int32_t s2v = (int32_t)(int8_t)(s2row[16 * k + (lane >> 2)] >> (8 * (lane & 3)));
+            xp[wave][64 * k + lane] = freeze(acc[k] + s2v);
+        }
+        wave_lds_sync();
+        const int4 t4 = reinterpret_cast<const int4*>(&xp[wave][0])[lane];  // four consecutive coefficients per lane
+        wave_lds_sync();
+        const int32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+        uint32_t f1[4], f0[4];
+#pragma unroll
+        for (int cidx = 0; cidx < 4; cidx++) {
+            const int32_t r1 = (tt[cidx] + (1 << 12) - 1) >> 13;  // power2round, high_low.rs:26-31
+            const int32_t r0 = tt[cidx] - (r1 << 13);
+            f1[cidx] = (uint32_t)r1;
+            f0[cidx] = (uint32_t)((1 << 12) - r0);                // BitPack(t0, 2^12 - 1, 2^12)
+        }
+        store_fields(pkb + 32 + (size_t)i * 320, f1, 10, lane);
+        store_fields(sk + T0_OFF + (size_t)i * 416, f0, 13, lane);
+    }
+    __syncthreads();
+    {   // pk out
+        uint32_t* pk_out = reinterpret_cast<uint32_t*>(A.pk + op * (size_t)PK_LEN);  // (PK_LEN is a multiple of 32: rows stay 4-byte aligned)
+        for (int i = threadIdx.x; i < PK_LEN / 4; i += 64 * SMW) pk_out[i] = pk_lds[i];
+    }
+    if (A.wipe) {  // rho' / K, s1, s2 of this key are not needed any more (types.rs:19: zeroize on drop); every other workgroup of the cluster has left
+        uint32_t* sw = reinterpret_cast<uint32_t*>(A.s_ws) + op * (size_t)(K + L) * (N / 4);
+        for (int i = threadIdx.x; i < (K + L) * (N / 4); i += 64 * SMW) sw[i] = 0;
+        if (threadIdx.x < 32) reinterpret_cast<uint32_t*>(A.hbuf + op * 128)[threadIdx.x] = 0;
+    }
+    if (wave != 0) return;
+    {   // tr <- H(pk, 64)                                                       ml_dsa.rs:99-101
+        constexpr int BLOCKS = PK_LEN / SHAKE256_RATE + 1;
+        auto msg_dword = [&](int off) -> uint32_t {
+            if (off + 4 <= PK_LEN) return pk_lds[off >> 2];
+            uint32_t v = off == PK_LEN ? 0x1Fu : 0u;
+            if (off + 4 == BLOCKS * SHAKE256_RATE) v |= 0x80000000u;
+            return v;
+        };
+        uint32_t v = 0;
+        const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
+#pragma unroll 1
+        for (int blk = 0; blk < BLOCKS; blk++) {
+            if (absorbs) {
+                const int off = blk * SHAKE256_RATE + 8 * c.word;
+                v ^= coop2_from_lohi(msg_dword(off), msg_dword(off + 4), c);
+            }
+            keccak_f1600_coop2(v, c);
+        }
+        uint32_t lo, hi;
+        coop2_to_lohi(v, lane, lo, hi);
+        if (c.active && c.word < 8) *reinterpret_cast<uint32_t*>(sk + 64 + 8 * c.word + 4 * (lane >> 5)) = lane < 32 ? lo : hi;
+    }
+}
+
+int launch_keygen_small(mldsa_ctx* ctx, const mldsa_params* p, const uint8_t* xi, uint8_t* pk, uint8_t* sk, size_t n_keys, int32_t* a_ws, uint8_t* hbuf,
+                        int32_t* s_ws, uint32_t* ctr, hipStream_t s, bool wipe) {
+    if (n_keys == 0) return MLDSA_OK;
+    SmallKeygenArgs A;
+    A.xi = xi; A.pk = pk; A.sk = sk; A.n_keys = (uint32_t)n_keys; A.a_ws = a_ws; A.hbuf = hbuf; A.s_ws = reinterpret_cast<uint8_t*>(s_ws); A.ctr = ctr;
+    A.fwd_tab = ctx->d_fwd_tw; A.inv_tab = ctx->d_inv_tw;
+    A.wipe = wipe ? 1 : 0;
+    const int roles = p->k * p->l + p->k + p->l, nb = (roles + SMW - 1) / SMW;
+    const dim3 grid((unsigned)(((n_keys + 7) / 8) * 8 * (size_t)nb)), block(64 * SMW);
+    if (p->set == MLDSA_44) hipLaunchKernelGGL((k_keygen_small<4, 4, 2>), grid, block, 0, s, A);
+    else if (p->set == MLDSA_65) hipLaunchKernelGGL((k_keygen_small<6, 5, 4>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((k_keygen_small<8, 7, 2>), grid, block, 0, s, A);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
 }  // namespace mldsa

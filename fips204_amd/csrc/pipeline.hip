@@ -407,11 +407,28 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
         else TRY(wait_zeroise(ctx, s));
     }
     int rc = MLDSA_OK;
+    bool wiped_by_kernel = false;
     for (size_t o = 0; o < n_keys && rc == MLDSA_OK; o += chunk) {
         const size_t n = (n_keys - o) < chunk ? (n_keys - o) : chunk;
         uint8_t *pko = pk + o * pkl, *sko = sk + o * skl;
         rc = [&]() -> int {
             if (wait_head) { MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_head_ev, 0)); wait_head = false; }
+            // a SMALL call: one launch (kernels_small.hip k_keygen_small), the same workspace rows and the same bytes out
+            if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && n <= ctx->small_keygen_max && n <= SMALL_FUSED_MAX) {
+                if (wait_rest) {
+                    MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
+                    wait_rest = false;
+                    ctx->zero_pending = false;
+                }
+#ifdef MLDSA_TEST_NO_ZEROISE
+                const bool wipe_in_kernel = false;
+#else
+                const bool wipe_in_kernel = true;
+#endif
+                STAGE("keygen_small", launch_keygen_small(ctx, p, xi + o * 32, pko, sko, n, w.a_hat, w.hbuf, w.s1s2, ctx->d_small_ctr, s, wipe_in_kernel));
+                wiped_by_kernel = wipe_in_kernel && n == n_keys;  // (a small call is one pass: everything secret is already cleared)
+                return MLDSA_OK;
+            }
             // 1: (rho, rho', K) <- H(xi || k || l, 128)                          ml_dsa.rs:68-74
             STAGE("seed_hash", launch_shake256_2(ctx, 128, xi + o * 32, 32, 32, nullptr, nullptr, 0, 0, (uint32_t)p->k | ((uint32_t)p->l << 8), 2,
                                                  w.hbuf, 128, n, s));
@@ -435,6 +452,13 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
     // rho' / K, s1 and s2 are secret: cleared on every path out, like the reference's zeroize-on-drop (types.rs:19).  Off the
     // caller's critical path: on a helper stream, the seed block first; the next op-level call of the context waits for it on
     // the device (OpGuard / above), destroy and regrow wait for the whole device.
+    if (wiped_by_kernel && rc == MLDSA_OK) {
+        // k_keygen_small's tail cleared each key's rows itself: no clearing launches (and no events) behind a small call.  What the
+        // residue probe looks at is exactly those rows (the alignment padding between them never held anything of this call).
+        ctx->secret_spans.push_back({z_lo, n_keys * 128});
+        ctx->secret_spans.push_back({z_mid, n_keys * (size_t)(p->k + p->l) * N});
+        return rc;
+    }
     ctx->secret_spans.push_back({z_lo, z_hi - z_lo});
     if (capturing || rc != MLDSA_OK) {
         MLDSA_WIPE(launch_zero(ctx, w.hbuf, z_hi - z_lo, s));

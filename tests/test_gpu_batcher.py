@@ -72,7 +72,9 @@ def test_many_threads_single_op_calls(hp, pset, lanes):
             assert got == want, (j, kind)
             assert got == (kind == 0), (j, kind)
         st = b.stats()
-        assert st["requests"] == 48 + 240 + 240 and st["batches"] < st["requests"] // 2 and st["largest_batch"] > 8
+        # it coalesced.  (How much depends on how long a batch keeps the device busy while Python's threads queue up behind it: with the
+        # single-launch kernels of round 5 a batch is two to three times shorter than before and three lanes drain the queue faster still.)
+        assert st["requests"] == 48 + 240 + 240 and st["batches"] <= st["requests"] * 3 // 4 and st["largest_batch"] >= 4
         # six public and six private keys: each expanded ONCE per lane (try_from_bytes + ExpandA), found in the table from then on
         assert 12 <= st["keys_expanded"] <= 12 * lanes and st["key_hits"] > 0
     finally:

@@ -202,3 +202,49 @@ def test_option_bounds(env):
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 1025) != 0 and lib.mldsa_set_option(h, OPT_SMALL_FUSED, -1) != 0
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 0) == 0 and hp.get_option(OPT_SMALL_FUSED) == 0
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 256) == 0
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_keygen_single_launch_equals_pipeline_equals_oracle(env, pset):
+    """key_gen_internal + into_bytes (src/ml_dsa.rs:57-134, src/lib.rs:247-250) for small calls as one launch (k_keygen_small): the keys of
+    1 ... 64-key calls are byte-identical to the six-launch pipeline's and to the oracle's, call sizes around the cluster layout's
+    boundaries, many calls back to back (the per-key counters return to zero), and no secret stays behind in the workspace."""
+    hp, sets = env
+    m = sets[pset]
+    rng = np.random.default_rng(60 + pset)
+    for n in (1, 2, 7, 8, 9, 33, 64):
+        xi = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
+        hp.set_option(OPT_SMALL_FUSED, 256)
+        pk_f, sk_f = m.keygen_from_seed(xi)
+        torch.cuda.synchronize()
+        scanned, nonzero = hp.secret_residue()
+        assert scanned > 0 and nonzero == 0, (n, nonzero)
+        hp.set_option(OPT_SMALL_FUSED, 0)
+        pk_u, sk_u = m.keygen_from_seed(xi)
+        torch.cuda.synchronize()
+        hp.set_option(OPT_SMALL_FUSED, 256)
+        assert torch.equal(pk_f, pk_u) and torch.equal(sk_f, sk_u), n
+        pkb, skb = pk_f.cpu().numpy(), sk_f.cpu().numpy()
+        for i in sorted({0, n // 2, n - 1}):
+            pk_o, sk_o = orc.keygen_from_seed(pset, xi[i])
+            assert pkb[i].tobytes() == orc.pk_into_bytes(pset, pk_o) and skb[i].tobytes() == orc.sk_into_bytes(pset, sk_o), (n, i)
+    xi = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(5)]
+    first = m.keygen_from_seed(xi)
+    for _ in range(100):
+        again = m.keygen_from_seed(xi)
+        assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+
+
+def test_acvp_keygen_one_key_per_call(env, acvp_keygen):
+    """the reference's own call shape: every ACVP keyGen vector as a call of ONE key (nist_vectors/mod.rs)"""
+    from conftest import PSET
+    hp, sets = env
+    hp.set_option(OPT_SMALL_FUSED, 256)
+    n = 0
+    for g in acvp_keygen["testGroups"]:
+        m = sets[PSET[g["parameterSet"]]]
+        for t in g["tests"]:
+            pk, sk = m.keygen_from_seed([bytes.fromhex(t["seed"])])
+            assert pk[0].cpu().numpy().tobytes() == bytes.fromhex(t["pk"]) and sk[0].cpu().numpy().tobytes() == bytes.fromhex(t["sk"]), t["tcId"]
+            n += 1
+    assert n == 75
