@@ -62,6 +62,9 @@ struct SmallVerifyArgs {
     const Twiddle *fwd_tab, *inv_tab;
 };
 
+// s_waitcnt vmcnt(0): the wave's outstanding vector-memory operations (loads and stores) have completed -- for a store: written to L2
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // the kernel's first by-value argument, read again from the kernarg segment (see field.h late_arg: same ABI assumption, same self-test)
 template <class T>
 __device__ __forceinline__ void reload_first_kernarg(T& out) {
@@ -173,7 +176,13 @@ __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A0, i
     }
 
     // ---------------------------------------------------------------- hand-over
-    __syncthreads();  // (workgroup-scope release of every wave's stores)
+    // Every wave waits for ITS OWN global stores to be acknowledged by L2 before the barrier: the barrier's workgroup-scope release does
+    // not wait for outstanding global stores on this target (the ISA shows s_waitcnt lgkmcnt(0) only), and thread 0's agent-scope fence
+    // below waits only for its own wave's -- without this the counter could be bumped while another wave's A_hat bytes are still on
+    // their way to L2.  (A full agent-scope release per wave -- buffer_wbl2 four times per workgroup -- is correct too and was measured:
+    // 256-op calls 123 -> 202 us.  Thread 0's buffer_wbl2 after the barrier writes back the whole L2, the other waves' lines included.)
+    if (NB > 1) wait_own_stores();
+    __syncthreads();
     if (NB > 1) {
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -418,7 +427,8 @@ __global__ __launch_bounds__(64 * SMW) void k_keygen_small(SmallKeygenArgs A0) {
         }
     }
 
-    // ---------------------------------------------------------------- hand-over
+    // ---------------------------------------------------------------- hand-over (as in k_verify_small: every wave releases its own stores first)
+    if (NB > 1) wait_own_stores();
     __syncthreads();
     if (NB > 1) {
         if (threadIdx.x == 0) {
