@@ -40,10 +40,12 @@
  *    arguments -- repeats can be captured into a hipGraph the second time it is seen and replayed from then
  *    on: one graph launch instead of ~100 kernel launches for a signing call, 5 ... 25 times less host time
  *    per call (27 us instead of 150 us for a 4096-op ML-DSA-65 signing call).  The device is not faster for
- *    it -- the signing loop is driven from device memory and never waits for the host either way, and a graph
- *    launch adds 20 ... 50 us of latency -- so MLDSA_OPT_GRAPHS defaults to replaying signing calls of up to
- *    16384 ops, where the host time is a sizeable share of the call; verify and keygen are 6 ... 8 kernels and
- *    are launched directly unless the option says otherwise.  Results are identical either way.
+ *    it -- the signing loop is driven from device memory and never waits for the host either way -- and a graph
+ *    launch adds 40 ... 60 us of latency: measured (round 5, every size from 1 to 262144 ops) a replayed signing
+ *    call is 3 ... 20 % SLOWER than the same call launched directly, waited for or issued back to back
+ *    (profiles/r05_sweep_batch_sizes_extras.json), so MLDSA_OPT_GRAPHS defaults to 0: every call is launched directly.
+ *    A host that is short of CPU time, not of latency, sets 1 (signing calls of up to 16384 ops replay) or 2
+ *    (every call).  Results are identical either way.
  */
 #ifndef MLDSA_HIP_H
 #define MLDSA_HIP_H
@@ -111,7 +113,7 @@ int mldsa_reserve(mldsa_ctx *ctx, int set, int op, size_t n_ops);
 int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
 
 /* Tuning knobs (per context).  Defaults are the measured best; none changes any result. */
-#define MLDSA_OPT_GRAPHS 1          /* hipGraph replay of repeated call shapes: 0 never, 1 (default) signing calls of <= 16384 ops, 2 every call */
+#define MLDSA_OPT_GRAPHS 1          /* hipGraph replay of repeated call shapes: 0 (default) never, 1 signing calls of <= 16384 ops, 2 every call */
 #define MLDSA_OPT_SPEC_TARGET 2     /* sign: candidate slots per speculative round (1 ... 524288, default 65536)       */
 #define MLDSA_OPT_SPEC_MAX 3        /* sign: most speculative candidates per op and round (1 ... 64, default 32)        */
 #define MLDSA_OPT_VA_BLOCKS_PER_CU 4 /* mldsa_verify_arith: workgroups per CU of the persistent grid (default 16)      */

@@ -25,9 +25,11 @@ def test_config3_ml_dsa_65_sign_at_65536(sets):
     ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
     m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, n, key_idx=b["kidx"])
     assert bool(host(ok).all())
-    # default graph policy: a call of this size is launched directly (replay only pays for calls of <= 16384 ops);
+    # graph policy 1: a call of this size is launched directly (only calls of <= 16384 ops replay);
     # MLDSA_OPT_GRAPHS = 2 replays it too, with the same signatures
     hp = m.hp
+    old_graphs = hp.get_option(1)
+    hp.set_option(1, 1)
     s0 = hp.stats()
     for _ in range(3):
         m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st)
@@ -39,7 +41,7 @@ def test_config3_ml_dsa_65_sign_at_65536(sets):
             m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st)
         assert hp.stats()["graph_replays"] - s0["graph_replays"] == 1 and torch.equal(sig[:4096], first)
     finally:
-        hp.set_option(1, 1)
+        hp.set_option(1, old_graphs)
 
 
 def test_config4_slice_ml_dsa_87_verify_at_131072(sets):

@@ -131,6 +131,7 @@ def test_sign_host_writes_page_locked_signatures_directly(sets, n, nk, passes, l
     os.environ.update(env)
     try:
         h2 = HotPath(0)
+        h2.set_option(1, 1)  # MLDSA_OPT_GRAPHS = 1 (not the default since round 5): signing calls of <= 16384 ops replay as hipGraphs
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
