@@ -113,4 +113,27 @@ __device__ __forceinline__ void expand_s_coop2_poly(const uint8_t* __restrict__ 
     }
 }
 
+// RAW ExpandMask (hashing.rs:281-313) for ONE polynomial by a wave: stream of SHAKE256(rho'' || kappa_r), the squeezed bytes themselves
+// (32 c per polynomial = BitPack(y)) into `row` -- what k_expand_mask<GB, true> writes.  `rho_pp`: the op's 64 bytes; kr = kappa + r
+// (u16 arithmetic, hashing.rs:293).
+template <int GB>
+__device__ __forceinline__ void expand_mask_coop2_poly(const uint8_t* __restrict__ rho_pp, uint32_t kr, uint8_t* __restrict__ row, int lane, const Coop2Lane& c) {
+    constexpr int ROW_BYTES = 32 * (GB + 1);
+    uint32_t lo = 0, hi = 0;
+    if (c.active && c.word < 8) {
+        lo = load_le32(rho_pp + 8 * c.word);
+        hi = load_le32(rho_pp + 8 * c.word + 4);
+    }
+    if (c.active && c.word == 8) lo = (kr & 0xFFFFu) | (0x1Fu << 16);
+    if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi = 0x80000000u;
+    uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
+#pragma unroll 1
+    for (int blk = 0; blk < 5; blk++) {
+        keccak_f1600_coop2(v, c);
+        coop2_to_lohi(v, lane, lo, hi);
+        const int off = blk * SHAKE256_RATE + 8 * c.word;
+        if (c.active && c.word < SHAKE256_RATE / 8 && off < ROW_BYTES) *reinterpret_cast<uint32_t*>(row + off + 4 * (lane >> 5)) = lane < 32 ? lo : hi;  // (rows are 8-byte aligned: 576, 640)
+    }
+}
+
 }  // namespace mldsa

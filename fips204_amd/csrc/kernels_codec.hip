@@ -401,57 +401,9 @@ __global__ __launch_bounds__(CBLOCK) void k_mu_coop(const uint8_t* __restrict__ 
     const Coop2Lane c = coop2_lane(lane);
     const size_t wave0 = (size_t)blockIdx.x * CWAVES + (threadIdx.x >> 6), stride = (size_t)gridDim.x * CWAVES;
     for (size_t op = wave0; op < n_ops; op += stride) {  // wave-uniform
-        const uint8_t* trp = tr + (key_idx ? key_idx[op] : op) * tr_stride;
-        const uint64_t m0 = msg_off[op0 + op], m1 = msg_off[op0 + op + 1];
-        bool bad_off = !(msg_off[0] <= m0 && m0 <= m1 && m1 <= msg_off[n_call]);
-        const uint8_t* mp = msgs + m0;
-        size_t mlen = (size_t)(m1 - m0), clen = 0;
-        bad_off |= mlen != 0 && msgs == nullptr;  // offsets that name bytes of a NULL array
-        const uint8_t* cp = nullptr;
-        if (ctx_off) {
-            const uint64_t c0 = ctx_off[op0 + op], c1 = ctx_off[op0 + op + 1];
-            bad_off |= !(ctx_off[0] <= c0 && c0 <= c1 && c1 <= ctx_off[n_call]);
-            cp = ctxs + c0;
-            clen = (size_t)(c1 - c0);
-            bad_off |= clen != 0 && ctxs == nullptr;
-        }
-        const int flag = bad_off ? 2 : clen > 255 ? 1 : (key_bad ? key_bad[op] : 0);
-        const bool live = !bad_off && clen <= 255;
-        if (!live) mlen = clen = 0;
-        const size_t pre = (mode == MLDSA_MODE_INTERNAL) ? 0 : 2 + clen;
-        const size_t total = live ? 64 + pre + mlen : 0;
-        const size_t blocks = live ? total / SHAKE256_RATE + 1 : 0;
-        auto byte_at = [&](size_t pos) -> uint32_t {
-            if (pos < total) {
-                if (pos < 64) return trp[pos];
-                if (pos < 64 + pre) {
-                    const size_t q = pos - 64;
-                    return q == 0 ? (uint32_t)(mode == MLDSA_MODE_PREHASH ? 1 : 0) : q == 1 ? (uint32_t)clen : cp[q - 2];
-                }
-                return mp[pos - 64 - pre];
-            }
-            return pos == total ? 0x1Fu : 0u;
-        };
-        auto dword_at = [&](size_t pos) -> uint32_t {
-            if (pos + 4 <= 64) return load_le32(trp + pos);
-            if (pos >= 64 + pre && pos + 4 <= total) return load_le32(mp + (pos - 64 - pre));
-            if (pos > total) return 0u;
-            return byte_at(pos) | (byte_at(pos + 1) << 8) | (byte_at(pos + 2) << 16) | (byte_at(pos + 3) << 24);
-        };
-        uint32_t v = 0;
-        const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
-        for (size_t b = 0; b < blocks; b++) {
-            if (absorbs) {
-                const size_t off = b * SHAKE256_RATE + 8 * (size_t)c.word;
-                const uint32_t lo = dword_at(off);
-                uint32_t hi = dword_at(off + 4);
-                if (b == blocks - 1 && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
-                v ^= coop2_from_lohi(lo, hi, c);
-            }
-            keccak_f1600_coop2(v, c);
-        }
         uint32_t lo, hi;
-        coop2_to_lohi(v, lane, lo, hi);
+        const int flag = mu_coop2(tr + (key_idx ? key_idx[op] : op) * tr_stride, mode, msgs, msg_off, ctxs, ctx_off, op0 + op, n_call,
+                                  key_bad ? key_bad[op] : 0, lo, hi, lane, c);
         if (c.active && c.word < 8) reinterpret_cast<uint32_t*>(mu + op * mu_stride)[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
         if (lane == 0 && ctx_bad) ctx_bad[op] = flag;
     }

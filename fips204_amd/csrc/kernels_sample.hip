@@ -450,23 +450,7 @@ __global__ __launch_bounds__(64 * SWAVES) void k_expand_mask_coop(const uint8_t*
         const size_t slot = g / l;
         const uint32_t r = (uint32_t)(g % l);
         const size_t op = op_idx ? op_idx[slot] : slot;
-        uint32_t lo = 0, hi = 0;
-        if (c.active && c.word < 8) {
-            const uint8_t* src = rho_pp + op * rho_stride + 8 * c.word;
-            lo = load_le32(src);
-            hi = load_le32(src + 4);
-        }
-        if (c.active && c.word == 8) lo = (((uint32_t)kappa[kappa_by_slot ? slot : op] + r) & 0xFFFFu) | (0x1Fu << 16);  // hashing.rs:293 (u16 arithmetic)
-        if (c.active && c.word == SHAKE256_RATE / 8 - 1) hi = 0x80000000u;
-        uint32_t v = c.active ? coop2_from_lohi(lo, hi, c) : 0u;
-        uint8_t* row = reinterpret_cast<uint8_t*>(y) + g * (size_t)ROW_BYTES;
-#pragma unroll 1
-        for (int blk = 0; blk < 5; blk++) {
-            keccak_f1600_coop2(v, c);
-            coop2_to_lohi(v, lane, lo, hi);
-            const int off = blk * SHAKE256_RATE + 8 * c.word;
-            if (c.active && c.word < SHAKE256_RATE / 8 && off < ROW_BYTES) *reinterpret_cast<uint32_t*>(row + off + 4 * (lane >> 5)) = lane < 32 ? lo : hi;  // (rows are 8-byte aligned: 576, 640)
-        }
+        expand_mask_coop2_poly<GB>(rho_pp + op * rho_stride, (uint32_t)kappa[kappa_by_slot ? slot : op] + r, reinterpret_cast<uint8_t*>(y) + g * (size_t)ROW_BYTES, lane, c);
     }
 }
 

@@ -77,66 +77,13 @@ __device__ __forceinline__ void reload_first_kernarg(T& out) {
     for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = ka[i];
 }
 
-// ---- role: mu = H(tr | M', 64) by one wave (keccak_coop2.h: one state per wave).  The checks and the byte layout
-// are k_mu's (kernels_codec.hip): offsets are never trusted, a ctx longer than 255 bytes or a malformed pair refuses the op before
-// a byte of it is read; flag as there.
+// ---- role: mu = H(tr | M', 64) by one wave (verify_dev.h mu_coop2: k_mu's checks, flags and bytes)
 __device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t op, int lane, const Coop2Lane& c) {
     size_t key = A.key_idx ? A.key_idx[op] : op;
     int key_bad = 0;
     if (A.key_idx && key >= A.n_keys) { key = 0; key_bad = 2; }
-    const uint8_t* trp = A.tr + key * 64;
-    const size_t n_call = A.n_ops;
-    const uint64_t m0 = A.msg_off[op], m1 = A.msg_off[op + 1];
-    bool bad_off = !(A.msg_off[0] <= m0 && m0 <= m1 && m1 <= A.msg_off[n_call]);
-    const uint8_t* mp = A.msgs + m0;
-    size_t mlen = (size_t)(m1 - m0), clen = 0;
-    bad_off |= mlen != 0 && A.msgs == nullptr;
-    const uint8_t* cp = nullptr;
-    if (A.ctx_off) {
-        const uint64_t c0 = A.ctx_off[op], c1 = A.ctx_off[op + 1];
-        bad_off |= !(A.ctx_off[0] <= c0 && c0 <= c1 && c1 <= A.ctx_off[n_call]);
-        cp = A.ctxs + c0;
-        clen = (size_t)(c1 - c0);
-        bad_off |= clen != 0 && A.ctxs == nullptr;
-    }
-    const int flag = bad_off ? 2 : clen > 255 ? 1 : key_bad;
-    const bool live = !bad_off && clen <= 255;
-    if (!live) mlen = clen = 0;
-    const int mode = A.mode;
-    const size_t pre = (mode == MLDSA_MODE_INTERNAL) ? 0 : 2 + clen;
-    const size_t total = live ? 64 + pre + mlen : 0;
-    const size_t blocks = live ? total / SHAKE256_RATE + 1 : 0;  // the pad always fits in the last block
-    auto byte_at = [&](size_t pos) -> uint32_t {
-        if (pos < total) {
-            if (pos < 64) return trp[pos];
-            if (pos < 64 + pre) {
-                const size_t q = pos - 64;
-                return q == 0 ? (uint32_t)(mode == MLDSA_MODE_PREHASH ? 1 : 0) : q == 1 ? (uint32_t)clen : cp[q - 2];
-            }
-            return mp[pos - 64 - pre];
-        }
-        return pos == total ? 0x1Fu : 0u;
-    };
-    auto dword_at = [&](size_t pos) -> uint32_t {  // whole dwords of tr and of the message by one byte-granular load, boundaries from bytes
-        if (pos + 4 <= 64) return load_le32(trp + pos);
-        if (pos >= 64 + pre && pos + 4 <= total) return load_le32(mp + (pos - 64 - pre));
-        if (pos > total) return 0u;
-        return byte_at(pos) | (byte_at(pos + 1) << 8) | (byte_at(pos + 2) << 16) | (byte_at(pos + 3) << 24);
-    };
-    uint32_t v = 0;
-    const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
-    for (size_t b = 0; b < blocks; b++) {  // wave-uniform
-        if (absorbs) {
-            const size_t off = b * SHAKE256_RATE + 8 * (size_t)c.word;
-            const uint32_t lo = dword_at(off);
-            uint32_t hi = dword_at(off + 4);
-            if (b == blocks - 1 && c.word == SHAKE256_RATE / 8 - 1) hi ^= 0x80000000u;
-            v ^= coop2_from_lohi(lo, hi, c);
-        }
-        keccak_f1600_coop2(v, c);
-    }
     uint32_t lo, hi;
-    coop2_to_lohi(v, lane, lo, hi);
+    const int flag = mu_coop2(A.tr + key * 64, A.mode, A.msgs, A.msg_off, A.ctxs, A.ctx_off, op, A.n_ops, key_bad, lo, hi, lane, c);
     if (c.active && c.word < 8) reinterpret_cast<uint32_t*>(A.mu_ws + op * 64)[2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
     if (lane == 0) A.flag_ws[op] = flag;
 }
@@ -567,6 +514,345 @@ int launch_keygen_small(mldsa_ctx* ctx, const mldsa_params* p, const uint8_t* xi
     if (p->set == MLDSA_44) hipLaunchKernelGGL((k_keygen_small<4, 4, 2>), grid, block, 0, s, A);
     else if (p->set == MLDSA_65) hipLaunchKernelGGL((k_keygen_small<6, 5, 4>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((k_keygen_small<8, 7, 2>), grid, block, 0, s, A);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+// ====================================================================================================================
+// The prologue of sign_internal (src/ml_dsa.rs:181-204) for SMALL calls as ONE launch.
+//
+// The batch pipeline enqueues nine kernels before the first round: the key check, ExpandA, a clearing of the round control block, mu,
+// a copy of rnd, rho'' = H(K | rnd | mu), a clearing of the key-range flags, the key-range check and the first active list -- 43 us
+// of kernels and eight boundaries for one op (profiles/r05_small_call_timeline_sign_n1.json: the first round starts 65 us into the
+// call).  Here every op owns a cluster of workgroups: one wave per polynomial of A_hat (absent when the caller keeps A_hat with its
+// keys) and ONE wave for everything else of the op, in order: key index check, mu (mu_coop2), rnd | mu row, rho'' (one more
+// permutation), kappa / done / status (a refused op's signature zeroed), the key-range check of the op's unit (K inverse transforms).
+// Every workgroup bumps ONE counter of the call; the last one to arrive builds the first active list (in op order) and the round
+// control block.  Same workspace rows, same values as the nine kernels (the active list's order is not part of the contract: the
+// batch kernel fills it with atomics).
+template <int K, int L, bool CACHED>
+__global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignPrologueArgs A0) {
+    constexpr int NA = CACHED ? 0 : K * L, ROLES = NA + 1, NB = (ROLES + SMW - 1) / SMW;
+    __shared__ uint32_t blk_lds[SMW * EA_COOP_BLK_DWORDS];
+    __shared__ uint32_t row_lds[24];  // rnd | mu of the op (one op wave per workgroup at most)
+    __shared__ uint32_t wave_cnt[SMW];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t member = q % NB;
+    const size_t op = (size_t)(q / NB) * 8 + xcd;
+    const uint32_t n = A0.n;
+    if (op >= n) return;  // (whole workgroup)
+    const Coop2Lane c = coop2_lane(lane);
+    const int role = (int)member * SMW + wave;
+    // (The argument struct has some forty scalars; every step below re-reads it from the kernarg segment -- reload_first_kernarg -- and
+    //  the compiler keeps only that step's fields: held in registers from the kernel's entry, 19-26 of them spilled.)
+    if (role < NA) {
+        // 5: A_hat <- ExpandA(rho)                                            ml_dsa.rs:181
+        expand_a_coop2_poly<K, L>(A0.rho, 32, A0.key_idx, A0.a_ws, op * NA + (size_t)role, A0.key_idx ? A0.n_keys : 0u, blk_lds + wave * EA_COOP_BLK_DWORDS,
+                                  lane, c);
+    } else if (role == NA) {
+        size_t key = op;
+        int bad = 0;
+        uint32_t lo, hi;
+        {   // the key index (the C ABI's promise: an out-of-range index never reaches memory), then 6: mu <- H(tr || M', 64)   ml_dsa.rs:185-196
+            SmallSignPrologueArgs A;
+            reload_first_kernarg(A);
+            int key_bad = 0;
+            if (A.key_idx) {
+                const uint32_t kraw = A.key_idx[op];
+                key = kraw < A.n_keys ? kraw : 0u;
+                key_bad = kraw < A.n_keys ? 0 : 2;
+                if (lane == 0) A.kidx_out[op] = (uint32_t)key;
+            }
+            bad = mu_coop2(A.tr + key * 64, A.mode, A.msgs, A.msg_off, A.ctxs, A.ctx_off, A.op0 + op, A.n_call, key_bad, lo, hi, lane, c);
+        }
+        {   // the op's rnd | mu row; 7: rho'' <- H(K || rnd || mu, 64)          ml_dsa.rs:199-201   (128 bytes: one block)
+            SmallSignPrologueArgs A;
+            reload_first_kernarg(A);
+            if (lane < 8) row_lds[lane] = load_le32(A.rnd + op * 32 + 4 * lane);
+            if (c.active && c.word < 8) row_lds[8 + 2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
+            wave_lds_sync();
+            if (lane < 24) reinterpret_cast<uint32_t*>(A.rnd_mu + op * 96)[lane] = row_lds[lane];
+            uint32_t l2 = 0, h2 = 0;
+            if (c.active && c.word < 4) {
+                l2 = load_le32(A.cap_k + key * 32 + 8 * c.word);
+                h2 = load_le32(A.cap_k + key * 32 + 8 * c.word + 4);
+            } else if (c.active && c.word < 16) {
+                l2 = row_lds[2 * (c.word - 4)];
+                h2 = row_lds[2 * (c.word - 4) + 1];
+            } else if (c.active && c.word == 16) {
+                l2 = 0x1Fu;
+                h2 = 0x80000000u;
+            }
+            uint32_t v = c.active ? coop2_from_lohi(l2, h2, c) : 0u;
+            keccak_f1600_coop2(v, c);
+            coop2_to_lohi(v, lane, l2, h2);
+            if (c.active && c.word < 8) reinterpret_cast<uint32_t*>(A.rho_pp + op * 64)[2 * c.word + (lane >> 5)] = lane < 32 ? l2 : h2;
+        }
+        {   // 8: kappa <- 0; a refused op (ctx too long, lib.rs:274; bad key index / offsets) is done at once with an all-zero signature
+            SmallSignPrologueArgs A;
+            reload_first_kernarg(A);
+            if (lane == 0) {
+                A.kappa[op] = 0;
+                A.bad_op[op] = bad;
+                A.done[op] = bad;
+                if (A.status) A.status[op] = bad == 0 ? MLDSA_OK : bad == 1 ? MLDSA_ERR_CTX_LEN : MLDSA_ERR_PARAM;
+            }
+            if (bad)
+                for (size_t b = lane; b < A.sig_len; b += 64) A.sigs[op * A.sig_len + b] = 0;
+        }
+        {   // is the unit's s2 within [-eta, eta]?  (k_key_range: a key that expand_private decoded out of range takes the reference's
+            // two-transform hint stage)
+            SmallSignPrologueArgs A;
+            reload_first_kernarg(A);
+            if (op < A.units) {
+                const size_t ukey = A.units_by_op ? key : op;
+                InvTw tw;
+                load_inv_tw(tw, A.inv_tab, lane);
+                bool oor = false;
+#pragma unroll 1
+                for (int i = 0; i < K; i++) {
+                    int32_t r[4];
+                    load_packed(r, A.s2 + (ukey * K + i) * (size_t)N, lane);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) r[k] = mont_mul(reduce32(r[k]), 1);  // mont_reduce(x_hat_mont) = x_hat
+                    ntt_inv_wave(r, tw, lane, F_MONT);                                // canonical [0, q)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int32_t cen = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);
+                        oor |= (cen < 0 ? -cen : cen) > A.eta;
+                    }
+                }
+                const bool any = __ballot(oor) != 0ull;
+                if (lane == 0) A.key_oor[op] = any ? 1 : 0;
+            } else if (lane == 0) {
+                A.key_oor[op] = 0;
+            }
+        }
+    }
+    // ---------------------------------------------------------------- the call's counter: the last workgroup finishes
+    wait_own_stores();
+    __syncthreads();
+    SmallSignPrologueArgs A;
+    reload_first_kernarg(A);
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t seen = __hip_atomic_fetch_add(&A.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = seen == n * (uint32_t)NB - 1u;
+        if (last) __hip_atomic_store(&A.ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // active = every op that was not refused, in op order (n <= 256: one thread per op); the round control block: zero but for the count
+    {
+        const uint32_t i = threadIdx.x;
+        const bool live = i < n && A.done[i] == 0;
+        const unsigned long long b = __ballot(live);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (int w2 = 0; w2 < SMW; w2++) {
+            if (w2 < wave) base += wave_cnt[w2];
+            total += wave_cnt[w2];
+        }
+        if (live) A.act0[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = i;
+        uint32_t* cw = reinterpret_cast<uint32_t*>(A.ctl);
+        for (uint32_t d = threadIdx.x; d < sizeof(RoundCtl) / 4; d += 64 * SMW) cw[d] = d == 0 ? total : 0u;  // cnt[0] is the first field
+    }
+}
+
+int launch_sign_prologue_small(mldsa_ctx* ctx, const mldsa_params* p, const SmallSignPrologueArgs& A, bool cached, hipStream_t s) {
+    if (A.n == 0) return MLDSA_OK;
+    static_assert(offsetof(RoundCtl, cnt) == 0 && sizeof(RoundCtl) % 4 == 0, "k_sign_prologue_small writes the control block by dwords");
+    const int roles = (cached ? 0 : p->k * p->l) + 1, nb = (roles + SMW - 1) / SMW;
+    const dim3 grid((unsigned)((((size_t)A.n + 7) / 8) * 8 * (size_t)nb)), block(64 * SMW);
+#define MLDSA_SP(KK, LL)                                                                                              \
+    do {                                                                                                              \
+        if (cached) hipLaunchKernelGGL((k_sign_prologue_small<KK, LL, true>), grid, block, 0, s, A);                    \
+        else hipLaunchKernelGGL((k_sign_prologue_small<KK, LL, false>), grid, block, 0, s, A);                          \
+    } while (0)
+    if (p->set == MLDSA_44) MLDSA_SP(4, 4);
+    else if (p->set == MLDSA_65) MLDSA_SP(6, 5);
+    else MLDSA_SP(8, 7);
+#undef MLDSA_SP
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+// ====================================================================================================================
+// The first half of a signing round (ml_dsa.rs:215-240) for SMALL rounds as ONE launch: y = ExpandMask(rho'', kappa), w = invNTT(A_hat o
+// NTT(y)), w1 = HighBits(w), c~ = H(mu | w1Encode(w1)), c = SampleInBall(c~), c_hat = NTT(c) -- five launches of the batch pipeline
+// (ExpandMask 15.7, sign_w 11.1, the c~ hash 20.2, SampleInBall 11.4, NTT(c) 4.8 us for the 32 candidate rows of one op).  Every
+// candidate ROW owns a cluster: one wave per polynomial of y (expand_mask_coop2_poly); the last workgroup to arrive transforms y_j
+// (wave j mod 4, with the y risk flags), computes the K rows of w (wave i mod 4: 24-bit planes out, HighBits / w1Encode into LDS beside mu,
+// the w risk bits), hashes mu | w1 from LDS, samples c and transforms it.  The rows it leaves -- y, w, w1, c~, c, c_hat, the risk flags
+// -- are byte for byte those of the five kernels, so k_sign_tail / k_resolve / k_compact follow unchanged.
+template <int K, int L, int GB, bool G2HI, int CT, bool APACK>
+__global__ __launch_bounds__(64 * SMW) void k_sign_front_small(SmallSignFrontArgs A0) {
+    constexpr int YCB = GB + 1, ROW_BYTES = 32 * YCB;
+    constexpr int BITS = G2HI ? 4 : 6;
+    constexpr int W1_LEN = K * 32 * BITS;
+    constexpr int NB = (L + SMW - 1) / SMW;
+    __shared__ __attribute__((aligned(16))) int4 zh[L][64];
+    __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t msg_lds[(64 + W1_LEN) / 4];  // mu | w1Encode(w1)
+    __shared__ uint32_t ct_lds[16], bw_lds[36];
+    __shared__ int s_last, s_risk;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t member = q % NB;
+    const size_t g = (size_t)(q / NB) * 8 + xcd;  // the row
+    if (g >= *A0.ns_gen || g >= A0.rows_cap) return;  // (whole workgroup)
+    const Coop2Lane c = coop2_lane(lane);
+    const int role = (int)member * SMW + wave;
+    const size_t op = A0.gen_op[g];
+    // ---------------------------------------------------------------- phase 1: 11: y <- ExpandMask(rho'', kappa)      ml_dsa.rs:215
+    if (role < L)
+        expand_mask_coop2_poly<GB>(A0.rho_pp + op * 64, (uint32_t)A0.gen_kappa[g] + (uint32_t)role,
+                                   reinterpret_cast<uint8_t*>(A0.y) + (g * L + (size_t)role) * (size_t)ROW_BYTES, lane, c);
+    // ---------------------------------------------------------------- hand-over (as in k_verify_small)
+    if (NB > 1) wait_own_stores();
+    __syncthreads();
+    if (NB > 1) {
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const uint32_t seen = __hip_atomic_fetch_add(&A0.ctr[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = seen == (uint32_t)(NB - 1);
+            if (last) __hip_atomic_store(&A0.ctr[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    // ---------------------------------------------------------------- tail
+    SmallSignFrontArgs A;
+    reload_first_kernarg(A);
+    for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * SMW) tw_lds[i] = A.fwd_tab[i];
+    for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * SMW) tw_lds[FWD_TW * 64 + i] = A.inv_tab[i];
+    if (threadIdx.x < 16) msg_lds[threadIdx.x] = load_le32(A.mu + op * 96 + 4 * threadIdx.x);
+    if (threadIdx.x == 0) s_risk = 0;
+    __syncthreads();
+    const LdsTw ftw{tw_lds, lane};
+    const LdsTw itw{tw_lds + FWD_TW * 64, lane};
+#pragma unroll 1
+    for (int j = wave; j < L; j += SMW) {  // NTT(y_j), and: can this polynomial fail ||z||inf < gamma1 - beta?  (some |y| >= gamma1 - 2 beta)
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(A.y) + (g * L + (size_t)j) * (size_t)ROW_BYTES;
+        int32_t r[4];
+        bool near = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r[k] = y_from_raw<YCB>(y_raw_dword<YCB>(src, k, lane), lane);  // |y| <= gamma1 < q: no reduction
+            near |= (r[k] < 0 ? -r[k] : r[k]) >= A.y_risk_bound;
+        }
+        const bool any_near = __ballot(near) != 0ull;
+        if (lane == 0) A.yrisk[g * L + (size_t)j] = any_near ? 1 : 0;
+        ntt_fwd_wave(r, ftw, lane);
+        zh[j][lane] = make_int4(r[0], r[1], r[2], r[3]);
+    }
+    __syncthreads();
+    using ARow = std::conditional_t<APACK, Packed3, int4>;
+    const size_t aop = A.a_idx[g];
+    const ARow* arow = APACK ? reinterpret_cast<const ARow*>(reinterpret_cast<const uint32_t*>(A.a_hat) + (aop * K * (size_t)L) * PACKED_POLY_DWORDS)
+                             : reinterpret_cast<const ARow*>(A.a_hat + (aop * K * (size_t)L) * N);
+    auto coeffs = [](const ARow& v) -> int4 {
+        if constexpr (APACK) return unpack24(v); else return v;
+    };
+#pragma unroll 1
+    for (int i = wave; i < K; i += SMW) {  // 12: w_i <- invNTT(A_hat[i] o y_hat); 13-14: w1_i = HighBits(w_i), w1Encode       ml_dsa.rs:218-232
+        int64_t acc64[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const int4 zv = zh[j][lane];
+            const int4 a4 = coeffs(arow[(unsigned)((i * L + j) * 64) + (unsigned)lane]);
+            acc64[0] += (int64_t)a4.x * zv.x;
+            acc64[1] += (int64_t)a4.y * zv.y;
+            acc64[2] += (int64_t)a4.z * zv.z;
+            acc64[3] += (int64_t)a4.w * zv.w;
+        }
+        int32_t acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = mont_reduce64(acc64[k]);
+        ntt_inv_wave(acc, itw, lane, F_MONT2);
+        const Packed3 pw = pack24((uint32_t)acc[0], (uint32_t)acc[1], (uint32_t)acc[2], (uint32_t)acc[3]);
+        uint32_t* wp = reinterpret_cast<uint32_t*>(A.w) + (g * K + (size_t)i) * (size_t)PACKED_POLY_DWORDS;
+        wp[lane] = pw.a;
+        wp[64 + lane] = pw.b;
+        wp[128 + lane] = pw.c;
+        uint32_t hb[4];
+        bool near = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int32_t r1, r0;
+            decompose<G2HI>(acc[k], r1, r0);  // HighBits = r1 (high_low.rs:104-111)
+            hb[k] = (uint32_t)r1;
+            near |= (r0 < 0 ? -r0 : r0) >= A.w_risk_bound;
+        }
+        pack_w1_strided<G2HI>(hb, reinterpret_cast<uint8_t*>(msg_lds) + 64 + (size_t)i * (32 * BITS), lane);
+        if (__ballot(near) != 0ull && lane == 0) atomicOr(&s_risk, 1 << i);  // bit i: some |LowBits(w_i)| >= gamma2 - 2 beta
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) A.wrisk[g] = (uint8_t)s_risk;
+    {   // w1 row out (the batch kernels keep it in the workspace too)
+        uint32_t* w1o = reinterpret_cast<uint32_t*>(A.w1 + g * (size_t)W1_LEN);
+        for (int i = threadIdx.x; i < W1_LEN / 4; i += 64 * SMW) w1o[i] = msg_lds[16 + i];
+    }
+    if (wave != 0) return;
+    // 15: c~ <- H(mu || w1Encode(w1), lambda / 4)                          ml_dsa.rs:233
+    {
+        constexpr int DATA = 64 + W1_LEN, BLOCKS = DATA / SHAKE256_RATE + 1;
+        auto msg_dword = [&](int off) -> uint32_t {
+            if (off + 4 <= DATA) return msg_lds[off >> 2];
+            uint32_t v = off == DATA ? 0x1Fu : 0u;
+            if (off + 4 == BLOCKS * SHAKE256_RATE) v |= 0x80000000u;
+            return v;
+        };
+        uint32_t v = 0;
+        const bool absorbs = c.active && c.word < SHAKE256_RATE / 8;
+#pragma unroll 1
+        for (int blk = 0; blk < BLOCKS; blk++) {
+            if (absorbs) {
+                const int off = blk * SHAKE256_RATE + 8 * c.word;
+                v ^= coop2_from_lohi(msg_dword(off), msg_dword(off + 4), c);
+            }
+            keccak_f1600_coop2(v, c);
+        }
+        uint32_t lo, hi;
+        coop2_to_lohi(v, lane, lo, hi);
+        if (c.active && c.word < CT / 8) {
+            const uint32_t mine = lane < 32 ? lo : hi;
+            ct_lds[2 * c.word + (lane >> 5)] = mine;
+            *reinterpret_cast<uint32_t*>(A.ctilde + g * 64 + 8 * c.word + 4 * (lane >> 5)) = mine;
+        }
+        wave_lds_sync();
+    }
+    // 16: c <- SampleInBall(c~); 17: c_hat <- NTT(c)                      ml_dsa.rs:237-240
+    const uint32_t creg = sample_in_ball_coop2<CT>(reinterpret_cast<const uint8_t*>(ct_lds), A.tau, bw_lds, lane, c);
+    reinterpret_cast<uint32_t*>(A.c8)[g * 64 + lane] = creg;
+    int32_t r[4] = {(int8_t)(creg & 0xFF), (int8_t)((creg >> 8) & 0xFF), (int8_t)((creg >> 16) & 0xFF), (int8_t)(creg >> 24)};
+    ntt_fwd_wave(r, ftw, lane);
+    store_packed(r, A.c_hat + g * (size_t)N, lane);
+}
+
+int launch_sign_front_small(mldsa_ctx* ctx, const mldsa_params* p, const SmallSignFrontArgs& A, bool a_packed, hipStream_t s) {
+    (void)ctx;
+    if (A.rows_cap == 0) return MLDSA_OK;
+    const int nb = (p->l + SMW - 1) / SMW;
+    const dim3 grid((unsigned)((((size_t)A.rows_cap + 7) / 8) * 8 * (size_t)nb)), block(64 * SMW);
+#define MLDSA_SF(KK, LL, GB, G2, CT)                                                                                       \
+    do {                                                                                                                   \
+        if (a_packed) hipLaunchKernelGGL((k_sign_front_small<KK, LL, GB, G2, CT, true>), grid, block, 0, s, A);              \
+        else hipLaunchKernelGGL((k_sign_front_small<KK, LL, GB, G2, CT, false>), grid, block, 0, s, A);                      \
+    } while (0)
+    if (p->set == MLDSA_44) MLDSA_SF(4, 4, 17, false, 32);
+    else if (p->set == MLDSA_65) MLDSA_SF(6, 5, 19, true, 48);
+    else MLDSA_SF(8, 7, 19, true, 64);
+#undef MLDSA_SF
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

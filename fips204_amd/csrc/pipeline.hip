@@ -124,6 +124,7 @@ int ensure_workspace(mldsa_ctx *ctx, size_t bytes) {
 struct ZeroSpan { void *p; size_t bytes; };
 static bool clear_in_background(mldsa_ctx *ctx, hipStream_t s, const ZeroSpan *head, const ZeroSpan *rest, int n_rest) {
     hipStream_t z = parallel_stream(ctx, s);
+    ctx->zero_stream = z;
     bool ok = hipEventRecord(ctx->zero_fork_ev, s) == hipSuccess && hipStreamWaitEvent(z, ctx->zero_fork_ev, 0) == hipSuccess;
     if (ok && head) {
         MLDSA_WIPE(launch_zero(ctx, head->p, head->bytes, z));
@@ -718,6 +719,24 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.rule, pl.spec_max, (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu), w.act[par], w.kappa, p->l, w.slot_op,
                                           w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
                                           pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
+    // A SMALL round (rows * L polynomials within the cooperative ExpandMask's range, one candidate per slot generated here): ExpandMask,
+    // sign_w, the c~ hash, SampleInBall and NTT(c) as ONE launch (kernels_small.hip k_sign_front_small); the same rows come out.
+    const size_t rows_cap = std::min<size_t>(pl.ns_max, 0xFFFFFFFFu);
+    if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && ctx->small_sign_front && !gen2 && !pre_in && !export_sg && rows_cap <= SMALL_FUSED_MAX &&
+        rows_cap * (size_t)p->l <= ctx->coop_mask_max) {
+        SmallSignFrontArgs A{};
+        A.ns_gen = ns_gen_dev; A.rho_pp = w.rho_pp; A.gen_kappa = w.gen_kappa; A.gen_op = w.gen_op; A.a_idx = own_a ? w.gen_op : w.gen_key;
+        A.a_hat = own_a ? w.a_hat : a_hat_keys; A.mu = w.rnd_mu + 32; A.y = w.y; A.w = w.w; A.w1 = w.w1; A.ctilde = w.ctilde; A.c8 = w.c8; A.c_hat = w.c;
+        A.wrisk = w.wrisk; A.yrisk = w.yrisk; A.ctr = ctx->d_small_ctr; A.fwd_tab = ctx->d_fwd_tw; A.inv_tab = ctx->d_inv_tw;
+        A.w_risk_bound = p->gamma2 - 2 * p->beta; A.y_risk_bound = p->gamma1 - 2 * p->beta; A.tau = p->tau; A.rows_cap = (uint32_t)rows_cap;
+        STAGE("sign_front_small", launch_sign_front_small(ctx, p, A, own_a, s));
+        STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
+                                            ns_hint, s, w.wrisk, w.yrisk, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
+        STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, w.y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
+                                        m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
+        STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1], nullptr));
+        return MLDSA_OK;
+    }
     // 11: y <- ExpandMask(rho'', kappa)                               :215
     STAGE("expand_mask", launch_expand_mask(ctx, set, w.rho_pp, 64, w.gen_kappa, 1, w.gen_op, w.y, gen_hint, s, nullptr, ns_gen_dev, true));
     // the PREVIOUS round's finished signatures -> the caller's host memory, on a helper stream (a small, fixed number of
@@ -816,18 +835,42 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     const size_t o = a.offset, n = a.n;
     int32_t *st = a.status ? a.status + o : nullptr;
     const int32_t *key_bad = nullptr;
-    if (a.key_idx) {
+    const bool fork = side_ok && own_a && n >= 4096 && ctx->opt_side_prologue;
+    const bool small = ctx->opt_coop_hash && ctx->opt_small_fused > 0 && n <= ctx->small_sign_max && n <= 256 && !fork;
+    if (a.key_idx && !small) {
         TRY(launch_sanitize_keys(ctx, a.key_idx + o, a.n_keys, n, w.kidx, w.key_bad, s));
         key_bad = w.key_bad;
     }
     const ChunkKeys c = chunk_keys(p, w, a);
     const size_t key_base = a.key_idx ? 0 : o;
-    const bool fork = side_ok && own_a && n >= 4096 && ctx->opt_side_prologue;
     hipStream_t side = s;
     if (fork) {
         side = parallel_stream(ctx, s);
         MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(side, ctx->fork_ev, 0));
+    }
+    // A SMALL call: the whole prologue -- key check, ExpandA, mu, rho'', key-range check, first active list, control block -- is ONE
+    // launch (kernels_small.hip k_sign_prologue_small) instead of the nine below; same rows, same values.
+    if (small) {
+        if (ctx->zero_wait_after_ea) {  // (no ExpandA beside the previous call's clearing here: it is part of the one launch)
+            MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
+            ctx->zero_wait_after_ea = false;
+            ctx->zero_pending = false;
+        }
+        if (a.inputs_ev) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, a.inputs_ev, 0));
+        const bool by_op = oor_by_op(a);
+        SmallSignPrologueArgs A{};
+        A.key_idx = a.key_idx ? a.key_idx + o : nullptr;
+        A.n_keys = (uint32_t)std::min<size_t>(a.n_keys, 0xFFFFFFFFu);
+        A.rho = a.rho + key_base * 32; A.cap_k = a.cap_k + key_base * 32; A.tr = a.tr + key_base * 64; A.s2 = c.s2k;
+        A.mode = a.mode; A.msgs = a.msgs; A.msg_off = a.msg_off; A.ctxs = a.ctxs; A.ctx_off = a.ctx_off; A.op0 = o; A.n_call = a.n_total;
+        A.rnd = a.rnd + o * 32; A.n = (uint32_t)n;
+        A.a_ws = w.a_hat; A.kidx_out = w.kidx; A.rnd_mu = w.rnd_mu; A.rho_pp = w.rho_pp; A.bad_op = w.bad_op; A.done = w.done; A.status = st;
+        A.kappa = w.kappa; A.act0 = w.act[0]; A.ctl = w.ctl; A.sigs = c.sg; A.sig_len = (size_t)p->sig_len; A.key_oor = w.key_oor;
+        A.units = (uint32_t)(a.key_idx ? (by_op ? n : a.n_keys) : n); A.units_by_op = by_op ? 1 : 0; A.eta = p->eta;
+        A.ctr = ctx->d_small_ctr; A.inv_tab = ctx->d_inv_tw;
+        STAGE("sign_prologue_small", launch_sign_prologue_small(ctx, p, A, !own_a, s));
+        return MLDSA_OK;
     }
     // 5: A_hat <- ExpandA(rho), once per signature                        ml_dsa.rs:181
     if (own_a) STAGE("expand_a", launch_expand_a(ctx, a.set, a.rho + key_base * 32, 32, c.kidx, w.a_hat, n, s, true));
@@ -993,7 +1036,17 @@ int wait_zeroise(mldsa_ctx *ctx, hipStream_t s) {
         while ((e = hipEventQuery(ctx->zero_ev)) == hipErrorNotReady) std::this_thread::yield();
         if (e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "waiting for the previous call's background clearing inside a stream capture", e);
     } else {
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
+        hipError_t e = hipStreamWaitEvent(s, ctx->zero_ev, 0);
+        if (e != hipSuccess) {
+            // Seen when a capture of this context was invalidated by another thread's device-wide wait and the helper stream the
+            // clearing ran on still counted as capturing for the runtime ("operation not permitted on an event last recorded in a
+            // capturing stream").  The ordering this wait stands for is not optional -- the clearing must not run into this call's
+            // fresh rows -- so it is established on the host instead (the clearing is sub-millisecond).
+            (void)hipGetLastError();
+            e = ctx->zero_stream ? hipStreamSynchronize(ctx->zero_stream) : hipErrorUnknown;
+            if (e != hipSuccess) { (void)hipGetLastError(); e = device_sync_quiesced(); }
+            if (e != hipSuccess) return set_error(MLDSA_ERR_DEVICE, "waiting for the previous call's background clearing", e);
+        }
     }
     ctx->zero_pending = false;
     return MLDSA_OK;
@@ -1157,7 +1210,13 @@ void drop_graphs(mldsa_ctx *ctx) {
 }
 
 int run_op(mldsa_ctx *ctx, hipStream_t s, int op, size_t n_ops, const void *key, size_t key_len,
-           const std::function<int(hipStream_t)> &enqueue, bool allow_graph) {
+           const std::function<int(hipStream_t)> &enqueue_fn, bool allow_graph) {
+    // Every launcher checks hipGetLastError() after its launch, and that error is sticky per host thread: what a TOLERATED call before
+    // this point left behind (destroying the graphs of a replaced workspace, best-effort event bookkeeping after an invalidated
+    // capture ...) must not be taken for the failure of the first kernel launched here.  Found with the capture-under-fire test once
+    // small signing calls had become short enough for it: "operation not permitted on an event last recorded in a capturing stream"
+    // reported by a launch that had nothing to do with events.
+    auto enqueue = [&](hipStream_t st) { (void)hipGetLastError(); return enqueue_fn(st); };
     // MLDSA_OPT_GRAPHS: 0 never; 1 signing calls of up to GRAPH_AUTO_MAX_OPS ops -- ~100 launches for a few ms of device
     // work, where the 0.15-0.4 ms of host time a directly launched call costs is a sizeable share of the call; 2 every
     // op-level call.  A replayed graph is NOT faster on the device (the device-driven loop never waits for the host):

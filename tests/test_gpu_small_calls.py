@@ -248,3 +248,78 @@ def test_acvp_keygen_one_key_per_call(env, acvp_keygen):
             assert pk[0].cpu().numpy().tobytes() == bytes.fromhex(t["pk"]) and sk[0].cpu().numpy().tobytes() == bytes.fromhex(t["sk"]), t["tcId"]
             n += 1
     assert n == 75
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_sign_fused_prologue_and_round_front_equal_pipeline_equal_oracle(env, pset):
+    """sign_internal (src/ml_dsa.rs:153-337) for small calls: the prologue as one launch (k_sign_prologue_small, calls of <= 256 ops) and
+    the first half of a round as one launch (k_sign_front_small, rounds of <= 819 candidate rows = calls of <= 25 ops).  Signatures of
+    the fused paths = the batch pipeline's (MLDSA_OPT_SMALL_FUSED = 0) = the oracle's, byte for byte, at call sizes either side of
+    both limits, for the three modes, with refused ops (ctx of 256 bytes, key index out of range, a malformed offset pair) in the
+    batch, with A_hat kept by the caller (mldsa_sign_cached_a), and no secret left in the workspace afterwards."""
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    hp, sets = env
+    m = sets[pset]
+    rng = np.random.default_rng(300 + pset)
+    nk = 3
+    xi = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(nk)]
+    pk, sk = m.keygen_from_seed(xi)
+    sks, pks = m.private_keys_from_bytes(sk), m.public_keys_from_bytes(pk)
+    sk_o = [orc.keygen_from_seed(pset, x)[1] for x in xi]
+    a_hat = m.expand_a_for_keys(pks)
+    for n in (1, 3, 25, 26, 64, 256, 257):
+        for mode in ((0, 1, 2) if n in (3, 26) else (0,)):
+            msgs = [rng.integers(0, 256, int(rng.choice([0, 1, 32, 70, 71, 300])), dtype=np.uint8).tobytes() for _ in range(n)]
+            ctxs = [b"" if mode == 1 else rng.integers(0, 256, int(rng.choice([0, 0, 5, 255])), dtype=np.uint8).tobytes() for _ in range(n)]
+            rnd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+            kidx_h = rng.integers(0, nk, n).astype(np.int32)
+            refuse_ctx, refuse_key = (1, 2) if n >= 3 else (None, None)
+            if refuse_ctx is not None and mode != 1:
+                ctxs[refuse_ctx] = b"z" * 256
+            if refuse_key is not None:
+                kidx_h[refuse_key] = nk + 5
+            mb, mo = _cat_with_offsets(msgs, m.device)
+            cb, co = _cat_with_offsets(ctxs, m.device)
+            d_rnd, kidx = torch.from_numpy(rnd).cuda(), torch.from_numpy(kidx_h).cuda()
+            out = {}
+            for label, fused, ah in (("fused", 256, None), ("pipeline", 0, None), ("fused_cached_a", 256, a_hat)):
+                hp.set_option(OPT_SMALL_FUSED, fused)
+                sig = torch.full((n, m.SIG_LEN), 0x5A, dtype=torch.uint8, device="cuda")
+                st = torch.full((n,), 77, dtype=torch.int32, device="cuda")
+                m.sign_device(sks, mb, mo, d_rnd, sig, n, cb, co, kidx, mode, status=st, a_hat=ah)
+                torch.cuda.synchronize()
+                out[label] = (sig.cpu().numpy(), st.cpu().numpy())
+                scanned, nonzero = hp.secret_residue()
+                assert scanned > 0 and nonzero == 0, (label, n, nonzero)
+            hp.set_option(OPT_SMALL_FUSED, 256)
+            for label in ("pipeline", "fused_cached_a"):
+                assert np.array_equal(out["fused"][0], out[label][0]) and np.array_equal(out["fused"][1], out[label][1]), (n, mode, label)
+            sig, st = out["fused"]
+            for i in range(n):
+                bad_ctx = len(ctxs[i]) > 255
+                bad_key = kidx_h[i] >= nk
+                if bad_ctx or bad_key:
+                    assert st[i] == (-1 if bad_key else -2) and not sig[i].any(), (n, i, st[i])   # MLDSA_ERR_PARAM / MLDSA_ERR_CTX_LEN, all-zero signature
+                elif i < 6 or i == n - 1:
+                    assert st[i] == 0 and sig[i].tobytes() == orc.sign_internal(pset, sk_o[kidx_h[i]], msgs[i], rnd[i].tobytes(), ctx=ctxs[i], mode=mode), (n, mode, i)
+            good = [i for i in range(n) if len(ctxs[i]) <= 255 and kidx_h[i] < nk]
+            ver = m.verify(pks, [msgs[i] for i in good], torch.from_numpy(sig[good]).cuda(), ctxs=[ctxs[i] for i in good], key_idx=kidx_h[good].astype(np.uint32), mode=mode)
+            assert ver.all(), (n, mode)
+
+
+def test_acvp_siggen_one_op_per_call(env, acvp_siggen):
+    """the reference's own call shape: every ACVP sigGen vector as a signing call of ONE operation (nist_vectors/mod.rs:94-146)"""
+    from conftest import PSET
+    hp, sets = env
+    hp.set_option(OPT_SMALL_FUSED, 256)
+    n = 0
+    for g in acvp_siggen["testGroups"]:
+        m = sets[PSET[g["parameterSet"]]]
+        for t in g["tests"]:
+            skb = bytes.fromhex(t["sk"])
+            sks = m.private_keys_from_bytes(torch.frombuffer(bytearray(skb), dtype=torch.uint8).cuda().view(1, -1))
+            rnd = bytes.fromhex(t["rnd"]) if "rnd" in t and t["rnd"] else bytes(32)
+            sig = m.try_sign_with_seed(sks, [bytes.fromhex(t["message"])], [rnd], mode=1)
+            assert sig[0].cpu().numpy().tobytes() == bytes.fromhex(t["signature"]), t["tcId"]
+            n += 1
+    assert n == 60
