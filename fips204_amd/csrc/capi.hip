@@ -163,8 +163,8 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = host_malloc_quiesced((void **)&ctx->h_ctl, 2 * sizeof(RoundCtl));
-    if (e == hipSuccess) e = malloc_quiesced((void **)&ctx->d_small_ctr, SMALL_FUSED_MAX * sizeof(uint32_t));
-    if (e == hipSuccess) e = memset_quiesced(ctx->d_small_ctr, 0, SMALL_FUSED_MAX * sizeof(uint32_t));
+    if (e == hipSuccess) e = malloc_quiesced((void **)&ctx->d_small_ctr, SMALL_CTR_ENTRIES * sizeof(uint32_t));
+    if (e == hipSuccess) e = memset_quiesced(ctx->d_small_ctr, 0, SMALL_CTR_ENTRIES * sizeof(uint32_t));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);

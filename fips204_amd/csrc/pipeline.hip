@@ -721,9 +721,11 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
                                           pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
     // A SMALL round (rows * L polynomials within the cooperative ExpandMask's range, one candidate per slot generated here): ExpandMask,
     // sign_w, the c~ hash, SampleInBall and NTT(c) as ONE launch (kernels_small.hip k_sign_front_small); the same rows come out.
+    // (The launch covers every row the workspace can hold -- rows past the round's count leave at once -- so a round that turns out larger
+    //  than its plan is still complete; the PLAN decides whether the round is small enough for the cooperative form to pay.)
     const size_t rows_cap = std::min<size_t>(pl.ns_max, 0xFFFFFFFFu);
-    if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && ctx->small_sign_front && !gen2 && !pre_in && !export_sg && rows_cap <= SMALL_FUSED_MAX &&
-        rows_cap * (size_t)p->l <= ctx->coop_mask_max) {
+    if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && ctx->small_sign_front && !gen2 && !pre_in && !export_sg && rows_cap <= SMALL_CTR_ENTRIES &&
+        gen_hint * (size_t)p->l <= ctx->coop_mask_max) {
         SmallSignFrontArgs A{};
         A.ns_gen = ns_gen_dev; A.rho_pp = w.rho_pp; A.gen_kappa = w.gen_kappa; A.gen_op = w.gen_op; A.a_idx = own_a ? w.gen_op : w.gen_key;
         A.a_hat = own_a ? w.a_hat : a_hat_keys; A.mu = w.rnd_mu + 32; A.y = w.y; A.w = w.w; A.w1 = w.w1; A.ctilde = w.ctilde; A.c8 = w.c8; A.c_hat = w.c;

@@ -554,7 +554,10 @@ int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, in
  *   mldsa_batcher_sign     PrivateKey::try_from_bytes(sk)?.try_sign_with_seed(rnd, msg, ctx) (lib.rs:268-296): MLDSA_ERR_CTX_LEN for a
  *                          ctx longer than 255 bytes (the signature is then all zero)
  *   mldsa_batcher_keygen   KG::keygen_from_seed(xi) (lib.rs:247-250)
- * mode as in mldsa_verify / mldsa_sign (MLDSA_MODE_PREHASH: msg = OID | PH(M)). */
+ * mode as in mldsa_verify / mldsa_sign (MLDSA_MODE_PREHASH: msg = OID | PH(M)).
+ * Platform: the batcher's parking and spinning use Linux futex words and the x86 `pause` hint (the platform ROCm runs on); built with
+ * -DMLDSA_BATCHER_PORTABLE (or on another OS / architecture) it falls back to a condition variable and std::this_thread::yield --
+ * same semantics, more wake-up latency (csrc/batcher.cpp; both builds run the same CPU test). */
 typedef struct mldsa_batcher mldsa_batcher;
 typedef struct {
     uint64_t batches, requests, largest_batch; /* batches run, requests served, largest batch */
