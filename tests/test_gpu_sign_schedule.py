@@ -171,15 +171,17 @@ def test_async_plan_exponent_option(hp, sets):
 def test_soak_random_shapes_knobs_and_modes_against_the_oracle(hp, sets):
     """A seeded, time-bounded version of the reference's `forever` loop: random parameter set, batch size (1 ... 70 000,
     log-uniform), key count, message / ctx lengths, interface mode and library knobs (graph replay, speculation target and
-    width, planned rounds -> the extra-round path, signing lanes, synchronous / asynchronous signing), keygen -> sign ->
+    width, planned rounds -> the extra-round path, signing lanes, synchronous / asynchronous signing, the size limit of the
+    single-launch small-call kernels), keygen -> sign ->
     verify -> flip -> verify on the device, with a sample of every iteration's keys, signatures and verdicts compared with
     the oracle.  Shapes repeat and alternate on ONE context, so workspace regrowth, the graph cache and the loop's control
     block are exercised the way a long-running service would."""
     seconds = float(os.environ.get("MLDSA_SOAK_SECONDS", "60"))
     seed = int(os.environ.get("MLDSA_SOAK_SEED", "20260203"))
+    max_n = int(os.environ.get("MLDSA_SOAK_MAX_N", "70000"))  # (a small limit keeps the run on the small-call kernels: thousands of calls)
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
-    defaults = {o: hp.get_option(o) for o in (1, 2, 3, 6, 7, 10)}  # 10 = MLDSA_OPT_SIGN_LOOKAHEAD
+    defaults = {o: hp.get_option(o) for o in (1, 2, 3, 6, 7, 10, 13)}  # 10 = MLDSA_OPT_SIGN_LOOKAHEAD, 13 = MLDSA_OPT_SMALL_FUSED
     it = 0
     shapes = []
     try:
@@ -190,13 +192,13 @@ def test_soak_random_shapes_knobs_and_modes_against_the_oracle(hp, sets):
             if shapes and rng.random() < 0.3:
                 n, nk = shapes[int(rng.integers(len(shapes)))]  # a shape seen before: graph-cache hits
             else:
-                n = int(np.exp(rng.uniform(0, np.log(70000))))
+                n = int(np.exp(rng.uniform(0, np.log(max_n))))
                 nk = int(min(n, np.exp(rng.uniform(0, np.log(600)))))
                 shapes.append((n, nk))
             mode = int(rng.choice([0, 0, 1, 2]))
             knobs = {1: int(rng.choice([0, 1, 2])), 2: int(rng.choice([1024, 8192, 40000, 65536, 150000])),
                      3: int(rng.choice([1, 4, 32, 64])), 6: int(rng.choice([0, 0, 1, 3])), 7: int(rng.choice([1, 1, 2])),
-                     10: int(rng.choice([0, 1, 2]))}
+                     10: int(rng.choice([0, 1, 2])), 13: int(rng.choice([256, 256, 0, 40, 1024]))}
             for o, v in knobs.items():
                 hp.set_option(o, v)
             tag = b"soak%d-" % it
