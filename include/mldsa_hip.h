@@ -134,18 +134,24 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                        2 = for every set.  Signatures are identical */
 #define MLDSA_OPT_WORKSPACE_CAP_MB 11 /* most MiB of device memory the context's workspace may take (0 = default: whatever the device gives).  A call
                                        whose full pass does not fit runs in smaller passes (see workspace_shrinks: the context lowers its candidates
-                                       per speculative round -- MLDSA_OPT_SPEC_TARGET reads back smaller -- and then its ops per pass, and keeps
-                                       the smaller values); results are identical.  For hosts
+                                       per speculative round and then its ops per pass, and keeps the smaller values until the cap is raised or
+                                       removed; the options the caller set -- MLDSA_OPT_SPEC_TARGET ... -- are never rewritten, and a call that
+                                       cannot be served at any size leaves the context as it found it); results are identical.  For hosts
                                        that share the GPU with other work; a cap too small even for a 1024-op pass fails the call with MLDSA_ERR_NOMEM */
 #define MLDSA_OPT_COOP_HASH 12 /* 1 (default): the sponges of SMALL calls -- the fixed-shape SHAKE256 hashes (c_tilde, rho'', tr, the keygen seed) up to
-                                * 4 096 ops, the signer's ExpandMask and ExpandA up to 4 096 polynomials -- run wave-cooperatively, one state over 25
-                                * lanes: 3.8 instead of 9.4 us per permutation of a latency-bound call (csrc/keccak_coop.h).  0: always the
-                                * lane-per-state form of the large batches.  Results are identical. */
-#define MLDSA_OPT_SMALL_FUSED 13 /* most ops of a verification call that runs as ONE kernel launch (csrc/kernels_small.hip: every op owns a cluster of
-                                    workgroups for ExpandA, mu and SampleInBall; the last one to finish carries on with the arithmetic, the c_tilde hash
-                                    and the verdict).  Default 256 (measured crossover against the batch pipeline: ~350 ops); 0 = always the batch pipeline (six
-                                    launches on three streams); at most 1024.  Needs MLDSA_OPT_COOP_HASH = 1.  Results are bit-identical either way;
-                                    a one-op call takes 53 instead of 105 us, 64 ops 62 instead of 116, 256 ops 123 instead of 143. */
+                                * 4 096 ops, mu and SampleInBall up to 1 024 ops, ExpandA / ExpandS / the signer's ExpandMask up to 4 096 polynomials -- run
+                                * wave-cooperatively, ONE state per wave in bit-interleaved form (csrc/keccak_coop2.h): 2.2 instead of 9.4 us per
+                                * permutation of a latency-bound call.  0: always the lane-per-state form of the large batches.  Results are
+                                * identical. */
+#define MLDSA_OPT_SMALL_FUSED 13 /* most ops of a call that runs on the single-launch kernels of csrc/kernels_small.hip.  Verification: ONE launch
+                                    (every op owns a cluster of workgroups for ExpandA, mu and SampleInBall; the last one to finish carries on with
+                                    the arithmetic, the c_tilde hash and the verdict).  Key generation: ONE launch (one wave per polynomial of A_hat,
+                                    s1, s2; the last workgroup does the arithmetic, the packing and tr); at most 256 keys whatever the value.
+                                    Signing: the prologue is one launch (calls of at most 256 ops) and so is the first half of every round planned
+                                    at <= 819 candidate rows (ExpandMask, w = A y, the c_tilde hash, SampleInBall, NTT(c)).  Default 256 (measured
+                                    crossovers against the batch pipeline: ~350 verifications, ~400 keys); 0 = always the batch pipeline; at most
+                                    1024.  Needs MLDSA_OPT_COOP_HASH = 1.  Results are bit-identical either way; one ML-DSA-65 op: verify 50 instead
+                                    of 105 us, key generation 73 instead of 166, signing 133 instead of 227. */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,

@@ -103,4 +103,10 @@ done; done
 for f in gpurun_out/small_${R}pipe/unprofiled_*.txt; do cat "$f"; done > "$OUT/small_call_unprofiled_wall_batch_pipeline.txt"
 note small_call_unprofiled_wall_batch_pipeline.txt "MLDSA_SMALL_FUSED=0 python3 tools/latency_probe.py <op> <n> 200"
 ./tools/batcher_bench_bin 65 1.5 0 1,8,64 1 > "$OUT/batcher_single_op_callers.json" 2>> "$ERR"; note batcher_single_op_callers.json "./tools/batcher_bench_bin 65 1.5 0 1,8,64 1"
+# ---- soaks (SOAK=0 skips them): the seeded randomised soak of tests/test_gpu_sign_schedule.py, once kept on the small-call kernels, once over every size
+if [ "${SOAK:-1}" != 0 ]; then
+  { MLDSA_SOAK_SECONDS=${SOAK_SMALL_S:-240} MLDSA_SOAK_SEED=77 MLDSA_SOAK_MAX_N=400 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s -q 2>&1 | grep -E "^soak:|passed|failed|Error" ;
+    MLDSA_SOAK_SECONDS=${SOAK_LONG_S:-420} MLDSA_SOAK_SEED=5151 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s -q 2>&1 | grep -E "^soak:|passed|failed|Error" ; } > "$OUT/soak_long.txt"
+  note soak_long.txt "MLDSA_SOAK_SECONDS=240 MLDSA_SOAK_SEED=77 MLDSA_SOAK_MAX_N=400 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s  (small calls only: every result of ~19 000 keygen -> sign -> verify -> flip -> verify iterations against the oracle);  MLDSA_SOAK_SECONDS=420 MLDSA_SOAK_SEED=5151 ... (sizes 1 .. 70 000)"
+fi
 ls -la "$OUT"
