@@ -159,12 +159,17 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->zero_head_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->small_done_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_fork_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->graph_join_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = host_malloc_quiesced((void **)&ctx->h_ctl, 2 * sizeof(RoundCtl));
-    if (e == hipSuccess) e = malloc_quiesced((void **)&ctx->d_small_ctr, SMALL_CTR_ENTRIES * sizeof(uint32_t));
-    if (e == hipSuccess) e = memset_quiesced(ctx->d_small_ctr, 0, SMALL_CTR_ENTRIES * sizeof(uint32_t));
+    if (e == hipSuccess) e = host_malloc_quiesced((void **)&ctx->h_ctl, 2 * sizeof(RoundCtl), hipHostMallocMapped);
+    if (e == hipSuccess && hipHostGetDevicePointer((void **)&ctx->h_ctl_dev, ctx->h_ctl, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->h_ctl_dev = nullptr;  // (then every signing call copies its control block down, as large calls do)
+    }
+    if (e == hipSuccess) e = malloc_quiesced((void **)&ctx->d_small_ctr, SMALL_CTR_SETS * SMALL_CTR_ENTRIES * sizeof(uint32_t));
+    if (e == hipSuccess) e = memset_quiesced(ctx->d_small_ctr, 0, SMALL_CTR_SETS * SMALL_CTR_ENTRIES * sizeof(uint32_t));
     if (e != hipSuccess) {
         mldsa_ctx_destroy(ctx);
         return set_error(MLDSA_ERR_DEVICE, "mldsa_ctx_create: table upload / stream setup", e);
@@ -218,6 +223,7 @@ void mldsa_ctx_destroy(mldsa_ctx *ctx) {
     if (ctx->zero_fork_ev) (void)hipEventDestroy(ctx->zero_fork_ev);
     if (ctx->zero_ev) (void)hipEventDestroy(ctx->zero_ev);
     if (ctx->zero_head_ev) (void)hipEventDestroy(ctx->zero_head_ev);
+    if (ctx->small_done_ev) (void)hipEventDestroy(ctx->small_done_ev);
     if (ctx->d_fwd_tw) (void)free_quiesced(ctx->d_fwd_tw);
     if (ctx->d_inv_tw) (void)free_quiesced(ctx->d_inv_tw);
     delete ctx;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include "ctx.h"
+#include "sign_slots_dev.h"
 #include "keccak.h"
 #include "rounding.h"
 #include "sampler_dev.h"
@@ -425,43 +426,9 @@ __global__ __launch_bounds__(256) void k_make_slots(RoundCtl* __restrict__ ctl, 
                                                     uint16_t* __restrict__ gen_kappa, uint32_t* __restrict__ gen_key, int may_use_pre,
                                                     int may_gen2, const uint32_t* __restrict__ ypos, uint32_t* __restrict__ slot_y) {
     const uint32_t m = ctl->cnt[parity];
-    uint32_t spec = m ? rule.spec(m, spec_max) : 1u;
-    // ns_cap = the slots the workspace was carved for (plan_sign: the rule's maximum over every m, >= the batch): never exceeded,
-    // whatever rule and count arrive here
-    if (m && (unsigned long long)m * spec > ns_cap) spec = ns_cap / m ? ns_cap / m : 1u;
-    const uint32_t ns = m * spec;
-    const bool use_pre = may_use_pre && spec == 1u && ctl->gen_par[parity ^ 1] == 2u;  // gen_par[parity ^ 1]: not written here
-    const uint32_t gen = use_pre ? 0u : (may_gen2 && spec == 1u) ? 2u : 1u;
-    const uint32_t ns_gen = gen == 2u ? 2u * m : gen == 1u ? ns : 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl->cnt[parity ^ 1] = 0;
-        ctl->m = m;
-        ctl->m_par[parity] = m;
-        ctl->spec = spec;
-        ctl->gen_par[parity] = gen;
-        ctl->use_pre = use_pre ? 1u : 0u;
-        ctl->ns = ns;
-        ctl->ns_gen = ns_gen;
-        ctl->slots_total += ns_gen;  // candidates generated (statistics: a second candidate counts whether or not it is ever tested)
-        ctl->ops_total += gen ? m : 0u;
-        ctl->rounds += m ? 1u : 0u;
-    }
-    const uint32_t top = ns > ns_gen ? ns : ns_gen;
-    for (uint32_t sidx = blockIdx.x * 256 + threadIdx.x; sidx < top; sidx += gridDim.x * 256) {
-        if (sidx < ns) {  // the candidates this round tests
-            const uint32_t op = act[sidx / spec];
-            slot_op[sidx] = op;
-            slot_kappa[sidx] = (uint16_t)(kappa[op] + (sidx % spec) * (uint32_t)l);
-            slot_y[sidx] = use_pre ? 2u * ypos[sidx] + 1u : gen == 2u ? 2u * sidx : sidx;
-        }
-        if (sidx < ns_gen) {  // the rows this round generates
-            const uint32_t per = gen == 2u ? 2u : spec;
-            const uint32_t op = act[sidx / per];
-            gen_op[sidx] = op;
-            gen_kappa[sidx] = (uint16_t)(kappa[op] + (sidx % per) * (uint32_t)l);
-            if (gen_key) gen_key[sidx] = key_idx ? key_idx[op] : op;  // row of a per-key A_hat table
-        }
-    }
+    const uint32_t spec = m ? rule.spec(m, spec_max) : 1u;
+    make_slots_body(ctl, parity, m, spec, ctl->gen_par[parity ^ 1] /* not written here */, ns_cap, act, kappa, l, slot_op, slot_kappa, key_idx, gen_op,
+                    gen_kappa, gen_key, may_use_pre, may_gen2, ypos, slot_y, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, false);
 }
 
 // Speculative rounds, second half: one wave per unfinished op.  accept[] holds the verdict of stage 1 for each of the op's
@@ -537,6 +504,39 @@ __global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int
         } else if (exp_list) {
             exp_list[atomicAdd(&ctl->exp_cnt, 1u)] = op;  // finished in this round: its signature is complete (k_export_done)
         }
+    }
+}
+
+// The same for a SMALL call (at most 256 ops: ONE workgroup, so every count is the workgroup's own), with what would otherwise be two more
+// launches behind it: (i) the counts the host's end-of-call check reads -- the survivors and the call's statistics -- go to device-visible
+// host memory (host_ctl) instead of a copy of the control block behind the last round (a 4 us blit kernel and its gap on a 130 us call);
+// every round overwrites them, the host looks after the last one.  (ii) With next.on the round that follows is opened here as well
+// (make_slots_body for the other parity, on the list just built): no k_make_slots launch between two rounds of a small call.
+__global__ __launch_bounds__(256) void k_compact_small(CompactSmallArgs A) {
+    RoundCtl* const ctl = A.ctl;
+    const int parity = A.parity;
+    const uint32_t m = ctl->m;
+    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+        const uint32_t op = A.act_in[i];
+        if (!A.done[op]) {
+            const uint32_t j = atomicAdd(&ctl->cnt[parity ^ 1], 1u);
+            A.act_out[j] = op;
+            if (A.ypos_out) A.ypos_out[j] = i;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's list entries (and counts) have reached L2 before the barrier
+    __syncthreads();
+    const uint32_t left = __hip_atomic_load(&ctl->cnt[parity ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (A.host_ctl && threadIdx.x == 0) {
+        A.host_ctl->cnt[parity ^ 1] = left;
+        A.host_ctl->cnt[parity] = ctl->cnt[parity];
+        A.host_ctl->slots_total = ctl->slots_total;
+        A.host_ctl->ops_total = ctl->ops_total;
+    }
+    if (A.next_on) {
+        const uint32_t spec = left ? A.rule.spec(left, A.spec_max) : 1u;
+        make_slots_body(ctl, parity ^ 1, left, spec, ctl->gen_par[parity], A.ns_cap, A.act_out, A.kappa, A.l, A.slot_op, A.slot_kappa, A.key_idx, A.gen_op,
+                        A.gen_kappa, A.gen_key, 0, 0, A.ypos_out, A.slot_y, threadIdx.x, 256u, false);
     }
 }
 
@@ -628,6 +628,23 @@ __global__ __launch_bounds__(256) void k_sanitize_keys(const uint32_t* __restric
 // memset(dst, 0, bytes) as a kernel (any alignment): the captured pipelines consist of kernel nodes only -- memset and
 // memcpy nodes of a replayed hipGraph were observed to run out of order with the kernels around them (ROCm 7.2).
 __global__ __launch_bounds__(256) void k_zero(uint8_t* __restrict__ dst, size_t bytes) {
+    const size_t head = (size_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15);
+    const size_t h = head < bytes ? head : bytes;
+    const size_t n16 = (bytes - h) / 16;
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    int4* mid = reinterpret_cast<int4*>(dst + h);
+    for (size_t i = tid; i < n16; i += stride) mid[i] = make_int4(0, 0, 0, 0);
+    const size_t tail0 = h + n16 * 16;
+    if (tid < h) dst[tid] = 0;
+    if (tid < bytes - tail0) dst[tail0 + tid] = 0;
+}
+
+// k_zero behind the last planned round of a SMALL synchronous signing call, enqueued before the host has seen the outcome (its launch costs
+// the host ~10 us: better spent while the rounds still run than after them).  It clears only if no op is left unfinished -- the extra
+// rounds the host would add need rho'', kappa and the lists -- which every workgroup reads for itself.  (The control block may lie in the
+// span: a workgroup that finds it cleared already reads the same zero.)
+__global__ __launch_bounds__(256) void k_zero_if_done(const RoundCtl* __restrict__ ctl, int parity, uint8_t* __restrict__ dst, size_t bytes) {
+    if (__hip_atomic_load(&ctl->cnt[parity], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const size_t head = (size_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15);
     const size_t h = head < bytes ? head : bytes;
     const size_t n16 = (bytes - h) / 16;
@@ -947,6 +964,12 @@ int launch_compact(mldsa_ctx*, RoundCtl* ctl, int parity, const uint32_t* act_in
     return MLDSA_OK;
 }
 
+int launch_compact_small(mldsa_ctx*, const CompactSmallArgs& A, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(256), 0, s, A);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
 int launch_export_done(mldsa_ctx* ctx, RoundCtl* ctl, int round, const uint32_t* exp_list, const uint8_t* sigs, uint8_t* host, size_t sig_len,
                        size_t ops_hint, hipStream_t snap_stream, hipStream_t s) {
     (void)snap_stream;
@@ -992,6 +1015,13 @@ int launch_sanitize_keys(mldsa_ctx*, const uint32_t* key_idx, size_t n_keys, siz
 int launch_zero(mldsa_ctx* ctx, void* dst, size_t bytes, hipStream_t s) {
     if (bytes == 0) return MLDSA_OK;
     hipLaunchKernelGGL(k_zero, dim3(grid_for(ctx, bytes / 16 + 1, 256, 8)), dim3(256), 0, s, static_cast<uint8_t*>(dst), bytes);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_zero_if_done(mldsa_ctx* ctx, const RoundCtl* ctl, int parity, void* dst, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return MLDSA_OK;
+    hipLaunchKernelGGL(k_zero_if_done, dim3(grid_for(ctx, bytes / 16 + 1, 256, 8)), dim3(256), 0, s, ctl, parity, static_cast<uint8_t*>(dst), bytes);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -25,6 +25,7 @@
 // Workgroup b belongs to XCD b mod 8 (round-robin dispatch): the clusters are laid out so that all workgroups of an operation share
 // an XCD, i.e. the L2 that holds the A_hat rows they hand over.
 #include "ctx.h"
+#include "sign_slots_dev.h"
 #include "challenge_dev.h"
 #include "expand_coop_dev.h"
 #include "keccak_coop2.h"
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
     __shared__ uint32_t blk_lds[SMW * EA_COOP_BLK_DWORDS];
     __shared__ uint32_t row_lds[24];  // rnd | mu of the op (one op wave per workgroup at most)
     __shared__ uint32_t wave_cnt[SMW];
+    __shared__ uint32_t s_spec0;
     __shared__ int s_last;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -662,6 +664,21 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
         if (live) A.act0[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = i;
         uint32_t* cw = reinterpret_cast<uint32_t*>(A.ctl);
         for (uint32_t d = threadIdx.x; d < sizeof(RoundCtl) / 4; d += 64 * SMW) cw[d] = d == 0 ? total : 0u;  // cnt[0] is the first field
+        // ... and round 0 is opened right here (k_make_slots' work for parity 0 on the list just built; the rule's table is walked in the
+        // kernarg segment by one thread)
+        if (A.slots0) {
+            if (threadIdx.x == 0) {
+                uint32_t sp = 1;
+                while (total && sp < A.spec_max && sp < 64 &&
+                       total <= late_arg<uint32_t>((unsigned)(offsetof(SmallSignPrologueArgs, rule) + offsetof(SpecRule, thr)) + 4u * sp))
+                    sp++;
+                s_spec0 = sp;
+            }
+            wait_own_stores();  // the list and the cleared control block have reached L2 before any thread of the workgroup reads them
+            __syncthreads();
+            make_slots_body(A.ctl, 0, total, s_spec0, 0u, A.ns_cap, A.act0, A.kappa, A.l, A.slot_op, A.slot_kappa, A.key_idx ? A.kidx_out : nullptr,
+                            A.gen_op, A.gen_kappa, A.gen_key, 0, 0, nullptr, A.slot_y, threadIdx.x, 64u * SMW, true);
+        }
     }
 }
 

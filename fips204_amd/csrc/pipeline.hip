@@ -524,6 +524,8 @@ struct SignWs {
     uint16_t *kappa, *slot_kappa, *gen_kappa;
     uint32_t *act[2], *ypos[2], *slot_op, *gen_op, *gen_key, *slot_y, *kidx, *exp_list;
     RoundCtl *ctl;
+    uint32_t *small_ctr = nullptr;  // not a carve: this lane's set of arrival counters (ctx->d_small_ctr; set by sign_batch)
+    RoundCtl *host_ctl = nullptr;  // not a carve: device-visible host memory k_compact of a SMALL call reports its counts in (launch_compact); set by sign_batch
     size_t bytes = 0;
     uint8_t *base = nullptr;
     SignWs() = default;
@@ -711,32 +713,50 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
                               size_t ns_hint, const uint32_t *kidx, const int32_t *s1, const int32_t *s2, const int32_t *t0,
                               const int32_t *a_hat_keys, uint8_t *sg, hipStream_t s, bool oor_by_op, bool pre_in = false,
                               bool gen2 = false, uint8_t *export_sg = nullptr, hipStream_t exp_stream = nullptr,
-                              bool exp_pending = false) {
+                              bool exp_pending = false, bool slots_ready = false, bool slots_next = false) {
+    // slots_ready / slots_next (small calls, w.host_ctl set): this round was opened by the previous round's k_compact_small already / this
+    // round's k_compact_small opens the next one
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
+    const bool small_compact = w.host_ctl != nullptr && !export_sg;
+    auto compact = [&]() -> int {
+        if (small_compact) {
+            CompactSmallArgs C{};
+            C.ctl = w.ctl; C.parity = par; C.act_in = w.act[par]; C.done = w.done; C.act_out = w.act[par ^ 1]; C.ypos_out = w.ypos[par ^ 1];
+            C.host_ctl = w.host_ctl; C.next_on = slots_next ? 1 : 0;
+            C.rule = pl.rule; C.spec_max = pl.spec_max; C.ns_cap = (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu); C.kappa = w.kappa; C.l = p->l;
+            C.slot_op = w.slot_op; C.slot_kappa = w.slot_kappa; C.key_idx = kidx; C.gen_op = w.gen_op; C.gen_kappa = w.gen_kappa;
+            C.gen_key = own_a ? nullptr : w.gen_key; C.slot_y = w.slot_y;
+            STAGE("compact", launch_compact_small(ctx, C, s));
+        } else {
+            STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1], export_sg ? w.exp_list : nullptr));
+        }
+        return MLDSA_OK;
+    };
     const uint32_t *ns_gen_dev = &w.ctl->ns_gen;  // rows generated this round (the tail kernels read ctl->ns themselves)
     const size_t gen_hint = gen2 ? 2 * ns_hint : ns_hint;  // grids of the generating kernels (a round that tests ready rows finds ns_gen = 0)
-    STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.rule, pl.spec_max, (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu), w.act[par], w.kappa, p->l, w.slot_op,
-                                          w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
-                                          pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
+    if (!(slots_ready && small_compact))
+        STAGE("make_slots", launch_make_slots(ctx, w.ctl, par, pl.rule, pl.spec_max, (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu), w.act[par], w.kappa, p->l, w.slot_op,
+                                              w.slot_kappa, kidx, w.gen_op, w.gen_kappa, own_a ? nullptr : w.gen_key, gen_hint, s,
+                                              pre_in ? 1 : 0, gen2 ? 1 : 0, w.ypos[par], w.slot_y));
     // A SMALL round (rows * L polynomials within the cooperative ExpandMask's range, one candidate per slot generated here): ExpandMask,
     // sign_w, the c~ hash, SampleInBall and NTT(c) as ONE launch (kernels_small.hip k_sign_front_small); the same rows come out.
     // (The launch covers every row the workspace can hold -- rows past the round's count leave at once -- so a round that turns out larger
     //  than its plan is still complete; the PLAN decides whether the round is small enough for the cooperative form to pay.)
     const size_t rows_cap = std::min<size_t>(pl.ns_max, 0xFFFFFFFFu);
-    if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && ctx->small_sign_front && !gen2 && !pre_in && !export_sg && rows_cap <= SMALL_CTR_ENTRIES &&
+    if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && ctx->small_sign_front && !gen2 && !pre_in && !export_sg && w.small_ctr && rows_cap <= SMALL_CTR_ENTRIES &&
         gen_hint * (size_t)p->l <= ctx->coop_mask_max) {
         SmallSignFrontArgs A{};
         A.ns_gen = ns_gen_dev; A.rho_pp = w.rho_pp; A.gen_kappa = w.gen_kappa; A.gen_op = w.gen_op; A.a_idx = own_a ? w.gen_op : w.gen_key;
         A.a_hat = own_a ? w.a_hat : a_hat_keys; A.mu = w.rnd_mu + 32; A.y = w.y; A.w = w.w; A.w1 = w.w1; A.ctilde = w.ctilde; A.c8 = w.c8; A.c_hat = w.c;
-        A.wrisk = w.wrisk; A.yrisk = w.yrisk; A.ctr = ctx->d_small_ctr; A.fwd_tab = ctx->d_fwd_tw; A.inv_tab = ctx->d_inv_tw;
+        A.wrisk = w.wrisk; A.yrisk = w.yrisk; A.ctr = w.small_ctr; A.fwd_tab = ctx->d_fwd_tw; A.inv_tab = ctx->d_inv_tw;
         A.w_risk_bound = p->gamma2 - 2 * p->beta; A.y_risk_bound = p->gamma1 - 2 * p->beta; A.tau = p->tau; A.rows_cap = (uint32_t)rows_cap;
         STAGE("sign_front_small", launch_sign_front_small(ctx, p, A, own_a, s));
         STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
                                             ns_hint, s, w.wrisk, w.yrisk, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
         STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, w.y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
                                         m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
-        STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1], nullptr));
+        TRY(compact());
         return MLDSA_OK;
     }
     // 11: y <- ExpandMask(rho'', kappa)                               :215
@@ -769,8 +789,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     // for each op's first surviving candidate, bytes straight into the op's signature
     STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
                                     m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
-    STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1],
-                                    export_sg ? w.exp_list : nullptr));
+    TRY(compact());
     if (export_sg) TRY(launch_export_snap(ctx, w.ctl, round, s));  // how far the completion-order list has grown: this round's range
     return MLDSA_OK;
 }
@@ -831,7 +850,11 @@ void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
 // side_ok: the lane-per-op kernels of the prologue (mu, rho'', the key-range check, the first active list: latency-bound, one wave
 // per SIMD or less) may run on the context's helper stream underneath ExpandA, like the verifier's (one lane only: the helper
 // stream is the second lane's)
-int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignArgs &a, hipStream_t s, bool side_ok) {
+// slots0_plan / slots0_done (optional): when the prologue is the ONE launch of a small call, its last workgroup opens round 0 as well
+// (k_make_slots' work, from this plan's rule) and *slots0_done says so
+int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignArgs &a, hipStream_t s, bool side_ok,
+                  const SignPlan *slots0_plan = nullptr, bool *slots0_done = nullptr) {
+    if (slots0_done) *slots0_done = false;
     hipStream_t const main_stream = s;
     const bool own_a = a.a_hat_keys == nullptr;
     const size_t o = a.offset, n = a.n;
@@ -870,7 +893,14 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
         A.a_ws = w.a_hat; A.kidx_out = w.kidx; A.rnd_mu = w.rnd_mu; A.rho_pp = w.rho_pp; A.bad_op = w.bad_op; A.done = w.done; A.status = st;
         A.kappa = w.kappa; A.act0 = w.act[0]; A.ctl = w.ctl; A.sigs = c.sg; A.sig_len = (size_t)p->sig_len; A.key_oor = w.key_oor;
         A.units = (uint32_t)(a.key_idx ? (by_op ? n : a.n_keys) : n); A.units_by_op = by_op ? 1 : 0; A.eta = p->eta;
-        A.ctr = ctx->d_small_ctr; A.inv_tab = ctx->d_inv_tw;
+        A.ctr = w.small_ctr; A.inv_tab = ctx->d_inv_tw;
+        if (slots0_plan && slots0_done) {
+            const SignPlan &pl = *slots0_plan;
+            A.slots0 = 1; A.spec_max = pl.spec_max; A.ns_cap = (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu); A.l = p->l; A.rule = pl.rule;
+            A.slot_op = w.slot_op; A.slot_kappa = w.slot_kappa; A.gen_op = w.gen_op; A.gen_kappa = w.gen_kappa; A.gen_key = own_a ? nullptr : w.gen_key;
+            A.slot_y = w.slot_y;
+            *slots0_done = true;
+        }
         STAGE("sign_prologue_small", launch_sign_prologue_small(ctx, p, A, !own_a, s));
         return MLDSA_OK;
     }
@@ -932,9 +962,13 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
         MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
         MLDSA_HIP_CHECK(hipStreamWaitEvent(lanes[1].st, ctx->fork_ev, 0));
     }
-    for (int i = 0; i < n_lanes; i++) TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st, n_lanes == 1));
-    // 10: while (z, h) = bottom                                            ml_dsa.rs:212
     const int rounds = (int)pl.m_hint.size();
+    bool slots0[2] = {false, false};  // round 0 opened by the (small) prologue's own launch
+    for (int i = 0; i < n_lanes; i++) {
+        const bool ask = rounds > 0 && lanes[i].w.host_ctl != nullptr && lanes[i].a.export_sigs == nullptr;
+        TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st, n_lanes == 1, ask ? &pl : nullptr, ask ? &slots0[i] : nullptr));
+    }
+    // 10: while (z, h) = bottom                                            ml_dsa.rs:212
     // Two candidates per op generated at once (k_make_slots): where the plan expects two one-candidate rounds in a row, on a batch
     // large enough for sign_w to be bound by re-reading A_hat.  Rounds pair up: (generate two, test the first) then (test the second).
     const bool look = lookahead_on(ctx, p) && lanes[0].a.n >= LOOKAHEAD_MIN_OPS;
@@ -949,7 +983,8 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
             const ChunkKeys c = chunk_keys(p, L.w, L.a);
             // the plan is for a full slice; a short last one only makes its grids generous
             TRY(enqueue_sign_round(ctx, p, L.w, pl, round, std::min(pl.m_hint[round], L.a.n), pl.ns_hint[round], c.kidx, c.s1k, c.s2k, c.t0k,
-                                   c.ak, c.sg, L.st, oor_by_op(L.a), gen2_prev, gen2, exporting ? c.xsg : nullptr, exp_stream, round > 0));
+                                   c.ak, c.sg, L.st, oor_by_op(L.a), gen2_prev, gen2, exporting ? c.xsg : nullptr, exp_stream, round > 0,
+                                   /*slots_ready=*/round > 0 || slots0[i], /*slots_next=*/round + 1 < rounds));
         }
         gen2_prev = gen2;
     }
@@ -982,9 +1017,31 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
 int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl, SignLane *lanes, int n_lanes, hipStream_t s) {
     int round = (int)pl.m_hint.size();
     for (int i = 0; i < n_lanes; i++)
-        MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], lanes[i].w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
-    for (;;) {
-        MLDSA_HIP_CHECK(hipStreamSynchronize(s));
+        if (!lanes[i].w.host_ctl)  // (a small call's last k_compact has written what is read below to h_ctl itself)
+            MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], lanes[i].w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
+    // A small call (one lane, its counts arrive in h_ctl by themselves): the clearing of its secrets is enqueued HERE, behind an event the
+    // host waits for instead of the stream -- the launch costs the host ~10 us, which it has while the rounds run and would otherwise spend
+    // after them, with the caller waiting (timeline of a one-op call: 22 us between the end of the wait and the return).  The kernel clears
+    // only if nothing is left unfinished (k_zero_if_done); otherwise the extra rounds below and sign_batch's background clearing follow.
+    ctx->sign_wiped_inline = false;
+    bool inline_wipe = false;
+    if (n_lanes == 1 && lanes[0].w.host_ctl && !lanes[0].a.export_sigs && round > 0 && hipEventRecord(ctx->small_done_ev, s) == hipSuccess) {
+        uint8_t *secrets = reinterpret_cast<uint8_t *>(lanes[0].w.y);
+        MLDSA_WIPE(launch_zero_if_done(ctx, lanes[0].w.ctl, round & 1, secrets, (size_t)(lanes[0].w.base + lanes[0].w.bytes - secrets), s));
+        inline_wipe = hipEventRecord(ctx->zero_ev, s) == hipSuccess;
+        if (!inline_wipe) (void)hipGetLastError();
+    } else {
+        (void)hipGetLastError();
+    }
+    for (bool first = true;; first = false) {
+        if (first && inline_wipe) {
+            if (hipEventSynchronize(ctx->small_done_ev) != hipSuccess) {
+                (void)hipGetLastError();
+                MLDSA_HIP_CHECK(hipStreamSynchronize(s));
+            }
+        } else {
+            MLDSA_HIP_CHECK(hipStreamSynchronize(s));
+        }
         bool left = false;
         for (int i = 0; i < n_lanes; i++) {
             ctx->last_sign_slots += ctx->h_ctl[i].slots_total;
@@ -994,7 +1051,10 @@ int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl,
             }
             left |= ctx->h_ctl[i].cnt[round & 1] != 0;
         }
-        if (!left) break;
+        if (!left) {
+            ctx->sign_wiped_inline = first && inline_wipe;  // (k_zero_if_done saw the same zero: the clearing is on its way)
+            break;
+        }
         for (int i = 0; i < n_lanes; i++) {
             const SignLane &L = lanes[i];
             const ChunkKeys c = chunk_keys(p, L.w, L.a);
@@ -1004,13 +1064,13 @@ int sign_chunk_finish(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl,
                 const bool exporting = L.a.export_sigs != nullptr && n_lanes == 1;
                 TRY(enqueue_sign_round(ctx, p, L.w, pl, round + e, 64, std::min<size_t>(pl.ns_max, 2048), c.kidx, c.s1k, c.s2k, c.t0k, c.ak,
                                        c.sg, s, oor_by_op(L.a), false, false, exporting ? c.xsg : nullptr,
-                                       exporting ? parallel_stream(ctx, s) : nullptr, false));
+                                       exporting ? parallel_stream(ctx, s) : nullptr, false, /*slots_ready=*/e == 1, /*slots_next=*/e == 0));
                 if (exporting) {  // an extra round exports its own finishers right away
                     TRY(enqueue_export(ctx, p, L.w, round + e, 64, c.sg, c.xsg, s, parallel_stream(ctx, s)));
                     MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->exp_join_ev, 0));
                 }
             }
-            MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], L.w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
+            if (!L.w.host_ctl) MLDSA_HIP_CHECK(hipMemcpyAsync(&ctx->h_ctl[i], L.w.ctl, sizeof(RoundCtl), hipMemcpyDeviceToHost, s));
         }
         round += 2;
     }
@@ -1071,6 +1131,10 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     size_t ws_off = 0;
     for (int i = 0; i < n_lanes; i++) {
         lanes[i].w = SignWs(static_cast<uint8_t *>(ctx->ws) + ws_off, p, per_lane, pl.ns_max, own_a, lookahead_on(ctx, p));
+        static_assert(sizeof(lanes) / sizeof(lanes[0]) <= SMALL_CTR_SETS, "one set of arrival counters per lane");
+        lanes[i].w.small_ctr = ctx->d_small_ctr + (size_t)i * SMALL_CTR_ENTRIES;
+        // a small call's k_compact (one workgroup: at most 256 unfinished ops) reports to the host itself (see launch_compact)
+        if (per_lane <= 256 && ctx->h_ctl_dev && !pl.m_hint.empty()) lanes[i].w.host_ctl = ctx->h_ctl_dev + i;
         ws_off += lanes[i].w.bytes;
     }
     if (ctx->ws_bytes < ws_off) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");
@@ -1132,7 +1196,14 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
             uint8_t *secrets = reinterpret_cast<uint8_t *>(lanes[i].w.y);
             spans[i] = {secrets, (size_t)(lanes[i].w.base + lanes[i].w.bytes - secrets)};
         }
-        if (clear_in_background(ctx, s, nullptr, spans, n_lanes)) {
+        if (ctx->sign_wiped_inline) {  // a small call: sign_chunk_finish enqueued the clearing behind the last round, zero_ev follows it on `s`
+            ctx->sign_wiped_inline = false;
+            ctx->zero_stream = s;
+            ctx->zero_pending = true;
+            ctx->zero_head_valid = false;
+            ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));
+            ctx->zero_hi = ws_off;
+        } else if (clear_in_background(ctx, s, nullptr, spans, n_lanes)) {
             ctx->zero_pending = true;
             ctx->zero_head_valid = false;
             ctx->zero_lo = (size_t)(reinterpret_cast<uint8_t *>(lanes[0].w.y) - static_cast<uint8_t *>(ctx->ws));

@@ -147,11 +147,12 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                     (every op owns a cluster of workgroups for ExpandA, mu and SampleInBall; the last one to finish carries on with
                                     the arithmetic, the c_tilde hash and the verdict).  Key generation: ONE launch (one wave per polynomial of A_hat,
                                     s1, s2; the last workgroup does the arithmetic, the packing and tr); at most 256 keys whatever the value.
-                                    Signing: the prologue is one launch (calls of at most 256 ops) and so is the first half of every round planned
-                                    at <= 819 candidate rows (ExpandMask, w = A y, the c_tilde hash, SampleInBall, NTT(c)).  Default 256 (measured
+                                    Signing: the prologue is one launch (calls of at most 256 ops; it opens round 0 as well, and one launch between
+                                    rounds compacts the active list and opens the next) and so is the first half of every round planned at <= 819
+                                    candidate rows (ExpandMask, w = A y, the c_tilde hash, SampleInBall, NTT(c)).  Default 256 (measured
                                     crossovers against the batch pipeline: ~350 verifications, ~400 keys); 0 = always the batch pipeline; at most
                                     1024.  Needs MLDSA_OPT_COOP_HASH = 1.  Results are bit-identical either way; one ML-DSA-65 op: verify 50 instead
-                                    of 105 us, key generation 73 instead of 166, signing 133 instead of 227. */
+                                    of 105 us, key generation 73 instead of 166, signing 127 instead of 227. */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,

@@ -167,6 +167,41 @@ def test_async_plan_exponent_option(hp, sets):
         hp.set_option(9, 0)
 
 
+# ------------------------------------------------------------------------------ two lanes in their small rounds
+def test_two_signing_lanes_in_small_rounds_side_by_side(hp, sets):
+    """Two lanes (MLDSA_OPT_SIGN_LANES = 2, calls of >= 8 192 ops) run their rounds side by side on two streams.  With one candidate
+    per op the late rounds of BOTH lanes are small enough for the single-launch round front (k_sign_front_small), whose workgroups hand
+    over through arrival counters: every lane has its own (found by the soak, seed 5151: with one array for both, a row's last workgroup
+    could be named early and read half-written masks -- a different, later candidate was signed about once in a thousand calls).  The same
+    batch 60 times: every signature every time, a sample against the oracle (ml_dsa.rs:212-330: the FIRST accepted candidate)."""
+    m = sets[65]  # (l = 5: a row's masks come from TWO workgroups -- ML-DSA-44's four fit one, which hands over to nobody)
+    n = 8200
+    b = make_batch(m, n, 3, b"lanes2small")
+    want = oracle_sigs(65, b, range(0, n, 401))
+    sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    old = {o: hp.get_option(o) for o in (1, 3, 7)}
+    hp.set_option(1, 0)
+    hp.set_option(3, 1)  # MLDSA_OPT_SPEC_MAX: one candidate per op, ~35 rounds, most of them small
+    hp.set_option(7, 2)  # MLDSA_OPT_SIGN_LANES
+    try:
+        first = None
+        for it in range(60):
+            sig.zero_()
+            m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st)
+            got = host(sig).copy()
+            assert int(host(st).min()) == 0 and int(host(st).max()) == 0
+            if first is None:
+                first = got
+                for g, w in zip(first[::401], want):
+                    assert g.tobytes() == w
+            else:
+                assert np.array_equal(got, first), f"call {it}: ops {np.nonzero((got != first).any(axis=1))[0][:8]} differ"
+    finally:
+        for o, v in old.items():
+            hp.set_option(o, v)
+
+
 # ------------------------------------------------------------------------------ soak (tests/integration.rs:22-53 `forever`)
 def test_soak_random_shapes_knobs_and_modes_against_the_oracle(hp, sets):
     """A seeded, time-bounded version of the reference's `forever` loop: random parameter set, batch size (1 ... 70 000,

@@ -103,6 +103,10 @@ done; done
 for f in gpurun_out/small_${R}pipe/unprofiled_*.txt; do cat "$f"; done > "$OUT/small_call_unprofiled_wall_batch_pipeline.txt"
 note small_call_unprofiled_wall_batch_pipeline.txt "MLDSA_SMALL_FUSED=0 python3 tools/latency_probe.py <op> <n> 200"
 ./tools/batcher_bench_bin 65 1.5 0 1,8,64 1 > "$OUT/batcher_single_op_callers.json" 2>> "$ERR"; note batcher_single_op_callers.json "./tools/batcher_bench_bin 65 1.5 0 1,8,64 1"
+# ---- the host's side of a one-op signing call (HIP API calls beside the kernels)
+( cd /tmp && CALL_GAP_US=400 rocprofv3 --hip-trace --kernel-trace --output-format csv -d "$OUT/hat" -o t -- python3 "$OLDPWD/tools/latency_probe.py" sign 1 40 > /dev/null 2>&1 )
+python3 tools/host_api_timeline.py "$OUT/hat" > "$OUT/host_api_sign_n1.txt" 2>> "$ERR"; rm -rf "$OUT/hat"
+note host_api_sign_n1.txt "cd /tmp && CALL_GAP_US=400 rocprofv3 --hip-trace --kernel-trace --output-format csv -- python3 tools/latency_probe.py sign 1 40; python3 tools/host_api_timeline.py"
 # ---- soaks (SOAK=0 skips them): the seeded randomised soak of tests/test_gpu_sign_schedule.py, once kept on the small-call kernels, once over every size
 if [ "${SOAK:-1}" != 0 ]; then
   { MLDSA_SOAK_SECONDS=${SOAK_SMALL_S:-240} MLDSA_SOAK_SEED=77 MLDSA_SOAK_MAX_N=400 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s -q 2>&1 | grep -E "^soak:|passed|failed|Error" ;
