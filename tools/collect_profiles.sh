@@ -26,6 +26,8 @@ note() { python3 -c 'import json,sys; print(json.dumps({"file": sys.argv[1], "co
 # line FILE COMMAND...: run COMMAND, keep the last JSON line of its stdout as FILE
 line() { f=$1; shift; "$@" 2>> "$ERR" | grep "^{" | tail -1 > "$OUT/$f"; note "$f" "$*"; }
 
+# ---- the GPU suite on this box, on this library
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -2 > "$OUT/gpu_suite.txt"; note gpu_suite.txt "python -m pytest tests -m gpu -q  (summary line)"
 # ---- bench lines
 line bench_default.json python bench.py
 cp bench_extras.json "$OUT/bench_default_extras.json" 2>/dev/null && note bench_default_extras.json "python bench.py  (the side file named in the line)"
