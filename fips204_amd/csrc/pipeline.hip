@@ -593,16 +593,32 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
     const size_t tgt = std::min<size_t>((size_t)std::min(ctx->opt_spec_target, ctx->spec_target_cap), std::max<size_t>(n * pl.spec_max, 1));
     pl.spec_target = (uint32_t)tgt;
     // candidates per speculative round (>= the threshold above): rows = what such a round generates
-    const size_t rows = std::max(tgt, std::min<size_t>((size_t)ctx->opt_spec_rows, std::max<size_t>(n * pl.spec_max, 1)));
+    size_t rows = std::max(tgt, std::min<size_t>((size_t)ctx->opt_spec_rows, std::max<size_t>(n * pl.spec_max, 1)));
+    double alpha = (double)ctx->opt_spec_alpha / 100.0;
+    // A SMALL call (the ones whose prologue is one launch): a round of up to coop_mask_max / l candidate rows runs its first half as ONE
+    // launch on the cooperative sponges (k_sign_front_small, ~45 us whatever the rows), a larger one on the five lane-per-state kernels
+    // (~115 us for the 2 048 rows that 64 ops x 32 candidates make).  So such a call speculates only as far as the single launch reaches:
+    // floor(rows_small / m) candidates per op -- 25 for 32 ML-DSA-65 ops (0.4 % of them need a second round) instead of 32 -- as long as
+    // that leaves every op of round 0 a dozen candidates (ctx->small_sign_spec: with fewer, the extra rounds cost more than the five
+    // kernels; EXPERIMENTS.md).  The signatures do not depend on it (the FIRST accepted candidate, ml_dsa.rs:212-330).
+    const mldsa_params *pp = params_of(set);
+    const size_t rows_small = (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && ctx->small_sign_front && ctx->small_sign_spec && pp) ? ctx->coop_mask_max / (size_t)pp->l : 0;
+    const bool small_rule = rows_small >= n * (size_t)std::max(1L, ctx->small_sign_spec) && n <= ctx->small_sign_max && n <= 256 && rows > rows_small;
+    size_t tgt_eff = tgt;
+    if (small_rule) {
+        rows = rows_small;
+        tgt_eff = std::min(tgt, rows_small);
+        alpha = 1.0;  // (floor: m * spec(m) never exceeds rows_small)
+    }
+    pl.spec_target = (uint32_t)tgt_eff;
     pl.spec_rows = (uint32_t)rows;
     pl.ns_max = std::max(n, rows);
     // candidates per op for m unfinished ops: 1 while m * 2 > tgt, then round((rows / m) ^ alpha), at most spec_max.  alpha = 1
     // fills every speculative round to `rows` candidates; alpha < 1 gives mid-size rounds fewer (more, smaller rounds: fewer
     // wasted candidates and ExpandMask launches that fit whole layers, against one more round's fixed cost)
     {
-        const double alpha = (double)ctx->opt_spec_alpha / 100.0;
         auto spec_of = [&](double m) -> uint32_t {
-            if (m < 1 || m * 2 > (double)tgt) return 1;
+            if (m < 1 || m * 2 > (double)tgt_eff) return 1;
             const double s = std::floor(std::pow((double)rows / m, alpha) + (alpha < 1.0 ? 0.5 : 0.0));
             return (uint32_t)std::max(1.0, std::min((double)pl.spec_max, s));
         };

@@ -3,7 +3,7 @@
 beside the kernels (--kernel-trace).  usage (on the GPU box):
     cd /tmp && CALL_GAP_US=400 rocprofv3 --hip-trace --kernel-trace --output-format csv -d DIR -o t -- python3 $REPO/tools/latency_probe.py sign 1 40
     python3 tools/host_api_timeline.py DIR > timeline.txt
-Picks a call from the middle of the run (calls are separated by the probe's 400 us pause)."""
+Picks the call of median device span (calls are separated by the probe's 400 us pause)."""
 import csv
 import glob
 import sys
@@ -23,7 +23,8 @@ def main():
         if a - groups[-1][-1][1] > 200_000:
             groups.append([])
         groups[-1].append((a, b))
-    g = groups[len(groups) * 2 // 3]
+    groups = [g for g in groups[len(groups) // 4:] if g]  # (past the warm-up calls)
+    g = sorted(groups, key=lambda g: g[-1][1] - g[0][0])[len(groups) // 2]  # the call of median device span
     t0, t1 = g[0][0] - 120_000, g[-1][1] + 60_000
     first = None
     for a, b, kind, name in ev:

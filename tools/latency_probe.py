@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the time of a SMALL call go?  tools/latency_probe.py <verify|sign|keygen> <n_ops> [calls]
-Device-resident ML-DSA-65 call of n_ops ops, repeated with a stream synchronisation after each: prints the median wall time per call.
+Device-resident ML-DSA-65 (environment SET = 44 / 65 / 87) call of n_ops ops, repeated with a stream synchronisation after each: prints the median wall time per call.
 Run it under `rocprofv3 --kernel-trace --stats` to get the kernels' own durations next to it (the difference is launch + wait)."""
 import sys
 import time
@@ -17,7 +17,7 @@ calls = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 hp = HotPath(0)
 hp.set_option(1, int(__import__("os").environ.get("GRAPHS", "0")))
 hp.set_option(12, int(__import__("os").environ.get("COOP", "1")))  # MLDSA_OPT_COOP_HASH
-wl = bench.WholeOp(hp, 65, "verify", max(n, 64), 0)
+wl = bench.WholeOp(hp, int(__import__("os").environ.get("SET", "65")), "verify", max(n, 64), 0)
 ml = wl.ml
 xi = torch.randint(0, 256, (max(n, 64), 32), dtype=torch.uint8, device="cuda")
 pk = torch.empty((max(n, 64), ml.PK_LEN), dtype=torch.uint8, device="cuda")
