@@ -253,7 +253,8 @@ def test_acvp_keygen_one_key_per_call(env, acvp_keygen):
 @pytest.mark.parametrize("pset", [44, 65, 87])
 def test_sign_fused_prologue_and_round_front_equal_pipeline_equal_oracle(env, pset):
     """sign_internal (src/ml_dsa.rs:153-337) for small calls: the prologue as one launch (k_sign_prologue_small, calls of <= 256 ops) and
-    the first half of a round as one launch (k_sign_front_small, rounds of <= 819 candidate rows = calls of <= 25 ops).  Signatures of
+    the first half of a round as one launch (k_sign_front_small, rounds planned at <= 819 candidate rows), with the bookkeeping between
+    rounds folded in (round 0 opened by the prologue, k_compact_small, k_zero_if_done) and the small calls' own speculation rule.  Signatures of
     the fused paths = the batch pipeline's (MLDSA_OPT_SMALL_FUSED = 0) = the oracle's, byte for byte, at call sizes either side of
     both limits, for the three modes, with refused ops (ctx of 256 bytes, key index out of range, a malformed offset pair) in the
     batch, with A_hat kept by the caller (mldsa_sign_cached_a), and no secret left in the workspace afterwards."""
@@ -305,6 +306,51 @@ def test_sign_fused_prologue_and_round_front_equal_pipeline_equal_oracle(env, ps
             good = [i for i in range(n) if len(ctxs[i]) <= 255 and kidx_h[i] < nk]
             ver = m.verify(pks, [msgs[i] for i in good], torch.from_numpy(sig[good]).cuda(), ctxs=[ctxs[i] for i in good], key_idx=kidx_h[good].astype(np.uint32), mode=mode)
             assert ver.all(), (n, mode)
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_small_signing_calls_whose_plan_leaves_ops_unfinished(env, pset):
+    """A small synchronous call enqueues the clearing of its secrets BEFORE the host has looked at the outcome (k_zero_if_done, behind
+    the event the host waits for).  With one planned round of one candidate per op most ops are still unfinished when the host
+    looks: the kernel must have left rho'', kappa and the lists alone, the extra rounds (opened by k_make_slots launches again, then by
+    k_compact_small) finish every op, the signatures are the oracle's, and nothing secret stays behind afterwards.  The asynchronous
+    call (no host wait: MLDSA_ERR_AGAIN for what is left) and the planned-rounds call agree op by op."""
+    hp, sets = env
+    m = sets[pset]
+    rng = np.random.default_rng(900 + pset)
+    nk = 2
+    xi = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(nk)]
+    pk, sk = m.keygen_from_seed(xi)
+    sks = m.private_keys_from_bytes(sk)
+    sk_o = [orc.keygen_from_seed(pset, x)[1] for x in xi]
+    old = {o: hp.get_option(o) for o in (3, 6)}
+    try:
+        for n in (1, 5, 40, 256):
+            msgs = [rng.integers(0, 256, 33, dtype=np.uint8).tobytes() for _ in range(n)]
+            rnd = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(n)]
+            kidx = rng.integers(0, nk, n).astype(np.uint32)
+            hp.set_option(3, old[3]); hp.set_option(6, old[6])
+            want = host_bytes(m.try_sign_with_seed(sks, msgs, rnd, key_idx=kidx))
+            s0 = hp.stats()["sign_extra_rounds"]
+            hp.set_option(3, 1)   # MLDSA_OPT_SPEC_MAX: one candidate per op
+            hp.set_option(6, 1)   # MLDSA_OPT_SIGN_ROUNDS: one planned round
+            for rep in range(3):
+                got = host_bytes(m.try_sign_with_seed(sks, msgs, rnd, key_idx=kidx))
+                assert np.array_equal(got, want), (pset, n, rep)
+                scanned, nonzero = hp.secret_residue()
+                assert scanned > 0 and nonzero == 0, (pset, n, nonzero)
+            if n >= 5:
+                assert hp.stats()["sign_extra_rounds"] > s0, (pset, n)   # (one op may well be accepted at once)
+            for i in range(min(n, 4)):
+                assert want[i].tobytes() == orc.sign_internal(pset, sk_o[int(kidx[i])], msgs[i], rnd[i], mode=0), (pset, n, i)
+    finally:
+        for o, v in old.items():
+            hp.set_option(o, v)
+
+
+def host_bytes(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
 
 
 def test_acvp_siggen_one_op_per_call(env, acvp_siggen):

@@ -49,7 +49,8 @@ def test_the_kernels_design_names_have_rows():
     stats = [n for n in man["files"] if "kernel_stats" in n and n.endswith(".csv")]
     text = "".join(open(os.path.join(ROOT, "profiles", n)).read() for n in stats)
     for k in ("k_expand_a<", "k_verify_main<", "k_shake256_2<", "k_mu", "k_sample_in_ball<", "k_verify_arith<", "k_expand_mask<", "k_sign_tail<", "k_resolve<",
-              "k_verify_small<", "k_keygen_small<", "k_sign_prologue_small<", "k_sign_front_small<", "k_expand_a_coop<", "k_expand_mask_coop<", "k_expand_s_coop<", "k_shake256_2_coop<", "k_mu_coop", "k_sample_in_ball_coop<"):
+              "k_verify_small<", "k_keygen_small<", "k_sign_prologue_small<", "k_sign_front_small<", "k_expand_a_coop<", "k_expand_mask_coop<", "k_expand_s_coop<", "k_shake256_2_coop<", "k_mu_coop", "k_sample_in_ball_coop<",
+              "k_compact_small", "k_zero_if_done", "k_make_slots", "k_compact("):
         assert k in text, k
 
 
