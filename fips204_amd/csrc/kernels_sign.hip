@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int
 // The same for a SMALL call (at most 256 ops: ONE workgroup, so every count is the workgroup's own), with what would otherwise be two more
 // launches behind it: (i) the counts the host's end-of-call check reads -- the survivors and the call's statistics -- go to device-visible
 // host memory (host_ctl) instead of a copy of the control block behind the last round (a 4 us blit kernel and its gap on a 130 us call);
-// every round overwrites them, the host looks after the last one.  (ii) With next.on the round that follows is opened here as well
+// every round overwrites them, the host looks after the last one.  (ii) With next_on the round that follows is opened here as well
 // (make_slots_body for the other parity, on the list just built): no k_make_slots launch between two rounds of a small call.
 __global__ __launch_bounds__(256) void k_compact_small(CompactSmallArgs A) {
     RoundCtl* const ctl = A.ctl;

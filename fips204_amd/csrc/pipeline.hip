@@ -584,7 +584,7 @@ struct SignPlan {
     std::vector<int> one_cand;            // per round: the plan expects one candidate per op (the device decides for itself)
 };
 
-SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, double plan_stop = 0.0) {
+static SignPlan plan_sign_compute(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, double plan_stop) {
     SignPlan pl;
     pl.spec_max = (uint32_t)ctx->opt_spec_max;
     // a small batch cannot fill the target however many candidates each op gets: cap it so that the
@@ -682,6 +682,38 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
         pl.one_cand.resize((size_t)ctx->opt_sign_rounds);
     }
     return pl;
+}
+
+// The plan of a call shape is asked for twice per call (the workspace size, then the call itself) and costs up to ~400 pow() -- 10 ... 15 us
+// for a 64 ... 256-op call, before its first launch.  A service repeats its shapes: the last few plans are kept per thread, keyed by
+// everything plan_sign_compute reads.
+SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, double plan_stop = 0.0) {
+    struct Key {
+        long v[16];
+        double d[2];
+    };
+    struct Entry {
+        Key key;
+        SignPlan pl;
+        bool valid = false;
+    };
+    Key k;
+    memset(&k, 0, sizeof(k));
+    k.v[0] = set; k.v[1] = (long)n; k.v[2] = async_mode ? 1 : 0; k.v[3] = ctx->opt_spec_max; k.v[4] = ctx->opt_spec_target; k.v[5] = ctx->spec_target_cap;
+    k.v[6] = ctx->opt_spec_rows; k.v[7] = ctx->opt_spec_alpha; k.v[8] = ctx->opt_coop_hash; k.v[9] = ctx->opt_small_fused; k.v[10] = ctx->small_sign_front;
+    k.v[11] = ctx->small_sign_spec; k.v[12] = (long)ctx->coop_mask_max; k.v[13] = (long)ctx->small_sign_max; k.v[14] = ctx->opt_sign_rounds;
+    k.d[0] = plan_stop; k.d[1] = ctx->async_stop;
+    constexpr int SLOTS = 4;
+    thread_local Entry cache[SLOTS];
+    thread_local int next = 0;
+    for (int i = 0; i < SLOTS; i++)
+        if (cache[i].valid && memcmp(&cache[i].key, &k, sizeof(k)) == 0) return cache[i].pl;
+    Entry &e = cache[next];
+    next = (next + 1) % SLOTS;
+    e.key = k;
+    e.pl = plan_sign_compute(ctx, set, n, async_mode, plan_stop);
+    e.valid = true;
+    return e.pl;
 }
 }  // namespace
 
