@@ -215,7 +215,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
     // A SMALL call is all latency: it runs as ONE launch (kernels_small.hip: per op a cluster of workgroups for ExpandA | mu | SampleInBall,
     // the last one to finish carries on with the arithmetic, the c~ hash and the verdict) instead of the six launches on three
     // streams below.  Same device code, same workspace rows, same verdicts (MLDSA_OPT_SMALL_FUSED: the largest such call; 0 = never).
-    if (!wire && ctx->opt_coop_hash && n_ops <= (size_t)ctx->opt_small_fused && n_ops <= SMALL_FUSED_MAX && n_ops <= chunk) {
+    if (!wire && ctx->opt_coop_hash && n_ops <= small_ops_limit(ctx->opt_small_fused, p) && n_ops <= chunk) {
         VerifyWs w(ctx->ws, p, chunk, a_hat_keys == nullptr, wire_keys);
         STAGE("verify_small", launch_verify_small(ctx, p, mode, rho, 32, a_hat_keys, tr, t1, n_keys, key_idx, msgs, msg_off, ctxs, ctx_off, sigs, ok,
                                                   n_ops, w.a_hat, w.c, w.mu_w1, w.ctx_bad, ctx->d_small_ctr, s));
@@ -415,7 +415,7 @@ int keygen_batch(mldsa_ctx *ctx, int set, const uint8_t *xi, uint8_t *pk, uint8_
         rc = [&]() -> int {
             if (wait_head) { MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_head_ev, 0)); wait_head = false; }
             // a SMALL call: one launch (kernels_small.hip k_keygen_small), the same workspace rows and the same bytes out
-            if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && n <= ctx->small_keygen_max && n <= SMALL_FUSED_MAX) {
+            if (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && n <= small_ops_limit((long)ctx->small_keygen_max, p)) {
                 if (wait_rest) {
                     MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
                     wait_rest = false;
@@ -603,7 +603,7 @@ static SignPlan plan_sign_compute(const mldsa_ctx *ctx, int set, size_t n, bool 
     // kernels; EXPERIMENTS.md).  The signatures do not depend on it (the FIRST accepted candidate, ml_dsa.rs:212-330).
     const mldsa_params *pp = params_of(set);
     const size_t rows_small = (ctx->opt_coop_hash && ctx->opt_small_fused > 0 && ctx->small_sign_front && ctx->small_sign_spec && pp) ? ctx->coop_mask_max / (size_t)pp->l : 0;
-    const bool small_rule = rows_small >= n * (size_t)std::max(1L, ctx->small_sign_spec) && n <= ctx->small_sign_max && n <= 256 && rows > rows_small;
+    const bool small_rule = rows_small >= n * (size_t)std::max(1L, ctx->small_sign_spec) && n <= ctx->small_sign_max && n <= 256 && n <= small_ops_limit(ctx->opt_small_fused, pp) && rows > rows_small;
     size_t tgt_eff = tgt;
     if (small_rule) {
         rows = rows_small;
@@ -909,7 +909,7 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     int32_t *st = a.status ? a.status + o : nullptr;
     const int32_t *key_bad = nullptr;
     const bool fork = side_ok && own_a && n >= 4096 && ctx->opt_side_prologue;
-    const bool small = ctx->opt_coop_hash && ctx->opt_small_fused > 0 && n <= ctx->small_sign_max && n <= 256 && !fork;
+    const bool small = ctx->opt_coop_hash && n <= small_ops_limit(ctx->opt_small_fused, p) && n <= ctx->small_sign_max && n <= 256 && !fork;
     if (a.key_idx && !small) {
         TRY(launch_sanitize_keys(ctx, a.key_idx + o, a.n_keys, n, w.kidx, w.key_bad, s));
         key_bad = w.key_bad;

@@ -143,10 +143,13 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                 * wave-cooperatively, ONE state per wave in bit-interleaved form (csrc/keccak_coop2.h): 2.2 instead of 9.4 us per
                                 * permutation of a latency-bound call.  0: always the lane-per-state form of the large batches.  Results are
                                 * identical. */
-#define MLDSA_OPT_SMALL_FUSED 13 /* most ops of a call that runs on the single-launch kernels of csrc/kernels_small.hip.  Verification: ONE launch
+#define MLDSA_OPT_SMALL_FUSED 13 /* most ops of a call that runs on the single-launch kernels of csrc/kernels_small.hip, counted in ML-DSA-65 ops: the
+                                    limit of another set scales with the polynomials of A_hat per op -- value * 30 / (k l): 256 means 480 ML-DSA-44
+                                    ops, 256 ML-DSA-65 ops, 137 ML-DSA-87 ops (measured crossovers per set: profiles/r05_ab_small_limits_per_set.txt).
+                                    Verification: ONE launch
                                     (every op owns a cluster of workgroups for ExpandA, mu and SampleInBall; the last one to finish carries on with
                                     the arithmetic, the c_tilde hash and the verdict).  Key generation: ONE launch (one wave per polynomial of A_hat,
-                                    s1, s2; the last workgroup does the arithmetic, the packing and tr); at most 256 keys whatever the value.
+                                    s1, s2; the last workgroup does the arithmetic, the packing and tr); at most 256 ML-DSA-65 keys' worth whatever the value.
                                     Signing: the prologue is one launch (calls of at most 256 ops; it opens round 0 as well, and one launch between
                                     rounds compacts the active list and opens the next) and so is the first half of every round planned at <= 819
                                     candidate rows (ExpandMask, w = A y, the c_tilde hash, SampleInBall, NTT(c)).  Default 256 (measured

@@ -18,6 +18,7 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 OPT_SMALL_FUSED = 13
+FUSED_ON = 512   # (counted in ML-DSA-65 ops: 274 ML-DSA-87 ops -- every size below stays on the single-launch kernels for all three sets)
 
 
 @pytest.fixture(scope="module")
@@ -66,7 +67,7 @@ def _batch(pset, keys, n_ops, seed, modes=(0,)):
 
 
 def _verify(m, hp, pks, ops, fused, mode, a_hat=None):
-    hp.set_option(OPT_SMALL_FUSED, 256 if fused else 0)
+    hp.set_option(OPT_SMALL_FUSED, FUSED_ON if fused else 0)
     from fips204_amd.ml_dsa import _cat_with_offsets
     n = len(ops)
     mb, mo = _cat_with_offsets([o["msg"] for o in ops], m.device)
@@ -151,7 +152,7 @@ def test_refusals_are_per_op_and_identical(env):
         want[i] = 0
     res = {}
     for fused in (True, False):
-        hp.set_option(OPT_SMALL_FUSED, 256 if fused else 0)
+        hp.set_option(OPT_SMALL_FUSED, FUSED_ON if fused else 0)
         ok = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
         m.verify_device(pks, mb, mo_bad, sg, ok, n, cb, co, kidx, 0)
         torch.cuda.synchronize()
@@ -202,6 +203,35 @@ def test_option_bounds(env):
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 1025) != 0 and lib.mldsa_set_option(h, OPT_SMALL_FUSED, -1) != 0
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 0) == 0 and hp.get_option(OPT_SMALL_FUSED) == 0
     assert lib.mldsa_set_option(h, OPT_SMALL_FUSED, 256) == 0
+
+
+@pytest.mark.parametrize("pset,limit", [(44, 480), (65, 256), (87, 137)])
+def test_the_limit_counts_ml_dsa_65_ops(env, pset, limit):
+    """MLDSA_OPT_SMALL_FUSED counts ML-DSA-65 ops; another set's limit scales with the A_hat polynomials per op (value * 30 / (k l)): with
+    the default 256 a verification call of `limit` ops is one launch (stage "verify_small" of the library's own profile), one op more
+    runs the batch pipeline -- measured crossovers per set: profiles/r05_ab_small_limits_per_set.txt.  Same verdicts either way."""
+    hp, sets = env
+    m = sets[pset]
+    hp.set_option(OPT_SMALL_FUSED, 256)
+    keys, pks = _keys(m, pset, 2, 77 + pset)
+    ops = _batch(pset, keys, 6, 78 + pset)
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    for n, small in ((limit, True), (limit + 1, False)):
+        many = [ops[i % len(ops)] for i in range(n)]
+        mb, mo = _cat_with_offsets([o["msg"] for o in many], m.device)
+        cb, co = _cat_with_offsets([o["ctx"] for o in many], m.device)
+        sg = torch.frombuffer(bytearray(b"".join(o["sig"] for o in many)), dtype=torch.uint8).cuda().view(n, -1)
+        kidx = torch.tensor([o["key"] for o in many], dtype=torch.int32, device="cuda")
+        ok = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        hp.profile_enable(True)
+        try:
+            m.verify_device(pks, mb, mo, sg, ok, n, cb, co, kidx, 0)
+            torch.cuda.synchronize()
+            stages = str(hp.profile_report())
+        finally:
+            hp.profile_enable(False)
+        assert ("verify_small" in stages) == small, (pset, n, stages[:300])
+        assert ok.cpu().numpy().tolist() == [int(o["want"]) for o in many], (pset, n)
 
 
 @pytest.mark.parametrize("pset", [44, 65, 87])
@@ -283,7 +313,7 @@ def test_sign_fused_prologue_and_round_front_equal_pipeline_equal_oracle(env, ps
             cb, co = _cat_with_offsets(ctxs, m.device)
             d_rnd, kidx = torch.from_numpy(rnd).cuda(), torch.from_numpy(kidx_h).cuda()
             out = {}
-            for label, fused, ah in (("fused", 256, None), ("pipeline", 0, None), ("fused_cached_a", 256, a_hat)):
+            for label, fused, ah in (("fused", FUSED_ON, None), ("pipeline", 0, None), ("fused_cached_a", FUSED_ON, a_hat)):
                 hp.set_option(OPT_SMALL_FUSED, fused)
                 sig = torch.full((n, m.SIG_LEN), 0x5A, dtype=torch.uint8, device="cuda")
                 st = torch.full((n,), 77, dtype=torch.int32, device="cuda")

@@ -105,6 +105,11 @@ done; done
 for f in gpurun_out/small_${R}pipe/unprofiled_*.txt; do cat "$f"; done > "$OUT/small_call_unprofiled_wall_batch_pipeline.txt"
 note small_call_unprofiled_wall_batch_pipeline.txt "MLDSA_SMALL_FUSED=0 python3 tools/latency_probe.py <op> <n> 200"
 ./tools/batcher_bench_bin 65 1.5 0 1,8,64 1 > "$OUT/batcher_single_op_callers.json" 2>> "$ERR"; note batcher_single_op_callers.json "./tools/batcher_bench_bin 65 1.5 0 1,8,64 1"
+# ---- same-box A/Bs behind the small-call defaults (AB=0 skips them)
+if [ "${AB:-1}" != 0 ]; then
+  tools/ab_small_limits.sh > "$OUT/ab_small_limits_per_set.txt" 2>> "$ERR"; note ab_small_limits_per_set.txt "tools/ab_small_limits.sh  (per parameter set: single-launch kernels forced up to 1 024 ops against the batch pipeline, verify / keygen / sign calls of 96 ... 512 ops: where the crossovers are)"
+  tools/ab_small_sign.sh > "$OUT/ab_small_sign_switches.txt" 2>> "$ERR"; note ab_small_sign_switches.txt "tools/ab_small_sign.sh  (default against MLDSA_SMALL_SIGN_SPEC=0 / 1, MLDSA_SMALL_SIGN_FRONT=0, MLDSA_SMALL_FUSED=0: wall time per signing call, ML-DSA-44 / 65 / 87, 1 ... 256 ops)"
+fi
 # ---- the host's side of a one-op signing call (HIP API calls beside the kernels)
 ( cd /tmp && CALL_GAP_US=400 rocprofv3 --hip-trace --kernel-trace --output-format csv -d "$OUT/hat" -o t -- python3 "$OLDPWD/tools/latency_probe.py" sign 1 40 > /dev/null 2>&1 )
 python3 tools/host_api_timeline.py "$OUT/hat" > "$OUT/host_api_sign_n1.txt" 2>> "$ERR"; rm -rf "$OUT/hat"

@@ -12,8 +12,31 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import csrc_hash  # noqa: E402
 
 
+def extra(r):
+    """files measured later on the SAME library (tools/collect_extra.sh): appended to the manifest, refused if the library differs"""
+    src = os.path.join(ROOT, "gpurun_out", f"extra_{r}")
+    build = json.load(open(os.path.join(src, "BUILD.json")))
+    mp = os.path.join(ROOT, "profiles", f"{r}_MANIFEST.json")
+    man = json.load(open(mp))
+    if build["csrc_hash"] != man["csrc_hash"] or build["lib_sha256"] != man["lib_sha256"]:
+        sys.exit(f"extra files were measured on another library (sources {build['csrc_hash'][:12]} / lib {build['lib_sha256'][:12]}, manifest "
+                 f"{man['csrc_hash'][:12]} / {man['lib_sha256'][:12]}): not added")
+    for e in (json.loads(ln) for ln in open(os.path.join(src, "MANIFEST.jsonl")) if ln.strip()):
+        p = os.path.join(src, e["file"])
+        if not os.path.exists(p) or os.path.getsize(p) == 0:
+            print("missing or empty:", e["file"])
+            continue
+        dst = f"{r}_{e['file']}"
+        shutil.copyfile(p, os.path.join(ROOT, "profiles", dst))
+        man["files"][dst] = {"command": e["command"] + "  (tools/collect_extra.sh: a later run on the same library)", "bytes": os.path.getsize(p)}
+        print("added", dst)
+    json.dump(man, open(mp, "w"), indent=1, sort_keys=True)
+
+
 def main():
     r = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    if "--extra" in sys.argv:
+        return extra(r)
     src = os.path.join(ROOT, "gpurun_out", f"final_{r}")
     build = json.load(open(os.path.join(src, "BUILD.json")))
     entries = [json.loads(ln) for ln in open(os.path.join(src, "MANIFEST.jsonl")) if ln.strip()]
