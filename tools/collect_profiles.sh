@@ -118,6 +118,6 @@ note host_api_sign_n1.txt "cd /tmp && CALL_GAP_US=400 rocprofv3 --hip-trace --ke
 if [ "${SOAK:-1}" != 0 ]; then
   { MLDSA_SOAK_SECONDS=${SOAK_SMALL_S:-240} MLDSA_SOAK_SEED=77 MLDSA_SOAK_MAX_N=400 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s -q 2>&1 | grep -E "^soak:|passed|failed|Error" ;
     MLDSA_SOAK_SECONDS=${SOAK_LONG_S:-420} MLDSA_SOAK_SEED=5151 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s -q 2>&1 | grep -E "^soak:|passed|failed|Error" ; } > "$OUT/soak_long.txt"
-  note soak_long.txt "MLDSA_SOAK_SECONDS=240 MLDSA_SOAK_SEED=77 MLDSA_SOAK_MAX_N=400 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s  (small calls only: every result of ~19 000 keygen -> sign -> verify -> flip -> verify iterations against the oracle);  MLDSA_SOAK_SECONDS=420 MLDSA_SOAK_SEED=5151 ... (sizes 1 .. 70 000)"
+  note soak_long.txt "MLDSA_SOAK_SECONDS=${SOAK_SMALL_S:-240} MLDSA_SOAK_SEED=77 MLDSA_SOAK_MAX_N=400 python -m pytest tests/test_gpu_sign_schedule.py -m gpu -k soak -s  (small calls only: every result of the keygen -> sign -> verify -> flip -> verify iterations against the oracle, ~80 iterations per second);  MLDSA_SOAK_SECONDS=${SOAK_LONG_S:-420} MLDSA_SOAK_SEED=5151 ... (sizes 1 .. 70 000)"
 fi
 ls -la "$OUT"
