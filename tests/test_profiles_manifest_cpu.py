@@ -60,3 +60,14 @@ def test_bench_reads_only_this_rounds_pmc_files():
     for w in ("verify65", "verify_arith44", "sign65"):
         t, by, fn = pmc.pmc_traffic(w)
         assert fn == f"r05_pmc_{w}.json" and fn in man["files"] and t and t > 0
+
+
+def test_the_library_built_here_is_the_library_that_was_measured():
+    """the build is deterministic (no paths or dates in the code object): the libmldsa_hip.so that `make` produces from this tree has the
+    sha256 the manifest recorded on the GPU box -- the profiles describe this binary, not merely these sources"""
+    import pytest
+    lib = os.path.join(ROOT, "fips204_amd", "csrc", "libmldsa_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built (the driver's build() step comes first)")
+    man = json.load(open(MANIFEST))
+    assert csrc_hash.lib_sha256() == man["lib_sha256"], "the library in this tree is not the one the r05 profiles were measured on (stale build? rebuild with make -C fips204_amd/csrc)"
