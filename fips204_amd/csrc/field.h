@@ -31,9 +31,10 @@ __device__ __forceinline__ int4 unpack24(const Packed3& p) {
 typedef uint32_t __attribute__((aligned(1))) u32_any;
 typedef uint64_t __attribute__((aligned(1))) u64_any;
 typedef uint16_t __attribute__((aligned(1))) u16_any;
-template <int CB>
+template <int CB, bool NT = false>
 __device__ __forceinline__ uint32_t y_raw_dword(const uint8_t* poly, int k, int lane) {
-    return *reinterpret_cast<const u32_any*>(poly + 8 * CB * k + ((lane * CB) >> 3));
+    const u32_any* p = reinterpret_cast<const u32_any*>(poly + 8 * CB * k + ((lane * CB) >> 3));
+    if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
 }
 template <int CB>
 __device__ __forceinline__ int32_t y_from_raw(uint32_t raw, int lane) {
@@ -41,6 +42,51 @@ __device__ __forceinline__ int32_t y_from_raw(uint32_t raw, int lane) {
 }
 __device__ __forceinline__ Packed3 pack24(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {  // all < 2^24
     return Packed3{c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8)};
+}
+
+// ---- Cache policy of the streaming kernels (round 6; EXPERIMENTS.md "Round 6", profiles/r06_ab_memory_path_*.txt).
+// Rows that a launch reads exactly ONCE -- A_hat, z / c and the signature bytes in k_verify_main and the config-2 kernel -- are loaded
+// nontemporal (`global_load ... nt`): k_verify_main -8 %, the config-2 kernel 0.582 -> 0.635 of the HBM peak, same-box A/B.  The signer's
+// rows are NOT: adjacent candidate rows share their A_hat through the XCD's L2 (nt there: sign_w +12 %), and y / w are read again by the
+// tail kernels.  MLDSA_EXP (default 0 = the shipped library; `make variants` + tools/ab_variants.py for the A/Bs) switches the measured
+// variants: the two adopted policies OFF (bits 1 and 8), and the rejected ones ON.
+#ifndef MLDSA_EXP
+#define MLDSA_EXP 0
+#endif
+constexpr bool NT_A_VERIFY = (MLDSA_EXP & 2) == 0;      // adopted: A_hat rows of k_verify_main / the config-2 kernel by nontemporal loads (bit 1: off)
+constexpr bool NT_ZC = (MLDSA_EXP & 256) == 0;          // adopted: their read-once z, c and signature bytes too (bit 8: off)
+constexpr bool EXP_NT_A_SIGN = (MLDSA_EXP & 1) != 0;    // rejected (sign_w +12 %): the signer's A_hat rows by nontemporal loads
+constexpr bool EXP_NT_STORE = (MLDSA_EXP & 4) != 0;     // rejected (+-0.5 %, config 2 -1.5 %): every w / w1 row by nontemporal stores
+constexpr bool EXP_LDSDMA = (MLDSA_EXP & 8) != 0;       // rejected (sign_w +3 %, 5 -> 3 waves per SIMD): the signer's A_hat rows by LDS-DMA
+constexpr int EXP_PRIO = (MLDSA_EXP & 16) ? 1 : (MLDSA_EXP & 32) ? 3 : 0;  // rejected (0 / -1.6 %): s_setprio of the c~ hash / SampleInBall / NTT(c) waves
+constexpr bool EXP_NT_DMA = (MLDSA_EXP & 64) != 0;      // with EXP_LDSDMA: the DMA with the nt policy (aux = 2; sign_w +5 %)
+constexpr bool EXP_NT_STORE_W1 = (MLDSA_EXP & (4 | 128)) != 0;  // rejected (+-0.3 %): bit 7 = the packed w / w1 rows only (not config 2's int32 w')
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ Packed3 load_row(const Packed3* p) {
+    if constexpr (NT) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);  // (three dword loads: the compiler merges them into one dwordx3 ... nt)
+        return Packed3{__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2)};
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ int4 load_row(const int4* p) {
+    if constexpr (NT) {
+        const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
+        return make_int4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT = EXP_NT_STORE_W1, class T>
+__device__ __forceinline__ void store_row(T* p, T v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT, class T>
+__device__ __forceinline__ T load_once(const T* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p); else return *p;
 }
 
 // a * b * 2^-32 mod q, result in (-q, q); |a*b| < 2^31 * q.  Same computation as the reference's

@@ -78,9 +78,11 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
             if constexpr (APACK) return unpack24(v); else return v;
         };
         const int4* trow = reinterpret_cast<const int4*>(t1 + (key * K) * (size_t)N);
+        // (nontemporal, field.h "Cache policy": the op's own ExpandA output is read exactly once -- APACK; a per-key A_hat kept by the caller is
+        //  shared by the ops of that key and stays on the default policy)
         ARow av[L];
 #pragma unroll
-        for (int j = 0; j < L; j++) av[j] = arow[(unsigned)(j * 64) + ul];
+        for (int j = 0; j < L; j++) av[j] = load_row<NT_A_VERIFY && APACK>(&arow[(unsigned)(j * 64) + ul]);
         int4 tv = trow[ul];
         // ---- (c_tilde, z, h) <- sigDecode: z in the forward loop, the hint bytes requested here and decoded after it
         const uint8_t* zsrc = sigs + op * sig_len + ctilde_len;
@@ -97,13 +99,13 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
                 for (int k = 0; k < 4; k++) {
                     // one byte-granular dword load per field (field.h; the same encoding as the signer's raw y); hints follow z:
                     // the over-read is in-buffer
-                    r[k] = y_from_raw<CB>(y_raw_dword<CB>(src, k, (int)ul), (int)ul);
+                    r[k] = y_from_raw<CB>(y_raw_dword<CB, NT_ZC>(src, k, (int)ul), (int)ul);
                     const int32_t a = r[k] < 0 ? -r[k] : r[k];
                     mx = a > mx ? a : mx;
                 }
                 zbad |= mx >= zbound;
             } else {  // c: k_sample_in_ball<.., C8>'s bytes, the lane's four coefficients in its dword
-                const uint32_t d = reinterpret_cast<const uint32_t*>(c)[op * 64 + ul];
+                const uint32_t d = load_once<NT_ZC>(reinterpret_cast<const uint32_t*>(c) + op * 64 + ul);
                 r[0] = (int8_t)(d & 0xFF); r[1] = (int8_t)((d >> 8) & 0xFF); r[2] = (int8_t)((d >> 16) & 0xFF); r[3] = (int8_t)(d >> 24);
             }
             ntt_fwd_wave(r, ftw, lane);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(64 * VW) __attribute__((amdgpu_waves_per_eu(MINW)))
             int32_t acc[4];
             if (i + 1 < K) {  // next row: in flight during this row's inverse transform
 #pragma unroll
-                for (int j = 0; j < L; j++) av[j] = arow[(unsigned)(((i + 1) * L + j) * 64) + ul];
+                for (int j = 0; j < L; j++) av[j] = load_row<NT_A_VERIFY && APACK>(&arow[(unsigned)(((i + 1) * L + j) * 64) + ul]);
                 tv = trow[(unsigned)((i + 1) * 64) + ul];
             }
             // hint bits of coefficients 64 k + lane: mask word 2 k + (lane >> 5).  One dword per lane (lane l holds word l & 7),
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(CBLOCK) void k_shake256_2(const uint8_t* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* tile = tiles + wave * 64 * H_STRIDE;
     if (n_dev) n_ops = *n_dev;  // the signer's rounds: the count lives on the device, the grid is sized from its expectation
+    if constexpr (EXP_PRIO != 0) __builtin_amdgcn_s_setprio(EXP_PRIO);  // (experiment: the latency chain ahead of the streaming kernels beside it)
     for (size_t base_op = (size_t)blockIdx.x * CBLOCK; base_op < n_ops; base_op += (size_t)gridDim.x * CBLOCK) {
         const size_t op = base_op + threadIdx.x;
         const bool valid = op < n_ops;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(BLOCK) void k_ntt_c8(const uint32_t *__restrict__ i
     if (n_dev) n_polys = *n_dev;
     const size_t wave = (size_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const size_t n_waves = (size_t)gridDim.x * WAVES_PER_BLOCK;
+    if constexpr (EXP_PRIO != 0) __builtin_amdgcn_s_setprio(EXP_PRIO);
     FwdTw tw;
     load_fwd_tw(tw, tab, lane);
     uint32_t nxt = 0;
@@ -265,6 +266,12 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     __shared__ int4 zh[AW][NZ][64];
     __shared__ int32_t xp_kg[KG ? AW : 1][KG ? N : 1];  // strided -> four consecutive coefficients per lane (t1 / t0 packing)
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
+    // (experiment, MLDSA_EXP bit 3: the A_hat row of the signer's kernel arrives by LDS-DMA, one buffer per wave, instead of in registers)
+    constexpr bool DMA = EXP_LDSDMA && APACK && !HAS_C && !KG && W1 == 2 && K == 6;  // (the ML-DSA-65 signer only)
+    constexpr bool NT_A = HAS_C ? NT_A_VERIFY : (EXP_NT_A_SIGN && !KG);
+    constexpr int ROW_BYTES = L * PACKED_POLY_DWORDS * 4, ROW_PIECES = (ROW_BYTES + 1023) / 1024;
+    constexpr int DMA_STORES = 3 + (W1 == 2 ? 1 : 12);  // store instructions of one row's epilogue (w planes + w1Encode), issued behind the next row's DMA
+    __shared__ uint32_t a_lds[DMA ? AW : 1][DMA ? ROW_PIECES * 256 : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (n_dev) n_ops = *n_dev;  // the signer's rounds: slots of this round, known only on the device
@@ -292,8 +299,24 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
         // row 0 of A_hat (and of t1) is requested before the transforms
         ARow av[L];
         int4 tv = make_int4(0, 0, 0, 0);
+        // row `i` of this op's A_hat -> the wave's LDS buffer: ROW_PIECES wave-instructions of 1 KiB, the last one EXEC-masked to the row
+        auto dma_row = [&](int i) {
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(arow) + (size_t)i * ROW_BYTES;
+#if defined(__HIP_DEVICE_COMPILE__)  // (gfx950 builtins and inline assembly: not for the host pass of hipcc)
 #pragma unroll
-        for (int j = 0; j < L; j++) av[j] = arow[j * 64 + lane];
+            for (int t = 0; t < ROW_PIECES; t++)
+                if (t * 1024 + lane * 16 < ROW_BYTES)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(src + t * 1024 + lane * 16), &a_lds[wave][t * 256], 16, 0, EXP_NT_DMA ? 2 : 0);
+#else
+            (void)src; (void)a_lds;
+#endif
+        };
+        if constexpr (DMA) {
+            dma_row(0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < L; j++) av[j] = load_row<NT_A>(&arow[j * 64 + lane]);
+        }
         if constexpr (HAS_C) tv = reinterpret_cast<const int4 *>(t1 + (key * K) * (size_t)N)[lane];
         // ---- forward transforms, next polynomial loaded one ahead
         int32_t nr[4];
@@ -308,7 +331,8 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
 #pragma unroll
                 for (int k = 0; k < 4; k++) nr[k] = (int32_t)y_raw_dword<YCB>(src, k, lane);
             } else {
-                load_strided(nr, z + poly * (size_t)N, lane);
+#pragma unroll
+                for (int k = 0; k < 4; k++) nr[k] = load_once<NT_ZC && HAS_C>(z + poly * (size_t)N + 64 * k + lane);
             }
         };
         load_z(zrow);
@@ -340,7 +364,10 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
                 store_fields(kg.sk + op * kg.sk_len + 128 + (size_t)j * (32 * kg.ebits), f, kg.ebits, lane);
             }
             if (j + 1 < L) load_z(zrow + j + 1);
-            else if (HAS_C && j + 1 == L) load_strided(nr, c + op * (size_t)N, lane);
+            else if (HAS_C && j + 1 == L) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) nr[k] = load_once<NT_ZC>(c + op * (size_t)N + 64 * k + lane);
+            }
             ntt_fwd_wave(r, ftw, lane);
             if (HAS_C && j == L) {
 #pragma unroll
@@ -356,6 +383,25 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
             // 64-bit accumulation, one Montgomery reduction per coefficient and row (field.h): |a| < 2^24 (what ExpandA
             // produces), |z_hat| < 9 q, at most L + 1 <= 8 terms: |sum| < 2^54 = the reduction's input bound
             int64_t acc64[4] = {0, 0, 0, 0};
+            if constexpr (DMA) {  // the row's DMA has landed once nothing but the previous row's DMA_STORES stores is outstanding (VM operations retire in order)
+                if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_STORES) : "memory");
+            }
+            if constexpr (DMA) {
+                // read by hand: a compiler-visible LDS read of the DMA's buffer makes hipcc wait vmcnt(0) in front of it, i.e. for the
+                // previous row's stores as well
+#if defined(__HIP_DEVICE_COMPILE__)
+                const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&a_lds[wave][lane * 3];
+#pragma unroll
+                for (int j = 0; j < L; j++)
+                    asm volatile("ds_read_b32 %0, %3 offset:%4\n\tds_read_b32 %1, %3 offset:%5\n\tds_read_b32 %2, %3 offset:%6"
+                                 : "=&v"(av[j].a), "=&v"(av[j].b), "=&v"(av[j].c)
+                                 : "v"(la), "n"(j * 768), "n"(j * 768 + 4), "n"(j * 768 + 8)
+                                 : "memory");
+#pragma unroll
+                for (int j = 0; j < L; j++) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[j].a), "+v"(av[j].b), "+v"(av[j].c)::"memory");
+#endif
+            }
 #pragma unroll
             for (int j = 0; j < L; j++) {
                 const int4 zv = zh[wave][j][lane];
@@ -374,8 +420,13 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
             }
             int32_t acc[4];
             if (i + 1 < K) {  // next row: in flight during this row's inverse transform
+                if constexpr (DMA) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this row has been read out of the buffer
+                    dma_row(i + 1);
+                } else {
 #pragma unroll
-                for (int j = 0; j < L; j++) av[j] = arow[((i + 1) * L + j) * 64 + lane];
+                    for (int j = 0; j < L; j++) av[j] = load_row<NT_A>(&arow[((i + 1) * L + j) * 64 + lane]);
+                }
                 if constexpr (HAS_C) tv = reinterpret_cast<const int4 *>(t1 + (key * K + i + 1) * (size_t)N)[lane];
             }
 #pragma unroll
@@ -418,11 +469,13 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
                 // polynomial instead of 1 024, stored and loaded like the first three quarters of a strided polynomial
                 const Packed3 pw = pack24((uint32_t)acc[0], (uint32_t)acc[1], (uint32_t)acc[2], (uint32_t)acc[3]);
                 uint32_t *wp = reinterpret_cast<uint32_t *>(w_out) + (op * K + i) * (size_t)PACKED_POLY_DWORDS;
-                wp[lane] = pw.a;
-                wp[64 + lane] = pw.b;
-                wp[128 + lane] = pw.c;
+                store_row(wp + lane, pw.a);
+                store_row(wp + 64 + lane, pw.b);
+                store_row(wp + 128 + lane, pw.c);
             } else {
-                store_strided(acc, w_out + (op * K + i) * (size_t)N, lane);
+                int32_t *wq = w_out + (op * K + i) * (size_t)N;
+#pragma unroll
+                for (int k = 0; k < 4; k++) store_row<EXP_NT_STORE>(wq + 64 * k + lane, acc[k]);
             }
             if constexpr (W1 != 0) {
                 constexpr bool G2HI = W1 == 2;

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(64) void k_sample_in_ball(const uint8_t* __restrict
     __shared__ uint32_t b_lds[64 * SIB_BLK_STRIDE];
     const int lane = threadIdx.x;
     if (n_dev) n_ops = *n_dev;
+    if constexpr (EXP_PRIO != 0) __builtin_amdgcn_s_setprio(EXP_PRIO);
     uint32_t* bw = b_lds + lane * SIB_BLK_STRIDE;
     for (size_t wave_base = (size_t)blockIdx.x * 64; wave_base < n_ops; wave_base += (size_t)gridDim.x * 64) {
         const size_t op = wave_base + lane;

