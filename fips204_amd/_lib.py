@@ -61,7 +61,7 @@ OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SPEC_MAX, OPT_VA_BLOCKS_PER_CU, OPT_GRAPH_CACHE
 OPT_SIGN_LANES, OPT_SIGN_CT0_EXACT, OPT_SIGN_ASYNC_EXP, OPT_SIGN_LOOKAHEAD, OPT_WORKSPACE_CAP_MB = 7, 8, 9, 10, 11
 OPT_COOP_HASH = 12
 OPT_SMALL_FUSED = 13
-ABI_VERSION = 5
+ABI_VERSION = 6
 ERR_PARAM, ERR_CTX_LEN, ERR_DEVICE, ERR_NOMEM, ERR_AGAIN = -1, -2, -3, -4, -5
 ROUND_POWER2ROUND, ROUND_DECOMPOSE, ROUND_HIGH_BITS, ROUND_LOW_BITS, ROUND_MAKE_HINT, ROUND_USE_HINT = range(6)
 
@@ -159,6 +159,7 @@ _SIGNATURES = {
     "mldsa_sign_host_group": [_P, _I, _I, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P, _SZ],
     "mldsa_keygen_host_group": [_P, _I, _P, _P, _P, _SZ],
     "mldsa_group_allgather": [_P, C.POINTER(_P), _SZ, _I],
+    "mldsa_group_rccl_info": [_P, C.c_char_p, _SZ],
 }
 _RESTYPES = {"mldsa_ctx_destroy": None, "mldsa_last_error": C.c_char_p, "mldsa_get_option": C.c_long,
              "mldsa_group_destroy": None, "mldsa_group_ctx": _P, "mldsa_batcher_destroy": None}

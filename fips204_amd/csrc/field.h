@@ -132,6 +132,39 @@ __device__ __forceinline__ int32_t to_mont(int32_t x) { return mont_mul(x, R2_MO
 // scalar registers from the kernel's entry: the empty asm makes the segment pointer opaque at that point, so the load can neither be
 // hoisted nor kept live across what lies in between.  byte_offset = offsetof(first by-value argument struct, field): relies on the
 // code-object ABI putting that struct at byte 0 of the segment -- checked by a self-test at context creation (k_late_arg_selftest).
+// A toolchain that lays the segment out differently fails that self-test; the way out is a build with -DMLDSA_NO_LATE_ARG (`make
+// nolatearg`): every kernel that uses late arguments then copies its argument struct into LDS at entry (late_args_begin, through the
+// compiler's own addressing of the by-value argument) and late_arg / reload_first_kernarg read that copy -- slower (the values arrive in
+// vector registers), same results (tests/test_gpu_small_calls.py runs the suite's signing cases on that build).
+#if defined(MLDSA_NO_LATE_ARG)
+constexpr unsigned LATE_ARGS_MAX_DWORDS = 192;
+static __shared__ uint32_t late_args_copy[LATE_ARGS_MAX_DWORDS];
+template <class A>
+__device__ __forceinline__ void late_args_begin(const A& a) {  // at the top of the kernel, before any return: the whole workgroup passes here
+    static_assert(sizeof(A) % 4 == 0 && sizeof(A) <= 4 * LATE_ARGS_MAX_DWORDS, "argument struct fits the LDS copy");
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&a);
+    for (unsigned i = threadIdx.x; i < sizeof(A) / 4; i += blockDim.x) late_args_copy[i] = w[i];
+    __syncthreads();
+}
+template <class T>
+__device__ __forceinline__ T late_arg(unsigned byte_offset) {
+    static_assert(sizeof(T) % 4 == 0 || sizeof(T) < 4, "dword-sized fields (or smaller, inside one dword)");
+    T v;
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t lo = late_args_copy[byte_offset / 4], hi = late_args_copy[byte_offset / 4 + 1];
+        const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+        __builtin_memcpy(&v, &u, 8);
+    } else {
+        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)late_args_copy[byte_offset / 4]) >> (8 * (byte_offset & 3));
+        __builtin_memcpy(&v, &u, sizeof(T));
+    }
+    return v;
+}
+template <class T>
+__device__ __forceinline__ void reload_first_kernarg(T& out, const T& arg) { out = arg; }
+#else
+template <class A>
+__device__ __forceinline__ void late_args_begin(const A&) {}
 template <class T>
 __device__ __forceinline__ T late_arg(unsigned byte_offset) {
     typedef const char __attribute__((address_space(4))) * kptr;
@@ -139,5 +172,18 @@ __device__ __forceinline__ T late_arg(unsigned byte_offset) {
     asm volatile("" : "+s"(ka));
     return *(const T __attribute__((address_space(4)))*)(ka + byte_offset);
 }
+// the kernel's first by-value argument, read again from the kernarg segment (same ABI assumption, same self-test); `arg` = that argument
+template <class T>
+__device__ __forceinline__ void reload_first_kernarg(T& out, const T& arg) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    (void)arg;
+    typedef const uint32_t __attribute__((address_space(4))) * kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    uint32_t* w = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = ka[i];
+}
+#endif
 
 }  // namespace mldsa

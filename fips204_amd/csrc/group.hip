@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <string>
 #include <thread>
 
 #include "ctx.h"
@@ -32,6 +33,8 @@ struct mldsa_group {
     std::mutex call_mu;  // one group call at a time
     // RCCL (optional, mldsa_group_allgather)
     void *rccl = nullptr;
+    std::string rccl_how, rccl_path;  // "reused" (the copy the process had mapped already) / "loaded", and the file that was bound
+    int rccl_version = 0;             // ncclGetVersion of that file
     std::vector<void *> comms;
     bool rccl_tried = false;
     std::vector<hipStream_t> gather_streams;
@@ -122,6 +125,38 @@ using namespace mldsa;
 
 #define REQUIRE(cond, msg) \
     do { if (!(cond)) return set_error(MLDSA_ERR_PARAM, msg); } while (0)
+
+// RCCL is loaded, not linked (hosts that never gather pay nothing for it).  ORDER MATTERS in a process that has an RCCL already: a
+// Python host has mapped torch's own copy (torch/lib/librccl.so, SONAME librccl.so.1, built against torch's HIP runtime), and a second
+// RCCL from /opt/rocm/lib beside it would put two collective runtimes on one HIP runtime.  So: (1) whatever the process has mapped
+// under the SONAME (RTLD_NOLOAD: never loads anything), (2) the same question for the unversioned name, (3) the usual search --
+// LD_LIBRARY_PATH, this library's rpath (/opt/rocm/lib) --, (4) the ROCm path spelled out.  Reports how and which file was bound.
+static void *load_rccl(std::string *how, std::string *path, int *version) {
+    static const struct { const char *name; int flags; const char *how; } order[] = {
+        {"librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD, "reused"},
+        {"librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD, "reused"},
+        {"librccl.so.1", RTLD_NOW | RTLD_LOCAL, "loaded"},
+        {"librccl.so", RTLD_NOW | RTLD_LOCAL, "loaded"},
+        {"/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL, "loaded"},
+    };
+    for (const auto &o : order) {
+        void *h = dlopen(o.name, o.flags);
+        if (!h) continue;
+        void *sym = dlsym(h, "ncclAllGather");
+        if (!sym) { dlclose(h); continue; }
+        Dl_info info;
+        if (how) *how = o.how;
+        if (path) *path = (dladdr(sym, &info) && info.dli_fname) ? info.dli_fname : o.name;
+        if (version) {
+            typedef int (*ver_t)(int *);
+            ver_t get = (ver_t)dlsym(h, "ncclGetVersion");
+            int v = 0;
+            *version = (get && get(&v) == 0) ? v : 0;
+        }
+        return h;
+    }
+    return nullptr;
+}
 
 extern "C" {
 
@@ -339,9 +374,7 @@ int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, in
         g->rccl_tried = true;
         // single-process communicators over the group's devices (ncclCommInitAll); RCCL is loaded here, not linked: hosts that
         // never gather pay nothing for it
-        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+        void *h = load_rccl(&g->rccl_how, &g->rccl_path, &g->rccl_version);
         if (h) {
             typedef int (*init_all_t)(void **, int, const int *);
             init_all_t init_all = (init_all_t)dlsym(h, "ncclCommInitAll");
@@ -387,6 +420,25 @@ int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, in
         MLDSA_HIP_CHECK(hipStreamSynchronize(g->gather_streams[i]));
     }
     return MLDSA_OK;
+}
+
+// Which RCCL does / would this process gather with?  g != NULL: what the group's first RCCL gather bound (MLDSA_ERR_PARAM before it).
+// g == NULL: a probe -- the loader's search is run without creating a communicator or touching a device (day-one preflight,
+// tools/scale_preflight.py; the handle is released again).  buf <- "<reused|loaded> <file>"; returns ncclGetVersion's code (e.g. 22606),
+// 0 if the library does not say, MLDSA_ERR_DEVICE if no RCCL can be loaded.
+int mldsa_group_rccl_info(const mldsa_group *g, char *buf, size_t buf_len) {
+    std::string how, path;
+    int version = 0;
+    if (g) {
+        REQUIRE(g->rccl, "mldsa_group_rccl_info: this group has not gathered with RCCL");
+        how = g->rccl_how; path = g->rccl_path; version = g->rccl_version;
+    } else {
+        void *h = load_rccl(&how, &path, &version);
+        if (!h) return set_error(MLDSA_ERR_DEVICE, "mldsa_group_rccl_info: no librccl.so could be loaded");
+        dlclose(h);
+    }
+    if (buf && buf_len) snprintf(buf, buf_len, "%s %s", how.c_str(), path.c_str());
+    return version;
 }
 
 }  // extern "C"

@@ -342,6 +342,7 @@ template <int K, int L, bool G2HI>
 __global__ __launch_bounds__(64 * GWAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_sign_tail(
     SignTailArgs args) {
     typedef SignTailArgs A;
+    late_args_begin(args);  // (a no-op unless built with -DMLDSA_NO_LATE_ARG, field.h)
     constexpr size_t sig_len = TailConst<K, L>::SIG_LEN;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];     // strided -> 4 consecutive coefficients per lane (z packing)
@@ -455,6 +456,7 @@ static_assert(offsetof(ResolveArgs, ct0_exact) == offsetof(SignTailArgs, ct0_exa
 template <int K, int L, bool G2HI>
 __global__ __launch_bounds__(64 * GWAVES) void k_resolve(ResolveArgs args) {
     typedef ResolveArgs A;
+    late_args_begin(args);
     constexpr size_t sig_len = TailConst<K, L>::SIG_LEN;
     __shared__ Twiddle tw_lds[INV_TW * 64];
     __shared__ int32_t xpose[GWAVES][N];
@@ -847,6 +849,7 @@ static bool tail_consts_match(const mldsa_params* p) {
 // SignTailArgs the way k_sign_tail does, reads every field both ways -- as a normal argument and through late_arg at its
 // offsetof() -- and reports the fields that differ; a context is not created on a mismatch.
 __global__ void k_late_arg_selftest(SignTailArgs args, uint32_t* mismatch) {
+    late_args_begin(args);
     uint32_t bad = 0;
     int bit = 0;
 #define MLDSA_LATE_CHECK(ARGS, field, normal)                                    \

@@ -66,18 +66,6 @@ struct SmallVerifyArgs {
 // s_waitcnt vmcnt(0): the wave's outstanding vector-memory operations (loads and stores) have completed -- for a store: written to L2
 __device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// the kernel's first by-value argument, read again from the kernarg segment (see field.h late_arg: same ABI assumption, same self-test)
-template <class T>
-__device__ __forceinline__ void reload_first_kernarg(T& out) {
-    static_assert(sizeof(T) % 4 == 0, "whole dwords");
-    typedef const uint32_t __attribute__((address_space(4))) * kptr;
-    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    uint32_t* w = reinterpret_cast<uint32_t*>(&out);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = ka[i];
-}
-
 // ---- role: mu = H(tr | M', 64) by one wave (verify_dev.h mu_coop2: k_mu's checks, flags and bytes)
 __device__ __forceinline__ void small_role_mu(const SmallVerifyArgs& A, size_t op, int lane, const Coop2Lane& c) {
     size_t key = A.key_idx ? A.key_idx[op] : op;
@@ -148,7 +136,7 @@ __global__ __launch_bounds__(64 * SMW) void k_verify_small(SmallVerifyArgs A0, i
     // The tail reads its arguments afresh from the kernarg segment (field.h late_arg): what phase 1 used dies with it, what the tail
     // uses is loaded here -- otherwise all ~25 scalars of the argument struct stay live across both and four of them spill.
     SmallVerifyArgs A;
-    reload_first_kernarg(A);
+    reload_first_kernarg(A, A0);
     for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * SMW) tw_lds[i] = A.fwd_tab[i];
     for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * SMW) tw_lds[FWD_TW * 64 + i] = A.inv_tab[i];
     if (threadIdx.x < 16) msg_lds[threadIdx.x] = reinterpret_cast<const uint32_t*>(A.mu_ws + op * 64)[threadIdx.x];
@@ -393,7 +381,7 @@ __global__ __launch_bounds__(64 * SMW) void k_keygen_small(SmallKeygenArgs A0) {
 
     // ---------------------------------------------------------------- tail
     SmallKeygenArgs A;
-    reload_first_kernarg(A);
+    reload_first_kernarg(A, A0);
     for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * SMW) tw_lds[i] = A.fwd_tab[i];
     for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * SMW) tw_lds[FWD_TW * 64 + i] = A.inv_tab[i];
     uint8_t* pkb = reinterpret_cast<uint8_t*>(pk_lds);
@@ -544,6 +532,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
     const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
     const uint32_t member = q % NB;
     const size_t op = (size_t)(q / NB) * 8 + xcd;
+    late_args_begin(A0);  // (a no-op unless built with -DMLDSA_NO_LATE_ARG, field.h)
     const uint32_t n = A0.n;
     if (op >= n) return;  // (whole workgroup)
     const Coop2Lane c = coop2_lane(lane);
@@ -560,7 +549,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
         uint32_t lo, hi;
         {   // the key index (the C ABI's promise: an out-of-range index never reaches memory), then 6: mu <- H(tr || M', 64)   ml_dsa.rs:185-196
             SmallSignPrologueArgs A;
-            reload_first_kernarg(A);
+            reload_first_kernarg(A, A0);
             int key_bad = 0;
             if (A.key_idx) {
                 const uint32_t kraw = A.key_idx[op];
@@ -572,7 +561,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
         }
         {   // the op's rnd | mu row; 7: rho'' <- H(K || rnd || mu, 64)          ml_dsa.rs:199-201   (128 bytes: one block)
             SmallSignPrologueArgs A;
-            reload_first_kernarg(A);
+            reload_first_kernarg(A, A0);
             if (lane < 8) row_lds[lane] = load_le32(A.rnd + op * 32 + 4 * lane);
             if (c.active && c.word < 8) row_lds[8 + 2 * c.word + (lane >> 5)] = lane < 32 ? lo : hi;
             wave_lds_sync();
@@ -595,7 +584,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
         }
         {   // 8: kappa <- 0; a refused op (ctx too long, lib.rs:274; bad key index / offsets) is done at once with an all-zero signature
             SmallSignPrologueArgs A;
-            reload_first_kernarg(A);
+            reload_first_kernarg(A, A0);
             if (lane == 0) {
                 A.kappa[op] = 0;
                 A.bad_op[op] = bad;
@@ -608,7 +597,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
         {   // is the unit's s2 within [-eta, eta]?  (k_key_range: a key that expand_private decoded out of range takes the reference's
             // two-transform hint stage)
             SmallSignPrologueArgs A;
-            reload_first_kernarg(A);
+            reload_first_kernarg(A, A0);
             if (op < A.units) {
                 const size_t ukey = A.units_by_op ? key : op;
                 InvTw tw;
@@ -638,7 +627,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_prologue_small(SmallSignProlo
     wait_own_stores();
     __syncthreads();
     SmallSignPrologueArgs A;
-    reload_first_kernarg(A);
+    reload_first_kernarg(A, A0);
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const uint32_t seen = __hip_atomic_fetch_add(&A.ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -749,7 +738,7 @@ __global__ __launch_bounds__(64 * SMW) void k_sign_front_small(SmallSignFrontArg
     }
     // ---------------------------------------------------------------- tail
     SmallSignFrontArgs A;
-    reload_first_kernarg(A);
+    reload_first_kernarg(A, A0);
     for (int i = threadIdx.x; i < FWD_TW * 64; i += 64 * SMW) tw_lds[i] = A.fwd_tab[i];
     for (int i = threadIdx.x; i < INV_TW * 64; i += 64 * SMW) tw_lds[FWD_TW * 64 + i] = A.inv_tab[i];
     if (threadIdx.x < 16) msg_lds[threadIdx.x] = load_le32(A.mu + op * 96 + 4 * threadIdx.x);

@@ -268,7 +268,7 @@ int verify_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const ui
             // ops 0.3 %: not used there).
             hipStream_t cs = s;
             const bool small_call = ctx->opt_coop_hash && n * (size_t)(p->k * p->l) <= ctx->coop_a_max;
-            if (!a_hat_keys && !(ctx->opt_sib_third && small_call)) cs = aux;
+            if (!a_hat_keys && !small_call) cs = aux;
             else if (!a_hat_keys) {
                 cs = parallel_stream(ctx, s, aux);
                 if (cs != aux && cs != s) MLDSA_HIP_CHECK(hipStreamWaitEvent(cs, ctx->fork_ev, 0));
@@ -594,7 +594,9 @@ static SignPlan plan_sign_compute(const mldsa_ctx *ctx, int set, size_t n, bool 
     pl.spec_target = (uint32_t)tgt;
     // candidates per speculative round (>= the threshold above): rows = what such a round generates
     size_t rows = std::max(tgt, std::min<size_t>((size_t)ctx->opt_spec_rows, std::max<size_t>(n * pl.spec_max, 1)));
-    double alpha = (double)ctx->opt_spec_alpha / 100.0;
+    // candidates per op in a speculative round = round((rows / m) ^ alpha): 1 fills every round to `rows`; 0.85 measured 1.5-2.2 % faster for
+    // all three sets (mid-size rounds get fewer: fewer wasted candidates, ExpandMask launches that fit whole layers; EXPERIMENTS.md round 3)
+    double alpha = 0.85;
     // A SMALL call (the ones whose prologue is one launch): a round of up to coop_mask_max / l candidate rows runs its first half as ONE
     // launch on the cooperative sponges (k_sign_front_small, ~45 us whatever the rows), a larger one on the five lane-per-state kernels
     // (~115 us for the 2 048 rows that 64 ops x 32 candidates make).  So such a call speculates only as far as the single launch reaches:
@@ -700,7 +702,7 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
     Key k;
     memset(&k, 0, sizeof(k));
     k.v[0] = set; k.v[1] = (long)n; k.v[2] = async_mode ? 1 : 0; k.v[3] = ctx->opt_spec_max; k.v[4] = ctx->opt_spec_target; k.v[5] = ctx->spec_target_cap;
-    k.v[6] = ctx->opt_spec_rows; k.v[7] = ctx->opt_spec_alpha; k.v[8] = ctx->opt_coop_hash; k.v[9] = ctx->opt_small_fused; k.v[10] = ctx->small_sign_front;
+    k.v[6] = ctx->opt_spec_rows; k.v[8] = ctx->opt_coop_hash; k.v[9] = ctx->opt_small_fused; k.v[10] = ctx->small_sign_front;
     k.v[11] = ctx->small_sign_spec; k.v[12] = (long)ctx->coop_mask_max; k.v[13] = (long)ctx->small_sign_max; k.v[14] = ctx->opt_sign_rounds;
     k.d[0] = plan_stop; k.d[1] = ctx->async_stop;
     constexpr int SLOTS = 4;
@@ -895,33 +897,25 @@ void zeroise_sign_ws(mldsa_ctx *ctx, const SignWs &w, hipStream_t s) {
 }
 
 // steps 1-8 of Algorithm 7 for one lane's slice of a chunk: enqueue only (capturable)
-// side_ok: the lane-per-op kernels of the prologue (mu, rho'', the key-range check, the first active list: latency-bound, one wave
-// per SIMD or less) may run on the context's helper stream underneath ExpandA, like the verifier's (one lane only: the helper
-// stream is the second lane's)
+// (the lane-per-op kernels of the prologue -- mu, rho'', the key-range check, the first active list -- follow ExpandA on the same stream:
+//  forking them onto the helper stream underneath ExpandA, like the verifier's, measured 8.25 against 8.19 ms per 65 536 ML-DSA-65
+//  signatures and was removed in round 6 with its knob)
 // slots0_plan / slots0_done (optional): when the prologue is the ONE launch of a small call, its last workgroup opens round 0 as well
 // (k_make_slots' work, from this plan's rule) and *slots0_done says so
-int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignArgs &a, hipStream_t s, bool side_ok,
+int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const SignArgs &a, hipStream_t s,
                   const SignPlan *slots0_plan = nullptr, bool *slots0_done = nullptr) {
     if (slots0_done) *slots0_done = false;
-    hipStream_t const main_stream = s;
     const bool own_a = a.a_hat_keys == nullptr;
     const size_t o = a.offset, n = a.n;
     int32_t *st = a.status ? a.status + o : nullptr;
     const int32_t *key_bad = nullptr;
-    const bool fork = side_ok && own_a && n >= 4096 && ctx->opt_side_prologue;
-    const bool small = ctx->opt_coop_hash && n <= small_ops_limit(ctx->opt_small_fused, p) && n <= ctx->small_sign_max && n <= 256 && !fork;
+    const bool small = ctx->opt_coop_hash && n <= small_ops_limit(ctx->opt_small_fused, p) && n <= ctx->small_sign_max && n <= 256;
     if (a.key_idx && !small) {
         TRY(launch_sanitize_keys(ctx, a.key_idx + o, a.n_keys, n, w.kidx, w.key_bad, s));
         key_bad = w.key_bad;
     }
     const ChunkKeys c = chunk_keys(p, w, a);
     const size_t key_base = a.key_idx ? 0 : o;
-    hipStream_t side = s;
-    if (fork) {
-        side = parallel_stream(ctx, s);
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s));
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(side, ctx->fork_ev, 0));
-    }
     // A SMALL call: the whole prologue -- key check, ExpandA, mu, rho'', key-range check, first active list, control block -- is ONE
     // launch (kernels_small.hip k_sign_prologue_small) instead of the nine below; same rows, same values.
     if (small) {
@@ -957,15 +951,11 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     // the previous signing call may still be clearing its secrets on a helper stream (sign_batch): ExpandA (public, below the
     // cleared span) was allowed to start beside it, everything from here on writes into that span
     if (ctx->zero_wait_after_ea) {
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(side, ctx->zero_ev, 0));
+        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, ctx->zero_ev, 0));
         ctx->zero_wait_after_ea = false;
         ctx->zero_pending = false;
     }
-    if (a.inputs_ev) {  // the host path's uploads of everything but the keys ran beside ExpandA
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(s, a.inputs_ev, 0));
-        if (side != s) MLDSA_HIP_CHECK(hipStreamWaitEvent(side, a.inputs_ev, 0));
-    }
-    s = side;  // ---- the small kernels below: on the helper stream when forked, joined at the end
+    if (a.inputs_ev) MLDSA_HIP_CHECK(hipStreamWaitEvent(s, a.inputs_ev, 0));  // the host path's uploads of everything but the keys ran beside ExpandA
     // the signature buffer is not cleared: every op's bytes come from its accepted attempt, a refused op (k_init_active) or
     // one an asynchronous call leaves unfinished (k_mark_unfinished) gets its zeros there
     TRY(launch_zero(ctx, w.ctl, sizeof(RoundCtl), s));
@@ -986,10 +976,6 @@ int sign_prologue(mldsa_ctx *ctx, const mldsa_params *p, const SignWs &w, const 
     }
     // 8: kappa <- 0; active = all ops with a legal ctx and key index
     TRY(launch_init_active(ctx, n, w.bad_op, w.done, w.kappa, st, w.act[0], w.ctl, c.sg, (size_t)p->sig_len, s));
-    if (fork) {
-        MLDSA_HIP_CHECK(hipEventRecord(ctx->join_ev, side));
-        MLDSA_HIP_CHECK(hipStreamWaitEvent(main_stream, ctx->join_ev, 0));
-    }
     return MLDSA_OK;
 }
 
@@ -1014,7 +1000,7 @@ int sign_chunk_enqueue(mldsa_ctx *ctx, const mldsa_params *p, const SignPlan &pl
     bool slots0[2] = {false, false};  // round 0 opened by the (small) prologue's own launch
     for (int i = 0; i < n_lanes; i++) {
         const bool ask = rounds > 0 && lanes[i].w.host_ctl != nullptr && lanes[i].a.export_sigs == nullptr;
-        TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st, n_lanes == 1, ask ? &pl : nullptr, ask ? &slots0[i] : nullptr));
+        TRY(sign_prologue(ctx, p, lanes[i].w, lanes[i].a, lanes[i].st, ask ? &pl : nullptr, ask ? &slots0[i] : nullptr));
     }
     // 10: while (z, h) = bottom                                            ml_dsa.rs:212
     // Two candidates per op generated at once (k_make_slots): where the plan expects two one-candidate rounds in a row, on a batch
@@ -1203,9 +1189,9 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     int rc = MLDSA_OK;
     for (size_t o = 0; o < n_ops && rc == MLDSA_OK; o += chunk) {
         const size_t n_chunk = (n_ops - o) < chunk ? (n_ops - o) : chunk;
-        struct { int op, n_lanes; long spec_target, spec_rows, spec_alpha, spec_max, rounds, ahead; SignArgs a[2]; } key;
+        struct { int op, n_lanes; long spec_target, spec_rows, spec_max, rounds, ahead; SignArgs a[2]; } key;
         memset(&key, 0, sizeof(key));  // the struct is the graph key: no indeterminate padding
-        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = std::min(ctx->opt_spec_target, ctx->spec_target_cap); key.spec_rows = ctx->opt_spec_rows; key.spec_alpha = ctx->opt_spec_alpha; key.spec_max = ctx->opt_spec_max;
+        key.op = MLDSA_OP_SIGN; key.n_lanes = n_lanes; key.spec_target = std::min(ctx->opt_spec_target, ctx->spec_target_cap); key.spec_rows = ctx->opt_spec_rows; key.spec_max = ctx->opt_spec_max;
         key.rounds = (long)pl.m_hint.size();  // the planned rounds (options, the asynchronous stop threshold) shape the launch sequence
         key.ahead = ctx->opt_lookahead;
         int live = 0;

@@ -76,9 +76,10 @@ extern "C" {
 #define MLDSA_MODE_PREHASH 2   /* mu = H(tr | 0x01 | len(ctx) | ctx | OID | PH(M)); msg = OID|PH(M) */
 
 /* Bumped whenever a struct of this header grows or an entry point changes its meaning (4: mldsa_stats has 6 fields, the group
- * calls take device-resident slices, offset tables are validated; 5: key-lifetime calls of the batcher, MLDSA_OPT_SMALL_FUSED).
+ * calls take device-resident slices, offset tables are validated; 5: key-lifetime calls of the batcher, MLDSA_OPT_SMALL_FUSED;
+ * 6: the environment is read only under MLDSA_TUNING_ENV=1, three closed knobs are gone, mldsa_group_rccl_info).
  * mldsa_abi_version() reports the library's. */
-#define MLDSA_ABI_VERSION 5
+#define MLDSA_ABI_VERSION 6
 int mldsa_abi_version(void);
 
 typedef struct mldsa_ctx mldsa_ctx;
@@ -158,6 +159,39 @@ int mldsa_ctx_set_workspace(mldsa_ctx *ctx, void *dev_buf, size_t bytes);
                                     of 105 us, key generation 73 instead of 166, signing 127 instead of 227. */
 int mldsa_set_option(mldsa_ctx *ctx, int option, long value);
 long mldsa_get_option(const mldsa_ctx *ctx, int option);
+
+/* Environment.  By DEFAULT THE LIBRARY READS NOTHING FROM THE ENVIRONMENT THAT CHANGES WHAT IT LAUNCHES: a signing library is not
+ * re-scheduled by whatever MLDSA_* variables a host process happens to carry.  The measurement knobs below are honoured only when the
+ * process also sets MLDSA_TUNING_ENV=1 (or the library was built with -DMLDSA_TUNING); mldsa_ctx_create then takes them as the INITIAL
+ * value of the option / context field beside them (out-of-range values are ignored; mldsa_set_option still overrides).  They exist for
+ * same-box A/Bs (tools/ab_*.sh, tools/coop_thresholds.sh, the soak of tests/test_gpu_sign_schedule.py); results never depend on them.
+ * tests/test_source_guards_cpu.py: every getenv() of the library is named here.
+ *   MLDSA_TUNING_ENV            1 = read the knobs below (anything else, or unset: none of them is read)
+ *   MLDSA_GRAPHS                MLDSA_OPT_GRAPHS (0 ... 2)
+ *   MLDSA_COOP_HASH             MLDSA_OPT_COOP_HASH (0 / 1)
+ *   MLDSA_SMALL_FUSED           MLDSA_OPT_SMALL_FUSED (0 ... 1024)
+ *   MLDSA_SMALL_KEYGEN_MAX      most keys of a single-launch key generation (ML-DSA-65 keys; default 256, under MLDSA_OPT_SMALL_FUSED)
+ *   MLDSA_SMALL_SIGN_MAX        most ops of a signing call whose prologue is one launch (default 256)
+ *   MLDSA_SMALL_SIGN_FRONT      0 = small signing rounds on the five batch kernels instead of the single-launch round front (default 1)
+ *   MLDSA_SMALL_SIGN_SPEC       candidates per op a small call must keep in round 0 to speculate only as far as that launch reaches (default 12; 0 = never)
+ *   MLDSA_COOP_HASH_MAX, MLDSA_COOP_MASK_MAX, MLDSA_COOP_A_MAX, MLDSA_COOP_MU_MAX, MLDSA_COOP_SIB_MAX
+ *                               largest launch (ops resp. polynomials) that takes the wave-cooperative sponge: fixed-shape hashes, ExpandMask,
+ *                               ExpandA (default 4096 each), mu, SampleInBall (default 1024 each); all under MLDSA_OPT_COOP_HASH
+ *   MLDSA_SPEC_TARGET           MLDSA_OPT_SPEC_TARGET
+ *   MLDSA_SPEC_MAX              MLDSA_OPT_SPEC_MAX
+ *   MLDSA_SPEC_ROWS             sign: candidates generated per speculative round (default 65536; beside MLDSA_OPT_SPEC_TARGET)
+ *   MLDSA_SIGN_LANES            MLDSA_OPT_SIGN_LANES
+ *   MLDSA_LOOKAHEAD             MLDSA_OPT_SIGN_LOOKAHEAD
+ *   MLDSA_VA_BLOCKS_PER_CU      MLDSA_OPT_VA_BLOCKS_PER_CU
+ *   MLDSA_HOST_SUB_VERIFY, MLDSA_HOST_SUB_SIGN
+ *                               *_host calls: ops per sub-batch (verify, keygen; default 8192) and of the last sub-batch (sign; default 16384)
+ *   MLDSA_HOST_DIRECT           0 = mldsa_sign_host never exports signatures round by round into a page-locked caller buffer (default 1)
+ *   MLDSA_WORKSPACE_CAP_MB      MLDSA_OPT_WORKSPACE_CAP_MB
+ *   MLDSA_PASS_OPS, MLDSA_PASS_OPS_SIGN
+ *                               ops resident per pass of a pipeline = what the workspace is sized for (default 131072 verify / keygen, 262144 sign)
+ * One more variable is read regardless (it changes what is PRINTED, nothing that runs):
+ *   MLDSA_DEBUG_IGNORED         1 = report on stderr every HIP error the library tolerates and clears (host_common.h)
+ * Removed in ABI 6 with their code paths (A/Bs closed, EXPERIMENTS.md): MLDSA_SIB_THIRD_STREAM, MLDSA_SIDE_PROLOGUE, MLDSA_SPEC_ALPHA. */
 /* counters for tests and bench.py: graphs captured / replayed, direct (un-captured) op-level calls, workspace growths,
  * extra signing rounds, and workspace_shrinks = how often the context made its passes smaller (the speculative rows of a signing pass
  * first, then the ops per pass) because the workspace of a full pass did not fit -- the device, MLDSA_OPT_WORKSPACE_CAP_MB or a caller-owned
@@ -545,6 +579,12 @@ int mldsa_group_sync(mldsa_group *g); /* waits for the streams of the last devic
  * context records behind its calls -- no host synchronisation is needed between mldsa_verify / mldsa_verify_group and this
  * call); buffers filled by anything else must be complete before the call.  Returns when every buffer is gathered. */
 int mldsa_group_allgather(mldsa_group *g, uint8_t *const *bufs, size_t n_ops, int use_rccl);
+/* Which RCCL the gather binds.  The library is loaded on first use in this order: the copy the process has ALREADY mapped under the
+ * SONAME librccl.so.1 (a Python host: torch's own torch/lib/librccl.so -- two RCCLs on one HIP runtime are avoided), then the usual
+ * search (LD_LIBRARY_PATH, the rpath /opt/rocm/lib).  g != NULL: what this group's first RCCL gather bound (MLDSA_ERR_PARAM before it);
+ * g == NULL: a probe that runs the same search without creating a communicator or touching a device.  buf <- "<reused|loaded> <file>";
+ * returns ncclGetVersion's code (e.g. 22606), 0 if unknown, MLDSA_ERR_DEVICE if no RCCL can be loaded. */
+int mldsa_group_rccl_info(const mldsa_group *g, char *buf, size_t buf_len);
 
 /* ---- single-operation callers: a batcher in front of the batched path ---------------------------
  * The reference's API is ONE operation per call (src/traits.rs:118-308 Signer, 330-362 Verifier, 28-104 KeyGen); a shim that keeps

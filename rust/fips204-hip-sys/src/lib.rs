@@ -33,7 +33,7 @@ pub const MLDSA_87: c_int = 87;
 pub const MLDSA_MODE_PURE: c_int = 0;
 pub const MLDSA_MODE_INTERNAL: c_int = 1;
 pub const MLDSA_MODE_PREHASH: c_int = 2;
-pub const MLDSA_ABI_VERSION: c_int = 5;
+pub const MLDSA_ABI_VERSION: c_int = 6;
 pub const MLDSA_OP_KEYGEN: c_int = 1;
 pub const MLDSA_OP_SIGN: c_int = 2;
 pub const MLDSA_OP_VERIFY: c_int = 3;
@@ -251,6 +251,7 @@ extern "C" {
     pub fn mldsa_keygen_group(g: *mut mldsa_group, set: c_int, slices: *const mldsa_keygen_slice, wait: c_int) -> c_int;
     pub fn mldsa_group_sync(g: *mut mldsa_group) -> c_int;
     pub fn mldsa_group_allgather(g: *mut mldsa_group, bufs: *const *mut u8, n_ops: usize, use_rccl: c_int) -> c_int;
+    pub fn mldsa_group_rccl_info(g: *const mldsa_group, buf: *mut c_char, buf_len: usize) -> c_int;
     pub fn mldsa_batcher_create(ctx: *mut mldsa_ctx, set: c_int, max_batch: usize, max_wait_us: c_uint, cache_keys: usize,
         out: *mut *mut mldsa_batcher) -> c_int;
     pub fn mldsa_batcher_create_on(device_ids: *const c_int, n: c_int, set: c_int, max_batch: usize, max_wait_us: c_uint, cache_keys: usize,

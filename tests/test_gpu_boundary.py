@@ -142,7 +142,8 @@ def test_small_passes_give_identical_results(sets):
         bad[::3, 100] ^= 1
         return host(pk), host(sk), host(sig), mm.verify(mm.public_keys_from_bytes(pk), msgs, bad, key_idx=kidx)
     want = run(m)
-    old = {k: os.environ.get(k) for k in ("MLDSA_PASS_OPS", "MLDSA_PASS_OPS_SIGN")}
+    old = {k: os.environ.get(k) for k in ("MLDSA_PASS_OPS", "MLDSA_PASS_OPS_SIGN", "MLDSA_TUNING_ENV")}
+    os.environ["MLDSA_TUNING_ENV"] = "1"  # the knobs are read only when the process asks for them (include/mldsa_hip.h "Environment")
     os.environ["MLDSA_PASS_OPS"] = "512"
     os.environ["MLDSA_PASS_OPS_SIGN"] = "512"
     try:
@@ -495,3 +496,29 @@ def test_argument_errors_never_abort(sets):
     pk, sk = m.keygen_from_seed([shake(b"err-key", 0)])
     sig = m.try_sign_with_seed(m.private_keys_from_bytes(sk), [b"still works"], [bytes(32)])
     assert m.verify(m.public_keys_from_bytes(pk), [b"still works"], sig).all()
+
+
+def test_environment_knobs_are_read_only_when_the_process_asks_for_them():
+    """include/mldsa_hip.h "Environment": a host's MLDSA_* variables do not re-schedule the library; MLDSA_TUNING_ENV=1 turns the
+    measurement knobs on, per mldsa_ctx_create.  (Results never depend on them; what is checked is the option each knob shadows.)"""
+    from fips204_amd.hotpath import HotPath
+    names = ("MLDSA_TUNING_ENV", "MLDSA_SIGN_LANES", "MLDSA_SMALL_FUSED", "MLDSA_GRAPHS", "MLDSA_SPEC_TARGET")
+    old = {k: os.environ.get(k) for k in names}
+    OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SIGN_LANES, OPT_SMALL_FUSED = 1, 2, 7, 13
+    try:
+        os.environ.update({"MLDSA_SIGN_LANES": "2", "MLDSA_SMALL_FUSED": "0", "MLDSA_GRAPHS": "2", "MLDSA_SPEC_TARGET": "4096"})
+        got = {}
+        for switch in (None, "0", "yes", "1"):
+            os.environ.pop("MLDSA_TUNING_ENV", None)
+            if switch is not None:
+                os.environ["MLDSA_TUNING_ENV"] = switch
+            h = HotPath(0)
+            try:
+                got[switch] = tuple(h.get_option(o) for o in (OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SIGN_LANES, OPT_SMALL_FUSED))
+            finally:
+                h.close()
+        assert got[None] == got["0"] == got["yes"] == (0, 65536, 1, 256), got   # the defaults: nothing was read
+        assert got["1"] == (2, 4096, 2, 0), got
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)

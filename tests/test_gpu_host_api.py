@@ -127,6 +127,8 @@ def test_sign_host_writes_page_locked_signatures_directly(sets, n, nk, passes, l
     env = {"MLDSA_PASS_OPS_SIGN": str(passes)} if passes else {}
     if lanes != 1:
         env["MLDSA_SIGN_LANES"] = str(lanes)
+    if env:
+        env["MLDSA_TUNING_ENV"] = "1"  # the knobs are read only when the process asks for them (include/mldsa_hip.h "Environment")
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:

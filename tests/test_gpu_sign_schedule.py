@@ -326,6 +326,7 @@ def test_rounds_just_below_a_speculation_threshold_fit_the_workspace(n, env):
     candidate, whatever the speculation)."""
     from fips204_amd.hotpath import HotPath
     from fips204_amd.ml_dsa import MlDsa
+    env = dict(env, MLDSA_TUNING_ENV="1") if env else {}
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:

@@ -8,6 +8,7 @@ refusal the boundary knows (malformed offsets, ctx > 255 bytes, key index out of
 hints), keys shared and distinct, A_hat kept by the caller (mldsa_verify_cached_a), and many calls back to back (the counters must
 return to zero).  Reference tests mirrored: tests/nist_vectors/mod.rs:148-203, tests/integration.rs:63-119, fuzz/fuzz_targets/fuzz_all.rs:25-37."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -399,3 +400,22 @@ def test_acvp_siggen_one_op_per_call(env, acvp_siggen):
             assert sig[0].cpu().numpy().tobytes() == bytes.fromhex(t["signature"]), t["tcId"]
             n += 1
     assert n == 60
+
+
+# ------------------------------------------------------------------------------ the -DMLDSA_NO_LATE_ARG build (field.h)
+def test_the_build_without_late_arguments_gives_the_same_bytes():
+    """A toolchain that lays the kernarg segment out differently fails mldsa_ctx_create's self-test (field.h late_arg); the fallback build
+    (`make nolatearg`: late arguments from an LDS copy of the kernel's argument struct) must then be a drop-in: keys, signatures and
+    verdicts of one-op, small and 20 000-op calls of all three parameter sets equal the oracle's (ml_dsa.rs:57-134, 153-337, 351-437)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "fips204_amd", "csrc")
+    lib = os.path.join(root, "tests", "_build", "libmldsa_hip_nolatearg.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(os.path.join(csrc, f)) for f in ("kernels_sign.hip", "kernels_small.hip", "field.h", "pipeline.hip")):
+        subprocess.check_call(["make", "-C", csrc, "-j8", "nolatearg"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "nolatearg_scenarios.py"), lib], capture_output=True, text=True, timeout=1200, cwd=root)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(res) >= 12 and all(res.values()), res

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MLDSA_TUNING_ENV=1  # the library reads its measurement knobs only when asked to (include/mldsa_hip.h "Environment")
 # Where do the single-launch kernels stop paying, per parameter set?  Same-box A/B of MLDSA_SMALL_FUSED (default 256) against 0 for
 # verification, key generation and signing calls of 96 ... 512 ops (tools/latency_probe.py, wall time per call).
 for S in 44 65 87; do

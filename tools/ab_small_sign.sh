@@ -1,4 +1,5 @@
 #!/bin/bash
+export MLDSA_TUNING_ENV=1  # the library reads its measurement knobs only when asked to (include/mldsa_hip.h "Environment")
 # Same-box A/B of the small signing calls' switches (environment, read at context creation): the single-launch round front, the small
 # calls' own speculation rule, the single-launch kernels as a whole.  ML-DSA-44 / 65 / 87, wall time per call (tools/latency_probe.py).
 for S in 44 65 87; do

@@ -86,7 +86,7 @@ for op in verify sign keygen; do
   sqpass coop_${op}_n64 "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "$PWD/tools/latency_probe.py" $op 64 40
 done
 for op in verify sign keygen; do  # the same calls through the batch pipeline: the stand-alone cooperative kernels (k_expand_a_coop, k_shake256_2_coop, k_expand_s_coop, k_expand_mask_coop ...)
-  MLDSA_SMALL_FUSED=0 sqpass coop_${op}_pipeline_n64 "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "$PWD/tools/latency_probe.py" $op 64 40
+  MLDSA_TUNING_ENV=1 MLDSA_SMALL_FUSED=0 sqpass coop_${op}_pipeline_n64 "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" "$PWD/tools/latency_probe.py" $op 64 40
 done
 # ---- small-call kernel timelines (one-op, 64-op, 1 024-op verify / sign / keygen; the batch pipeline's verify beside the single launch)
 tools/collect_small_calls.sh $R > /dev/null 2>> "$ERR"
@@ -95,7 +95,7 @@ for f in gpurun_out/small_$R/unprofiled_*.txt; do cat "$f"; done > "$OUT/small_c
 for f in "$OUT"/${R}_small_call_*; do b=$(basename "$f"); mv "$f" "$OUT/${b#${R}_}"; note "${b#${R}_}" "tools/collect_small_calls.sh $R  (rocprofv3 --kernel-trace --stats -- python3 tools/latency_probe.py <op> <n> 60; tools/small_call_timeline.py)"; done
 note small_call_unprofiled_wall.txt "python3 tools/latency_probe.py <op> <n> 200 (no profiler): the wall time the timelines decompose"
 # the batch pipeline the single-launch kernels replace (MLDSA_SMALL_FUSED=0): the same calls, timelines and kernel stats beside the others
-MLDSA_SMALL_FUSED=0 tools/collect_small_calls.sh ${R}pipe "verify sign keygen" "1 64" > /dev/null 2>> "$ERR"
+MLDSA_TUNING_ENV=1 MLDSA_SMALL_FUSED=0 tools/collect_small_calls.sh ${R}pipe "verify sign keygen" "1 64" > /dev/null 2>> "$ERR"
 for op in verify sign keygen; do for n in 1 64; do
   cp gpurun_out/small_${R}pipe/${R}pipe_small_call_timeline_${op}_n$n.json "$OUT/small_call_timeline_${op}_n${n}_batch_pipeline.json" 2>/dev/null
   note small_call_timeline_${op}_n${n}_batch_pipeline.json "MLDSA_SMALL_FUSED=0 tools/collect_small_calls.sh (the batch pipeline the single-launch kernels replace)"

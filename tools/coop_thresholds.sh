@@ -1,4 +1,5 @@
 #!/bin/bash
+export MLDSA_TUNING_ENV=1  # the library reads its measurement knobs only when asked to (include/mldsa_hip.h "Environment")
 # where the wave-cooperative sponges stop paying: tools/coop_thresholds.sh -- device-resident ML-DSA-65 calls of n ops with each
 # cooperative kernel forced on (limit 2^20) or off (limit 0) at that size, the others at their defaults
 for op in verify sign keygen; do

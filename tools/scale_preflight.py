@@ -132,6 +132,35 @@ def check_group(devices, per_dev, pset=65):
     return report
 
 
+def rccl_report(import_torch=True):
+    """Which RCCL the library's group gather binds in THIS process (mldsa_group_rccl_info(NULL): the loader's search without a communicator or a
+    device) beside the one torch has mapped: in a Python host they must be the same file ("reused ..."), never two RCCLs on one HIP runtime."""
+    import ctypes as C
+    rep = {}
+    if import_torch:
+        import torch  # noqa: F401  (maps torch/lib/librccl.so, SONAME librccl.so.1)
+        try:
+            v = torch.cuda.nccl.version()
+            rep["torch_rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+        except Exception as e:  # noqa: BLE001
+            rep["torch_rccl_version"] = "unknown: %r" % (e,)
+    mapped = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})
+    rep["rccl_mapped_before_probe"] = mapped
+    from fips204_amd import _lib
+    lib = _lib.load()
+    buf = C.create_string_buffer(1024)
+    ver = lib.mldsa_group_rccl_info(None, buf, len(buf))
+    if ver < 0:
+        rep["library_rccl"] = "failed: no librccl.so could be loaded"
+        return rep
+    how, _, path = buf.value.decode().partition(" ")
+    rep["library_rccl"] = {"how": how, "file": path, "version_code": ver}
+    if mapped:
+        same = os.path.realpath(path) in {os.path.realpath(m) for m in mapped}
+        rep["library_rccl_is_the_mapped_one"] = "ok" if (how == "reused" and same) else "failed: the process had %r mapped, the library bound %s %r" % (mapped, how, path)
+    return rep
+
+
 def run_bench(n, extra=()):
     """step 3: bench.py --gpus n as a child process (never an exec from a process that has touched the GPU)"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-pmc",
@@ -217,9 +246,15 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="no GPU: N gloo ranks exercise the shard / gather / min-max / line path")
     ap.add_argument("--rank-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--skip-bench", action="store_true")
+    ap.add_argument("--rccl-report", action="store_true", help="only: which librccl the library would bind in this process (no GPU needed)")
+    ap.add_argument("--no-torch", action="store_true", help="with --rccl-report: do not import torch first (a C / C++ / Rust host)")
     args = ap.parse_args()
     if args.rank_worker:
         return dry_run_worker()
+    if args.rccl_report:
+        rep = rccl_report(import_torch=not args.no_torch)
+        print(json.dumps(rep))
+        return 1 if any(isinstance(v, str) and v.startswith("failed") for v in rep.values()) else 0
     t0 = time.time()
     if args.dry_run:
         rep = dry_run(args.gpus or 2)
@@ -232,6 +267,7 @@ def main():
         n = args.gpus or n_vis
         devices = list(range(min(n, n_vis)))
         rep = {"devices_visible": n_vis, "devices_checked": devices}
+        rep.update(rccl_report())
         per_dev = {}
         for d in devices:
             try:
