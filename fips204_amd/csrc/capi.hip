@@ -754,6 +754,9 @@ int mldsa_pk_expand(mldsa_ctx *ctx, int set, const uint8_t *pk, uint8_t *rho, ui
     ENTER(ctx, "mldsa_pk_expand");
     REQUIRE(params_of(set), "mldsa_pk_expand: unknown parameter set");
     REQUIRE(n_keys == 0 || (pk && rho && tr && t1_d2_hat_mont), "mldsa_pk_expand: NULL pointer");
+    // (no workspace, but the profiling marks of the call live in the context: two threads expanding keys on one context while
+    //  mldsa_profile_enable is on raced on them -- found by the host sanitizer leg, tests/cpp/fuzz_host.cpp)
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);
     return pk_expand_batch(ctx, set, pk, rho, tr, t1_d2_hat_mont, n_keys, (hipStream_t)stream);
 }
 
@@ -762,6 +765,7 @@ int mldsa_sk_expand(mldsa_ctx *ctx, int set, const uint8_t *sk, uint8_t *rho, ui
     ENTER(ctx, "mldsa_sk_expand");
     REQUIRE(params_of(set), "mldsa_sk_expand: unknown parameter set");
     REQUIRE(n_keys == 0 || (sk && rho && cap_k && tr && s_1_hat_mont && s_2_hat_mont && t_0_hat_mont), "mldsa_sk_expand: NULL pointer");
+    std::lock_guard<std::mutex> lk(ctx->op_mutex);  // (the profiling marks: see mldsa_pk_expand)
     return sk_expand_batch(ctx, set, sk, rho, cap_k, tr, s_1_hat_mont, s_2_hat_mont, t_0_hat_mont, n_keys, (hipStream_t)stream);
 }
 

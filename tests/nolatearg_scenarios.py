@@ -53,7 +53,7 @@ def run_all(lib_path):
             good = all(bytes(sig_h[i]) == orc.sign_internal(pset, okeys[kidx[i]][1], msgs[i], rnd[i], ctx=ctxs[i], mode=orc.MODE_PURE) for i in range(0, n, step))
             bad = sig.clone()
             bad[::3, 40] ^= 1
-            v = np.asarray(m.verify(pks, msgs, bad, ctxs=ctxs, key_idx=kidx).cpu())
+            v = np.asarray(m.verify(pks, msgs, bad, ctxs=ctxs, key_idx=kidx))
             good &= bool((~v[::3]).all() and v[1::3].all() and v[2::3].all())
             out[f"sign_verify{pset}_n{n}"] = bool(good)
     hp.close()
