@@ -78,6 +78,8 @@ def compact_line(full, also=None, extras_file=EXTRAS_FILE):
         line["reference_published"] = _pick(pub, ("value", "us_per_op"))
     if "ranks" in full:
         line["ranks"] = _pick(full["ranks"], ("min", "max"))
+    if full.get("step_ms"):  # spread over the K timed steps (event marks on the launch stream): three numbers
+        line["step_ms"] = {k: _num(full["step_ms"].get(k), 5) for k in ("min", "median", "max")}
     if also:
         out = {}
         for name, sub in also.items():

@@ -11,32 +11,85 @@ from .pmc import LIVE_PMC, pmc_traffic
 from .workloads import MixedStream, WholeOp, make_workload
 
 
-def timed_steps(wl, world, steps, first):
-    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks."""
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def read_sclk(device=0):
+    """the GPU's current shader clock in MHz (the starred line of pp_dpm_sclk in sysfs, else `rocm-smi --showclocks`), or None.  One read
+    costs ~0.1 ms (sysfs): taken OUTSIDE the timed region only."""
+    import glob
+    import re
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for ln in open(path):
+                if "*" in ln:
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", ln)
+                    if m:
+                        return {"mhz": int(m.group(1)), "source": path}
+        except OSError:
+            pass
+    try:
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showclocks", "-d", str(device)], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"sclk clock level.*?\((\d+)\s*Mhz\)", out, flags=re.I)
+        if m:
+            return {"mhz": int(m.group(1)), "source": "rocm-smi --showclocks"}
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def clock_ramp(wl, first, min_ms=200.0):
+    """>= min_ms of the workload's own steps BEFORE the counted warm-up: the GPU idled (clocks down) while the inputs were built and the CPU
+    oracle checked them.  Outside `steps` / `warmup`; what was run is reported in the side file."""
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < min_ms and n < 100000:
+        for _ in range(8):
+            wl.step(first + n)
+            n += 1
+        torch.cuda.synchronize()
+    return {"steps": n, "ms": round((time.perf_counter() - t0) * 1e3, 2)}
+
+
+def timed_steps(wl, world, steps, first, marks=64):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks.
+    An event is recorded on the launch stream every ceil(steps / marks) steps (a few microseconds of host time each, hidden behind the
+    device work of the steps): timed_steps.step_ms = min / median / max over those chunks, per step."""
+    stride = max(1, -(-steps // max(1, marks)))
+    n_marks = -(-steps // stride)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_marks + 1)]
     barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()
+    evs[0].record()
     for i in range(steps):
         wl.step(first + i)
+        if (i + 1) % stride == 0 or i + 1 == steps:
+            evs[(i + stride) // stride].record()
     if hasattr(wl, "finish_steps"):
         wl.finish_steps()  # inside the timed region: e.g. the mixed stream re-signs what its asynchronous calls left over
-    ev1.record()
+    ev_end = torch.cuda.Event(enable_timing=True)
+    ev_end.record()
     torch.cuda.synchronize()
     barrier(world)
     dt = time.perf_counter() - t0
     timed_steps.local_s = dt  # this rank's own time (run_one reports min / max over ranks beside `value`)
-    return max_over_ranks(dt, world), ev0.elapsed_time(ev1)
+    per = []
+    for j in range(n_marks):
+        in_chunk = min(stride, steps - j * stride)
+        per.append(evs[j].elapsed_time(evs[j + 1]) / in_chunk)
+    per.sort()
+    timed_steps.step_ms = {"min": per[0], "median": per[len(per) // 2], "max": per[-1], "steps_per_mark": stride} if per else None
+    return max_over_ranks(dt, world), evs[0].elapsed_time(ev_end)
 
 
 def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_fed=False, cpu_budget_s=None):
     wl = make_workload(name, hp, args.batch if name == args.workload else 0, rank, world)
     if rank == 0:
         wl.check()
+    ramp = clock_ramp(wl, 0)  # (outside steps / warmup; in the side file)
     for i in range(warmup):
         wl.step(i)
     torch.cuda.synchronize()
+    sclk0 = read_sclk() if rank == 0 else None
     whole = isinstance(wl, WholeOp)
     units_per_step = getattr(wl, "ops_per_step", wl.batch)
 
@@ -44,6 +97,8 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     # hipGraph), barrier + synchronize on both sides, max over ranks -> `value`
     st0 = hp.stats() if hasattr(hp, "stats") else None
     dt, ev_ms = timed_steps(wl, world, steps, warmup)
+    step_ms = timed_steps.step_ms
+    sclk1 = read_sclk() if rank == 0 else None
     kern_ms = ev_ms / steps / wl.kernel_launches_per_step()
     value = units_per_step * world * steps / dt
     ranks = None
@@ -60,7 +115,7 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     stages, dt_prof = None, None
     if whole:
         hp.profile_enable(True)
-        dt_prof, _ = timed_steps(wl, world, steps, warmup + steps)
+        dt_prof, _ = timed_steps(wl, world, steps, warmup + steps, marks=0)
         stages = hp.profile_report()
         hp.profile_enable(False)
 
@@ -129,6 +184,13 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     elif traffic_file:
         line["roofline"]["traffic_source"] = "profiles/" + traffic_file
     line["launch_mode"] = launch_mode
+    # spread of the timed region (event marks on the launch stream) and the clock state either side of it: what tells a slow box or a
+    # clock that had not ramped from a regression (the value itself stays total units / wall time of exactly K steps)
+    if step_ms:
+        line["step_ms"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in step_ms.items()}
+    line["clock_ramp"] = dict(ramp, note="the workload's own steps before the counted warm-up, outside steps / warmup")
+    line["sclk"] = {"before_timed_region": sclk0, "after_timed_region": sclk1,
+                    "note": "read on the idle device just before / just after the timed region (MHz; null = not readable on this box)"}
     if ranks:
         line["ranks"] = ranks
     if isinstance(wl, MixedStream):

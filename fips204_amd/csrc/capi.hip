@@ -698,6 +698,7 @@ static int verify_call(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, co
     const mldsa_params *p = params_of(set);
     if (n_ops == 0) return MLDSA_OK;
     OpGuard guard(ctx, s);
+    if (guard.rc != MLDSA_OK) return guard.rc;  // not ordered behind the previous call's clearing of its secrets
     int rc = reserve_workspace(ctx, p, MLDSA_OP_VERIFY, n_ops, a_hat == nullptr, n_keys, pk_wire ? (key_idx ? 2 : 1) : 0);
     if (rc != MLDSA_OK) return rc;
     struct { int op, set, mode; const void *rho, *a_hat, *tr, *t1, *pk; size_t n_keys; const void *key_idx, *msgs, *msg_off, *ctxs, *ctx_off, *sigs, *ok;
@@ -796,6 +797,7 @@ int mldsa_get_public_key(mldsa_ctx *ctx, int set, const uint8_t *rho, const uint
             "mldsa_get_public_key: NULL pointer");
     if (n_keys == 0) return MLDSA_OK;
     OpGuard guard(ctx, (hipStream_t)stream);
+    if (guard.rc != MLDSA_OK) return guard.rc;
     int rc = reserve_workspace(ctx, p, MLDSA_OP_KEYGEN, n_keys, true);
     if (rc != MLDSA_OK) return rc;
     return get_public_key_batch(ctx, set, rho, tr, s_1_hat_mont, s_2_hat_mont, pk_rho, pk_tr, pk_t1_d2_hat_mont, n_keys, (hipStream_t)stream);

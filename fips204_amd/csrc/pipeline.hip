@@ -768,7 +768,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     // round's k_compact_small opens the next one
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
-    const bool small_compact = w.host_ctl != nullptr && !export_sg;
+    const bool small_compact = w.host_ctl != nullptr;  // (sign_batch sets host_ctl only for calls that do not export)
     auto compact = [&]() -> int {
         if (small_compact) {
             CompactSmallArgs C{};
@@ -1168,7 +1168,9 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
         static_assert(sizeof(lanes) / sizeof(lanes[0]) <= SMALL_CTR_SETS, "one set of arrival counters per lane");
         lanes[i].w.small_ctr = ctx->d_small_ctr + (size_t)i * SMALL_CTR_ENTRIES;
         // a small call's k_compact (one workgroup: at most 256 unfinished ops) reports to the host itself (see launch_compact)
-        if (per_lane <= 256 && ctx->h_ctl_dev && !pl.m_hint.empty()) lanes[i].w.host_ctl = ctx->h_ctl_dev + i;
+        // (never for a call that exports its signatures round by round: its rounds end with the batch k_compact, which does not report --
+        //  one predicate for "k_compact_small writes h_ctl" (enqueue_sign_round) and "the copy of the control block is skipped" (sign_chunk_finish))
+        if (per_lane <= 256 && ctx->h_ctl_dev && !pl.m_hint.empty() && !export_sigs) lanes[i].w.host_ctl = ctx->h_ctl_dev + i;
         ws_off += lanes[i].w.bytes;
     }
     if (ctx->ws_bytes < ws_off) return set_error(MLDSA_ERR_NOMEM, "sign: workspace not reserved");

@@ -107,3 +107,25 @@ def test_side_file_is_written_beside_bench_py(tmp_path):
     assert paths == [str(tmp_path / "bench_extras.json")] and json.load(open(paths[0])) == {"a": {"b": 1.5}}
     os.mkdir(tmp_path / "gpurun_out")
     assert len(bline.write_extras(str(tmp_path), {"a": 1})) == 2
+
+
+def test_line_carries_the_spread_of_the_timed_steps_and_the_side_object_the_clocks():
+    """the one driver-timed number came without spread or clock state.  runner.run_one now runs >= 200 ms of the
+    workload before the counted warm-up, marks the timed steps with events and reads sclk either side; the line gets three numbers
+    (step_ms min / median / max), the side file the rest -- and the worst case still fits."""
+    full, also = _worst_case()
+    full["step_ms"] = {"min": 1.7012345678, "median": 1.7312345678, "max": 1.9912345678, "steps_per_mark": 2}
+    full["clock_ramp"] = {"steps": 120, "ms": 207.5, "note": "x" * 300}
+    full["sclk"] = {"before_timed_region": {"mhz": 2400, "source": "/sys/class/drm/card1/device/pp_dpm_sclk"}, "after_timed_region": None, "note": "x" * 300}
+    line = bline.compact_line(full, also)
+    text = bline.check_line(line)
+    assert len(text) <= bline.MAX_LINE_BYTES
+    assert line["step_ms"] == {"min": 1.7012, "median": 1.7312, "max": 1.9912}
+    assert "clock_ramp" not in line and "sclk" not in line   # side file only
+    # the runner's helpers without a GPU: the sysfs reader returns None or a dict, never raises
+    from benchlib import runner
+    got = runner.read_sclk()
+    assert got is None or (isinstance(got["mhz"], int) and got["source"])
+    import inspect
+    src = inspect.getsource(runner.run_one)
+    assert src.index("clock_ramp(wl, 0)") < src.index("for i in range(warmup)") < src.index("timed_steps(wl, world, steps, warmup)")
