@@ -122,6 +122,8 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->small_keygen_max = (size_t)env_long("MLDSA_SMALL_KEYGEN_MAX", 0, (long)SMALL_FUSED_MAX, (long)ctx->small_keygen_max);
     ctx->small_sign_max = (size_t)env_long("MLDSA_SMALL_SIGN_MAX", 0, 256, (long)ctx->small_sign_max);
     ctx->small_sign_front = env_long("MLDSA_SMALL_SIGN_FRONT", 0, 1, ctx->small_sign_front);
+    ctx->small_sign_back = env_long("MLDSA_SMALL_SIGN_BACK", 0, 1, ctx->small_sign_back);
+    ctx->small_back_slots_max = (size_t)env_long("MLDSA_SMALL_BACK_SLOTS_MAX", 0, 1 << 20, (long)ctx->small_back_slots_max);
     ctx->small_sign_spec = env_long("MLDSA_SMALL_SIGN_SPEC", 0, 32, ctx->small_sign_spec);
     ctx->coop_hash_max = (size_t)env_long("MLDSA_COOP_HASH_MAX", 0, 1 << 20, (long)ctx->coop_hash_max);
     ctx->coop_mask_max = (size_t)env_long("MLDSA_COOP_MASK_MAX", 0, 1 << 20, (long)ctx->coop_mask_max);

@@ -162,6 +162,11 @@ __device__ __forceinline__ T late_arg(unsigned byte_offset) {
 }
 template <class T>
 __device__ __forceinline__ void reload_first_kernarg(T& out, const T& arg) { out = arg; }
+// a whole sub-struct of the first argument, by reference (read where the reference is used)
+template <class T>
+__device__ __forceinline__ const T& late_ref(unsigned byte_offset) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(late_args_copy) + byte_offset);
+}
 #else
 template <class A>
 __device__ __forceinline__ void late_args_begin(const A&) {}
@@ -171,6 +176,15 @@ __device__ __forceinline__ T late_arg(unsigned byte_offset) {
     kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka));
     return *(const T __attribute__((address_space(4)))*)(ka + byte_offset);
+}
+// a whole sub-struct of the first argument, by reference: its fields are loaded from the kernarg segment where the reference is used,
+// not at the kernel's entry
+template <class T>
+__device__ __forceinline__ const T& late_ref(unsigned byte_offset) {
+    typedef const char __attribute__((address_space(4))) * kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *(const T*)(ka + byte_offset);
 }
 // the kernel's first by-value argument, read again from the kernarg segment (same ABI assumption, same self-test); `arg` = that argument
 template <class T>

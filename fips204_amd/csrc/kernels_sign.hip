@@ -514,11 +514,11 @@ __global__ __launch_bounds__(256) void k_compact(RoundCtl* __restrict__ ctl, int
 // host memory (host_ctl) instead of a copy of the control block behind the last round (a 4 us blit kernel and its gap on a 130 us call);
 // every round overwrites them, the host looks after the last one.  (ii) With next_on the round that follows is opened here as well
 // (make_slots_body for the other parity, on the list just built): no k_make_slots launch between two rounds of a small call.
-__global__ __launch_bounds__(256) void k_compact_small(CompactSmallArgs A) {
+__device__ __forceinline__ void compact_small_body(const CompactSmallArgs& A, uint32_t tid) {  // one workgroup of 256 threads
     RoundCtl* const ctl = A.ctl;
     const int parity = A.parity;
     const uint32_t m = ctl->m;
-    for (uint32_t i = threadIdx.x; i < m; i += 256) {
+    for (uint32_t i = tid; i < m; i += 256) {
         const uint32_t op = A.act_in[i];
         if (!A.done[op]) {
             const uint32_t j = atomicAdd(&ctl->cnt[parity ^ 1], 1u);
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_compact_small(CompactSmallArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's list entries (and counts) have reached L2 before the barrier
     __syncthreads();
     const uint32_t left = __hip_atomic_load(&ctl->cnt[parity ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (A.host_ctl && threadIdx.x == 0) {
+    if (A.host_ctl && tid == 0) {
         A.host_ctl->cnt[parity ^ 1] = left;
         A.host_ctl->cnt[parity] = ctl->cnt[parity];
         A.host_ctl->slots_total = ctl->slots_total;
@@ -538,7 +538,311 @@ __global__ __launch_bounds__(256) void k_compact_small(CompactSmallArgs A) {
     if (A.next_on) {
         const uint32_t spec = left ? A.rule.spec(left, A.spec_max) : 1u;
         make_slots_body(ctl, parity ^ 1, left, spec, ctl->gen_par[parity], A.ns_cap, A.act_out, A.kappa, A.l, A.slot_op, A.slot_kappa, A.key_idx, A.gen_op,
-                        A.gen_kappa, A.gen_key, 0, 0, A.ypos_out, A.slot_y, threadIdx.x, 256u, false);
+                        A.gen_kappa, A.gen_key, 0, 0, A.ypos_out, A.slot_y, tid, 256u, false);
+    }
+}
+__global__ __launch_bounds__(256) void k_compact_small(CompactSmallArgs A) { compact_small_body(A, threadIdx.x); }
+
+// ------------------------------------------------------------------------------------
+// The SECOND half of a small signing round as ONE launch (calls of <= 256 ops; the first half is k_sign_front_small): the tests of every
+// candidate (k_sign_tail), the one signature of each op's first survivor (k_resolve) and the bookkeeping that opens the next round
+// (k_compact_small) hand over inside the launch, the way the single-launch verify / keygen / round-front kernels do.
+//   * every op of the active list owns a cluster of ceil(spec / 4) workgroups, one wave per candidate: stage 1 of the iteration, the tests
+//     that can reject (tail_attempt<!FULL>), verdict to accept[];
+//   * the last workgroup of the cluster to arrive (arrival counter of the op's list position, release / acquire at agent scope, nobody
+//     spins) builds the signature of the FIRST survivor with its four waves side by side: z_j by wave j mod 4 (norm test, bytes),
+//     then the K hint rows by wave i mod 4 (one transform per row, hint bits as four ballot masks per row into LDS), then the verdict
+//     (weight <= omega, ML-DSA-44: ||c t0||inf) and the hint bytes from the masks.  k_resolve runs the same iteration on ONE wave:
+//     11 inverse transforms in a row, 13 us of a one-op call; here three or four.  A survivor the hint stage rejects (1 %) gives way to
+//     the next one, as in the reference's loop (ml_dsa.rs:212-330);
+//   * the workgroup that finishes the LAST op of the round compacts the active list, reports to the host's control block and opens the
+//     next round (compact_small_body).
+// Same rows in, same bytes out as the three kernels (tests/test_gpu_small_calls.py: fused = pipeline = oracle).
+struct SmallSignBackArgs {
+    TailPtrs a;          // (offset 0: tail_attempt reads these from the kernarg segment)
+    uint8_t* sigs;
+    int ct0_exact, oor_by_op;
+    RoundCtl* ctl;
+    const Twiddle* inv_tab;
+    const uint32_t *act, *slot_y, *key_idx;
+    const uint8_t *wrisk, *yrisk, *key_oor;
+    uint16_t* kappa;
+    int32_t *done, *accept;
+    uint32_t* ctr;       // [ops_cap + 1] arrival counters (zero between launches): one per list position, one for the round
+    uint32_t ops_cap, members, clusters;  // clusters: list positions the grid covers at once (a multiple of 8)
+    CompactSmallArgs C;
+};
+static_assert(offsetof(SmallSignBackArgs, a) == 0 && offsetof(SmallSignBackArgs, ct0_exact) == offsetof(SignTailArgs, ct0_exact), "tail_attempt's kernarg offsets");
+
+// the whole iteration for ONE candidate by the workgroup's four waves; every wave returns the same verdict
+template <int K, int L, bool G2HI>
+__device__ __forceinline__ bool resolve_coop4(int ct0_exact, size_t yrow, size_t key, bool s2_oor, uint8_t* sig, int32_t (*xpose)[N],
+                                              unsigned long long (*hmask)[4], int32_t* row_max, int* s_zbad, const LdsTw& itw, int lane, int wave) {
+    constexpr int gb = TailConst<K, L>::GB, beta = TailConst<K, L>::BETA, omega = TailConst<K, L>::OMEGA, ctilde_len = TailConst<K, L>::CTILDE;
+    constexpr int32_t GAMMA2 = G2HI ? (Q - 1) / 32 : (Q - 1) / 88;
+    constexpr bool CT0_CAN_FAIL = !G2HI;
+    constexpr int32_t gamma1 = 1 << gb;
+    constexpr int cb = gb + 1, YCB = cb;
+    auto wave_max = [](int32_t x) {
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) {
+            const int32_t o = __shfl_xor(x, mm);
+            x = o > x ? o : x;
+        }
+        return x;
+    };
+    if (threadIdx.x == 0) *s_zbad = 0;
+    const int4 cv = reinterpret_cast<const int4*>(late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, c_hat)) + yrow * N)[lane];
+    if (wave == 0 && lane < ctilde_len) sig[lane] = late_arg<const uint8_t*>((unsigned)offsetof(TailPtrs, ctilde))[yrow * 64 + lane];
+    __syncthreads();
+    // ---- z_j = y_j + invNTT(c_hat o s1_hat_j): norm test and bytes (ml_dsa.rs:243-280, encodings.rs:238-276)
+#pragma unroll 1
+    for (int j = wave; j < L; j += GWAVES) {
+        int32_t v[4], r[4], zc4[4];
+        load_packed(v, late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, s1)) + (key * L + j) * (size_t)N, lane);
+        const uint8_t* xb = reinterpret_cast<const uint8_t*>(late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, y))) + (yrow * L + j) * (size_t)(32 * YCB);
+        uint32_t x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = *reinterpret_cast<const u32_any*>(xb + k * (8 * YCB) + ((lane * YCB) >> 3));
+        r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+        ntt_inv_wave(r, itw, lane, F_MONT);
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int32_t zs = y_from_raw<YCB>(x[k], lane) + r[k];
+            const int32_t zc = zs - ((((Q / 2) - zs) >> 31) & Q);
+            zc4[k] = zc;
+            bad |= (zc < 0 ? -zc : zc) >= gamma1 - beta;
+        }
+        if (__ballot(bad) != 0ull && lane == 0) *s_zbad = 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) xpose[wave][64 * k + lane] = zc4[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int4 z4 = reinterpret_cast<const int4*>(xpose[wave])[lane];
+        const int32_t zz[4] = {z4.x, z4.y, z4.z, z4.w};
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {  // BitPack(z, gamma1 - 1, gamma1): field = gamma1 - z
+            const uint64_t f = (uint64_t)(uint32_t)(gamma1 - zz[t]);
+            const int sh = t * cb;
+            lo |= f << sh;
+            if (sh + cb > 64) hi |= (uint32_t)(f >> (64 - sh));
+        }
+        constexpr int NBYTES = YCB / 2;
+        uint8_t* dst = sig + ctilde_len + (size_t)j * (32 * YCB) + (size_t)lane * NBYTES;
+        *reinterpret_cast<u64_any*>(dst) = lo;
+        if constexpr (NBYTES == 10) *reinterpret_cast<u16_any*>(dst + 8) = (uint16_t)hi;
+        else dst[8] = (uint8_t)hi;
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- hint rows: h_i = [HighBits(w_i + invNTT(c_hat o (t0_hat_i - s2_hat_i))) != HighBits(w_i)]  (tail_attempt, stage 2)
+#pragma unroll 1
+    for (int i = wave; i < K; i += GWAVES) {
+        int32_t v[4], v2[4], r[4], base[4];
+        load_packed(v, late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, t0)) + (key * K + i) * (size_t)N, lane);
+        load_packed(v2, late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, s2)) + (key * K + i) * (size_t)N, lane);
+        const uint32_t* wq = reinterpret_cast<const uint32_t*>(late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, w))) + (yrow * K + i) * (size_t)PACKED_POLY_DWORDS;
+        const Packed3 wp{wq[lane], wq[64 + lane], wq[128 + lane]};
+        if (s2_oor) {
+            r[0] = mont_mul(cv.x, v2[0]); r[1] = mont_mul(cv.y, v2[1]); r[2] = mont_mul(cv.z, v2[2]); r[3] = mont_mul(cv.w, v2[3]);
+            ntt_inv_wave(r, itw, lane, F_MONT);
+            const int4 w4 = unpack24(wp);
+            base[0] = caddq(w4.x - r[0]); base[1] = caddq(w4.y - r[1]); base[2] = caddq(w4.z - r[2]); base[3] = caddq(w4.w - r[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] -= v2[k];
+        }
+        r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+        ntt_inv_wave(r, itw, lane, F_MONT);
+        if (!s2_oor) {
+            const int4 w4 = unpack24(wp);
+            base[0] = w4.x; base[1] = w4.y; base[2] = w4.z; base[3] = w4.w;
+        }
+        int32_t dmax = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if constexpr (CT0_CAN_FAIL) {
+                int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);
+                tc = tc < 0 ? -tc : tc;
+                dmax = tc > dmax ? tc : dmax;
+            }
+            int32_t a1, a0, b1, b0;
+            const int32_t sum = base[k] + r[k] - Q;
+            decompose<G2HI>(caddq(sum), a1, a0);
+            decompose<G2HI>(base[k], b1, b0);
+            const unsigned long long mask = __ballot(a1 != b1);
+            if (lane == 0) hmask[i][k] = mask;
+        }
+        if constexpr (CT0_CAN_FAIL) {
+            dmax = wave_max(dmax);
+            if (lane == 0) row_max[i] = dmax;
+        }
+    }
+    __syncthreads();
+    int index = 0;
+#pragma unroll
+    for (int i = 0; i < K; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) index += __popcll(hmask[i][k]);
+    bool ok = *s_zbad == 0 && index <= omega;  // ml_dsa.rs:280, 313-315
+    if constexpr (CT0_CAN_FAIL) {
+        int32_t dmax = 0;
+#pragma unroll
+        for (int i = 0; i < K; i++) dmax = row_max[i] > dmax ? row_max[i] : dmax;
+        bool ct0_ok = dmax + (s2_oor ? 0 : beta) < GAMMA2;
+        if (!s2_oor && (!ct0_ok || ct0_exact)) {  // (workgroup-uniform: every wave read the same LDS words) ||c t0||inf proper, ml_dsa.rs:312
+            __syncthreads();
+#pragma unroll 1
+            for (int i = wave; i < K; i += GWAVES) {
+                int32_t v[4], r[4], tmax = 0;
+                load_packed(v, late_arg<const int32_t*>((unsigned)offsetof(TailPtrs, t0)) + (key * K + i) * (size_t)N, lane);
+                r[0] = mont_mul(cv.x, v[0]); r[1] = mont_mul(cv.y, v[1]); r[2] = mont_mul(cv.z, v[2]); r[3] = mont_mul(cv.w, v[3]);
+                ntt_inv_wave(r, itw, lane, F_MONT);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int32_t tc = r[k] - ((((Q / 2) - r[k]) >> 31) & Q);
+                    tc = tc < 0 ? -tc : tc;
+                    tmax = tc > tmax ? tc : tmax;
+                }
+                tmax = wave_max(tmax);
+                if (lane == 0) row_max[i] = tmax;
+            }
+            __syncthreads();
+            int32_t tmax = 0;
+#pragma unroll
+            for (int i = 0; i < K; i++) tmax = row_max[i] > tmax ? row_max[i] : tmax;
+            ct0_ok = tmax < GAMMA2;
+        }
+        ok = ok && ct0_ok;
+    }
+    if (ok && wave == 0) {  // HintBitPack (conversion.rs:277-328) from the rows' masks
+        uint8_t* hy = sig + ctilde_len + (size_t)L * (32 * cb);
+        for (int i = lane; i < omega + K; i += 64) hy[i] = 0;
+        int idx = 0;
+#pragma unroll 1
+        for (int i = 0; i < K; i++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long mask = hmask[i][k];
+                if ((mask >> lane) & 1ull) {
+                    const int rank = idx + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (rank < omega) hy[rank] = (uint8_t)(64 * k + lane);
+                }
+                idx += __popcll(mask);
+            }
+            if (lane == 0) hy[omega + i] = (uint8_t)(idx < 255 ? idx : 255);
+        }
+    }
+    __syncthreads();  // the LDS words are free for the next candidate
+    return ok;
+}
+
+template <int K, int L, bool G2HI>
+__global__ __launch_bounds__(64 * GWAVES) void k_sign_back_small(SmallSignBackArgs A0) {
+    typedef SmallSignBackArgs A;
+    late_args_begin(A0);
+    constexpr size_t sig_len = TailConst<K, L>::SIG_LEN;
+    __shared__ Twiddle tw_lds[INV_TW * 64];
+    __shared__ __attribute__((aligned(16))) int32_t xpose[GWAVES][N];
+    __shared__ unsigned long long hmask[K][4];
+    __shared__ int32_t row_max[K];
+    __shared__ int s_last, s_zbad;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x == 0 && LATE(A, ctl)->m == 0) {  // nothing left: one workgroup still reports and opens the (empty) next round, as k_compact_small would
+        compact_small_body(late_ref<CompactSmallArgs>((unsigned)offsetof(A, C)), threadIdx.x);
+        return;
+    }
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)LATE(A, ctl)->m), spec = (uint32_t)__builtin_amdgcn_readfirstlane((int)LATE(A, ctl)->spec);
+    const uint32_t xcd = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    const uint32_t members = LATE(A, members);
+    const uint32_t member0 = q % members;
+    const uint32_t i0 = (q / members) * 8 + xcd;  // first position in the active list; the cluster's workgroups share an XCD (and its L2)
+    const uint32_t n_members = (spec + GWAVES - 1) / GWAVES;  // workgroup-sized pieces of an op's candidates
+    if (m == 0 || i0 >= m || member0 >= n_members) return;  // (whole workgroup)
+    for (int t = threadIdx.x; t < INV_TW * 64; t += 64 * GWAVES) tw_lds[t] = LATE(A, inv_tab)[t];
+    __syncthreads();
+    const LdsTw itw{tw_lds, lane};
+    // The grid is sized from the PLAN of the round (clusters = expected unfinished ops + 6 sigma, members = the candidates per op the rule
+    // gives in that range); the device's own counts decide.  A round that turns out larger is still complete: a workgroup walks further
+    // list positions (stride = the grid's clusters) and further pieces of an op's candidates (stride = the grid's members).
+#pragma unroll 1
+    for (uint32_t i = i0; i < m; i += LATE(A, clusters)) {
+        // (the round's counts made opaque per iteration: what is derived from them -- lane masks, m - 1 ... -- is recomputed where it is used
+        //  instead of being hoisted out of the loop and spilled)
+        uint32_t ms = m, sp = spec;
+        asm volatile("" : "+s"(ms), "+s"(sp));
+        const uint32_t n_mem = (sp + GWAVES - 1) / GWAVES;
+        const uint32_t op = LATE(A, act)[i];
+        const size_t key = LATE(A, key_idx) ? LATE(A, key_idx)[op] : op;
+        const bool s2_oor = LATE(A, key_oor)[LATE(A, oor_by_op) ? op : key] != 0;
+        // ---------------------------------------------------------------- stage 1 of the op's candidates: one wave each
+        uint32_t pieces = 0;
+#pragma unroll 1
+        for (uint32_t member = member0; member < n_mem; member += LATE(A, members), pieces++) {
+            const uint32_t cand = member * GWAVES + (uint32_t)wave;
+            if (cand < sp) {
+                const size_t slot = (size_t)i * sp + cand;
+                const size_t yrow = LATE(A, slot_y)[slot];
+                const uint32_t f = (uint32_t)LATE(A, wrisk)[yrow];
+                const uint8_t* yr = LATE(A, yrisk) + yrow * L;
+                uint32_t zr = 0;
+#pragma unroll
+                for (int j = 0; j < L; j++) zr |= (yr[j] ? 1u : 0u) << j;
+                const uint32_t r_risky = s2_oor ? (1u << K) - 1u : (f & 0xFFu);
+                const bool ok = tail_attempt<K, L, G2HI, false>(A0.a, slot, yrow, key, r_risky, zr, s2_oor, nullptr, xpose[wave], itw, lane);
+                if (lane == 0) __hip_atomic_store(&LATE(A, accept)[slot], ok ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---------------------------------------------------------------- hand-over to the last workgroup of the op to arrive
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's own stores have reached L2 (kernels_small.hip, hand-over)
+        __syncthreads();
+        if (n_mem > 1) {
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                const uint32_t seen = __hip_atomic_fetch_add(&LATE(A, ctr)[i], pieces, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = seen + pieces == n_mem;
+                if (last) __hip_atomic_store(&LATE(A, ctr)[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = last;
+            }
+            __syncthreads();
+            if (!s_last) continue;  // (workgroup-uniform)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        // ---------------------------------------------------------------- the op's first survivor -> its signature (four waves)
+        const int mine = (uint32_t)lane < sp ? __hip_atomic_load(&LATE(A, accept)[(size_t)i * sp + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        unsigned long long mask = __ballot(mine != 0);  // (the same in every wave)
+        bool fin = false;
+        while (mask && !fin) {
+            const int j = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const size_t slot = (size_t)i * sp + j;
+            fin = resolve_coop4<K, L, G2HI>(LATE(A, ct0_exact), (size_t)LATE(A, slot_y)[slot], key, s2_oor, LATE(A, sigs) + (size_t)op * sig_len, xpose, hmask, row_max, &s_zbad, itw,
+                                            lane, wave);
+        }
+        if (threadIdx.x == 0) {
+            if (fin) LATE(A, done)[op] = 1;
+            else { uint16_t* kp = LATE(A, kappa) + op; *kp = (uint16_t)(*kp + sp * L); }  // ml_dsa.rs:281 / 316 for every candidate of the round
+        }
+        // ---------------------------------------------------------------- the round's last op: compaction, report, next round
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const uint32_t seen = __hip_atomic_fetch_add(&LATE(A, ctr)[LATE(A, ops_cap)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = seen == ms - 1;
+            if (last) __hip_atomic_store(&LATE(A, ctr)[LATE(A, ops_cap)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            compact_small_body(late_ref<CompactSmallArgs>((unsigned)offsetof(A, C)), threadIdx.x);
+            return;  // (the last op of the round: nothing follows)
+        }
     }
 }
 
@@ -930,11 +1234,11 @@ int launch_key_range(mldsa_ctx* ctx, const mldsa_params* p, const int32_t* s2, c
     return MLDSA_OK;
 }
 
-int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, const SpecRule& rule, uint32_t spec_max, uint32_t ns_cap, const uint32_t* act,
+int launch_make_slots(mldsa_ctx*, RoundCtl* ctl, int parity, const SpecRule& rule, uint32_t sp_max, uint32_t ns_cap, const uint32_t* act,
                       const uint16_t* kappa, int l, uint32_t* slot_op, uint16_t* slot_kappa, const uint32_t* key_idx,
                       uint32_t* gen_op, uint16_t* gen_kappa, uint32_t* gen_key, size_t slots_hint, hipStream_t s, int may_use_pre,
                       int may_gen2, const uint32_t* ypos, uint32_t* slot_y) {
-    hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, rule, spec_max, ns_cap, act, kappa, l,
+    hipLaunchKernelGGL(k_make_slots, dim3(blocks256(slots_hint)), dim3(256), 0, s, ctl, parity, rule, sp_max, ns_cap, act, kappa, l,
                        slot_op, slot_kappa, key_idx, gen_op, gen_kappa, gen_key, may_use_pre, may_gen2, ypos, slot_y);
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
@@ -963,6 +1267,29 @@ int launch_resolve(mldsa_ctx* ctx, const mldsa_params* p, const RoundCtl* ctl, c
 int launch_compact(mldsa_ctx*, RoundCtl* ctl, int parity, const uint32_t* act_in, const int32_t* done, uint32_t* act_out,
                    size_t ops_hint, hipStream_t s, uint32_t* ypos_out, uint32_t* exp_list) {
     hipLaunchKernelGGL(k_compact, dim3(blocks256(ops_hint)), dim3(256), 0, s, ctl, parity, act_in, done, act_out, ypos_out, exp_list);
+    MLDSA_HIP_CHECK(hipGetLastError());
+    return MLDSA_OK;
+}
+
+int launch_sign_back_small(mldsa_ctx* ctx, const mldsa_params* p, const SignBackSmall& B, const CompactSmallArgs& C, hipStream_t s) {
+    if (!tail_consts_match(p)) return set_error(MLDSA_ERR_PARAM, "sign_back_small: parameter table and compiled constants disagree");
+    if (!B.wrisk || !B.yrisk || !B.key_oor || !B.slot_y || !B.ctr || B.ops_cap == 0 || B.ops_cap > 256 || B.spec_cap == 0 || B.spec_cap > 64)
+        return set_error(MLDSA_ERR_PARAM, "sign_back_small: bad arguments");
+    SmallSignBackArgs A;
+    A.a = TailPtrs{B.c_hat, B.y, B.w, B.ctilde, B.s1, B.s2, B.t0};
+    A.sigs = B.sigs; A.ct0_exact = (int)ctx->opt_ct0_exact; A.oor_by_op = B.oor_by_op; A.ctl = B.ctl; A.inv_tab = ctx->d_inv_tw;
+    A.act = B.act; A.slot_y = B.slot_y; A.key_idx = B.key_idx; A.wrisk = B.wrisk; A.yrisk = B.yrisk; A.key_oor = B.key_oor; A.kappa = B.kappa;
+    A.done = B.done; A.accept = B.accept; A.ctr = B.ctr; A.ops_cap = B.ops_cap; A.C = C;
+    // the grid follows the round's plan; the kernel walks whatever the device's own counts add to it
+    const uint32_t ops_grid = std::min<uint32_t>(B.ops_cap, std::max<uint32_t>(B.ops_hint, 1u)), spec_grid = std::min<uint32_t>(B.spec_cap, std::max<uint32_t>(B.spec_hint, 1u));
+    A.members = (spec_grid + GWAVES - 1) / GWAVES;
+    A.clusters = 8u * ((ops_grid + 7u) / 8u);
+    const unsigned grid = A.members * A.clusters;
+#define MLDSA_BACK(KK, LL, G2) hipLaunchKernelGGL((k_sign_back_small<KK, LL, G2>), dim3(grid), dim3(64 * GWAVES), 0, s, A)
+    if (p->set == MLDSA_44) MLDSA_BACK(4, 4, false);
+    else if (p->set == MLDSA_65) MLDSA_BACK(6, 5, true);
+    else MLDSA_BACK(8, 7, true);
+#undef MLDSA_BACK
     MLDSA_HIP_CHECK(hipGetLastError());
     return MLDSA_OK;
 }

@@ -582,6 +582,7 @@ struct SignPlan {
     size_t ns_max = 0;
     std::vector<size_t> m_hint, ns_hint;  // per round: ops / slots the grids are sized for
     std::vector<int> one_cand;            // per round: the plan expects one candidate per op (the device decides for itself)
+    std::vector<uint32_t> spec_hi;        // per round: most candidates per op the rule gives over the range the count can fall in
 };
 
 static SignPlan plan_sign_compute(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, double plan_stop) {
@@ -673,6 +674,7 @@ static SignPlan plan_sign_compute(const mldsa_ctx *ctx, int set, size_t n, bool 
             if (t >= m_lo && t <= m_hi) ns_top = std::max(ns_top, (size_t)t * pl.rule.spec(pl.rule.thr[sidx], pl.spec_max));
         }
         pl.ns_hint.push_back(std::min(pl.ns_max, ns_top));
+        pl.spec_hi.push_back(pl.rule.spec((uint32_t)std::max(1.0, std::floor(m_lo)), pl.spec_max));  // (spec is non-increasing in m)
         // progress is planned with the FEWER candidates of the two (the count sitting just above a threshold of the rule must not
         // leave the call short of rounds: a synchronous call would pay two extra rounds and a host round trip, an asynchronous
         // one would report MLDSA_ERR_AGAIN)
@@ -682,6 +684,7 @@ static SignPlan plan_sign_compute(const mldsa_ctx *ctx, int set, size_t n, bool 
         pl.m_hint.resize((size_t)ctx->opt_sign_rounds);
         pl.ns_hint.resize((size_t)ctx->opt_sign_rounds);
         pl.one_cand.resize((size_t)ctx->opt_sign_rounds);
+        pl.spec_hi.resize((size_t)ctx->opt_sign_rounds);
     }
     return pl;
 }
@@ -769,18 +772,47 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     const int set = p->set, par = round & 1;
     const bool own_a = a_hat_keys == nullptr;
     const bool small_compact = w.host_ctl != nullptr;  // (sign_batch sets host_ctl only for calls that do not export)
+    auto compact_small_args = [&]() {
+        CompactSmallArgs C{};
+        C.ctl = w.ctl; C.parity = par; C.act_in = w.act[par]; C.done = w.done; C.act_out = w.act[par ^ 1]; C.ypos_out = w.ypos[par ^ 1];
+        C.host_ctl = w.host_ctl; C.next_on = slots_next ? 1 : 0;
+        C.rule = pl.rule; C.spec_max = pl.spec_max; C.ns_cap = (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu); C.kappa = w.kappa; C.l = p->l;
+        C.slot_op = w.slot_op; C.slot_kappa = w.slot_kappa; C.key_idx = kidx; C.gen_op = w.gen_op; C.gen_kappa = w.gen_kappa;
+        C.gen_key = own_a ? nullptr : w.gen_key; C.slot_y = w.slot_y;
+        return C;
+    };
     auto compact = [&]() -> int {
         if (small_compact) {
-            CompactSmallArgs C{};
-            C.ctl = w.ctl; C.parity = par; C.act_in = w.act[par]; C.done = w.done; C.act_out = w.act[par ^ 1]; C.ypos_out = w.ypos[par ^ 1];
-            C.host_ctl = w.host_ctl; C.next_on = slots_next ? 1 : 0;
-            C.rule = pl.rule; C.spec_max = pl.spec_max; C.ns_cap = (uint32_t)std::min<size_t>(pl.ns_max, 0xFFFFFFFFu); C.kappa = w.kappa; C.l = p->l;
-            C.slot_op = w.slot_op; C.slot_kappa = w.slot_kappa; C.key_idx = kidx; C.gen_op = w.gen_op; C.gen_kappa = w.gen_kappa;
-            C.gen_key = own_a ? nullptr : w.gen_key; C.slot_y = w.slot_y;
-            STAGE("compact", launch_compact_small(ctx, C, s));
+            STAGE("compact", launch_compact_small(ctx, compact_small_args(), s));
         } else {
             STAGE("compact", launch_compact(ctx, w.ctl, par, w.act[par], w.done, w.act[par ^ 1], m_hint, s, w.ypos[par ^ 1], export_sg ? w.exp_list : nullptr));
         }
+        return MLDSA_OK;
+    };
+    // The second half of the round: the tests of every candidate, the winner's signature per op, compaction + the next round's slots.  A
+    // SMALL call (<= 256 ops, its counts reported through host_ctl) runs it as ONE launch with the hand-overs inside (kernels_sign.hip
+    // k_sign_back_small); otherwise three kernels.
+    const bool back_small = small_compact && ctx->small_sign_back && ctx->opt_small_fused > 0 && w.small_ctr && !pre_in && !gen2 && !pl.m_hint.empty() &&
+                            pl.m_hint[0] <= 256 && pl.spec_max <= 64 && ns_hint <= ctx->small_back_slots_max;
+    auto second_half = [&](const int32_t *y_rows, const uint8_t *yrisk_rows) -> int {
+        if (back_small) {
+            SignBackSmall B{};
+            B.c_hat = w.c; B.y = y_rows; B.w = w.w; B.ctilde = w.ctilde; B.s1 = s1; B.s2 = s2; B.t0 = t0; B.sigs = sg; B.oor_by_op = oor_by_op ? 1 : 0; B.ctl = w.ctl;
+            B.act = w.act[par]; B.slot_y = w.slot_y; B.key_idx = kidx; B.wrisk = w.wrisk; B.yrisk = yrisk_rows; B.key_oor = w.key_oor; B.kappa = w.kappa; B.done = w.done;
+            B.accept = w.accept; B.ctr = w.small_ctr; B.ops_cap = (uint32_t)pl.m_hint[0]; B.spec_cap = pl.spec_max;
+            B.ops_hint = (uint32_t)std::min<size_t>(m_hint, 256); B.spec_hint = (size_t)round < pl.spec_hi.size() ? pl.spec_hi[(size_t)round] : pl.spec_max;
+            STAGE("sign_back_small", launch_sign_back_small(ctx, p, B, compact_small_args(), s));
+            return MLDSA_OK;
+        }
+        // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
+        // (in a speculative round: only the tests that can reject, one verdict per candidate)
+        STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, y_rows, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
+                                            ns_hint, s, w.wrisk, yrisk_rows, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
+        // speculative rounds only (the kernel leaves at once when the device chose one candidate per op): the whole iteration
+        // for each op's first surviving candidate, bytes straight into the op's signature
+        STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, y_rows, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
+                                        m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
+        TRY(compact());
         return MLDSA_OK;
     };
     const uint32_t *ns_gen_dev = &w.ctl->ns_gen;  // rows generated this round (the tail kernels read ctl->ns themselves)
@@ -802,11 +834,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
         A.wrisk = w.wrisk; A.yrisk = w.yrisk; A.ctr = w.small_ctr; A.fwd_tab = ctx->d_fwd_tw; A.inv_tab = ctx->d_inv_tw;
         A.w_risk_bound = p->gamma2 - 2 * p->beta; A.y_risk_bound = p->gamma1 - 2 * p->beta; A.tau = p->tau; A.rows_cap = (uint32_t)rows_cap;
         STAGE("sign_front_small", launch_sign_front_small(ctx, p, A, own_a, s));
-        STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, w.y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
-                                            ns_hint, s, w.wrisk, w.yrisk, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
-        STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, w.y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
-                                        m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
-        TRY(compact());
+        TRY(second_half(w.y, w.yrisk));
         return MLDSA_OK;
     }
     // 11: y <- ExpandMask(rho'', kappa)                               :215
@@ -831,15 +859,7 @@ static int enqueue_sign_round(mldsa_ctx *ctx, const mldsa_params *p, const SignW
     STAGE("sample_in_ball", launch_sample_in_ball(ctx, set, w.ctilde, 64, w.c8, gen_hint, s, ns_gen_dev, true));
     // 17: c_hat <- NTT(c)                                             :240
     STAGE("ntt_c", launch_ntt_c8(ctx, w.c8, w.c, gen_hint, s, ns_gen_dev));
-    // 18-33: <<c s1>>, <<c s2>>, z, r0, checks, <<c t0>>, h, checks, sigEncode   :240-336
-    // (in a speculative round: only the tests that can reject, one verdict per candidate)
-    STAGE("sign_tail", launch_sign_tail(ctx, p, w.c, y, w.w, w.ctilde, w.slot_op, kidx, s1, s2, t0, w.kappa, w.done, sg, w.ctl, w.accept,
-                                        ns_hint, s, w.wrisk, yrisk, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
-    // speculative rounds only (the kernel leaves at once when the device chose one candidate per op): the whole iteration
-    // for each op's first surviving candidate, bytes straight into the op's signature
-    STAGE("resolve", launch_resolve(ctx, p, w.ctl, w.act[par], w.accept, w.c, y, w.w, w.ctilde, kidx, s1, s2, t0, sg, w.done, w.kappa,
-                                    m_hint, s, w.key_oor, oor_by_op ? 1 : 0, w.slot_y));
-    TRY(compact());
+    TRY(second_half(y, yrisk));
     if (export_sg) TRY(launch_export_snap(ctx, w.ctl, round, s));  // how far the completion-order list has grown: this round's range
     return MLDSA_OK;
 }

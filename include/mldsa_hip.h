@@ -173,6 +173,8 @@ long mldsa_get_option(const mldsa_ctx *ctx, int option);
  *   MLDSA_SMALL_KEYGEN_MAX      most keys of a single-launch key generation (ML-DSA-65 keys; default 256, under MLDSA_OPT_SMALL_FUSED)
  *   MLDSA_SMALL_SIGN_MAX        most ops of a signing call whose prologue is one launch (default 256)
  *   MLDSA_SMALL_SIGN_FRONT      0 = small signing rounds on the five batch kernels instead of the single-launch round front (default 1)
+ *   MLDSA_SMALL_SIGN_BACK       0 = the second half of a small signing round (tests, the winner's signature, bookkeeping) as three kernels instead of one launch (default 1)
+ *   MLDSA_SMALL_BACK_SLOTS_MAX  ... in rounds planned at up to this many candidate slots (default 2560)
  *   MLDSA_SMALL_SIGN_SPEC       candidates per op a small call must keep in round 0 to speculate only as far as that launch reaches (default 12; 0 = never)
  *   MLDSA_COOP_HASH_MAX, MLDSA_COOP_MASK_MAX, MLDSA_COOP_A_MAX, MLDSA_COOP_MU_MAX, MLDSA_COOP_SIB_MAX
  *                               largest launch (ops resp. polynomials) that takes the wave-cooperative sponge: fixed-shape hashes, ExpandMask,

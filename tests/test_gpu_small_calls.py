@@ -419,3 +419,90 @@ def test_the_build_without_late_arguments_gives_the_same_bytes():
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert len(res) >= 12 and all(res.values()), res
+
+
+# ------------------------------------------------------------------------------ the fused second half of a small round (k_sign_back_small)
+def hashlib_shake(tag, i, n):
+    import hashlib
+    return hashlib.shake_256(tag + int(i).to_bytes(8, "little")).digest(n)
+
+
+@pytest.mark.parametrize("pset", [44, 65, 87])
+def test_small_signing_calls_with_out_of_range_keys_match_the_oracle(env, pset):
+    """k_sign_back_small builds the winner's signature on four waves (resolve_coop4); a key whose s2 leaves [-eta, eta] voids the bound the
+    one-transform hint rows rest on and takes the reference's two-transform form there as well (ml_dsa.rs:288-306).  Coherent worst-case
+    keys (every eta field all-ones) make that matter in about 1 signature in 500: 3 000 signatures in small calls of 1 ... 250 ops, every
+    byte against the oracle, and the same calls through the batch pipeline (MLDSA_OPT_SMALL_FUSED = 0)."""
+    hp, sets = env
+    m = sets[pset]
+    rng = np.random.default_rng(4100 + pset)
+    pk_o, sk_o = orc.keygen_from_seed(pset, bytes(range(7, 39)))
+    good = np.frombuffer(orc.sk_into_bytes(pset, sk_o), dtype=np.uint8)
+    p = m.params
+    eta_bits = 3 if p.eta == 2 else 4
+    s_off, s_len = 128, (p.k + p.l) * 32 * eta_bits
+    nk = 4
+    sk = np.tile(good, (nk, 1)).copy()
+    for i in range(nk):
+        sk[i, s_off:s_off + s_len] = 0xFF
+        sk[i, 0] ^= i
+    sks = m.private_keys_from_bytes(torch.from_numpy(sk).cuda())
+    sk_or = [orc.sk_try_from_bytes(pset, sk[i].tobytes()) for i in range(nk)]
+    total, done = 3000, 0
+    sizes = [1, 2, 5, 26, 64, 250]
+    call = 0
+    while done < total:
+        n = min(sizes[call % len(sizes)], total - done)
+        msgs = [hashlib_shake(b"oor-small-msg", done + i, 24) for i in range(n)]
+        rnd = [hashlib_shake(b"oor-small-rnd", done + i, 32) for i in range(n)]
+        kidx = ((np.arange(n) + call) % nk).astype(np.uint32)
+        want = orc.sign_batch_mt(pset, sk_or, kidx, msgs, rnd, 8, 1, mode=1)
+        for fused in ((FUSED_ON, 0) if call % 7 == 0 else (FUSED_ON,)):
+            hp.set_option(OPT_SMALL_FUSED, fused)
+            sig = m.try_sign_with_seed(sks, msgs, rnd, key_idx=kidx, mode=1).cpu().numpy()
+            bad = [i for i in range(n) if sig[i].tobytes() != want[i]]
+            assert not bad, (pset, n, fused, bad[:5])
+        hp.set_option(OPT_SMALL_FUSED, 256)
+        done += n
+        call += 1
+
+
+@pytest.mark.parametrize("pset,n,keep", [(65, 200, 12), (44, 256, 5), (87, 120, 1)])
+def test_a_round_with_far_fewer_ops_than_planned_walks_the_rest_itself(env, pset, n, keep):
+    """k_sign_back_small's grid is sized from the PLAN of the round (unfinished ops + 6 sigma, the candidates per op the rule gives there);
+    the device's own counts decide.  A call in which most ops are refused at the prologue (a ctx of 256 bytes: lib.rs:274) enters round 0
+    with far fewer ops than planned, so every op gets MORE candidates than the grid has workgroups for: the workgroups walk the further
+    pieces themselves.  (The other direction -- more ops than the grid's clusters -- is what the extra rounds of
+    test_small_signing_calls_whose_plan_leaves_ops_unfinished run.)  Signatures = the batch pipeline's = the oracle's."""
+    from fips204_amd.ml_dsa import _cat_with_offsets
+    hp, sets = env
+    m = sets[pset]
+    rng = np.random.default_rng(5200 + pset)
+    xi = [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(2)]
+    pk, sk = m.keygen_from_seed(xi)
+    sks, pks = m.private_keys_from_bytes(sk), m.public_keys_from_bytes(pk)
+    sk_o = [orc.keygen_from_seed(pset, x)[1] for x in xi]
+    live = set(int(i) for i in rng.choice(n, keep, replace=False))
+    msgs = [rng.integers(0, 256, 20, dtype=np.uint8).tobytes() for _ in range(n)]
+    ctxs = [b"ok" if i in live else b"z" * 256 for i in range(n)]
+    rnd = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    kidx_h = rng.integers(0, 2, n).astype(np.int32)
+    mb, mo = _cat_with_offsets(msgs, m.device)
+    cb, co = _cat_with_offsets(ctxs, m.device)
+    d_rnd, kidx = torch.from_numpy(rnd).cuda(), torch.from_numpy(kidx_h).cuda()
+    out = {}
+    for label, fused in (("fused", FUSED_ON), ("pipeline", 0)):
+        hp.set_option(OPT_SMALL_FUSED, fused)
+        sig = torch.full((n, m.SIG_LEN), 0x5A, dtype=torch.uint8, device="cuda")
+        st = torch.full((n,), 77, dtype=torch.int32, device="cuda")
+        m.sign_device(sks, mb, mo, d_rnd, sig, n, cb, co, kidx, 0, status=st)
+        torch.cuda.synchronize()
+        out[label] = (sig.cpu().numpy(), st.cpu().numpy())
+    hp.set_option(OPT_SMALL_FUSED, 256)
+    assert np.array_equal(out["fused"][0], out["pipeline"][0]) and np.array_equal(out["fused"][1], out["pipeline"][1])
+    sig, st = out["fused"]
+    for i in range(n):
+        if i in live:
+            assert st[i] == 0 and sig[i].tobytes() == orc.sign_internal(pset, sk_o[kidx_h[i]], msgs[i], rnd[i].tobytes(), ctx=ctxs[i], mode=0), i
+        else:
+            assert st[i] == -2 and not sig[i].any(), i
