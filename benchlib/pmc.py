@@ -4,12 +4,12 @@ import os
 
 from .constants import ROOT
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def pmc_traffic(name):
     """HBM bytes per launch from the PMC passes kept under profiles/ (tools/collect_profiles.sh): the dominant
-    kernel's figure, and per stage where collected.  Only THIS round's file counts (profiles/r05_MANIFEST.json ties it to the
+    kernel's figure, and per stage where collected.  Only THIS round's file counts (profiles/r06_MANIFEST.json ties it to the
     library it was taken on): when it is absent the answer is None and the line's `traffic` is null -- no older file stands in."""
     fn = f"{PROFILE_ROUND}_pmc_{name}.json"
     path = os.path.join(ROOT, "profiles", fn)

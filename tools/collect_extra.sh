@@ -1,7 +1,7 @@
 #!/bin/bash
 # One more measurement on the library the round's profiles were taken on, added to the manifest afterwards:
-#     gpurun -- 'tools/collect_extra.sh r05 ab_small_sign_spec.txt "<what>" <command...>'     (stdout of the command -> the file)
-#     python tools/finish_profiles.py r05 --extra      (back in the container: copies gpurun_out/extra_r05/* into profiles/ and appends them to
+#     gpurun -- 'tools/collect_extra.sh r06 ab_small_sign_spec.txt "<what>" <command...>'     (stdout of the command -> the file)
+#     python tools/finish_profiles.py r06 --extra      (back in the container: copies gpurun_out/extra_r06/* into profiles/ and appends them to
 #                                                        the manifest -- refused unless the sources' hash and the library's sha256 are the manifest's)
 set -u
 R=$1; F=$2; WHAT=$3; shift 3

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root, AFTER the last change under fips204_amd/csrc):
 #
-#     GIT_HEAD=$(git rev-parse HEAD) gpurun -- 'GIT_HEAD=... tools/collect_profiles.sh r05'
+#     make -C fips204_amd/csrc -j8 all nolatearg variants VARIANTS="258 1 8"        (the variants: for the memory-path A/B below)
+#     GIT_HEAD=$(git rev-parse HEAD) gpurun -- 'GIT_HEAD=... tools/collect_profiles.sh r06'
 #
 # bench lines (+ their side files), rocprofv3 kernel stats, HBM-traffic and SQ PMC passes (separate --pmc runs with --kernel-trace only,
 # the program itself directly after `--`), the small-call kernel timelines, the micro-benchmarks.  Everything lands in
@@ -9,7 +10,7 @@
 # back in the container) copies the summaries into profiles/ and writes profiles/${R}_MANIFEST.json (command, HEAD, sha256 of the
 # library, hash of the sources: tests/test_profiles_manifest_cpu.py).
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=$PWD/gpurun_out/final_$R
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -18,8 +19,9 @@ MAN="$OUT/MANIFEST.jsonl"
 python3 - > "$OUT/BUILD.json" <<PY
 import json, sys
 sys.path.insert(0, "tools")
-import csrc_hash
-print(json.dumps({"head": "${GIT_HEAD:-unknown}", "lib_sha256": csrc_hash.lib_sha256(), "csrc_hash": csrc_hash.csrc_hash()}))
+import csrc_hash, subprocess
+ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.strip()
+print(json.dumps({"head": "${GIT_HEAD:-unknown}", "lib_sha256": csrc_hash.lib_sha256(), "csrc_hash": csrc_hash.csrc_hash(), "hipcc_version": ver}))
 PY
 # note FILE "COMMAND": record what made FILE
 note() { python3 -c 'import json,sys; print(json.dumps({"file": sys.argv[1], "command": sys.argv[2]}))' "$1" "$2" >> "$MAN"; }
@@ -107,6 +109,15 @@ note small_call_unprofiled_wall_batch_pipeline.txt "MLDSA_SMALL_FUSED=0 python3 
 ./tools/batcher_bench_bin 65 1.5 0 1,8,64 1 > "$OUT/batcher_single_op_callers.json" 2>> "$ERR"; note batcher_single_op_callers.json "./tools/batcher_bench_bin 65 1.5 0 1,8,64 1"
 # ---- same-box A/Bs behind the small-call defaults (AB=0 skips them)
 if [ "${AB:-1}" != 0 ]; then
+  # round 6: the cache policy of the streaming kernels (field.h MLDSA_EXP; build/variants/*.so built from THESE sources) and the counters behind it
+  if [ -f build/variants/libmldsa_hip_exp258.so ]; then
+    python tools/ab_variants.py --reps 3 --variants base,258,1,8 --out gpurun_out/ab_variants_final.json > "$OUT/ab_memory_path.txt" 2>> "$ERR"
+    note ab_memory_path.txt "python tools/ab_variants.py --reps 3 --variants base,258,1,8  (base = the shipped library: nt loads of the verify side's read-once rows; 258 = that policy off; 1 = nt loads of the signer's A_hat; 8 = the signer's A_hat rows by LDS-DMA)"
+    tools/ab_variant_counters.sh $R "base 258 1 8" "verify65 verify_arith44 sign65" > /dev/null 2>> "$ERR"
+    cp gpurun_out/variant_counters/${R}_variant_counters_summary.txt "$OUT/ab_memory_path_counters.txt" 2>/dev/null
+    note ab_memory_path_counters.txt "tools/ab_variant_counters.sh $R 'base 258 1 8' 'verify65 verify_arith44 sign65'  (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum / SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAVES, separate passes, mean per launch of k_verify_arith / k_verify_main)"
+  fi
+  SIZES="1 8 32 64 128 256" tools/ab_small_back.sh > "$OUT/ab_small_sign_back.txt" 2>> "$ERR"; note ab_small_sign_back.txt "tools/ab_small_back.sh  (MLDSA_SMALL_SIGN_BACK = 1, the default: the second half of a small signing round as one launch, against 0: k_sign_tail + k_resolve + k_compact_small)"
   tools/ab_small_limits.sh > "$OUT/ab_small_limits_per_set.txt" 2>> "$ERR"; note ab_small_limits_per_set.txt "tools/ab_small_limits.sh  (per parameter set: single-launch kernels forced up to 1 024 ops against the batch pipeline, verify / keygen / sign calls of 96 ... 512 ops: where the crossovers are)"
   tools/ab_small_sign.sh > "$OUT/ab_small_sign_switches.txt" 2>> "$ERR"; note ab_small_sign_switches.txt "tools/ab_small_sign.sh  (default against MLDSA_SMALL_SIGN_SPEC=0 / 1, MLDSA_SMALL_SIGN_FRONT=0, MLDSA_SMALL_FUSED=0: wall time per signing call, ML-DSA-44 / 65 / 87, 1 ... 256 ops)"
 fi

@@ -3,7 +3,7 @@
 # rocprofv3 --kernel-trace --stats (the program itself after `--`), decomposed by tools/small_call_timeline.py into kernel time on the
 # device, launch gaps and host + sync time.  usage: tools/collect_small_calls.sh <round> [ops] [sizes]   -> profiles/<round>_small_call_*.json
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OPS=${2:-"verify sign keygen"}
 SIZES=${3:-"1 64 1024"}
 OUT=$PWD/gpurun_out/small_$R

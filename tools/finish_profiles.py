@@ -34,7 +34,7 @@ def extra(r):
 
 
 def main():
-    r = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    r = sys.argv[1] if len(sys.argv) > 1 else "r06"
     if "--extra" in sys.argv:
         return extra(r)
     src = os.path.join(ROOT, "gpurun_out", f"final_{r}")
@@ -49,7 +49,7 @@ def main():
         dst = f"{r}_{e['file']}"
         shutil.copyfile(p, os.path.join(ROOT, "profiles", dst))
         files[dst] = {"command": e["command"], "bytes": os.path.getsize(p)}
-    man = {"round": r, "head": build["head"], "lib_sha256": build["lib_sha256"], "csrc_hash": build["csrc_hash"],
+    man = {"round": r, "head": build["head"], "lib_sha256": build["lib_sha256"], "csrc_hash": build["csrc_hash"], "hipcc_version": build.get("hipcc_version"),
            "note": "every file below was produced by tools/collect_profiles.sh on one MI355X box from the library with this sha256, built from the "
                    "sources with this hash (tools/csrc_hash.py) at this commit", "files": files}
     json.dump(man, open(os.path.join(ROOT, "profiles", f"{r}_MANIFEST.json"), "w"), indent=1, sort_keys=True)
