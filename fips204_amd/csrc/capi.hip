@@ -320,6 +320,9 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
 
 long mldsa_get_option(const mldsa_ctx *ctx, int option) {
     if (!ctx) return MLDSA_ERR_PARAM;
+    // (the options are per-context state like everything else: read under the context's mutex -- a reader beside another thread's
+    //  mldsa_set_option was a data race, found by the ThreadSanitizer leg of tests/cpp/fuzz_host.cpp)
+    std::lock_guard<std::mutex> lk(const_cast<mldsa_ctx *>(ctx)->op_mutex);
     switch (option) {
         case MLDSA_OPT_GRAPHS: return ctx->opt_graphs;
         case MLDSA_OPT_SPEC_TARGET: return ctx->opt_spec_target;

@@ -55,6 +55,7 @@ __device__ __forceinline__ Packed3 pack24(uint32_t c0, uint32_t c1, uint32_t c2,
 #endif
 constexpr bool NT_A_VERIFY = (MLDSA_EXP & 2) == 0;      // adopted: A_hat rows of k_verify_main / the config-2 kernel by nontemporal loads (bit 1: off)
 constexpr bool NT_ZC = (MLDSA_EXP & 256) == 0;          // adopted: their read-once z, c and signature bytes too (bit 8: off)
+constexpr bool EXP_NT_A_KG = (MLDSA_EXP & 512) != 0;    // candidate: key generation's A_hat rows (read once per key) by nontemporal loads
 constexpr bool EXP_NT_A_SIGN = (MLDSA_EXP & 1) != 0;    // rejected (sign_w +12 %): the signer's A_hat rows by nontemporal loads
 constexpr bool EXP_NT_STORE = (MLDSA_EXP & 4) != 0;     // rejected (+-0.5 %, config 2 -1.5 %): every w / w1 row by nontemporal stores
 constexpr bool EXP_LDSDMA = (MLDSA_EXP & 8) != 0;       // rejected (sign_w +3 %, 5 -> 3 waves per SIMD): the signer's A_hat rows by LDS-DMA

@@ -124,10 +124,12 @@ Batch make_batch(Rng &r, size_t max_n) {
 std::atomic<int> g_low_memory{0};
 thread_local int t_own_workspace = 0;
 thread_local bool t_cap_before = false;  // the context had a workspace cap when the action began (another thread may lift it meanwhile)
+std::atomic<unsigned> g_cap_epoch{0};    // bumped around every change of a workspace cap: a cap that came AND went during an action still counts
+thread_local unsigned t_epoch_before = 0;
 bool acceptable(int rc, bool may_refuse, mldsa_ctx *ctx = nullptr) {
     g_calls++;
     if (rc == MLDSA_OK) return true;
-    const bool bounded = g_low_memory.load() > 0 || t_own_workspace > 0 || t_cap_before || (ctx && mldsa_get_option(ctx, MLDSA_OPT_WORKSPACE_CAP_MB) != 0);
+    const bool bounded = g_low_memory.load() > 0 || t_own_workspace > 0 || t_cap_before || g_cap_epoch.load() != t_epoch_before || (ctx && mldsa_get_option(ctx, MLDSA_OPT_WORKSPACE_CAP_MB) != 0);
     if ((rc == MLDSA_ERR_NOMEM && (bounded || !ctx)) || (may_refuse && rc == MLDSA_ERR_PARAM)) { g_refused++; return true; }
     return false;
 }
@@ -261,7 +263,10 @@ void act_options(mldsa_ctx *ctx, Rng &r) {
     if (rc == MLDSA_OK && mldsa_get_option(ctx, c.opt) != v && c.opt != MLDSA_OPT_SIGN_ASYNC_EXP) FAIL("option %d does not read back", c.opt);
     if (r.p(0.3)) {
         const long caps[] = {0, 0, 1, 8, 64, 1024};
-        if (mldsa_set_option(ctx, MLDSA_OPT_WORKSPACE_CAP_MB, caps[r.u(6)]) != MLDSA_OK) FAIL("workspace cap");
+        g_cap_epoch++;
+        const int rc_cap = mldsa_set_option(ctx, MLDSA_OPT_WORKSPACE_CAP_MB, caps[r.u(6)]);
+        g_cap_epoch++;
+        if (rc_cap != MLDSA_OK) FAIL("workspace cap");
     }
 }
 
@@ -357,6 +362,7 @@ void worker(mldsa_ctx *shared, int id, uint64_t seed, double seconds) {
     while (std::chrono::steady_clock::now() < t_end && !g_failed) {
         mldsa_ctx *ctx = r.p(0.6) ? shared : mine;       // the shared context: calls of several threads interleave on it
         void *s = r.p(0.5) ? stream : stream2;
+        t_epoch_before = g_cap_epoch.load();
         t_cap_before = mldsa_get_option(ctx, MLDSA_OPT_WORKSPACE_CAP_MB) != 0 || mldsa_get_option(mine, MLDSA_OPT_WORKSPACE_CAP_MB) != 0;
         const int a = (int)r.u(100);
         if (a < 22) act_verify(ctx, r, s, 4000);

@@ -19,8 +19,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "fips204_amd", "csrc", "libmldsa_hip.so")
 VAR = os.path.join(ROOT, "build", "variants")
-STEPS = {"sign65": (40, 5), "verify65": (100, 10), "verify_arith44": (2000, 500), "sign44": (40, 5), "sign87": (30, 5), "verify87": (60, 10)}
-STAGES = {"sign65": ("sign_w", "ctilde_hash", "sample_in_ball", "ntt_c", "sign_tail"), "verify65": ("verify_main", "expand_a", "ctilde_hash"), "verify_arith44": (),
+STEPS = {"keygen65": (60, 10), "keygen44": (60, 10), "keygen87": (40, 10), "sign65": (40, 5), "verify65": (100, 10), "verify_arith44": (2000, 500), "sign44": (40, 5), "sign87": (30, 5), "verify87": (60, 10)}
+STAGES = {"keygen65": (), "keygen44": (), "keygen87": (), "sign65": ("sign_w", "ctilde_hash", "sample_in_ball", "ntt_c", "sign_tail"), "verify65": ("verify_main", "expand_a", "ctilde_hash"), "verify_arith44": (),
           "sign44": ("sign_w", "ctilde_hash"), "sign87": ("sign_w", "ctilde_hash"), "verify87": ("verify_main", "expand_a")}
 
 
