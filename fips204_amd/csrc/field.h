@@ -49,13 +49,13 @@ __device__ __forceinline__ Packed3 pack24(uint32_t c0, uint32_t c1, uint32_t c2,
 // nontemporal (`global_load ... nt`): k_verify_main -8 %, the config-2 kernel 0.582 -> 0.635 of the HBM peak, same-box A/B.  The signer's
 // rows are NOT: adjacent candidate rows share their A_hat through the XCD's L2 (nt there: sign_w +12 %), and y / w are read again by the
 // tail kernels.  MLDSA_EXP (default 0 = the shipped library; `make variants` + tools/ab_variants.py for the A/Bs) switches the measured
-// variants: the two adopted policies OFF (bits 1 and 8), and the rejected ones ON.
+// variants: the adopted policies OFF (bits 1, 8 and 9), and the rejected ones ON.
 #ifndef MLDSA_EXP
 #define MLDSA_EXP 0
 #endif
 constexpr bool NT_A_VERIFY = (MLDSA_EXP & 2) == 0;      // adopted: A_hat rows of k_verify_main / the config-2 kernel by nontemporal loads (bit 1: off)
 constexpr bool NT_ZC = (MLDSA_EXP & 256) == 0;          // adopted: their read-once z, c and signature bytes too (bit 8: off)
-constexpr bool EXP_NT_A_KG = (MLDSA_EXP & 512) != 0;    // candidate: key generation's A_hat rows (read once per key) by nontemporal loads
+constexpr bool NT_A_KG = (MLDSA_EXP & 512) == 0;        // adopted: key generation's A_hat rows (read once per key) as well: +1.0 ... 1.7 % keys/s for the three sets (bit 9: off)
 constexpr bool EXP_NT_A_SIGN = (MLDSA_EXP & 1) != 0;    // rejected (sign_w +12 %): the signer's A_hat rows by nontemporal loads
 constexpr bool EXP_NT_STORE = (MLDSA_EXP & 4) != 0;     // rejected (+-0.5 %, config 2 -1.5 %): every w / w1 row by nontemporal stores
 constexpr bool EXP_LDSDMA = (MLDSA_EXP & 8) != 0;       // rejected (sign_w +3 %, 5 -> 3 waves per SIMD): the signer's A_hat rows by LDS-DMA

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * AW) void k_verify_arith(
     __shared__ Twiddle tw_lds[(FWD_TW + INV_TW) * 64];
     // (experiment, MLDSA_EXP bit 3: the A_hat row of the signer's kernel arrives by LDS-DMA, one buffer per wave, instead of in registers)
     constexpr bool DMA = EXP_LDSDMA && APACK && !HAS_C && !KG && W1 == 2 && K == 6;  // (the ML-DSA-65 signer only)
-    constexpr bool NT_A = HAS_C ? NT_A_VERIFY : KG ? EXP_NT_A_KG : EXP_NT_A_SIGN;
+    constexpr bool NT_A = HAS_C ? NT_A_VERIFY : KG ? NT_A_KG : EXP_NT_A_SIGN;
     constexpr int ROW_BYTES = L * PACKED_POLY_DWORDS * 4, ROW_PIECES = (ROW_BYTES + 1023) / 1024;
     constexpr int DMA_STORES = 3 + (W1 == 2 ? 1 : 12);  // store instructions of one row's epilogue (w planes + w1Encode), issued behind the next row's DMA
     __shared__ uint32_t a_lds[DMA ? AW : 1][DMA ? ROW_PIECES * 256 : 1];

@@ -109,6 +109,6 @@ def test_the_shipped_library_is_built_without_experiment_variants_and_with_late_
     fh = open(os.path.join(CSRC, "field.h")).read()
     assert re.search(r"#ifndef MLDSA_EXP\s*\n#define MLDSA_EXP 0\s*\n#endif", fh)
     # the adopted cache policy is on when MLDSA_EXP is 0, the rejected variants are off
-    assert "NT_A_VERIFY = (MLDSA_EXP & 2) == 0" in fh and "NT_ZC = (MLDSA_EXP & 256) == 0" in fh
+    assert "NT_A_VERIFY = (MLDSA_EXP & 2) == 0" in fh and "NT_ZC = (MLDSA_EXP & 256) == 0" in fh and "NT_A_KG = (MLDSA_EXP & 512) == 0" in fh
     for rejected in ("EXP_NT_A_SIGN", "EXP_NT_STORE", "EXP_LDSDMA", "EXP_NT_DMA"):
         assert re.search(r"constexpr bool %s = \(MLDSA_EXP & \d+\) != 0;" % rejected, fh), rejected

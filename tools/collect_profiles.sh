@@ -113,6 +113,8 @@ if [ "${AB:-1}" != 0 ]; then
   if [ -f build/variants/libmldsa_hip_exp258.so ]; then
     python tools/ab_variants.py --reps 3 --variants base,258,1,8 --out gpurun_out/ab_variants_final.json > "$OUT/ab_memory_path.txt" 2>> "$ERR"
     note ab_memory_path.txt "python tools/ab_variants.py --reps 3 --variants base,258,1,8  (base = the shipped library: nt loads of the verify side's read-once rows; 258 = that policy off; 1 = nt loads of the signer's A_hat; 8 = the signer's A_hat rows by LDS-DMA)"
+    python tools/ab_variants.py --reps 3 --variants base,512 --workloads keygen65,keygen44,keygen87 --out gpurun_out/ab_variants_keygen.json > "$OUT/ab_memory_path_keygen.txt" 2>> "$ERR"
+    note ab_memory_path_keygen.txt "python tools/ab_variants.py --reps 3 --variants base,512 --workloads keygen65,keygen44,keygen87  (512 = key generation's A_hat rows on the default cache policy instead of nontemporal)"
     tools/ab_variant_counters.sh $R "base 258 1 8" "verify65 verify_arith44 sign65" > /dev/null 2>> "$ERR"
     cp gpurun_out/variant_counters/${R}_variant_counters_summary.txt "$OUT/ab_memory_path_counters.txt" 2>/dev/null
     note ab_memory_path_counters.txt "tools/ab_variant_counters.sh $R 'base 258 1 8' 'verify65 verify_arith44 sign65'  (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum / SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAVES, separate passes, mean per launch of k_verify_arith / k_verify_main)"
