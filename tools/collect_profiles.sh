@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root, AFTER the last change under fips204_amd/csrc):
 #
-#     make -C fips204_amd/csrc -j8 all nolatearg variants VARIANTS="258 1 8"        (the variants: for the memory-path A/B below)
+#     make -C fips204_amd/csrc -j8 all nolatearg variants VARIANTS="258 1 8 512"    (the variants: for the memory-path A/B below)
 #     GIT_HEAD=$(git rev-parse HEAD) gpurun -- 'GIT_HEAD=... tools/collect_profiles.sh r06'
 #
 # bench lines (+ their side files), rocprofv3 kernel stats, HBM-traffic and SQ PMC passes (separate --pmc runs with --kernel-trace only,
