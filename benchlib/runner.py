@@ -36,17 +36,29 @@ def read_sclk(device=0):
     return None
 
 
-def clock_ramp(wl, first, min_ms=200.0):
+def clock_ramp(wl, first, min_ms=200.0, midway=None):
     """>= min_ms of the workload's own steps BEFORE the counted warm-up: the GPU idled (clocks down) while the inputs were built and the CPU
-    oracle checked them.  Outside `steps` / `warmup`; what was run is reported in the side file."""
+    oracle checked them.  Outside `steps` / `warmup`; what was run is reported in the side file.  `midway()` is called once, half way
+    (the shader clock is read THERE: a sysfs read between the warm-up and the timed region leaves the device idle for long enough that the
+    first ~12 steps of the timed region run on a clock that is still climbing -- profiles/r06_bench_step_marks_before_after.txt)."""
     t0 = time.perf_counter()
     n = 0
+    mid = None
+    burst = 8  # steps enqueued between two synchronisations: 8 at first, then ~60 ms worth (at most 128) -- the timed region enqueues its K
+    #            steps in one burst where a step is asynchronous, and the FIRST deep burst of a process can run slowly (early_pmc, bench.py)
     while (time.perf_counter() - t0) * 1e3 < min_ms and n < 100000:
-        for _ in range(8):
+        tb = time.perf_counter()
+        for _ in range(burst):
             wl.step(first + n)
             n += 1
+        if midway is not None and mid is None and (time.perf_counter() - t0) * 1e3 >= min_ms / 2:
+            mid = midway()  # (the steps just enqueued are still running where the workload's step is asynchronous)
         torch.cuda.synchronize()
-    return {"steps": n, "ms": round((time.perf_counter() - t0) * 1e3, 2)}
+        per_step_ms = (time.perf_counter() - tb) * 1e3 / burst
+        burst = int(min(128, max(8, 60.0 / max(per_step_ms, 1e-3))))
+    if midway is not None and mid is None:
+        mid = midway()
+    return {"steps": n, "ms": round((time.perf_counter() - t0) * 1e3, 2)}, mid
 
 
 def timed_steps(wl, world, steps, first, marks=64):
@@ -64,6 +76,7 @@ def timed_steps(wl, world, steps, first, marks=64):
         wl.step(first + i)
         if (i + 1) % stride == 0 or i + 1 == steps:
             evs[(i + stride) // stride].record()
+    timed_steps.enqueue_ms = (time.perf_counter() - t0) * 1e3  # how long the host took to enqueue the K steps (side file)
     if hasattr(wl, "finish_steps"):
         wl.finish_steps()  # inside the timed region: e.g. the mixed stream re-signs what its asynchronous calls left over
     ev_end = torch.cuda.Event(enable_timing=True)
@@ -76,6 +89,7 @@ def timed_steps(wl, world, steps, first, marks=64):
     for j in range(n_marks):
         in_chunk = min(stride, steps - j * stride)
         per.append(evs[j].elapsed_time(evs[j + 1]) / in_chunk)
+    timed_steps.marks_ms = [round(x, 4) for x in per]  # in time order (side file: which steps were the slow ones)
     per.sort()
     timed_steps.step_ms = {"min": per[0], "median": per[len(per) // 2], "max": per[-1], "steps_per_mark": stride} if per else None
     return max_over_ranks(dt, world), evs[0].elapsed_time(ev_end)
@@ -85,11 +99,12 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     wl = make_workload(name, hp, args.batch if name == args.workload else 0, rank, world)
     if rank == 0:
         wl.check()
-    ramp = clock_ramp(wl, 0)  # (outside steps / warmup; in the side file)
+    # (outside steps / warmup; in the side file.  Nothing but the warm-up, a synchronize and the barrier lies between the ramp and the timed
+    #  region: no file is read, no object is built there)
+    ramp, sclk0 = clock_ramp(wl, 0, min_ms=float(os.environ.get("BENCH_RAMP_MS", "200")), midway=read_sclk if rank == 0 else None)
     for i in range(warmup):
         wl.step(i)
     torch.cuda.synchronize()
-    sclk0 = read_sclk() if rank == 0 else None
     whole = isinstance(wl, WholeOp)
     units_per_step = getattr(wl, "ops_per_step", wl.batch)
 
@@ -98,6 +113,8 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     st0 = hp.stats() if hasattr(hp, "stats") else None
     dt, ev_ms = timed_steps(wl, world, steps, warmup)
     step_ms = timed_steps.step_ms
+    marks_ms = getattr(timed_steps, "marks_ms", None)
+    enqueue_ms = getattr(timed_steps, "enqueue_ms", None)
     sclk1 = read_sclk() if rank == 0 else None
     kern_ms = ev_ms / steps / wl.kernel_launches_per_step()
     value = units_per_step * world * steps / dt
@@ -188,9 +205,13 @@ def run_one(args, hp, rank, world, name, steps, warmup, cpu_baseline, with_host_
     # clock that had not ramped from a regression (the value itself stays total units / wall time of exactly K steps)
     if step_ms:
         line["step_ms"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in step_ms.items()}
+    if enqueue_ms is not None:
+        line["host_enqueue_ms"] = round(enqueue_ms, 3)  # the host's time to enqueue the K timed steps (it runs ahead of the device where a step is asynchronous)
+    if marks_ms:
+        line["step_ms_marks"] = marks_ms  # (side file only: benchlib/line.py does not copy it)
     line["clock_ramp"] = dict(ramp, note="the workload's own steps before the counted warm-up, outside steps / warmup")
     line["sclk"] = {"before_timed_region": sclk0, "after_timed_region": sclk1,
-                    "note": "read on the idle device just before / just after the timed region (MHz; null = not readable on this box)"}
+                    "note": "MHz (null = not readable on this box): before = half way through the clock ramp, while its steps run; after = right after the timed region's final synchronize (the device is idle again by then)"}
     if ranks:
         line["ranks"] = ranks
     if isinstance(wl, MixedStream):

@@ -128,4 +128,12 @@ def test_line_carries_the_spread_of_the_timed_steps_and_the_side_object_the_cloc
     assert got is None or (isinstance(got["mhz"], int) and got["source"])
     import inspect
     src = inspect.getsource(runner.run_one)
-    assert src.index("clock_ramp(wl, 0)") < src.index("for i in range(warmup)") < src.index("timed_steps(wl, world, steps, warmup)")
+    assert src.index("clock_ramp(wl, 0") < src.index("for i in range(warmup)") < src.index("timed_steps(wl, world, steps, warmup)")
+    # nothing that leaves the device idle for long (a sysfs read, a subprocess) between the warm-up and the timed region: the clock is read
+    # half way through the ramp, while its steps run
+    between = src[src.index("for i in range(warmup)"):src.index("timed_steps(wl, world, steps, warmup)")]
+    assert "read_sclk" not in between and "subprocess" not in between
+    # ... and the live PMC passes run before torch -- the HIP runtime -- is loaded (bench.py early_pmc: with the runtime mapped while a
+    # profiler session ran in another process, the first deep burst of launches ran slowly: the first dozen steps of the timed region)
+    bsrc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert bsrc.index("early_pmc(_ARGS)") < bsrc.index("\nimport torch")
