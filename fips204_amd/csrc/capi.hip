@@ -133,7 +133,7 @@ int mldsa_ctx_create(int device_id, mldsa_ctx **out) {
     ctx->opt_spec_target = env_long("MLDSA_SPEC_TARGET", 1, 524288, ctx->opt_spec_target);
     ctx->opt_spec_max = env_long("MLDSA_SPEC_MAX", 1, 64, ctx->opt_spec_max);
     ctx->opt_spec_rows = env_long("MLDSA_SPEC_ROWS", 1, 524288, ctx->opt_spec_rows);
-    ctx->opt_sign_lanes = env_long("MLDSA_SIGN_LANES", 1, 2, ctx->opt_sign_lanes);
+    ctx->opt_sign_lanes = env_long("MLDSA_SIGN_LANES", 0, 2, ctx->opt_sign_lanes);
     ctx->opt_lookahead = env_long("MLDSA_LOOKAHEAD", 0, 2, ctx->opt_lookahead);
     ctx->opt_va_blocks = env_long("MLDSA_VA_BLOCKS_PER_CU", 1, 64, ctx->opt_va_blocks);
     ctx->opt_host_sub_verify = env_long("MLDSA_HOST_SUB_VERIFY", 64, 65536, ctx->opt_host_sub_verify);
@@ -271,7 +271,7 @@ int mldsa_set_option(mldsa_ctx *ctx, int option, long value) {
             ctx->opt_sign_rounds = value;
             return MLDSA_OK;
         case MLDSA_OPT_SIGN_LANES:
-            REQUIRE(value == 1 || value == 2, "mldsa_set_option: MLDSA_OPT_SIGN_LANES is 1 or 2");
+            REQUIRE(value >= 0 && value <= 2, "mldsa_set_option: MLDSA_OPT_SIGN_LANES is 0 (auto), 1 or 2");
             ctx->opt_sign_lanes = value;
             return MLDSA_OK;
         case MLDSA_OPT_SIGN_ASYNC_EXP:

@@ -722,17 +722,29 @@ SignPlan plan_sign(const mldsa_ctx *ctx, int set, size_t n, bool async_mode, dou
 }
 }  // namespace
 
-// lanes of a chunk of `chunk` ops: two when the option asks for it and each would still be a sizeable batch
-static int sign_lanes_for(const mldsa_ctx *ctx, size_t chunk) { return (ctx->opt_sign_lanes >= 2 && chunk >= 8192) ? 2 : 1; }
+// Lanes of a chunk of `chunk` ops: two slices side by side (MLDSA_OPT_SIGN_LANES).  Measured per parameter set and size on three boxes
+// (profiles/r06_ab_sign_lanes_grid*.txt): with slices of >= 65 536 ops -- full-size launches in both chains -- two lanes win every time
+// (131 072 ... 262 144 ops: ML-DSA-65 +3.3 ... 4.9 %, 9.6 -> 9.9 ... 10.5 M/s; 44 +7 ... 12 %; 87 +2.5 ... 5.5 %); at 65 536 ops ML-DSA-44
+// still gains (+1.6 / +2.9 % on two boxes), 65 and 87 are within +-1.5 % from box to box; below that the half-size slices speculate more
+// and lose 4 ... 16 %.  0 (default) = two slices from that size on, 1 = never, 2 = for every call of >= 8 192 ops.
+static size_t sign_lanes_auto_min_ops(int set) { return set == MLDSA_44 ? 65536 : 131072; }
+static int sign_lanes_for(const mldsa_ctx *ctx, int set, size_t chunk) {
+    if (ctx->opt_sign_lanes >= 2) return chunk >= 8192 ? 2 : 1;
+    return ctx->opt_sign_lanes == 0 && chunk >= sign_lanes_auto_min_ops(set) ? 2 : 1;
+}
 static size_t lane_ops(size_t chunk, int n_lanes) { return n_lanes == 1 ? chunk : ((chunk + 1) / 2 + 255) & ~(size_t)255; }
 
 static bool lookahead_on(const mldsa_ctx *ctx, const mldsa_params *p);
 
 size_t sign_workspace_bytes(const mldsa_ctx *ctx, const mldsa_params *p, size_t n_ops, bool own_a) {
     const size_t chunk = std::min(n_ops, ctx->pass_ops_sign);
-    const int n_lanes = sign_lanes_for(ctx, chunk);
-    const size_t n = lane_ops(chunk, n_lanes);
-    return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a, lookahead_on(ctx, p)).bytes;
+    auto layout = [&](int n_lanes) {
+        const size_t n = lane_ops(chunk, n_lanes);
+        return n_lanes * SignWs(nullptr, p, n, plan_sign(ctx, p->set, n, true).ns_max, own_a, lookahead_on(ctx, p)).bytes;
+    };
+    // (a call that exports its signatures round by round -- mldsa_sign_host's direct path -- runs as ONE lane whatever the policy says,
+    //  sign_batch: room for either layout)
+    return sign_lanes_for(ctx, p->set, chunk) == 1 ? layout(1) : std::max(layout(1), layout(2));
 }
 
 // batches below this size generate one candidate per op and round: their sign_w is not bound by re-reading A_hat
@@ -1178,7 +1190,7 @@ int sign_batch(mldsa_ctx *ctx, int set, int mode, const uint8_t *rho, const uint
     if (n_ops == 0) return MLDSA_OK;
     const bool own_a = a_hat_keys == nullptr;
     const size_t chunk = std::min(n_ops, ctx->pass_ops_sign);
-    const int n_lanes = sign_lanes_for(ctx, chunk);
+    const int n_lanes = export_sigs ? 1 : sign_lanes_for(ctx, set, chunk);  // (the export hangs off lane 0's rounds: one lane)
     const size_t per_lane = lane_ops(chunk, n_lanes);
     const SignPlan pl = plan_sign(ctx, set, per_lane, async_mode, plan_stop);
     SignLane lanes[2];

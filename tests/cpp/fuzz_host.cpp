@@ -253,7 +253,7 @@ void act_host(mldsa_ctx *ctx, mldsa_group *grp, Rng &r, size_t max_n) {
 
 void act_options(mldsa_ctx *ctx, Rng &r) {
     struct { int opt; long lo, hi; } o[] = {{MLDSA_OPT_GRAPHS, 0, 2}, {MLDSA_OPT_SPEC_TARGET, 1, 200000}, {MLDSA_OPT_SPEC_MAX, 1, 64}, {MLDSA_OPT_VA_BLOCKS_PER_CU, 1, 64},
-                                           {MLDSA_OPT_GRAPH_CACHE, 1, 4}, {MLDSA_OPT_SIGN_ROUNDS, 0, 6}, {MLDSA_OPT_SIGN_LANES, 1, 2}, {MLDSA_OPT_SIGN_CT0_EXACT, 0, 1},
+                                           {MLDSA_OPT_GRAPH_CACHE, 1, 4}, {MLDSA_OPT_SIGN_ROUNDS, 0, 6}, {MLDSA_OPT_SIGN_LANES, 0, 2}, {MLDSA_OPT_SIGN_CT0_EXACT, 0, 1},
                                            {MLDSA_OPT_SIGN_ASYNC_EXP, 1, 12}, {MLDSA_OPT_SIGN_LOOKAHEAD, 0, 2}, {MLDSA_OPT_COOP_HASH, 0, 1}, {MLDSA_OPT_SMALL_FUSED, 0, 1024}};
     const auto &c = o[r.u(sizeof(o) / sizeof(o[0]))];
     const long v = r.p(0.1) ? c.hi + 1 + (long)r.u(10) : c.lo + (long)r.u((uint64_t)(c.hi - c.lo + 1));
@@ -374,9 +374,11 @@ void worker(mldsa_ctx *shared, int id, uint64_t seed, double seconds) {
         else if (a < 91 && ctx == mine) act_workspace(ctx, r, s);
         else if (a < 94 && id == 0) {  // the device runs short of memory for a while: the passes shrink, calls may be refused with MLDSA_ERR_NOMEM
             g_low_memory++;
+            g_cap_epoch++;  // (a shortage that came AND went while another thread's call ran still explains that call's NOMEM)
             stub_set_mem_limit((size_t)r.logu(1 << 20, 512 << 20));
             for (int i = 0; i < 4 && !g_failed; i++) { if (r.p(0.5)) act_verify(mine, r, s, 4000); else act_sign(mine, r, s, 2500); }
             stub_set_mem_limit((size_t)1 << 40);
+            g_cap_epoch++;
             g_low_memory--;
         } else if (a < 97) act_group(r);
         else if (ctx == mine) {  // a context comes and goes

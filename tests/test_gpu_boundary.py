@@ -517,7 +517,7 @@ def test_environment_knobs_are_read_only_when_the_process_asks_for_them():
                 got[switch] = tuple(h.get_option(o) for o in (OPT_GRAPHS, OPT_SPEC_TARGET, OPT_SIGN_LANES, OPT_SMALL_FUSED))
             finally:
                 h.close()
-        assert got[None] == got["0"] == got["yes"] == (0, 65536, 1, 256), got   # the defaults: nothing was read
+        assert got[None] == got["0"] == got["yes"] == (0, 65536, 0, 256), got   # the defaults: nothing was read
         assert got["1"] == (2, 4096, 2, 0), got
     finally:
         for k, v in old.items():

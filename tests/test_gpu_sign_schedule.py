@@ -202,6 +202,36 @@ def test_two_signing_lanes_in_small_rounds_side_by_side(hp, sets):
             hp.set_option(o, v)
 
 
+def test_default_policy_takes_two_lanes_from_131072_ops_and_signs_the_same(hp, sets):
+    """MLDSA_OPT_SIGN_LANES = 0 (the default): a call of >= 131 072 ops runs as two slices side by side (measured +3.5 ... 7 %,
+    profiles/r06_ab_sign_lanes_grid.txt), a smaller one as one.  The signatures do not depend on it: 131 072 ML-DSA-44 ops under the default
+    are byte for byte those of the one-lane call, a sample of them the oracle's, every one verifies on the device."""
+    m = sets[44]
+    n = 131072
+    assert hp.get_option(7) == 0
+    b = make_batch(m, n, 5, b"lanes-auto")
+    idx = range(0, n, 4099)
+    want = oracle_sigs(44, b, idx)
+    sig = torch.empty((n, m.SIG_LEN), dtype=torch.uint8, device="cuda")
+    st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    res = {}
+    try:
+        for lanes in (0, 1):
+            hp.set_option(7, lanes)
+            sig.zero_()
+            m.sign_device(b["sks"], b["mb"], b["mo"], b["rn"], sig, n, key_idx=b["kidx"], status=st)
+            assert int(host(st).min()) == 0 and int(host(st).max()) == 0
+            res[lanes] = host(sig).copy()
+    finally:
+        hp.set_option(7, 0)
+    assert np.array_equal(res[0], res[1]), f"ops {np.nonzero((res[0] != res[1]).any(axis=1))[0][:8]} differ between the default and one lane"
+    for g, w in zip(res[0][::4099], want):
+        assert g.tobytes() == w
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    m.verify_device(b["pks"], b["mb"], b["mo"], sig, ok, n, key_idx=b["kidx"])
+    assert int(host(ok).min()) == 1
+
+
 # ------------------------------------------------------------------------------ soak (tests/integration.rs:22-53 `forever`)
 def test_soak_random_shapes_knobs_and_modes_against_the_oracle(hp, sets):
     """A seeded, time-bounded version of the reference's `forever` loop: random parameter set, batch size (1 ... 70 000,
