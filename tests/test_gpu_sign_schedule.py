@@ -262,7 +262,7 @@ def test_soak_random_shapes_knobs_and_modes_against_the_oracle(hp, sets):
                 shapes.append((n, nk))
             mode = int(rng.choice([0, 0, 1, 2]))
             knobs = {1: int(rng.choice([0, 1, 2])), 2: int(rng.choice([1024, 8192, 40000, 65536, 150000])),
-                     3: int(rng.choice([1, 4, 32, 64])), 6: int(rng.choice([0, 0, 1, 3])), 7: int(rng.choice([1, 1, 2])),
+                     3: int(rng.choice([1, 4, 32, 64])), 6: int(rng.choice([0, 0, 1, 3])), 7: int(rng.choice([0, 1, 1, 2])),
                      10: int(rng.choice([0, 1, 2])), 13: int(rng.choice([256, 256, 0, 40, 1024]))}
             for o, v in knobs.items():
                 hp.set_option(o, v)
