@@ -112,3 +112,17 @@ def test_the_shipped_library_is_built_without_experiment_variants_and_with_late_
     assert "NT_A_VERIFY = (MLDSA_EXP & 2) == 0" in fh and "NT_ZC = (MLDSA_EXP & 256) == 0" in fh and "NT_A_KG = (MLDSA_EXP & 512) == 0" in fh
     for rejected in ("EXP_NT_A_SIGN", "EXP_NT_STORE", "EXP_LDSDMA", "EXP_NT_DMA"):
         assert re.search(r"constexpr bool %s = \(MLDSA_EXP & \d+\) != 0;" % rejected, fh), rejected
+
+
+def test_the_lane_policy_the_header_documents_is_the_one_the_pipeline_applies():
+    """MLDSA_OPT_SIGN_LANES = 0 (default since round 6): two slices from 131 072 ops on, ML-DSA-44 from 65 536 (profiles/r06_ab_sign_lanes_*).
+    The sizes live in pipeline.hip; the header states them; an exporting call stays one lane and the workspace holds either layout."""
+    pl = open(os.path.join(CSRC, "pipeline.hip")).read()
+    m = re.search(r"sign_lanes_auto_min_ops\(int set\) \{ return set == MLDSA_44 \? (\d+) : (\d+); \}", pl)
+    assert m and (int(m.group(1)), int(m.group(2))) == (65536, 131072)
+    hdr = open(os.path.join(ROOT, "include", "mldsa_hip.h")).read()
+    doc = hdr[hdr.index("#define MLDSA_OPT_SIGN_LANES 7"):hdr.index("#define MLDSA_OPT_SIGN_CT0_EXACT")]
+    assert "0 (default)" in doc and "131 072" in doc and "65 536" in doc
+    assert "opt_sign_lanes = 0" in open(os.path.join(CSRC, "ctx.h")).read()
+    assert "export_sigs ? 1 : sign_lanes_for(ctx, set, chunk)" in pl
+    assert "std::max(layout(1), layout(2))" in pl
